@@ -1,0 +1,178 @@
+"""Synthetic lduMatrix inputs (numpy only): the 7-point Poisson box of BASELINE.md §3.
+
+Cells are numbered x-fastest; internal faces are emitted in OpenFOAM's upper-triangular
+order (owner ascending, neighbour ascending within an owner): for cell c the faces to
+c+1, c+nx, c+nx*ny, in that order.  ``upper[f] = -1``,
+``diag[i] = (#neighbours of i in the GLOBAL mesh) + 1e-3 * (1 + (gi mod 7) / 7)`` with gi the
+global cell index, so a decomposed case assembles exactly the global matrix.
+
+A decomposed case carries OpenFOAM-style coupled interfaces:
+  processor patch : faceCells + neighbProcNo + bouCoeffs (= -offdiag, see HostMatrix.C:204)
+  cyclic patch    : faceCells + neighbPatchID + bouCoeffs
+ordered by ascending neighbour rank, both sides enumerating the shared faces identically
+(what HostMatrix.C:251-306 / :412-436 rely on).
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+IFACE_PROCESSOR = 0
+IFACE_CYCLIC = 1
+
+
+@dataclass
+class Interface:
+    kind: int
+    face_cells: np.ndarray           # int32
+    bou_coeffs: np.ndarray           # float64
+    neighb_proc: int = -1
+    neighb_patch: int = -1
+
+
+@dataclass
+class LduCase:
+    n_cells: int
+    lower_addr: np.ndarray           # int32 [F]  (owner)
+    upper_addr: np.ndarray           # int32 [F]  (neighbour)
+    diag: np.ndarray                 # float64 [N]
+    upper: np.ndarray                # float64 [F]
+    lower: Optional[np.ndarray]      # float64 [F] or None (symmetric)
+    interfaces: List[Interface] = field(default_factory=list)
+    global_index: Optional[np.ndarray] = None   # int64 [N] global cell id of each local cell
+    global_n: int = 0
+
+    @property
+    def symmetric(self):
+        return self.lower is None
+
+    @property
+    def n_faces(self):
+        return int(self.upper_addr.size)
+
+    @property
+    def nnz(self):
+        return self.n_cells + 2 * self.n_faces
+
+
+def box_faces(lx, ly, lz):
+    """(lower_addr, upper_addr) of an lx*ly*lz box in upper-triangular order."""
+    n = lx * ly * lz
+    c = np.arange(n, dtype=np.int32)
+    i = c % lx
+    j = (c // lx) % ly
+    k = c // (lx * ly)
+    mask = np.stack([i < lx - 1, j < ly - 1, k < lz - 1], axis=1)
+    nb = np.stack([c + 1, c + lx, c + lx * ly], axis=1)
+    own = np.broadcast_to(c[:, None], nb.shape)
+    return np.ascontiguousarray(own[mask]), np.ascontiguousarray(nb[mask])
+
+
+def _delta(gi):
+    return 1e-3 * (1.0 + (gi % 7) / 7.0)
+
+
+def poisson_block(gx, gy, gz, px=1, py=1, pz=1, rank=0, symmetric=True, periodic_x=False,
+                  off_upper=-1.0, off_lower=-1.0):
+    """Rank `rank`'s share of a gx*gy*gz Poisson box cut into px*py*pz equal blocks.
+
+    rank = bx + px*(by + py*bz).  periodic_x adds a cyclic patch pair (only with px == 1).
+    With symmetric=False the upper/lower coefficients are off_upper/off_lower.
+    """
+    assert gx % px == 0 and gy % py == 0 and gz % pz == 0
+    assert not (periodic_x and px != 1)
+    lx, ly, lz = gx // px, gy // py, gz // pz
+    bx, by, bz = rank % px, (rank // px) % py, rank // (px * py)
+    ox, oy, oz = bx * lx, by * ly, bz * lz
+    n = lx * ly * lz
+    lower_addr, upper_addr = box_faces(lx, ly, lz)
+    F = lower_addr.size
+    c = np.arange(n, dtype=np.int64)
+    i, j, k = c % lx, (c // lx) % ly, c // (lx * ly)
+    gi = (ox + i) + gx * ((oy + j) + gy * (oz + k))
+    gI, gJ, gK = ox + i, oy + j, oz + k
+    nnb = ((gI > 0).astype(np.float64) + (gI < gx - 1) + (gJ > 0) + (gJ < gy - 1) + (gK > 0)
+           + (gK < gz - 1))
+    if periodic_x:
+        nnb = nnb + (gI == 0) + (gI == gx - 1)
+    diag = nnb + _delta(gi)
+    if symmetric:
+        upper = np.full(F, off_upper, dtype=np.float64)
+        lower = None
+    else:
+        upper = np.full(F, off_upper, dtype=np.float64)
+        lower = np.full(F, off_lower, dtype=np.float64)
+
+    # coupled interfaces, ascending neighbour rank: -z, -y, -x, +x, +y, +z
+    cl = np.arange(n, dtype=np.int32)
+    ifaces = []
+
+    def add_proc(cond, nrank, to_higher):
+        cells = np.ascontiguousarray(cl[cond])
+        # true off-diagonal entry = -bouCoeffs; row owner < column owner => "upper" coefficient
+        coeff = off_upper if (to_higher or symmetric) else off_lower
+        ifaces.append(Interface(IFACE_PROCESSOR, cells, np.full(cells.size, -coeff), nrank, -1))
+
+    if bz > 0:
+        add_proc(k == 0, rank - px * py, False)
+    if by > 0:
+        add_proc(j == 0, rank - px, False)
+    if bx > 0:
+        add_proc(i == 0, rank - 1, False)
+    if bx < px - 1:
+        add_proc(i == lx - 1, rank + 1, True)
+    if by < py - 1:
+        add_proc(j == ly - 1, rank + px, True)
+    if bz < pz - 1:
+        add_proc(k == lz - 1, rank + px * py, True)
+    if periodic_x:
+        left = np.ascontiguousarray(cl[i == 0])
+        right = np.ascontiguousarray(cl[i == lx - 1])
+        p0 = len(ifaces)
+        # row in `left`, column in `right` (> row): upper-type coefficient, and vice versa
+        ifaces.append(Interface(IFACE_CYCLIC, left, np.full(left.size, -off_upper), -1, p0 + 1))
+        ifaces.append(Interface(IFACE_CYCLIC, right,
+                                np.full(right.size, -(off_upper if symmetric else off_lower)), -1,
+                                p0))
+    return LduCase(n, lower_addr, upper_addr, diag, upper, lower, ifaces, gi, gx * gy * gz)
+
+
+def poisson_case(n, symmetric=True, **kw):
+    """Single-rank n^3 case of BASELINE.md §3 (asymmetric variant: upper -0.9, lower -1.1)."""
+    if not symmetric:
+        kw.setdefault("off_upper", -0.9)
+        kw.setdefault("off_lower", -1.1)
+    return poisson_block(n, n, n, symmetric=symmetric, **kw)
+
+
+def x_star(global_index, global_n):
+    """x*_i = sin(2 pi i / N) on the global numbering."""
+    return np.sin(2.0 * np.pi * global_index.astype(np.float64) / float(global_n))
+
+
+def apply_case(case: LduCase, x, halo_fn=None):
+    """y = A x straight from the LDU form (numpy; input generation only, not an oracle).
+
+    halo_fn(iface_index, send_values) -> neighbour values, for processor interfaces.
+    """
+    y = case.diag * x
+    lo, up = case.lower_addr, case.upper_addr
+    lower = case.upper if case.lower is None else case.lower
+    np.add.at(y, lo, case.upper * x[up])
+    np.add.at(y, up, lower * x[lo])
+    for idx, itf in enumerate(case.interfaces):
+        if itf.kind == IFACE_CYCLIC:
+            nb = case.interfaces[itf.neighb_patch].face_cells
+            np.add.at(y, itf.face_cells, -itf.bou_coeffs * x[nb])
+        elif halo_fn is not None:
+            np.add.at(y, itf.face_cells, -itf.bou_coeffs * halo_fn(idx, x[itf.face_cells]))
+    return y
+
+
+def rhs_for_x_star(case: LduCase, halo_from_global=True):
+    """b = A x* where neighbour-rank values of x* come from the analytic global formula."""
+    xs = x_star(case.global_index, case.global_n)
+    if not any(f.kind == IFACE_PROCESSOR for f in case.interfaces):
+        return apply_case(case, xs), xs
+    # neighbour cell of a processor face = same cell shifted by one in the cut direction
+    raise NotImplementedError("use rhs_global_slice for decomposed cases")

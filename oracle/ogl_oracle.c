@@ -1,0 +1,851 @@
+/*
+ * ogl_oracle.c -- CPU restatement ("oracle") of the hpsim/OGL hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see ogl_oracle.h).  Plain C, sequential, compiled with
+ * -ffp-contract=off and without -ffast-math so every product and sum rounds once, as
+ * Ginkgo's reference executor does on a baseline x86-64 build.
+ *
+ * PARITY: LDU conversion pinned by the reference's gtest vectors; Krylov arithmetic
+ * "parity unpinned" (Ginkgo absent) -- see the header.
+ */
+#include "ogl_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* small helpers                                                        */
+/* ------------------------------------------------------------------ */
+
+static void *xmalloc(size_t n) {
+    void *p = malloc(n ? n : 1);
+    if (!p) abort();
+    return p;
+}
+
+/* Stable counting sort of idx[0..m) by key[idx[i]] in [0, nkeys). */
+static void stable_sort_by_key(orc_label m, const orc_label *key, orc_label nkeys,
+                               const orc_label *idx_in, orc_label *idx_out) {
+    int64_t *count = (int64_t *)calloc((size_t)nkeys + 1, sizeof(int64_t));
+    if (!count) abort();
+    for (orc_label i = 0; i < m; ++i) count[key[idx_in[i]] + 1]++;
+    for (orc_label k = 0; k < nkeys; ++k) count[k + 1] += count[k];
+    for (orc_label i = 0; i < m; ++i) idx_out[count[key[idx_in[i]]]++] = idx_in[i];
+    free(count);
+}
+
+/* order[] = indices 0..m-1 sorted by (row[i], col[i]), ties by index (stable). */
+static void sort_row_col(orc_label m, const orc_label *row, const orc_label *col, orc_label nkeys,
+                         orc_label *order) {
+    orc_label *tmp0 = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)m);
+    orc_label *tmp1 = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)m);
+    for (orc_label i = 0; i < m; ++i) tmp0[i] = i;
+    stable_sort_by_key(m, col, nkeys, tmp0, tmp1); /* LSD: minor key first */
+    stable_sort_by_key(m, row, nkeys, tmp1, order);
+    free(tmp0);
+    free(tmp1);
+}
+
+/* ------------------------------------------------------------------ */
+/* HostMatrixFreeFunctions.C                                            */
+/* ------------------------------------------------------------------ */
+
+/* HostMatrixFreeFunctions.C:105-201.
+ * Upper entry of face f sits at (row=lower[f], col=upper[f]); its transpose (the lower
+ * entry) at (row=upper[f], col=lower[f]).  Both lists are ordered by (row, col)
+ * (:120-148), then every row emits its lower entries, the diagonal and its upper
+ * entries (:159-200).  permute points into [upper | lower (asym) | diag]. */
+void orc_init_local_sparsity(orc_label nrows, orc_label upper_nnz, int is_symmetric,
+                             const orc_label *upper, const orc_label *lower, orc_label *rows,
+                             orc_label *cols, orc_label *permute) {
+    const orc_label after_neighbours = is_symmetric ? upper_nnz : 2 * upper_nnz; /* :116 */
+    orc_label *ord_u = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)upper_nnz);
+    orc_label *ord_l = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)upper_nnz);
+    sort_row_col(upper_nnz, lower, upper, nrows, ord_u); /* rows of the upper triangle */
+    sort_row_col(upper_nnz, upper, lower, nrows, ord_l); /* rows of the lower triangle */
+
+    orc_label e = 0, uc = 0, lc = 0;
+    for (orc_label row = 0; row < nrows; ++row) {
+        while (lc < upper_nnz && upper[ord_l[lc]] == row) { /* :161-176 */
+            const orc_label f = ord_l[lc++];
+            rows[e] = row;
+            cols[e] = lower[f];
+            permute[e] = is_symmetric ? f : upper_nnz + f;
+            ++e;
+        }
+        rows[e] = row; /* :179-182 */
+        cols[e] = row;
+        permute[e] = after_neighbours + row;
+        ++e;
+        while (uc < upper_nnz && lower[ord_u[uc]] == row) { /* :185-199 */
+            const orc_label f = ord_u[uc++];
+            rows[e] = row;
+            cols[e] = upper[f];
+            permute[e] = f;
+            ++e;
+        }
+    }
+    free(ord_u);
+    free(ord_l);
+}
+
+/* HostMatrixFreeFunctions.C:21-30.  The reference expression
+ *     scale * (pos >= upper_nnz) ? diag[...] : upper[pos]
+ * parses as (scale * (pos >= upper_nnz)) ? diag : upper, so `scale` only acts as a
+ * truth value: out = diag when scale*(cond) != 0, else upper.  Kept as is. */
+void orc_symmetric_update(orc_label total_nnz, orc_label upper_nnz, const orc_label *permute,
+                          orc_scalar scale, const orc_scalar *diag, const orc_scalar *upper,
+                          orc_scalar *out) {
+    for (orc_label i = 0; i < total_nnz; ++i) {
+        const orc_label pos = permute[i];
+        const orc_scalar selector = scale * (orc_scalar)(pos >= upper_nnz);
+        out[i] = (selector != 0.0) ? diag[pos - upper_nnz] : upper[pos];
+    }
+}
+
+/* HostMatrixFreeFunctions.C:32-56 */
+void orc_symmetric_update_w_interface(orc_label total_nnz, orc_label diag_nnz,
+                                      orc_label upper_nnz, const orc_label *permute,
+                                      orc_scalar scale, const orc_scalar *diag,
+                                      const orc_scalar *upper, const orc_scalar *iface,
+                                      orc_scalar *out) {
+    for (orc_label i = 0; i < total_nnz; ++i) {
+        const orc_label pos = permute[i];
+        orc_scalar v;
+        if (pos < upper_nnz)
+            v = upper[pos];
+        else if (pos < upper_nnz + diag_nnz)
+            v = diag[pos - upper_nnz];
+        else
+            v = iface[pos - upper_nnz - diag_nnz];
+        out[i] = scale * v;
+    }
+}
+
+/* HostMatrixFreeFunctions.C:58-82 */
+void orc_non_symmetric_update_w_interface(orc_label total_nnz, orc_label diag_nnz,
+                                          orc_label upper_nnz, const orc_label *permute,
+                                          orc_scalar scale, const orc_scalar *diag,
+                                          const orc_scalar *upper, const orc_scalar *lower,
+                                          const orc_scalar *iface, orc_scalar *out) {
+    for (orc_label i = 0; i < total_nnz; ++i) {
+        const orc_label pos = permute[i];
+        orc_scalar v;
+        if (pos < upper_nnz)
+            v = upper[pos];
+        else if (pos < 2 * upper_nnz)
+            v = lower[pos - upper_nnz];
+        else if (pos < 2 * upper_nnz + diag_nnz)
+            v = diag[pos - 2 * upper_nnz];
+        else
+            v = iface[pos - 2 * upper_nnz - diag_nnz];
+        out[i] = scale * v;
+    }
+}
+
+/* HostMatrixFreeFunctions.C:85-102 */
+void orc_non_symmetric_update(orc_label total_nnz, orc_label upper_nnz,
+                              const orc_label *permute, orc_scalar scale,
+                              const orc_scalar *diag, const orc_scalar *upper,
+                              const orc_scalar *lower, orc_scalar *out) {
+    for (orc_label i = 0; i < total_nnz; ++i) {
+        const orc_label pos = permute[i];
+        if (pos < upper_nnz)
+            out[i] = scale * upper[pos];
+        else if (pos < 2 * upper_nnz)
+            out[i] = scale * lower[pos - upper_nnz];
+        else
+            out[i] = scale * diag[pos - 2 * upper_nnz];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* HostMatrix.C -- interfaces                                           */
+/* ------------------------------------------------------------------ */
+
+/* HostMatrix.C:159-178 */
+orc_label orc_count_interface_nnz(const orc_iface *ifaces, orc_label n_ifaces,
+                                  int proc_interfaces) {
+    orc_label ctr = 0;
+    for (orc_label i = 0; i < n_ifaces; ++i) {
+        const int is_proc = ifaces[i].kind == ORC_IFACE_PROCESSOR;
+        if (proc_interfaces ? is_proc : !is_proc) ctr += ifaces[i].size;
+    }
+    return ctr;
+}
+
+/* HostMatrix.C:180-207 */
+void orc_collect_interface_coeffs(const orc_iface *ifaces, orc_label n_ifaces, int local,
+                                  orc_scalar *out) {
+    orc_label k = 0;
+    for (orc_label i = 0; i < n_ifaces; ++i) {
+        const int is_proc = ifaces[i].kind == ORC_IFACE_PROCESSOR;
+        if (local ? !is_proc : is_proc)
+            for (orc_label f = 0; f < ifaces[i].size; ++f) out[k++] = ifaces[i].bou_coeffs[f];
+    }
+    for (orc_label j = 0; j < k; ++j) out[j] = out[j] * -1.0; /* :204 */
+}
+
+/* HostMatrix.C:251-306: std::map<neighbProcNo, faceCells...> walked in key order. */
+orc_label orc_create_communication_pattern(const orc_iface *ifaces, orc_label n_ifaces,
+                                           orc_label *target_ids, orc_label *target_sizes,
+                                           orc_label *send_idxs) {
+    orc_label n_procs = 0;
+    /* distinct neighbour ranks, ascending */
+    for (orc_label i = 0; i < n_ifaces; ++i) {
+        if (ifaces[i].kind != ORC_IFACE_PROCESSOR) continue;
+        const orc_label p = ifaces[i].neighb_proc;
+        orc_label pos = 0;
+        int found = 0;
+        while (pos < n_procs && target_ids[pos] <= p) {
+            if (target_ids[pos] == p) found = 1;
+            ++pos;
+        }
+        if (found) continue;
+        for (orc_label j = n_procs; j > pos; --j) target_ids[j] = target_ids[j - 1];
+        target_ids[pos] = p;
+        ++n_procs;
+    }
+    orc_label k = 0;
+    for (orc_label q = 0; q < n_procs; ++q) {
+        orc_label cnt = 0;
+        for (orc_label i = 0; i < n_ifaces; ++i) {
+            if (ifaces[i].kind != ORC_IFACE_PROCESSOR || ifaces[i].neighb_proc != target_ids[q])
+                continue;
+            for (orc_label f = 0; f < ifaces[i].size; ++f) send_idxs[k++] = ifaces[i].face_cells[f];
+            cnt += ifaces[i].size;
+        }
+        target_sizes[q] = cnt;
+    }
+    return n_procs;
+}
+
+/* HostMatrix.C:412-466 */
+void orc_init_non_local_sparsity(const orc_iface *ifaces, orc_label n_ifaces, orc_label *rows,
+                                 orc_label *cols, orc_label *permute) {
+    const orc_label nnz = orc_count_interface_nnz(ifaces, n_ifaces, 1);
+    orc_label *row_of = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)nnz);
+    orc_label *id = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)nnz);
+    orc_label *ord = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)nnz);
+    orc_label ctr = 0, max_row = 0;
+    for (orc_label i = 0; i < n_ifaces; ++i) { /* :418-431 */
+        if (ifaces[i].kind != ORC_IFACE_PROCESSOR) continue;
+        for (orc_label f = 0; f < ifaces[i].size; ++f) {
+            row_of[ctr] = ifaces[i].face_cells[f];
+            if (row_of[ctr] > max_row) max_row = row_of[ctr];
+            id[ctr] = ctr;
+            ++ctr;
+        }
+    }
+    stable_sort_by_key(nnz, row_of, max_row + 1, id, ord); /* :452-457 (by row only) */
+    for (orc_label e = 0; e < nnz; ++e) { /* :459-465 */
+        rows[e] = row_of[ord[e]];
+        cols[e] = ord[e];
+        permute[e] = ord[e];
+    }
+    free(row_of);
+    free(id);
+    free(ord);
+}
+
+/* HostMatrix.C:468-589 */
+void orc_init_local_sparsity_pattern(orc_label nrows, orc_label upper_nnz, int is_symmetric,
+                                     const orc_label *upper, const orc_label *lower,
+                                     const orc_iface *ifaces, orc_label n_ifaces, orc_label *rows,
+                                     orc_label *cols, orc_label *permute) {
+    const orc_label after_neighbours = is_symmetric ? upper_nnz : 2 * upper_nnz; /* :500 */
+    const orc_label local_nnz = nrows + 2 * upper_nnz;
+    const orc_label iface_nnz = orc_count_interface_nnz(ifaces, n_ifaces, 0);
+    orc_init_local_sparsity(nrows, upper_nnz, is_symmetric, upper, lower, rows, cols, permute);
+    if (!iface_nnz) return; /* :506 */
+
+    /* collect_local_interface_indices :385-410 -- only cyclic patches contribute */
+    orc_label *irow = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)iface_nnz);
+    orc_label *icol = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)iface_nnz);
+    orc_label m = 0;
+    for (orc_label i = 0; i < n_ifaces; ++i) {
+        if (ifaces[i].kind != ORC_IFACE_CYCLIC) continue;
+        const orc_label *nbr_cells = ifaces[ifaces[i].neighb_patch].face_cells; /* :324 */
+        for (orc_label f = 0; f < ifaces[i].size; ++f) {
+            irow[m] = ifaces[i].face_cells[f];
+            icol[m] = nbr_cells[f];
+            ++m;
+        }
+    }
+    orc_label *ord = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)m);
+    sort_row_col(m, irow, icol, nrows, ord); /* :510-515 */
+
+    orc_label *rows_c = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)local_nnz);
+    orc_label *cols_c = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)local_nnz);
+    orc_label *perm_c = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)local_nnz);
+    memcpy(rows_c, rows, sizeof(orc_label) * (size_t)local_nnz);
+    memcpy(cols_c, cols, sizeof(orc_label) * (size_t)local_nnz);
+    memcpy(perm_c, permute, sizeof(orc_label) * (size_t)local_nnz);
+
+    orc_label cur = 0, tot = 0;
+    for (orc_label k = 0; k < m; ++k) { /* :539-576 */
+        const orc_label idx = ord[k], r = irow[idx], c = icol[idx];
+        while (cur < local_nnz &&
+               (rows_c[cur] < r || (rows_c[cur] == r && cols_c[cur] <= c))) {
+            rows[tot] = rows_c[cur];
+            cols[tot] = cols_c[cur];
+            permute[tot] = perm_c[cur];
+            ++cur;
+            ++tot;
+        }
+        rows[tot] = r;
+        cols[tot] = c;
+        permute[tot] = after_neighbours + nrows + idx; /* :574 */
+        ++tot;
+    }
+    while (cur < local_nnz) { /* :580-585 */
+        rows[tot] = rows_c[cur];
+        cols[tot] = cols_c[cur];
+        permute[tot] = perm_c[cur];
+        ++cur;
+        ++tot;
+    }
+    free(irow);
+    free(icol);
+    free(ord);
+    free(rows_c);
+    free(cols_c);
+    free(perm_c);
+}
+
+/* HostMatrix.C:634-704 */
+void orc_update_local_matrix_data(orc_label nrows, orc_label upper_nnz, int is_symmetric,
+                                  const orc_scalar *diag, const orc_scalar *upper,
+                                  const orc_scalar *lower, const orc_iface *ifaces,
+                                  orc_label n_ifaces, const orc_label *permute,
+                                  orc_label total_nnz, orc_scalar *out) {
+    const orc_label iface_nnz = orc_count_interface_nnz(ifaces, n_ifaces, 0);
+    const orc_label diag_start = is_symmetric ? upper_nnz : 2 * upper_nnz; /* :666 */
+    const size_t src_n = (size_t)diag_start + (size_t)nrows + (size_t)iface_nnz;
+    orc_scalar *src = (orc_scalar *)xmalloc(sizeof(orc_scalar) * src_n);
+    memcpy(src, upper, sizeof(orc_scalar) * (size_t)upper_nnz);                   /* :644-650 */
+    if (!is_symmetric)
+        memcpy(src + upper_nnz, lower, sizeof(orc_scalar) * (size_t)upper_nnz);    /* :653-660 */
+    memcpy(src + diag_start, diag, sizeof(orc_scalar) * (size_t)nrows);           /* :663-669 */
+    if (iface_nnz)
+        orc_collect_interface_coeffs(ifaces, n_ifaces, 1, src + diag_start + nrows); /* :672-682 */
+    for (orc_label i = 0; i < total_nnz; ++i) out[i] = src[permute[i]];           /* :700-703 */
+    free(src);
+}
+
+/* HostMatrix.C:608-633 */
+void orc_update_local_matrix_data_host(orc_label nrows, orc_label upper_nnz, int is_symmetric,
+                                       orc_scalar scaling, const orc_scalar *diag,
+                                       const orc_scalar *upper, const orc_scalar *lower,
+                                       const orc_iface *ifaces, orc_label n_ifaces,
+                                       const orc_label *permute, orc_label total_nnz,
+                                       orc_scalar *out) {
+    const orc_label iface_nnz = orc_count_interface_nnz(ifaces, n_ifaces, 0);
+    if (iface_nnz) {
+        orc_scalar *cc = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)iface_nnz);
+        orc_collect_interface_coeffs(ifaces, n_ifaces, 1, cc);
+        if (is_symmetric)
+            orc_symmetric_update_w_interface(total_nnz, nrows, upper_nnz, permute, scaling, diag,
+                                             upper, cc, out);
+        else
+            orc_non_symmetric_update_w_interface(total_nnz, nrows, upper_nnz, permute, scaling,
+                                                 diag, upper, lower, cc, out);
+        free(cc);
+    } else if (is_symmetric) {
+        orc_symmetric_update(total_nnz, upper_nnz, permute, scaling, diag, upper, out);
+    } else {
+        orc_non_symmetric_update(total_nnz, upper_nnz, permute, scaling, diag, upper, lower, out);
+    }
+}
+
+/* HostMatrix.C:708-732 */
+void orc_update_non_local_matrix_data(const orc_iface *ifaces, orc_label n_ifaces,
+                                      const orc_label *permute, orc_label nnz, orc_scalar *out) {
+    orc_scalar *cc = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)nnz);
+    orc_collect_interface_coeffs(ifaces, n_ifaces, 0, cc);
+    for (orc_label e = 0; e < nnz; ++e) out[e] = cc[permute[e]];
+    free(cc);
+}
+
+/* ------------------------------------------------------------------ */
+/* Arithmetic                                                           */
+/* ------------------------------------------------------------------ */
+
+void orc_rowptr_from_rows(orc_label nrows, orc_label nnz, const orc_label *rows,
+                          orc_label *rowptr) {
+    for (orc_label r = 0; r <= nrows; ++r) rowptr[r] = 0;
+    for (orc_label e = 0; e < nnz; ++e) rowptr[rows[e] + 1]++;
+    for (orc_label r = 0; r < nrows; ++r) rowptr[r + 1] += rowptr[r];
+}
+
+void orc_spmv(orc_label n, const orc_label *rowptr, const orc_label *cols, const orc_scalar *vals,
+              const orc_scalar *x, orc_scalar *y) {
+    for (orc_label row = 0; row < n; ++row) {
+        orc_scalar sum = 0.0;
+        for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) sum += vals[k] * x[cols[k]];
+        y[row] = sum;
+    }
+}
+
+void orc_spmv_adv(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                  const orc_scalar *vals, orc_scalar alpha, const orc_scalar *x, orc_scalar beta,
+                  orc_scalar *y) {
+    for (orc_label row = 0; row < n; ++row) {
+        orc_scalar sum = y[row] * beta;
+        for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k)
+            sum += alpha * vals[k] * x[cols[k]];
+        y[row] = sum;
+    }
+}
+
+static int g_reduce_mode = ORC_REDUCE_SEQUENTIAL;
+static orc_label g_chunk_rows = 512;
+
+void orc_set_reduction(int mode, orc_label chunk_rows) {
+    g_reduce_mode = mode;
+    if (chunk_rows > 0) g_chunk_rows = chunk_rows;
+}
+
+/* The fixed reduction tree of the HIP kernels (ogl_amd/csrc/kernels.hip, block_reduce):
+ * 256 threads; thread t owns elements t, t+256, ... of the chunk, summed in order from 0;
+ * 64-lane xor tree (offsets 32,16,8,4,2,1); the 4 wave sums are added left to right. */
+#define ORC_BLOCK 256
+#define ORC_WAVE 64
+static orc_scalar block_tree(orc_scalar *acc /* [ORC_BLOCK] */) {
+    orc_scalar wsum[ORC_BLOCK / ORC_WAVE];
+    for (int w = 0; w < ORC_BLOCK / ORC_WAVE; ++w) {
+        orc_scalar *v = acc + w * ORC_WAVE, t[ORC_WAVE];
+        for (int off = ORC_WAVE / 2; off >= 1; off >>= 1) {
+            for (int l = 0; l < ORC_WAVE; ++l) t[l] = v[l] + v[l ^ off];
+            memcpy(v, t, sizeof(t));
+        }
+        wsum[w] = v[0];
+    }
+    orc_scalar s = wsum[0];
+    for (int w = 1; w < ORC_BLOCK / ORC_WAVE; ++w) s += wsum[w];
+    return s;
+}
+
+typedef orc_scalar (*term_fn)(const orc_scalar *a, const orc_scalar *b, orc_label i);
+static orc_scalar term_dot(const orc_scalar *a, const orc_scalar *b, orc_label i) {
+    return a[i] * b[i];
+}
+static orc_scalar term_abs(const orc_scalar *a, const orc_scalar *b, orc_label i) {
+    (void)b;
+    return fabs(a[i]);
+}
+static orc_scalar term_id(const orc_scalar *a, const orc_scalar *b, orc_label i) {
+    (void)b;
+    return a[i];
+}
+
+static orc_scalar reduce_blocked_partials(orc_label m, const orc_scalar *part) {
+    orc_scalar acc[ORC_BLOCK];
+    for (int t = 0; t < ORC_BLOCK; ++t) {
+        orc_scalar s = 0.0;
+        for (orc_label i = t; i < m; i += ORC_BLOCK) s += part[i];
+        acc[t] = s;
+    }
+    return block_tree(acc);
+}
+
+static orc_scalar reduce_terms(orc_label n, const orc_scalar *a, const orc_scalar *b, term_fn f) {
+    if (g_reduce_mode == ORC_REDUCE_SEQUENTIAL) {
+        orc_scalar s = 0.0;
+        for (orc_label i = 0; i < n; ++i) s += f(a, b, i);
+        return s;
+    }
+    const orc_label R = g_chunk_rows;
+    const orc_label n_chunks = (orc_label)(((int64_t)n + R - 1) / R);
+    orc_scalar *part = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)(n_chunks ? n_chunks : 1));
+    for (orc_label c = 0; c < n_chunks; ++c) {
+        orc_scalar acc[ORC_BLOCK];
+        for (int t = 0; t < ORC_BLOCK; ++t) {
+            orc_scalar s = 0.0;
+            for (orc_label j = t; j < R; j += ORC_BLOCK) {
+                const int64_t i = (int64_t)c * R + j;
+                if (i < n) s += f(a, b, (orc_label)i);
+            }
+            acc[t] = s;
+        }
+        part[c] = block_tree(acc);
+    }
+    const orc_scalar s = reduce_blocked_partials(n_chunks, part);
+    free(part);
+    return s;
+}
+
+orc_scalar orc_dot(orc_label n, const orc_scalar *a, const orc_scalar *b) {
+    return reduce_terms(n, a, b, term_dot);
+}
+orc_scalar orc_norm1(orc_label n, const orc_scalar *a) { return reduce_terms(n, a, 0, term_abs); }
+orc_scalar orc_sum(orc_label n, const orc_scalar *a) { return reduce_terms(n, a, 0, term_id); }
+
+/* ------------------------------------------------------------------ */
+/* Distributed pieces                                                   */
+/* ------------------------------------------------------------------ */
+
+static void global_sum(const orc_dist_matrix *A, orc_scalar *v, orc_label n) {
+    if (A->allreduce) A->allreduce(A->user, v, n);
+}
+
+/* distributed::Matrix::apply [UPSTREAM]: y = A_local x_local, then
+ * y = 1 * A_non_local * recv + 1 * y with the gathered neighbour values. */
+void orc_dist_spmv(const orc_dist_matrix *A, const orc_scalar *x, orc_scalar *y) {
+    orc_spmv(A->n, A->rowptr, A->cols, A->vals, x, y);
+    if (A->n_halo > 0) {
+        orc_scalar *send = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)A->n_send);
+        orc_scalar *recv = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)A->n_halo);
+        for (orc_label i = 0; i < A->n_send; ++i) send[i] = x[A->send_idxs[i]];
+        A->exchange(A->user, send, recv);
+        orc_spmv_adv(A->n, A->nl_rowptr, A->nl_cols, A->nl_vals, 1.0, recv, 1.0, y);
+        free(send);
+        free(recv);
+    }
+}
+
+/* r = b - A x as Ginkgo computes it: r = b; r = (-1) A x + 1 r (advanced apply), local
+ * part first, then the non-local part accumulates onto the stored local result. */
+static void dist_residual(const orc_dist_matrix *A, const orc_scalar *b, const orc_scalar *x,
+                          orc_scalar *r) {
+    memcpy(r, b, sizeof(orc_scalar) * (size_t)A->n);
+    orc_spmv_adv(A->n, A->rowptr, A->cols, A->vals, -1.0, x, 1.0, r);
+    if (A->n_halo > 0) {
+        orc_scalar *send = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)A->n_send);
+        orc_scalar *recv = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)A->n_halo);
+        for (orc_label i = 0; i < A->n_send; ++i) send[i] = x[A->send_idxs[i]];
+        A->exchange(A->user, send, recv);
+        orc_spmv_adv(A->n, A->nl_rowptr, A->nl_cols, A->nl_vals, -1.0, recv, 1.0, r);
+        free(send);
+        free(recv);
+    }
+}
+
+static orc_scalar dist_dot(const orc_dist_matrix *A, const orc_scalar *a, const orc_scalar *b) {
+    orc_scalar s = orc_dot(A->n, a, b);
+    global_sum(A, &s, 1);
+    return s;
+}
+
+static orc_scalar dist_norm1(const orc_dist_matrix *A, const orc_scalar *a) {
+    orc_scalar s = orc_norm1(A->n, a);
+    global_sum(A, &s, 1);
+    return s;
+}
+
+/* ------------------------------------------------------------------ */
+/* Stopping criterion                                                   */
+/* ------------------------------------------------------------------ */
+
+/* StoppingCriterion.H:197-209 */
+void orc_adapt_criterion(orc_label min_iter, orc_label frequency, int export_res,
+                         orc_label prev_solve_iters, int adapt_min_iter,
+                         orc_scalar relaxation_factor, orc_label norm_eval_limit,
+                         orc_scalar prev_rel_cost, orc_label *min_iter_out,
+                         orc_label *frequency_out) {
+    if (!export_res && prev_solve_iters > 0 && adapt_min_iter && prev_rel_cost > 0) {
+        min_iter = (orc_label)(prev_solve_iters * relaxation_factor);
+        const orc_scalar alpha =
+            sqrt(1.0 / (prev_solve_iters * (1.0 - relaxation_factor)) * prev_rel_cost);
+        orc_label f = (orc_label)(1 / alpha);
+        if (f < 1) f = 1;
+        frequency = norm_eval_limit < f ? norm_eval_limit : f;
+    }
+    *min_iter_out = min_iter;
+    *frequency_out = frequency;
+}
+
+/* StoppingCriterion.C:11-69.
+ *   xAvg = mean(x)                                     (:17-19; distributed compute_mean
+ *          [UPSTREAM]: local mean scaled by local_n/global_n, then summed over ranks)
+ *   Axref = A * (xAvg * 1)                             (:24-29)
+ *   t = b - Axref ; nf = sum(|t - r| + |t|) + SMALL    (:53-68)                        */
+orc_scalar orc_compute_normfactor(const orc_dist_matrix *A, const orc_scalar *r,
+                                  const orc_scalar *x, const orc_scalar *b) {
+    const orc_label n = A->n;
+    orc_scalar mean = orc_sum(n, x);
+    mean /= (orc_scalar)n;
+    mean *= (orc_scalar)n / (orc_scalar)A->global_n;
+    global_sum(A, &mean, 1);
+
+    orc_scalar *xavg = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)n);
+    orc_scalar *w = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)n);
+    for (orc_label i = 0; i < n; ++i) xavg[i] = mean;
+    orc_dist_spmv(A, xavg, w); /* w = Axref */
+    for (orc_label i = 0; i < n; ++i) {
+        orc_scalar t = b[i];
+        t -= 1.0 * w[i];                 /* b_sub_xstar = b - Axref        (:53-54) */
+        const orc_scalar part2 = fabs(t); /* norm_part2                    (:56)    */
+        t -= 1.0 * r[i];                 /* b_sub_xstar -= r               (:58)    */
+        t = fabs(t);                     /*                                (:59)    */
+        t += 1.0 * part2;                /*                                (:61)    */
+        w[i] = t;
+    }
+    orc_scalar nf = dist_norm1(A, w);    /* (:62-66) */
+    free(xavg);
+    free(w);
+    return nf + ORC_SMALL;               /* (:68) */
+}
+
+/* StoppingCriterion.C:71-151.  Returns 1 when the solver has to stop. */
+static int criterion_check(const orc_dist_matrix *A, const orc_criterion *c,
+                           orc_criterion_state *st, const orc_scalar *residual,
+                           const orc_scalar *x, const orc_scalar *b) {
+    if (st->iter > 0 && st->iter < c->min_iter) { /* :77-81 */
+        st->iter += 1;
+        return 0;
+    }
+    if (st->iter % c->frequency != 0) { /* :84-87 */
+        st->iter += 1;
+        return 0;
+    }
+    orc_scalar residual_norm = dist_norm1(A, residual); /* :92-97 */
+    st->n_evals += 1;
+    int result = 0;
+    if (st->iter == 0) { /* :102-111 */
+        st->norm_factor = orc_compute_normfactor(A, residual, x, b);
+        st->init_residual = residual_norm / st->norm_factor;
+    }
+    residual_norm /= st->norm_factor;                                  /* :113 */
+    if (c->export_res && st->history) st->history[st->iter] = residual_norm; /* :115-117 */
+    st->residual = residual_norm;                                      /* :119 */
+    if (st->iter >= c->max_iter) result = 1;                           /* :124 */
+    if (residual_norm < c->tolerance) result = 1;                      /* :128 */
+    if (c->rel_tol > 0 && residual_norm < c->rel_tol * st->init_residual) result = 1; /* :132 */
+    st->iter += 1;                                                     /* :143 */
+    return result;
+}
+
+static void criterion_reset(orc_criterion_state *st) {
+    orc_scalar *h = st->history;
+    memset(st, 0, sizeof(*st));
+    st->history = h;
+    st->norm_factor = 1.0; /* StoppingCriterion.H:136 */
+}
+
+/* ------------------------------------------------------------------ */
+/* Preconditioner                                                       */
+/* ------------------------------------------------------------------ */
+
+void orc_jacobi_generate_scalar(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                                const orc_scalar *vals, orc_scalar *inv_diag) {
+    for (orc_label row = 0; row < n; ++row) {
+        orc_scalar d = 0.0;
+        for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k)
+            if (cols[k] == row) d = vals[k];
+        inv_diag[row] = 1.0 / d;
+    }
+}
+
+/* Schwarz-wrapped local solver (Preconditioner.H:47-64): purely local apply. */
+static void precond_apply(orc_label n, const orc_scalar *inv_diag, const orc_scalar *r,
+                          orc_scalar *z) {
+    if (inv_diag)
+        for (orc_label i = 0; i < n; ++i) z[i] = r[i] * inv_diag[i];
+    else
+        memcpy(z, r, sizeof(orc_scalar) * (size_t)n); /* identity: copy */
+}
+
+/* ------------------------------------------------------------------ */
+/* CG  ([UPSTREAM] gko::solver::Cg::apply_dense_impl)                   */
+/* ------------------------------------------------------------------ */
+orc_label orc_cg(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                 const orc_scalar *inv_diag, const orc_criterion *crit,
+                 orc_criterion_state *st) {
+    const orc_label n = A->n;
+    const size_t bytes = sizeof(orc_scalar) * (size_t)n;
+    orc_scalar *r = (orc_scalar *)xmalloc(bytes), *z = (orc_scalar *)calloc(n ? n : 1, sizeof(orc_scalar));
+    orc_scalar *p = (orc_scalar *)calloc(n ? n : 1, sizeof(orc_scalar));
+    orc_scalar *q = (orc_scalar *)calloc(n ? n : 1, sizeof(orc_scalar));
+    if (!z || !p || !q) abort();
+    orc_scalar rho = 0.0, prev_rho = 1.0, beta = 0.0; /* initialize: r=b, z=p=q=0 */
+    criterion_reset(st);
+    dist_residual(A, b, x, r);
+    for (;;) {
+        precond_apply(n, inv_diag, r, z);
+        rho = dist_dot(A, r, z);
+        if (criterion_check(A, crit, st, r, x, b)) break;
+        { /* step_1: p = z + (rho / prev_rho) p */
+            const orc_scalar tmp = (prev_rho == 0.0) ? 0.0 : rho / prev_rho;
+            for (orc_label i = 0; i < n; ++i) p[i] = z[i] + tmp * p[i];
+        }
+        orc_dist_spmv(A, p, q);
+        beta = dist_dot(A, p, q);
+        if (beta != 0.0) { /* step_2: x += (rho/beta) p ; r -= (rho/beta) q */
+            const orc_scalar tmp = rho / beta;
+            for (orc_label i = 0; i < n; ++i) {
+                x[i] += tmp * p[i];
+                r[i] -= tmp * q[i];
+            }
+        }
+        prev_rho = rho; /* swap(prev_rho, rho); rho is recomputed next turn */
+    }
+    free(r);
+    free(z);
+    free(p);
+    free(q);
+    return st->iter;
+}
+
+/* ------------------------------------------------------------------ */
+/* BiCGStab ([UPSTREAM] gko::solver::Bicgstab::apply_dense_impl)        */
+/* Two criterion checks per turn (on r, then on s) -- which is why OGL  */
+/* doubles maxIter (StoppingCriterion.H:188) and halves the reported    */
+/* iteration count (GKOBiCGStab.H:114).                                 */
+/* ------------------------------------------------------------------ */
+orc_label orc_bicgstab(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                       const orc_scalar *inv_diag, const orc_criterion *crit,
+                       orc_criterion_state *st) {
+    const orc_label n = A->n;
+    const size_t cnt = n ? (size_t)n : 1;
+    orc_scalar *r = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *rr = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *y = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *s = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *t = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *z = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *v = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *p = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    if (!r || !rr || !y || !s || !t || !z || !v || !p) abort();
+    orc_scalar rho = 1.0, prev_rho = 1.0, alpha = 1.0, beta = 1.0, gamma = 1.0, omega = 1.0;
+    criterion_reset(st);
+    dist_residual(A, b, x, r);
+    memcpy(rr, r, sizeof(orc_scalar) * (size_t)n);
+    for (;;) {
+        rho = dist_dot(A, rr, r);
+        if (criterion_check(A, crit, st, r, x, b)) break;
+        { /* step_1: p = r + (rho/prev_rho)(alpha/omega) (p - omega v) */
+            if (prev_rho * omega != 0.0) {
+                const orc_scalar tmp = rho / prev_rho * alpha / omega;
+                for (orc_label i = 0; i < n; ++i) p[i] = r[i] + tmp * (p[i] - omega * v[i]);
+            } else {
+                memcpy(p, r, sizeof(orc_scalar) * (size_t)n);
+            }
+        }
+        precond_apply(n, inv_diag, p, y);
+        orc_dist_spmv(A, y, v);
+        beta = dist_dot(A, rr, v);
+        { /* step_2: alpha = rho / beta ; s = r - alpha v */
+            const orc_scalar tmp = (beta == 0.0) ? 0.0 : rho / beta;
+            alpha = tmp;
+            for (orc_label i = 0; i < n; ++i) s[i] = r[i] - tmp * v[i];
+        }
+        if (criterion_check(A, crit, st, s, x, b)) {
+            for (orc_label i = 0; i < n; ++i) x[i] += alpha * y[i]; /* finalize */
+            break;
+        }
+        precond_apply(n, inv_diag, s, z);
+        orc_dist_spmv(A, z, t);
+        gamma = dist_dot(A, s, t);
+        beta = dist_dot(A, t, t);
+        { /* step_3: omega = gamma / beta ; x += alpha y + omega z ; r = s - omega t */
+            const orc_scalar tmp = (beta == 0.0) ? 0.0 : gamma / beta;
+            omega = tmp;
+            for (orc_label i = 0; i < n; ++i) {
+                x[i] += alpha * y[i] + tmp * z[i];
+                r[i] = s[i] - tmp * t[i];
+            }
+        }
+        prev_rho = rho;
+    }
+    free(r); free(rr); free(y); free(s); free(t); free(z); free(v); free(p);
+    return st->iter;
+}
+
+/* ------------------------------------------------------------------ */
+/* "omp executor" baseline (single rank)                                */
+/* ------------------------------------------------------------------ */
+int orc_omp_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 0;
+#endif
+}
+
+orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                     const orc_scalar *inv_diag, const orc_criterion *crit,
+                     orc_criterion_state *st, int n_threads) {
+#ifndef _OPENMP
+    (void)A; (void)b; (void)x; (void)inv_diag; (void)crit; (void)st; (void)n_threads;
+    return -1;
+#else
+    if (A->n_halo > 0 || A->allreduce) return -1;
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    const orc_label n = A->n;
+    const size_t cnt = n ? (size_t)n : 1;
+    orc_scalar *r = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
+    orc_scalar *z = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
+    orc_scalar *p = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
+    orc_scalar *q = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
+    const orc_label *rowptr = A->rowptr, *cols = A->cols;
+    const orc_scalar *vals = A->vals;
+    orc_scalar rho = 0.0, prev_rho = 1.0, beta = 0.0, norm = 0.0;
+    criterion_reset(st);
+#pragma omp parallel for schedule(static)
+    for (orc_label row = 0; row < n; ++row) {
+        orc_scalar sum = b[row];
+        for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) sum += -1.0 * vals[k] * x[cols[k]];
+        r[row] = sum;
+        z[row] = p[row] = q[row] = 0.0;
+    }
+    for (;;) {
+        rho = 0.0;
+        norm = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : rho, norm)
+        for (orc_label i = 0; i < n; ++i) {
+            z[i] = inv_diag ? r[i] * inv_diag[i] : r[i];
+            rho += r[i] * z[i];
+            norm += fabs(r[i]);
+        }
+        /* criterion (same policy as criterion_check, norm already reduced) */
+        int stop = 0;
+        if (st->iter > 0 && st->iter < crit->min_iter) {
+            st->iter += 1;
+        } else if (st->iter % crit->frequency != 0) {
+            st->iter += 1;
+        } else {
+            st->n_evals += 1;
+            if (st->iter == 0) {
+                st->norm_factor = orc_compute_normfactor(A, r, x, b);
+                st->init_residual = norm / st->norm_factor;
+            }
+            norm /= st->norm_factor;
+            if (crit->export_res && st->history) st->history[st->iter] = norm;
+            st->residual = norm;
+            if (st->iter >= crit->max_iter) stop = 1;
+            if (norm < crit->tolerance) stop = 1;
+            if (crit->rel_tol > 0 && norm < crit->rel_tol * st->init_residual) stop = 1;
+            st->iter += 1;
+        }
+        if (stop) break;
+        const orc_scalar t1 = (prev_rho == 0.0) ? 0.0 : rho / prev_rho;
+#pragma omp parallel for schedule(static)
+        for (orc_label i = 0; i < n; ++i) p[i] = z[i] + t1 * p[i];
+        beta = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : beta)
+        for (orc_label row = 0; row < n; ++row) {
+            orc_scalar sum = 0.0;
+            for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) sum += vals[k] * p[cols[k]];
+            q[row] = sum;
+            beta += p[row] * sum;
+        }
+        if (beta != 0.0) {
+            const orc_scalar t2 = rho / beta;
+#pragma omp parallel for schedule(static)
+            for (orc_label i = 0; i < n; ++i) {
+                x[i] += t2 * p[i];
+                r[i] -= t2 * q[i];
+            }
+        }
+        prev_rho = rho;
+    }
+    free(r); free(z); free(p); free(q);
+    return st->iter;
+#endif
+}

@@ -1,0 +1,138 @@
+"""Oracle self-consistency for the part the reference cannot pin (Krylov arithmetic lives in
+Ginkgo, absent): assembled operator vs LDU definition, CG/BiCGStab vs scipy at solution
+level, criterion bookkeeping (StoppingCriterion.C:71-151).  "Parity unpinned" by the
+reference -- these only guard the restatement against itself and against scipy.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from ogl_amd import synthetic
+
+
+def assemble(oracle, case, host_path=False, scaling=1.0):
+    ifs = [oracle.Iface(f.kind, f.face_cells, f.bou_coeffs, f.neighb_proc, f.neighb_patch)
+           for f in case.interfaces]
+    rows, cols, perm = oracle.init_local_sparsity_pattern(case.n_cells, case.upper_addr,
+                                                          case.lower_addr, case.symmetric, ifs)
+    vals = oracle.update_local_matrix_data(case.diag, case.upper, case.lower, ifs, perm,
+                                           host_path=host_path, scaling=scaling)
+    rowptr = oracle.rowptr_from_rows(case.n_cells, rows)
+    return rowptr, cols, vals
+
+
+@pytest.mark.parametrize("sym", [True, False])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_assembled_operator_matches_ldu_definition(oracle, sym, periodic):
+    case = synthetic.poisson_block(5, 4, 3, symmetric=sym, periodic_x=periodic,
+                                   off_upper=-0.9, off_lower=-1.1 if not sym else -0.9)
+    rowptr, cols, vals = assemble(oracle, case)
+    # row-major, strictly increasing columns inside a row (data_validation.py's sortedness)
+    for r in range(case.n_cells):
+        c = cols[rowptr[r]:rowptr[r + 1]]
+        assert np.all(np.diff(c) > 0)
+    rng = np.random.default_rng(20241016)
+    x = rng.uniform(-1, 1, case.n_cells)
+    y = oracle.spmv(rowptr, cols, vals, x)
+    np.testing.assert_allclose(y, synthetic.apply_case(case, x), rtol=1e-13, atol=1e-13)
+
+
+def test_host_path_scaling_quirk(oracle):
+    # reorderOnHost: non-symmetric path scales, symmetric path ignores scale
+    case = synthetic.poisson_case(4, symmetric=False)
+    _, _, v1 = assemble(oracle, case, host_path=True, scaling=1.0)
+    _, _, v3 = assemble(oracle, case, host_path=True, scaling=3.0)
+    np.testing.assert_array_equal(v3, 3.0 * v1)
+    case = synthetic.poisson_case(4, symmetric=True)
+    _, _, v1 = assemble(oracle, case, host_path=True, scaling=1.0)
+    _, _, v3 = assemble(oracle, case, host_path=True, scaling=3.0)
+    np.testing.assert_array_equal(v3, v1)
+    _, _, vd = assemble(oracle, case, host_path=False)
+    np.testing.assert_array_equal(vd, v1)
+
+
+@pytest.mark.parametrize("precond", [False, True])
+def test_cg_solution_vs_scipy(oracle, precond):
+    case = synthetic.poisson_case(12)
+    rowptr, cols, vals = assemble(oracle, case)
+    A = sp.csr_matrix((vals, cols, rowptr), shape=(case.n_cells,) * 2)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = A @ xs
+    D = oracle.DistMatrix(rowptr, cols, vals)
+    inv = oracle.jacobi_generate_scalar(rowptr, cols, vals) if precond else None
+    res = oracle.cg(D, b, np.zeros_like(b), inv, tolerance=1e-13, rel_tol=0.0, max_iter=500)
+    x_ref, info = spla.cg(A, b, rtol=1e-14, atol=0.0, maxiter=2000)
+    assert info == 0
+    np.testing.assert_allclose(res.x, x_ref, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(res.x, xs, rtol=0, atol=1e-9)
+    # history bookkeeping: one entry per check, first = initial residual, last = final
+    assert res.history.size == res.n_iterations
+    assert res.history[0] == res.initial_residual
+    assert res.history[-1] == res.final_residual
+    assert res.final_residual < 1e-13
+    # normalised-L1 residual of the returned x, recomputed independently
+    r = b - A @ res.x
+    xbar = np.full_like(b, res.x.mean())
+    nf0 = np.abs(A @ np.zeros_like(b) - A @ np.zeros_like(b)).sum() + np.abs(b).sum() + 1e-15
+    assert res.norm_factor == pytest.approx(nf0, rel=1e-12)
+    assert np.abs(r).sum() / res.norm_factor == pytest.approx(res.final_residual, rel=1e-3)
+    del xbar
+
+
+def test_cg_criterion_max_iter_and_frequency(oracle):
+    case = synthetic.poisson_case(8)
+    rowptr, cols, vals = assemble(oracle, case)
+    D = oracle.DistMatrix(rowptr, cols, vals)
+    b = np.ones(case.n_cells)
+    res = oracle.cg(D, b, np.zeros_like(b), None, tolerance=0.0, rel_tol=0.0, max_iter=10)
+    assert res.n_iterations == 11      # nIterations = CG steps + 1
+    assert res.n_evals == 11
+    res = oracle.cg(D, b, np.zeros_like(b), None, tolerance=0.0, rel_tol=0.0, max_iter=10,
+                    frequency=4)
+    assert res.n_iterations == 13      # stops at the first evaluated check with iter >= 10
+    assert res.n_evals == 4            # iter 0, 4, 8, 12
+    res = oracle.cg(D, b, np.zeros_like(b), None, tolerance=2.0, rel_tol=0.0, max_iter=100,
+                    min_iter=5)
+    assert res.n_iterations == 1       # the iter==0 check is never skipped (:77)
+    res = oracle.cg(D, b, np.zeros_like(b), None, tolerance=1.0, rel_tol=0.0, max_iter=100,
+                    min_iter=5)
+    assert res.n_iterations == 6       # init residual == 1.0 is not < 1.0; next check at minIter
+    assert res.n_evals == 2
+
+
+def test_bicgstab_solution_vs_scipy(oracle):
+    case = synthetic.poisson_case(10, symmetric=False)
+    rowptr, cols, vals = assemble(oracle, case)
+    A = sp.csr_matrix((vals, cols, rowptr), shape=(case.n_cells,) * 2)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = A @ xs
+    D = oracle.DistMatrix(rowptr, cols, vals)
+    inv = oracle.jacobi_generate_scalar(rowptr, cols, vals)
+    res = oracle.bicgstab(D, b, np.zeros_like(b), inv, tolerance=1e-13, rel_tol=0.0, max_iter=500)
+    np.testing.assert_allclose(res.x, xs, rtol=0, atol=1e-9)
+    assert res.final_residual < 1e-13
+
+
+def test_blocked_reduction_equals_sequential_to_rounding(oracle):
+    rng = np.random.default_rng(20241016)
+    a, b = rng.uniform(-1, 1, 100003), rng.uniform(-1, 1, 100003)
+    s = oracle.dot(a, b)
+    oracle.set_reduction(oracle.REDUCE_BLOCKED, 512)
+    try:
+        t = oracle.dot(a, b)
+        n1 = oracle.norm1(a)
+    finally:
+        oracle.set_reduction(oracle.REDUCE_SEQUENTIAL)
+    assert t == pytest.approx(s, rel=1e-12, abs=1e-12)
+    assert n1 == pytest.approx(np.abs(a).sum(), rel=1e-13)
+
+
+def test_adaptive_policy(oracle):
+    # StoppingCriterion.H:199-209
+    assert oracle.adapt_criterion(0, 1, True, 50, prev_rel_cost=4.0) == (0, 1)      # export: off
+    assert oracle.adapt_criterion(0, 1, False, 50, prev_rel_cost=0.0) == (0, 1)     # cost 0: off
+    mi, fr = oracle.adapt_criterion(0, 1, False, 100, prev_rel_cost=1.0)
+    assert mi == 60 and fr == int(1 / np.sqrt(1.0 / (100 * 0.4)))
+    mi, fr = oracle.adapt_criterion(0, 1, False, 100000, prev_rel_cost=1.0)
+    assert fr == 100                                                                # normEvalLimit
