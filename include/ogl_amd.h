@@ -1,0 +1,286 @@
+/*
+ * ogl_amd.h -- C ABI of the MI355X-native sparse Krylov backend (libogl_amd.so).
+ *
+ * Drop-in boundary for the hot path of hpsim/OGL: the OpenFOAM lduMatrix::solver plug-ins
+ * GKOCG / GKOBiCGStab / GKOGMRES.  The reference has no FFI of its own: it is C++ that calls
+ * Ginkgo directly.  Every entry point below therefore names the reference C++ interface it
+ * replaces (file:line relative to the reference tree); INTEGRATION.md shows the binding a
+ * maintainer adds on the OpenFOAM side.
+ *
+ * Conventions
+ *   - plain C types only: label = int32_t (WM_LABEL_SIZE=32), scalar = double (WM_DP);
+ *   - host pointers are BORROWED for the duration of the call (OpenFOAM owns them);
+ *   - every function returns OGL_OK (0) or a negative ogl_status; the message is in
+ *     ogl_last_error() (thread local).  Nothing throws across this boundary;
+ *   - a solver handle is NOT thread-safe; one handle per (rank, field), as in the reference
+ *     (one MPI rank <-> one device, DevicePersistent/ExecutorHandler/ExecutorHandler.H:33,90-91);
+ *   - there is no CPU fallback: without a gfx950 device every compute call fails with
+ *     OGL_ERR_NO_DEVICE.  Only the ogl_host_* functions (pure host logic) run without a GPU.
+ */
+#ifndef OGL_AMD_H
+#define OGL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OGL_AMD_ABI_VERSION 1
+
+typedef int32_t ogl_label;
+typedef double ogl_scalar;
+
+typedef enum {
+    OGL_OK = 0,
+    OGL_ERR_INVALID = -1,     /* bad argument / unsupported keyword value (FatalError in the reference) */
+    OGL_ERR_NO_DEVICE = -2,   /* no usable gfx950 device */
+    OGL_ERR_HIP = -3,         /* a HIP runtime call failed */
+    OGL_ERR_COMM = -4,        /* RCCL / host transport failure */
+    OGL_ERR_STATE = -5,       /* call order violated (e.g. solve before set_matrix) */
+    OGL_ERR_UNSUPPORTED = -6  /* e.g. AMI/ACMI interfaces (HostMatrix.C:339-341,367-369) */
+} ogl_status;
+
+const char *ogl_last_error(void);
+int ogl_abi_version(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* fvSolution keywords (defaults are the CODE's defaults)           */
+/* ------------------------------------------------------------------------------------ */
+
+typedef enum { OGL_SOLVER_CG = 0, OGL_SOLVER_BICGSTAB = 1, OGL_SOLVER_GMRES = 2 } ogl_solver_kind;
+/* Solver/CG/GKOCG.H:120, Solver/BiCGStab/GKOBiCGStab.H, Solver/GMRES/GKOGMRES.H (TypeName) */
+
+typedef enum {
+    OGL_PRECOND_NONE = 0, /* Preconditioner.H:342 */
+    OGL_PRECOND_BJ = 1    /* Preconditioner.H:91-105 (Schwarz-wrapped Jacobi on the local matrix) */
+} ogl_precond_kind;
+
+typedef enum { OGL_FORMAT_COO = 0, OGL_FORMAT_CSR = 1, OGL_FORMAT_ELL = 2 } ogl_matrix_format;
+/* CsrMatrixWrapper.H:138-161.  All three select the same persistent device CSR here: the
+ * reference executor's Coo/Csr/Ell products accumulate a row in the same stored order. */
+
+typedef struct ogl_config {
+    int32_t solver;             /* ogl_solver_kind                               "solver"            */
+    int32_t preconditioner;     /* ogl_precond_kind                              "preconditioner"    */
+    int32_t max_block_size;     /* 1     Preconditioner.H:94                     "maxBlockSize"      */
+    int32_t caching;            /* 0     Preconditioner.H:405                    "caching"           */
+    double tolerance;           /* 1e-6  StoppingCriterion.H:167                 "tolerance"         */
+    double rel_tol;             /* 1e-6  StoppingCriterion.H:168                 "relTol"            */
+    int32_t max_iter;           /* 1000  StoppingCriterion.H:165                 "maxIter"           */
+    int32_t min_iter;           /* 0     StoppingCriterion.H:166                 "minIter"           */
+    int32_t eval_frequency;     /* 1     StoppingCriterion.H:173                 "evalFrequency"     */
+    int32_t norm_eval_limit;    /* 100   StoppingCriterion.H:171-172             "normEvalLimit"     */
+    double relaxation_factor;   /* 0.6   StoppingCriterion.H:174-175             "relaxationFactor"  */
+    int32_t adapt_min_iter;     /* 1     StoppingCriterion.H:176-177             "adaptMinIter"      */
+    int32_t matrix_format;      /* COO   CsrMatrixWrapper.H:250                  "matrixFormat"      */
+    int32_t regenerate;         /* 0     CsrMatrixWrapper.H:257                  "regenerate"        */
+    int32_t update_sys_matrix;  /* 1     CsrMatrixWrapper.H:259                  "updateSysMatrix"   */
+    int32_t update_rhs;         /* 1     lduLduBase.H:224                        "updateRHS"         */
+    int32_t update_init_guess;  /* 0     lduLduBase.H:235                        "updateInitGuess"   */
+    double scaling;             /* 1.0   HostMatrix.C:33, lduLduBase.H:242-252   "scaling"           */
+    int32_t reorder_on_host;    /* 0     HostMatrix.C:32                         "reorderOnHost"     */
+    int32_t export_res;         /* 0     CsrMatrixWrapper.H:247                  "export"            */
+    int32_t verbose;            /* 0     lduLduBase.H:49                         "verbose"           */
+    int32_t force_host_buffer;  /* 0     ExecutorHandler.H:136-139               "forceHostBuffer"   */
+    int32_t ranks_per_gpu;      /* 1     ExecutorHandler.H:135 (only 1 works)    "ranksPerGPU"       */
+    int32_t krylov_dim;         /* 0 = Ginkgo default (100); GMRES only; NOT a reference keyword   */
+    int32_t profile_kernels;    /* 0; 1 = hipEvent-time the in-loop SpMV (bench.py roofline leg)    */
+} ogl_config;
+
+/* Fill with the reference code's defaults. */
+void ogl_config_default(ogl_config *cfg);
+
+/* ------------------------------------------------------------------------------------ */
+/* lduMatrix view (what HostMatrix.C reads from `matrix`, `interfaces`, `interfaceBouCoeffs`) */
+/* ------------------------------------------------------------------------------------ */
+
+typedef enum { OGL_IFACE_PROCESSOR = 0, OGL_IFACE_CYCLIC = 1 } ogl_iface_kind;
+
+typedef struct ogl_interface {
+    int32_t kind;                  /* isA<processorLduInterface> / cyclicFvPatch  HostMatrix.C:170,400 */
+    ogl_label neighb_proc;         /* processorFvPatch::neighbProcNo()            HostMatrix.C:266     */
+    ogl_label neighb_patch;        /* cyclic: index (in this array) of neighbPatchID()  HostMatrix.C:319-324 */
+    ogl_label size;                /* interface().faceCells().size()                                    */
+    const ogl_label *face_cells;   /* interface().faceCells()                                           */
+    const ogl_scalar *bou_coeffs;  /* interfaceBouCoeffs[i]  (true off-diagonal = -bouCoeffs, :204)     */
+} ogl_interface;
+
+typedef struct ogl_ldu_view {
+    ogl_label n_cells;             /* matrix.diag().size()                        HostMatrix.C:34   */
+    ogl_label n_faces;             /* matrix.lduAddr().upperAddr().size()         HostMatrix.C:36   */
+    const ogl_label *lower_addr;   /* lduAddr().lowerAddr()                       HostMatrix.C:477  */
+    const ogl_label *upper_addr;   /* lduAddr().upperAddr()                       HostMatrix.C:481  */
+    const ogl_scalar *diag;        /* matrix.diag()                               HostMatrix.C:600  */
+    const ogl_scalar *upper;       /* matrix.upper()                              HostMatrix.C:598  */
+    const ogl_scalar *lower;       /* matrix.lower(); NULL <=> matrix.symmetric() HostMatrix.C:473  */
+    ogl_label n_interfaces;
+    const ogl_interface *interfaces;
+} ogl_ldu_view;
+
+/* solverPerformance fields the reference fills (lduLduBase.H:283-285) + its statistics block
+ * (lduLduBase.H:280-305). */
+typedef struct ogl_perf {
+    double initial_residual;
+    double final_residual;
+    int32_t n_iterations;   /* CG/GMRES: number of criterion checks (= steps + 1, StoppingCriterion.C:143);
+                               BiCGStab: checks / 2 (GKOBiCGStab.H:114) */
+    int32_t n_norm_evals;   /* checks that evaluated the residual norm */
+    double norm_factor;
+    double t_update_matrix_ms;  /* H2D + gather of the last ogl_solver_set_matrix */
+    double t_upload_ms;         /* b (and x) H2D */
+    double t_solve_ms;          /* delta_t_solve: solver->apply only (lduLduBase.H:275-276) */
+    double t_copy_back_ms;      /* x D2H (lduLduBase.H:278-279) */
+    double spmv_avg_ms;         /* mean in-loop SpMV kernel time (profile_kernels=1), else 0 */
+    int32_t spmv_launches;
+} ogl_perf;
+
+/* ------------------------------------------------------------------------------------ */
+/* Registry = objectRegistry analogue (DevicePersistent/Base/Base.H:53-137)             */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct ogl_registry ogl_registry;
+typedef struct ogl_solver ogl_solver;
+
+/* Replaces ExecutorHandler (ExecutorHandler.H:83-93: device id) + DeviceIdGuard
+ * (DeviceIdGuard.H:15-43).  device_id < 0 => rank / ranksPerGPU % n_devices once a communicator
+ * is attached, 0 otherwise.  `hip_stream` may carry an existing hipStream_t (e.g. torch's current
+ * stream) so the caller's events see the work; NULL => the registry creates its own stream. */
+int ogl_registry_create(ogl_registry **out, int device_id, void *hip_stream);
+void ogl_registry_destroy(ogl_registry *reg);
+
+/* --- communicators (ExecutorHandler.H:29-32,140-144,167-172) ----------------------- */
+
+/* Host-buffer transport (forceHostBuffer, ExecutorHandler.H:136-139): the host side owns the
+ * message passing (MPI in OpenFOAM); device data is staged through pinned host buffers. */
+typedef void (*ogl_allreduce_sum_fn)(void *user, double *values, int32_t n);
+/* send/recv are blocked by neighbour in ascending rank order; counts[i] entries each way. */
+typedef void (*ogl_neighbour_exchange_fn)(void *user, int32_t n_neighbours,
+                                          const int32_t *neighbour_ranks, const int32_t *counts,
+                                          const double *send, double *recv);
+int ogl_registry_set_host_comm(ogl_registry *reg, int32_t rank, int32_t n_ranks,
+                               ogl_allreduce_sum_fn allreduce, ogl_neighbour_exchange_fn exchange,
+                               void *user);
+
+/* Device transport: RCCL over xGMI (replaces the GPU-aware MPI communicator).  The 128-byte
+ * unique id is produced on rank 0 and broadcast by the host (MPI_Bcast in OpenFOAM). */
+#define OGL_RCCL_ID_BYTES 128
+int ogl_rccl_unique_id(void *id_out);
+int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n_ranks, const void *id);
+
+/* ------------------------------------------------------------------------------------ */
+/* The plug-in path                                                                      */
+/* ------------------------------------------------------------------------------------ */
+
+/* GKOCG/GKOBiCGStab/GKOGMRES constructor (Solver/CG/GKOCG.H:132-139): lookup-or-create by field
+ * name, like PersistentBase (Base.H:75-115).  The reference constructs a fresh solver object per
+ * solve and finds its device state in the registry; so does this. `cfg` is re-read on every call
+ * (the dictionary may change between time steps). */
+int ogl_solver_get_or_create(ogl_registry *reg, const char *field_name, const ogl_config *cfg,
+                             ogl_solver **out);
+
+/* HostMatrixWrapper constructor (HostMatrix.C:15-96): first call builds and uploads the sparsity
+ * pattern + ldu_mapping (init_local_sparsity_pattern :468-589, init_non_local_sparsity_pattern
+ * :438-466, create_communication_pattern :251-306); every call stages upper/lower/diag/interface
+ * coefficients through pinned buffers and permutes them on the device (update_local_matrix_data
+ * :592-705, update_non_local_matrix_data :708-732, MatrixInitFunctor::update
+ * CsrMatrixWrapper.H:74-136). */
+int ogl_solver_set_matrix(ogl_solver *s, const ogl_ldu_view *ldu);
+
+/* lduMatrix::solver::solve(psi, source, cmpt) (GKOCG.H:149-153 -> lduLduBase.H:189-308):
+ * upload source (updateRHS) and psi (first call / updateInitGuess), scale the RHS, (re)generate
+ * the preconditioner, run the Krylov loop, copy x back into psi, fill `perf`. */
+int ogl_solver_solve(ogl_solver *s, const ogl_scalar *source, ogl_scalar *psi, ogl_perf *perf);
+
+/* Residual history recorded with `export 1` (StoppingCriterion.C:115-117; the reference stores it
+ * but never writes it out).  Returns the number of entries copied (<= capacity) or a negative
+ * status.  Entry i = normalised residual at criterion check i. */
+int ogl_solver_history(ogl_solver *s, double *out, int32_t capacity);
+
+/* Per-field solver properties kept between solves (common/common.C:75-146):
+ * prevSolveIters(_final), _prev_solve (relative residual-evaluation cost), preconditionerCaching. */
+int ogl_solver_get_property(ogl_solver *s, const char *key, double *value);
+int ogl_solver_set_property(ogl_solver *s, const char *key, double value);
+
+/* ------------------------------------------------------------------------------------ */
+/* Device-resident entry points (benchmark / parity harness)                             */
+/* ------------------------------------------------------------------------------------ */
+
+/* solver->apply(b, x) alone on the resident vectors (lduLduBase.H:275-276): what the reference
+ * times as delta_t_solve. */
+int ogl_solver_apply_resident(ogl_solver *s, ogl_perf *perf);
+/* Overwrite the resident solution / RHS (PersistentVector update, Vector.H:52-62); NULL => zeros. */
+int ogl_solver_upload_solution(ogl_solver *s, const ogl_scalar *psi);
+int ogl_solver_upload_rhs(ogl_solver *s, const ogl_scalar *source);
+int ogl_solver_download_solution(ogl_solver *s, ogl_scalar *psi);
+
+/* y = A x through the in-loop SpMV kernel (dist_mtx::apply, StoppingCriterion.C:29). */
+int ogl_solver_spmv(ogl_solver *s, const ogl_scalar *x, ogl_scalar *y);
+/* `repeats` back-to-back in-loop SpMVs (fused with the p.q dot, as in the CG loop) on resident
+ * vectors, timed with HIP events on the solver's stream; avg_ms = per launch. */
+int ogl_solver_time_spmv(ogl_solver *s, int32_t repeats, double *avg_ms);
+/* Device reductions as used in the loop (deterministic fixed tree): dot, sum|a|, sum a. */
+int ogl_solver_reduce(ogl_solver *s, int32_t op /*0 dot,1 norm1,2 sum*/, const ogl_scalar *a,
+                      const ogl_scalar *b, double *out);
+/* Rows per reduction chunk of the device tree (the oracle's BLOCKED mode mirrors it in tests). */
+int ogl_reduction_chunk_rows(void);
+
+/* Persistent device matrix read-back (<field>_local_{rows,cols,ldu_map,coeffs} and the non-local
+ * twins, HostMatrix.C:40-69).  Sizes first (NULL arrays), then data. */
+typedef struct ogl_matrix_dims {
+    ogl_label n_rows;
+    ogl_label local_nnz;       /* nrows + 2*upper_nnz + local_interface_nnz  (HostMatrix.C:38-39) */
+    ogl_label non_local_nnz;   /* HostMatrix.C:55 */
+    ogl_label n_halo;          /* columns of the non-local matrix (CsrMatrixWrapper.H:185-188) */
+    ogl_label n_neighbours;
+    ogl_label n_send;
+} ogl_matrix_dims;
+int ogl_solver_matrix_dims(ogl_solver *s, ogl_matrix_dims *dims);
+int ogl_solver_get_local_matrix(ogl_solver *s, ogl_label *row_ptrs, ogl_label *cols,
+                                ogl_label *ldu_mapping, ogl_scalar *coeffs);
+int ogl_solver_get_non_local_matrix(ogl_solver *s, ogl_label *rows, ogl_label *cols,
+                                    ogl_label *ldu_mapping, ogl_scalar *coeffs);
+int ogl_solver_get_comm_pattern(ogl_solver *s, ogl_label *target_ids, ogl_label *target_sizes,
+                                ogl_label *send_idxs);
+
+/* ------------------------------------------------------------------------------------ */
+/* Pure host logic (runs without a GPU): HostMatrix/HostMatrixFreeFunctions.C:21-201     */
+/* ("free functions - for unit testing" in the reference, same argument order)           */
+/* ------------------------------------------------------------------------------------ */
+
+void ogl_host_init_local_sparsity(ogl_label nrows, ogl_label upper_nnz, int is_symmetric,
+                                  const ogl_label *upper, const ogl_label *lower, ogl_label *rows,
+                                  ogl_label *cols, ogl_label *permute);
+void ogl_host_symmetric_update(ogl_label total_nnz, ogl_label upper_nnz, const ogl_label *permute,
+                               ogl_scalar scale, const ogl_scalar *diag, const ogl_scalar *upper,
+                               ogl_scalar *out);
+void ogl_host_symmetric_update_w_interface(ogl_label total_nnz, ogl_label diag_nnz,
+                                           ogl_label upper_nnz, const ogl_label *permute,
+                                           ogl_scalar scale, const ogl_scalar *diag,
+                                           const ogl_scalar *upper, const ogl_scalar *iface,
+                                           ogl_scalar *out);
+void ogl_host_non_symmetric_update_w_interface(ogl_label total_nnz, ogl_label diag_nnz,
+                                               ogl_label upper_nnz, const ogl_label *permute,
+                                               ogl_scalar scale, const ogl_scalar *diag,
+                                               const ogl_scalar *upper, const ogl_scalar *lower,
+                                               const ogl_scalar *iface, ogl_scalar *out);
+void ogl_host_non_symmetric_update(ogl_label total_nnz, ogl_label upper_nnz,
+                                   const ogl_label *permute, ogl_scalar scale,
+                                   const ogl_scalar *diag, const ogl_scalar *upper,
+                                   const ogl_scalar *lower, ogl_scalar *out);
+
+/* Whole host-side pattern of one lduMatrix (HostMatrix.C:159-178,251-306,412-589) without touching
+ * a device: sizes with NULL arrays, then data.  Used by the CPU tests of the sharded path. */
+int ogl_host_pattern(const ogl_ldu_view *ldu, ogl_matrix_dims *dims, ogl_label *local_rows,
+                     ogl_label *local_cols, ogl_label *local_ldu_mapping, ogl_label *nl_rows,
+                     ogl_label *nl_cols, ogl_label *nl_ldu_mapping, ogl_label *target_ids,
+                     ogl_label *target_sizes, ogl_label *send_idxs);
+
+/* StoppingCriterion::build_dist_stopping_criterion's adaptive policy (StoppingCriterion.H:197-209). */
+void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,
+                              ogl_scalar prev_rel_cost, ogl_label *min_iter, ogl_label *frequency);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGL_AMD_H */

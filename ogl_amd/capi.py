@@ -1,0 +1,390 @@
+"""ctypes binding of include/ogl_amd.h (libogl_amd.so) -- the driver the tests and bench.py use.
+
+This is plumbing over the C ABI, not a second implementation: every compute call lands in the
+HIP library.  If the library is missing or no gfx950 device is visible the calls raise; there is
+no CPU path behind them.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libogl_amd.so")
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_COMM, ERR_STATE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+SOLVER_CG, SOLVER_BICGSTAB, SOLVER_GMRES = 0, 1, 2
+PRECOND_NONE, PRECOND_BJ = 0, 1
+FORMAT_COO, FORMAT_CSR, FORMAT_ELL = 0, 1, 2
+IFACE_PROCESSOR, IFACE_CYCLIC = 0, 1
+RCCL_ID_BYTES = 128
+
+_LP = C.POINTER(C.c_int32)
+_SP = C.POINTER(C.c_double)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("solver", C.c_int32), ("preconditioner", C.c_int32), ("max_block_size", C.c_int32),
+        ("caching", C.c_int32), ("tolerance", C.c_double), ("rel_tol", C.c_double),
+        ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("eval_frequency", C.c_int32),
+        ("norm_eval_limit", C.c_int32), ("relaxation_factor", C.c_double),
+        ("adapt_min_iter", C.c_int32), ("matrix_format", C.c_int32), ("regenerate", C.c_int32),
+        ("update_sys_matrix", C.c_int32), ("update_rhs", C.c_int32),
+        ("update_init_guess", C.c_int32), ("scaling", C.c_double), ("reorder_on_host", C.c_int32),
+        ("export_res", C.c_int32), ("verbose", C.c_int32), ("force_host_buffer", C.c_int32),
+        ("ranks_per_gpu", C.c_int32), ("krylov_dim", C.c_int32), ("profile_kernels", C.c_int32),
+    ]
+
+
+class Interface(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("neighb_proc", C.c_int32), ("neighb_patch", C.c_int32),
+                ("size", C.c_int32), ("face_cells", _LP), ("bou_coeffs", _SP)]
+
+
+class LduView(C.Structure):
+    _fields_ = [("n_cells", C.c_int32), ("n_faces", C.c_int32), ("lower_addr", _LP),
+                ("upper_addr", _LP), ("diag", _SP), ("upper", _SP), ("lower", _SP),
+                ("n_interfaces", C.c_int32), ("interfaces", C.POINTER(Interface))]
+
+
+class Perf(C.Structure):
+    _fields_ = [("initial_residual", C.c_double), ("final_residual", C.c_double),
+                ("n_iterations", C.c_int32), ("n_norm_evals", C.c_int32),
+                ("norm_factor", C.c_double), ("t_update_matrix_ms", C.c_double),
+                ("t_upload_ms", C.c_double), ("t_solve_ms", C.c_double),
+                ("t_copy_back_ms", C.c_double), ("spmv_avg_ms", C.c_double),
+                ("spmv_launches", C.c_int32)]
+
+
+class MatrixDims(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("local_nnz", C.c_int32), ("non_local_nnz", C.c_int32),
+                ("n_halo", C.c_int32), ("n_neighbours", C.c_int32), ("n_send", C.c_int32)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, _SP, C.c_int32)
+EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, _LP, _LP, _SP, _SP)
+
+# every symbol include/ogl_amd.h declares
+EXPORTED_SYMBOLS = [
+    "ogl_last_error", "ogl_abi_version", "ogl_config_default", "ogl_registry_create",
+    "ogl_registry_destroy", "ogl_registry_set_host_comm", "ogl_rccl_unique_id",
+    "ogl_registry_init_rccl", "ogl_solver_get_or_create", "ogl_solver_set_matrix",
+    "ogl_solver_solve", "ogl_solver_history", "ogl_solver_get_property",
+    "ogl_solver_set_property", "ogl_solver_apply_resident", "ogl_solver_upload_solution",
+    "ogl_solver_upload_rhs", "ogl_solver_download_solution", "ogl_solver_spmv",
+    "ogl_solver_time_spmv", "ogl_solver_reduce", "ogl_reduction_chunk_rows",
+    "ogl_solver_matrix_dims", "ogl_solver_get_local_matrix", "ogl_solver_get_non_local_matrix",
+    "ogl_solver_get_comm_pattern", "ogl_host_init_local_sparsity", "ogl_host_symmetric_update",
+    "ogl_host_symmetric_update_w_interface", "ogl_host_non_symmetric_update_w_interface",
+    "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
+]
+
+
+class OglError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libogl_amd status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Load libogl_amd.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (there is no fallback path)")
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.ogl_last_error.restype = C.c_char_p
+        _lib.ogl_registry_destroy.restype = None
+        _lib.ogl_config_default.restype = None
+        for name in ("ogl_host_init_local_sparsity", "ogl_host_symmetric_update",
+                     "ogl_host_symmetric_update_w_interface",
+                     "ogl_host_non_symmetric_update_w_interface", "ogl_host_non_symmetric_update",
+                     "ogl_host_adapt_criterion"):
+            getattr(_lib, name).restype = None
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise OglError(rc, lib().ogl_last_error().decode())
+    return rc
+
+
+def _l(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _s(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _pl(a):
+    return a.ctypes.data_as(_LP)
+
+
+def _ps(a):
+    return a.ctypes.data_as(_SP)
+
+
+def default_config(**kw):
+    """ogl_config with the reference code's defaults, overridden by keyword."""
+    cfg = Config()
+    lib().ogl_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+class LduArrays:
+    """Keeps the numpy arrays of an lduMatrix view alive next to the C struct."""
+
+    def __init__(self, case):
+        self.lower_addr, self.upper_addr = _l(case.lower_addr), _l(case.upper_addr)
+        self.diag, self.upper = _s(case.diag), _s(case.upper)
+        self.lower = None if case.lower is None else _s(case.lower)
+        self.ifaces = [(_l(f.face_cells), _s(f.bou_coeffs), f) for f in case.interfaces]
+        self.c_ifaces = (Interface * max(1, len(self.ifaces)))()
+        for i, (fc, bc, f) in enumerate(self.ifaces):
+            self.c_ifaces[i] = Interface(f.kind, f.neighb_proc, f.neighb_patch, fc.size, _pl(fc),
+                                         _ps(bc))
+        self.view = LduView(case.n_cells, self.upper_addr.size, _pl(self.lower_addr),
+                            _pl(self.upper_addr), _ps(self.diag), _ps(self.upper),
+                            None if self.lower is None else _ps(self.lower), len(self.ifaces),
+                            self.c_ifaces)
+
+
+class Registry:
+    """objectRegistry analogue: owns the device context and the per-field solvers."""
+
+    def __init__(self, device_id=-1, hip_stream=None):
+        self._h = C.c_void_p()
+        _check(lib().ogl_registry_create(C.byref(self._h), C.c_int(device_id),
+                                         C.c_void_p(hip_stream)))
+        self._cbs = None
+
+    def close(self):
+        if self._h:
+            lib().ogl_registry_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_host_comm(self, rank, n_ranks, allreduce, exchange):
+        """allreduce(np.ndarray) -> np.ndarray ; exchange(neighbours, counts, send) -> recv."""
+        def _ar(_u, v, n):
+            a = np.ctypeslib.as_array(v, shape=(n,))
+            a[:] = allreduce(a.copy())
+
+        def _ex(_u, nn, nbr, cnt, send, recv):
+            nb = np.ctypeslib.as_array(nbr, shape=(nn,)).copy()
+            ct = np.ctypeslib.as_array(cnt, shape=(nn,)).copy()
+            tot = int(ct.sum())
+            s = np.ctypeslib.as_array(send, shape=(tot,)).copy()
+            np.ctypeslib.as_array(recv, shape=(tot,))[:] = exchange(nb, ct, s)
+
+        self._cbs = (ALLREDUCE_FN(_ar), EXCHANGE_FN(_ex))
+        _check(lib().ogl_registry_set_host_comm(self._h, rank, n_ranks, self._cbs[0], self._cbs[1],
+                                                None))
+
+    def init_rccl(self, rank, n_ranks, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, RCCL_ID_BYTES)
+        _check(lib().ogl_registry_init_rccl(self._h, rank, n_ranks, buf))
+
+    def solver(self, field_name, cfg):
+        return Solver(self, field_name, cfg)
+
+
+def rccl_unique_id() -> bytes:
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    _check(lib().ogl_rccl_unique_id(buf))
+    return buf.raw
+
+
+class Solver:
+    """One GKOCG / GKOBiCGStab / GKOGMRES construction (lookup-or-create by field name)."""
+
+    def __init__(self, registry, field_name, cfg):
+        self.registry = registry
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _check(lib().ogl_solver_get_or_create(registry._h, field_name.encode(), C.byref(cfg),
+                                              C.byref(self._h)))
+        self._ldu = None
+
+    def set_matrix(self, case):
+        self._ldu = case if isinstance(case, LduArrays) else LduArrays(case)
+        _check(lib().ogl_solver_set_matrix(self._h, C.byref(self._ldu.view)))
+        return self
+
+    def solve(self, source, psi):
+        """Returns (psi_out, Perf).  psi is the initial guess (honoured per updateInitGuess)."""
+        b = _s(source)
+        x = np.array(psi, dtype=np.float64, copy=True)
+        perf = Perf()
+        _check(lib().ogl_solver_solve(self._h, _ps(b), _ps(x), C.byref(perf)))
+        return x, perf
+
+    def history(self, capacity=1 << 20):
+        out = np.zeros(capacity, np.float64)
+        n = _check(lib().ogl_solver_history(self._h, _ps(out), capacity))
+        return out[:n].copy()
+
+    def get_property(self, key):
+        v = C.c_double()
+        _check(lib().ogl_solver_get_property(self._h, key.encode(), C.byref(v)))
+        return v.value
+
+    def set_property(self, key, value):
+        _check(lib().ogl_solver_set_property(self._h, key.encode(), C.c_double(value)))
+
+    def apply_resident(self):
+        perf = Perf()
+        _check(lib().ogl_solver_apply_resident(self._h, C.byref(perf)))
+        return perf
+
+    def upload_solution(self, psi=None):
+        p = None if psi is None else _ps(_s(psi))
+        _check(lib().ogl_solver_upload_solution(self._h, p))
+
+    def upload_rhs(self, source=None):
+        p = None if source is None else _ps(_s(source))
+        _check(lib().ogl_solver_upload_rhs(self._h, p))
+
+    def download_solution(self):
+        out = np.zeros(self.dims().n_rows, np.float64)
+        _check(lib().ogl_solver_download_solution(self._h, _ps(out)))
+        return out
+
+    def spmv(self, x):
+        x = _s(x)
+        y = np.zeros_like(x)
+        _check(lib().ogl_solver_spmv(self._h, _ps(x), _ps(y)))
+        return y
+
+    def time_spmv(self, repeats):
+        ms = C.c_double()
+        _check(lib().ogl_solver_time_spmv(self._h, repeats, C.byref(ms)))
+        return ms.value
+
+    def reduce(self, op, a, b=None):
+        a = _s(a)
+        out = C.c_double()
+        pb = None
+        if b is not None:
+            b = _s(b)
+            pb = _ps(b)
+        _check(lib().ogl_solver_reduce(self._h, {"dot": 0, "norm1": 1, "sum": 2}[op], _ps(a), pb,
+                                       C.byref(out)))
+        return out.value
+
+    def dims(self):
+        d = MatrixDims()
+        _check(lib().ogl_solver_matrix_dims(self._h, C.byref(d)))
+        return d
+
+    def local_matrix(self):
+        d = self.dims()
+        rp = np.zeros(d.n_rows + 1, np.int32)
+        cols = np.zeros(d.local_nnz, np.int32)
+        mp = np.zeros(d.local_nnz, np.int32)
+        vals = np.zeros(d.local_nnz, np.float64)
+        _check(lib().ogl_solver_get_local_matrix(self._h, _pl(rp), _pl(cols), _pl(mp), _ps(vals)))
+        return rp, cols, mp, vals
+
+    def non_local_matrix(self):
+        d = self.dims()
+        rows, cols, mp = (np.zeros(d.non_local_nnz, np.int32) for _ in range(3))
+        vals = np.zeros(d.non_local_nnz, np.float64)
+        _check(lib().ogl_solver_get_non_local_matrix(self._h, _pl(rows), _pl(cols), _pl(mp),
+                                                     _ps(vals)))
+        return rows, cols, mp, vals
+
+    def comm_pattern(self):
+        d = self.dims()
+        ids, sizes = np.zeros(d.n_neighbours, np.int32), np.zeros(d.n_neighbours, np.int32)
+        send = np.zeros(d.n_send, np.int32)
+        _check(lib().ogl_solver_get_comm_pattern(self._h, _pl(ids), _pl(sizes), _pl(send)))
+        return ids, sizes, send
+
+
+# ------------------------------------------------------------------ pure host logic (no GPU)
+
+def host_init_local_sparsity(nrows, upper, lower, symmetric=True):
+    upper, lower = _l(upper), _l(lower)
+    nnz = nrows + 2 * upper.size
+    rows, cols, perm = (np.zeros(nnz, np.int32) for _ in range(3))
+    lib().ogl_host_init_local_sparsity(C.c_int32(nrows), C.c_int32(upper.size),
+                                       C.c_int(bool(symmetric)), _pl(upper), _pl(lower), _pl(rows),
+                                       _pl(cols), _pl(perm))
+    return rows, cols, perm
+
+
+def host_symmetric_update(permute, scale, diag, upper):
+    permute, diag, upper = _l(permute), _s(diag), _s(upper)
+    out = np.zeros(permute.size)
+    lib().ogl_host_symmetric_update(C.c_int32(permute.size), C.c_int32(upper.size), _pl(permute),
+                                    C.c_double(scale), _ps(diag), _ps(upper), _ps(out))
+    return out
+
+
+def host_non_symmetric_update(permute, scale, diag, upper, lower):
+    permute, diag, upper, lower = _l(permute), _s(diag), _s(upper), _s(lower)
+    out = np.zeros(permute.size)
+    lib().ogl_host_non_symmetric_update(C.c_int32(permute.size), C.c_int32(upper.size),
+                                        _pl(permute), C.c_double(scale), _ps(diag), _ps(upper),
+                                        _ps(lower), _ps(out))
+    return out
+
+
+def host_symmetric_update_w_interface(permute, scale, diag, upper, iface):
+    permute, diag, upper, iface = _l(permute), _s(diag), _s(upper), _s(iface)
+    out = np.zeros(permute.size)
+    lib().ogl_host_symmetric_update_w_interface(C.c_int32(permute.size), C.c_int32(diag.size),
+                                                C.c_int32(upper.size), _pl(permute),
+                                                C.c_double(scale), _ps(diag), _ps(upper),
+                                                _ps(iface), _ps(out))
+    return out
+
+
+def host_non_symmetric_update_w_interface(permute, scale, diag, upper, lower, iface):
+    permute, diag, upper, lower, iface = _l(permute), _s(diag), _s(upper), _s(lower), _s(iface)
+    out = np.zeros(permute.size)
+    lib().ogl_host_non_symmetric_update_w_interface(
+        C.c_int32(permute.size), C.c_int32(diag.size), C.c_int32(upper.size), _pl(permute),
+        C.c_double(scale), _ps(diag), _ps(upper), _ps(lower), _ps(iface), _ps(out))
+    return out
+
+
+def host_pattern(case):
+    """(dims, local (rows, cols, map), non-local (rows, cols, map), (ids, sizes, send_idxs))."""
+    arr = case if isinstance(case, LduArrays) else LduArrays(case)
+    d = MatrixDims()
+    none = None
+    _check(lib().ogl_host_pattern(C.byref(arr.view), C.byref(d), none, none, none, none, none,
+                                  none, none, none, none))
+    loc = [np.zeros(d.local_nnz, np.int32) for _ in range(3)]
+    nl = [np.zeros(d.non_local_nnz, np.int32) for _ in range(3)]
+    ids, sizes = np.zeros(d.n_neighbours, np.int32), np.zeros(d.n_neighbours, np.int32)
+    send = np.zeros(d.n_send, np.int32)
+    _check(lib().ogl_host_pattern(C.byref(arr.view), C.byref(d), *[_pl(a) for a in loc],
+                                  *[_pl(a) for a in nl], _pl(ids), _pl(sizes), _pl(send)))
+    return d, tuple(loc), tuple(nl), (ids, sizes, send)
+
+
+def host_adapt_criterion(cfg, prev_solve_iters, prev_rel_cost):
+    mi, fr = C.c_int32(), C.c_int32()
+    lib().ogl_host_adapt_criterion(C.byref(cfg), C.c_int32(prev_solve_iters),
+                                   C.c_double(prev_rel_cost), C.byref(mi), C.byref(fr))
+    return mi.value, fr.value

@@ -1,0 +1,330 @@
+// capi.cpp -- extern "C" entry points of include/ogl_amd.h.  No exception crosses this file.
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "solver.hpp"
+
+using namespace ogl;
+
+#define OGL_GUARD_BEGIN try {
+#define OGL_GUARD_END                                                         \
+    }                                                                         \
+    catch (const std::bad_alloc &) { return fail(OGL_ERR_HIP, "out of host memory"); } \
+    catch (const std::exception &e) { return fail(OGL_ERR_INVALID, "exception: %s", e.what()); } \
+    catch (...) { return fail(OGL_ERR_INVALID, "unknown exception"); }
+
+extern "C" int ogl_registry_create(ogl_registry **out, int device_id, void *hip_stream)
+{
+    OGL_GUARD_BEGIN
+    if (!out) return fail(OGL_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return fail(OGL_ERR_NO_DEVICE,
+                    "no HIP device visible: libogl_amd has no CPU path (gfx950 required)");
+    if (device_id < 0) device_id = 0;
+    if (device_id >= n_dev)
+        return fail(OGL_ERR_NO_DEVICE, "device %d requested, %d visible", device_id, n_dev);
+    hipDeviceProp_t prop;
+    OGL_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(OGL_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only",
+                    device_id, prop.gcnArchName);
+    OGL_HIP_CHECK(hipSetDevice(device_id));
+    auto reg = std::make_unique<ogl_registry>();
+    reg->device = device_id;
+    if (hip_stream) {
+        reg->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        OGL_HIP_CHECK(hipStreamCreateWithFlags(&reg->stream, hipStreamNonBlocking));
+        reg->own_stream = true;
+    }
+    reg->comm = std::make_unique<SelfComm>();
+    OGL_TRY(reg->stager.init(size_t(32) << 20));
+    *out = reg.release();
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" void ogl_registry_destroy(ogl_registry *reg) { delete reg; }
+
+extern "C" int ogl_registry_set_host_comm(ogl_registry *reg, int32_t rank, int32_t n_ranks,
+                                          ogl_allreduce_sum_fn allreduce,
+                                          ogl_neighbour_exchange_fn exchange, void *user)
+{
+    OGL_GUARD_BEGIN
+    if (!reg) return fail(OGL_ERR_INVALID, "registry is NULL");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(OGL_ERR_INVALID, "bad rank/n_ranks");
+    if (n_ranks > 1 && (!allreduce || !exchange))
+        return fail(OGL_ERR_INVALID, "host communicator needs both callbacks");
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    reg->comm = std::make_unique<HostComm>(rank, n_ranks, allreduce, exchange, user);
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_rccl_unique_id(void *id_out)
+{
+    OGL_GUARD_BEGIN
+    if (!id_out) return fail(OGL_ERR_INVALID, "id_out is NULL");
+    return RcclComm::unique_id(id_out);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n_ranks,
+                                      const void *id)
+{
+    OGL_GUARD_BEGIN
+    if (!reg || !id) return fail(OGL_ERR_INVALID, "registry/id is NULL");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(OGL_ERR_INVALID, "bad rank/n_ranks");
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    auto c = std::make_unique<RcclComm>();
+    OGL_TRY(c->init(rank, n_ranks, id));
+    reg->comm = std::move(c);
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+static int check_config(const ogl_config &c)
+{
+    if (c.solver < OGL_SOLVER_CG || c.solver > OGL_SOLVER_GMRES)
+        return fail(OGL_ERR_INVALID, "unknown solver kind %d", c.solver);
+    if (c.matrix_format < OGL_FORMAT_COO || c.matrix_format > OGL_FORMAT_ELL)
+        return fail(OGL_ERR_INVALID, "Matrix format %d not supported", c.matrix_format);  // CsrMatrixWrapper.H:159
+    if (c.ranks_per_gpu != 1)
+        return fail(OGL_ERR_UNSUPPORTED, "ranksPerGPU %d: only 1 works (Vector.H:78-82)", c.ranks_per_gpu);
+    if (c.max_iter < 0 || c.eval_frequency < 1 || c.norm_eval_limit < 1)
+        return fail(OGL_ERR_INVALID, "maxIter/evalFrequency/normEvalLimit out of range");
+    return OGL_OK;
+}
+
+extern "C" int ogl_solver_get_or_create(ogl_registry *reg, const char *field_name,
+                                        const ogl_config *cfg, ogl_solver **out)
+{
+    OGL_GUARD_BEGIN
+    if (!reg || !field_name || !cfg || !out) return fail(OGL_ERR_INVALID, "NULL argument");
+    OGL_TRY(check_config(*cfg));
+    auto &slot = reg->solvers[field_name];
+    if (!slot) {  // "initialising <name>"  (Base.H:98-113)
+        slot = std::make_unique<ogl_solver>();
+        slot->reg = reg;
+        slot->field = field_name;
+    }
+    slot->cfg = *cfg;  // the dictionary is re-read at every construction
+    *out = slot.get();
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_set_matrix(ogl_solver *s, const ogl_ldu_view *ldu)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !ldu) return fail(OGL_ERR_INVALID, "NULL argument");
+    return s->set_matrix(*ldu);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_solve(ogl_solver *s, const ogl_scalar *source, ogl_scalar *psi,
+                                ogl_perf *perf)
+{
+    OGL_GUARD_BEGIN
+    if (!s) return fail(OGL_ERR_INVALID, "NULL solver");
+    return s->solve(source, psi, perf);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_history(ogl_solver *s, double *out, int32_t capacity)
+{
+    if (!s || (!out && capacity > 0)) return fail(OGL_ERR_INVALID, "NULL argument");
+    const int n = std::min<int>(capacity, (int)s->history.size());
+    std::copy(s->history.begin(), s->history.begin() + n, out);
+    return n;
+}
+
+extern "C" int ogl_solver_get_property(ogl_solver *s, const char *key, double *value)
+{
+    if (!s || !key || !value) return fail(OGL_ERR_INVALID, "NULL argument");
+    auto it = s->props.find(key);
+    if (it == s->props.end()) return fail(OGL_ERR_INVALID, "no property %s", key);
+    *value = it->second;
+    return OGL_OK;
+}
+
+extern "C" int ogl_solver_set_property(ogl_solver *s, const char *key, double value)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !key) return fail(OGL_ERR_INVALID, "NULL argument");
+    s->props[key] = value;
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_apply_resident(ogl_solver *s, ogl_perf *perf)
+{
+    OGL_GUARD_BEGIN
+    if (!s) return fail(OGL_ERR_INVALID, "NULL solver");
+    if (perf) *perf = ogl_perf{};
+    return s->apply_resident(perf);
+    OGL_GUARD_END
+}
+
+static int upload_into(ogl_solver *s, DevBuf<double> ogl_solver::*which, bool ogl_solver::*flag,
+                       const double *src)
+{
+    if (!s) return fail(OGL_ERR_INVALID, "NULL solver");
+    if (!s->have_pattern) return fail(OGL_ERR_STATE, "upload before set_matrix");
+    OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    OGL_TRY(s->upload_vec(s->*which, src));
+    OGL_HIP_CHECK(hipStreamSynchronize(s->reg->stream));
+    s->*flag = true;
+    return OGL_OK;
+}
+
+extern "C" int ogl_solver_upload_solution(ogl_solver *s, const ogl_scalar *psi)
+{
+    OGL_GUARD_BEGIN
+    return upload_into(s, &ogl_solver::d_x, &ogl_solver::x_resident, psi);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_upload_rhs(ogl_solver *s, const ogl_scalar *source)
+{
+    OGL_GUARD_BEGIN
+    return upload_into(s, &ogl_solver::d_b, &ogl_solver::b_resident, source);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_download_solution(ogl_solver *s, ogl_scalar *psi)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !psi) return fail(OGL_ERR_INVALID, "NULL argument");
+    if (!s->x_resident) return fail(OGL_ERR_STATE, "no resident solution");
+    OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    return s->reg->stager.d2h(psi, s->d_x.p, (size_t)s->pat.n_rows * sizeof(double), s->reg->stream);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_spmv(ogl_solver *s, const ogl_scalar *x, ogl_scalar *y)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !x || !y) return fail(OGL_ERR_INVALID, "NULL argument");
+    if (!s->matrix_set) return fail(OGL_ERR_STATE, "spmv before set_matrix");
+    OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    hipStream_t st = s->reg->stream;
+    const size_t bytes = (size_t)s->pat.n_rows * sizeof(double);
+    OGL_TRY(s->reg->stager.h2d(s->d_w.p, x, bytes, st));
+    OGL_TRY(s->dist_spmv(SPMV_PLAIN, s->d_w.p, nullptr, s->d_q.p, nullptr, nullptr));
+    OGL_TRY(s->reg->stager.d2h(y, s->d_q.p, bytes, st));
+    OGL_HIP_CHECK(hipGetLastError());
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_time_spmv(ogl_solver *s, int32_t repeats, double *avg_ms)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !avg_ms) return fail(OGL_ERR_INVALID, "NULL argument");
+    return s->time_spmv(repeats, avg_ms);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_reduce(ogl_solver *s, int32_t op, const ogl_scalar *a, const ogl_scalar *b,
+                                 double *out)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !a || !out || (op == 0 && !b)) return fail(OGL_ERR_INVALID, "NULL argument");
+    if (!s->have_pattern) return fail(OGL_ERR_STATE, "reduce before set_matrix");
+    OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    hipStream_t st = s->reg->stream;
+    const int n = s->pat.n_rows;
+    const size_t bytes = (size_t)n * sizeof(double);
+    OGL_TRY(s->reg->stager.h2d(s->d_w.p, a, bytes, st));
+    if (op == 0) {
+        OGL_TRY(s->reg->stager.h2d(s->d_q.p, b, bytes, st));
+        launch_partials_dot(st, n, s->d_w.p, s->d_q.p, s->d_part0.p, nullptr);
+    } else if (op == 1) {
+        launch_partials_norm1(st, n, s->d_w.p, s->d_part0.p);
+    } else if (op == 2) {
+        launch_partials_sum(st, n, s->d_w.p, s->d_part0.p);
+    } else {
+        return fail(OGL_ERR_INVALID, "unknown reduction op %d", op);
+    }
+    FinArgs fa{};
+    fa.part[0] = s->d_part0.p;
+    fa.n_part = (int)n_chunks(n);
+    fa.n_sums = 1;
+    OGL_TRY(s->finalize(FIN_RAW, fa));
+    DevScalars h;
+    OGL_HIP_CHECK(hipMemcpyAsync(&h, s->d_scal.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    *out = h.sums[0];
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_reduction_chunk_rows(void) { return CHUNK_ROWS; }
+
+extern "C" int ogl_solver_matrix_dims(ogl_solver *s, ogl_matrix_dims *d)
+{
+    if (!s || !d) return fail(OGL_ERR_INVALID, "NULL argument");
+    if (!s->have_pattern) return fail(OGL_ERR_STATE, "no matrix yet");
+    d->n_rows = s->pat.n_rows;
+    d->local_nnz = s->pat.local_nnz;
+    d->non_local_nnz = s->pat.non_local_nnz;
+    d->n_halo = s->pat.non_local_nnz;
+    d->n_neighbours = (ogl_label)s->pat.target_ids.size();
+    d->n_send = (ogl_label)s->pat.send_idxs.size();
+    return OGL_OK;
+}
+
+template <class T>
+static int fetch(ogl_solver *s, T *dst, const T *dev, size_t count)
+{
+    if (!dst || count == 0) return OGL_OK;
+    return s->reg->stager.d2h(dst, dev, count * sizeof(T), s->reg->stream);
+}
+
+extern "C" int ogl_solver_get_local_matrix(ogl_solver *s, ogl_label *row_ptrs, ogl_label *cols,
+                                           ogl_label *ldu_mapping, ogl_scalar *coeffs)
+{
+    OGL_GUARD_BEGIN
+    if (!s) return fail(OGL_ERR_INVALID, "NULL solver");
+    if (!s->matrix_set) return fail(OGL_ERR_STATE, "no matrix yet");
+    OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    const size_t nnz = (size_t)s->pat.local_nnz;
+    OGL_TRY(fetch(s, row_ptrs, s->d_row_ptrs.p, (size_t)s->pat.n_rows + 1));
+    OGL_TRY(fetch(s, cols, s->d_cols.p, nnz));
+    OGL_TRY(fetch(s, ldu_mapping, s->d_ldu_mapping.p, nnz));
+    OGL_TRY(fetch(s, coeffs, s->d_vals.p, nnz));
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_get_non_local_matrix(ogl_solver *s, ogl_label *rows, ogl_label *cols,
+                                               ogl_label *ldu_mapping, ogl_scalar *coeffs)
+{
+    OGL_GUARD_BEGIN
+    if (!s) return fail(OGL_ERR_INVALID, "NULL solver");
+    if (!s->matrix_set) return fail(OGL_ERR_STATE, "no matrix yet");
+    OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    const size_t nnz = (size_t)s->pat.non_local_nnz;
+    if (rows) std::copy(s->pat.nl_rows.begin(), s->pat.nl_rows.end(), rows);
+    if (ldu_mapping) std::copy(s->pat.nl_ldu_mapping.begin(), s->pat.nl_ldu_mapping.end(), ldu_mapping);
+    OGL_TRY(fetch(s, cols, s->d_nl_cols.p, nnz));
+    OGL_TRY(fetch(s, coeffs, s->d_nl_vals.p, nnz));
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_get_comm_pattern(ogl_solver *s, ogl_label *target_ids,
+                                           ogl_label *target_sizes, ogl_label *send_idxs)
+{
+    if (!s) return fail(OGL_ERR_INVALID, "NULL solver");
+    if (!s->have_pattern) return fail(OGL_ERR_STATE, "no matrix yet");
+    if (target_ids) std::copy(s->pat.target_ids.begin(), s->pat.target_ids.end(), target_ids);
+    if (target_sizes) std::copy(s->pat.target_sizes.begin(), s->pat.target_sizes.end(), target_sizes);
+    if (send_idxs) std::copy(s->pat.send_idxs.begin(), s->pat.send_idxs.end(), send_idxs);
+    return OGL_OK;
+}

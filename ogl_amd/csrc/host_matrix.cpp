@@ -1,0 +1,392 @@
+// host_matrix.cpp -- see host_matrix.hpp.  Citations: reference HostMatrix/*.C.
+#include "host_matrix.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <tuple>
+
+namespace ogl {
+
+namespace {
+
+// Order one row segment by column; entries arrive in face order, so equal columns keep it.
+inline void sort_segment(ogl_label *cols, ogl_label *perm, ogl_label len)
+{
+    for (ogl_label i = 1; i < len; ++i) {
+        const ogl_label c = cols[i], p = perm[i];
+        ogl_label j = i;
+        while (j > 0 && cols[j - 1] > c) {
+            cols[j] = cols[j - 1];
+            perm[j] = perm[j - 1];
+            --j;
+        }
+        cols[j] = c;
+        perm[j] = p;
+    }
+}
+
+}  // namespace
+
+// HostMatrixFreeFunctions.C:105-201.  The reference sorts two face lists by (row, col) and then
+// interleaves them row by row as [lower entries | diagonal | upper entries].  Here every row's
+// three segments are sized by a counting pass, filled in face order and ordered by column, which
+// yields the same arrays in O(F) for OpenFOAM's upper-triangular face order.
+void init_local_sparsity(ogl_label nrows, ogl_label upper_nnz, bool is_symmetric,
+                         const ogl_label *upper, const ogl_label *lower, ogl_label *rows,
+                         ogl_label *cols, ogl_label *permute)
+{
+    const ogl_label after_neighbours = is_symmetric ? upper_nnz : 2 * upper_nnz;  // :116
+    std::vector<ogl_label> n_low(nrows, 0), n_up(nrows, 0);
+    for (ogl_label f = 0; f < upper_nnz; ++f) {
+        ++n_up[lower[f]];   // upper-triangle entry lives in row lower[f]   (:123-124)
+        ++n_low[upper[f]];  // its transpose lives in row upper[f]          (:139-140)
+    }
+    std::vector<int64_t> seg_low(nrows), seg_up(nrows);
+    int64_t off = 0;
+    for (ogl_label r = 0; r < nrows; ++r) {
+        seg_low[r] = off;
+        off += n_low[r];
+        rows[off] = r;  // diagonal (:179-182)
+        cols[off] = r;
+        permute[off] = after_neighbours + r;
+        ++off;
+        seg_up[r] = off;
+        off += n_up[r];
+    }
+    std::vector<int64_t> fill_low(seg_low), fill_up(seg_up);
+    for (ogl_label f = 0; f < upper_nnz; ++f) {
+        int64_t e = fill_up[lower[f]]++;
+        rows[e] = lower[f];
+        cols[e] = upper[f];
+        permute[e] = f;  // :188
+        e = fill_low[upper[f]]++;
+        rows[e] = upper[f];
+        cols[e] = lower[f];
+        permute[e] = is_symmetric ? f : upper_nnz + f;  // :164-165
+    }
+    for (ogl_label r = 0; r < nrows; ++r) {
+        sort_segment(cols + seg_low[r], permute + seg_low[r], n_low[r]);
+        sort_segment(cols + seg_up[r], permute + seg_up[r], n_up[r]);
+    }
+}
+
+void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *out)
+{
+    int64_t k = 0;
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+        const ogl_interface &itf = ldu.interfaces[i];
+        const bool is_proc = itf.kind == OGL_IFACE_PROCESSOR;
+        if (local ? is_proc : !is_proc) continue;
+        for (ogl_label f = 0; f < itf.size; ++f) out[k++] = itf.bou_coeffs[f] * -1.0;  // :204
+    }
+}
+
+bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p)
+{
+    if (ldu.n_cells != p.n_rows || ldu.n_faces != p.upper_nnz) return false;
+    if ((ldu.lower == nullptr) != p.symmetric) return false;
+    int64_t loc = 0, nl = 0;
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i)
+        (ldu.interfaces[i].kind == OGL_IFACE_PROCESSOR ? nl : loc) += ldu.interfaces[i].size;
+    return loc == p.local_iface_nnz && nl == p.non_local_nnz;
+}
+
+int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
+{
+    if (ldu.n_cells < 0 || ldu.n_faces < 0 || ldu.n_interfaces < 0)
+        return fail(OGL_ERR_INVALID, "negative size in ldu view");
+    if (ldu.n_cells > 0 && !ldu.diag) return fail(OGL_ERR_INVALID, "diag is NULL");
+    if (ldu.n_faces > 0 && (!ldu.lower_addr || !ldu.upper_addr || !ldu.upper))
+        return fail(OGL_ERR_INVALID, "face addressing / upper is NULL");
+    if (ldu.n_interfaces > 0 && !ldu.interfaces) return fail(OGL_ERR_INVALID, "interfaces is NULL");
+    const ogl_label N = ldu.n_cells, F = ldu.n_faces;
+    for (ogl_label f = 0; f < F; ++f)
+        if (ldu.lower_addr[f] < 0 || ldu.lower_addr[f] >= N || ldu.upper_addr[f] < 0 ||
+            ldu.upper_addr[f] >= N)
+            return fail(OGL_ERR_INVALID, "face %d addresses a cell outside [0,%d)", f, N);
+
+    p = HostPattern{};
+    p.n_rows = N;
+    p.upper_nnz = F;
+    p.symmetric = (ldu.lower == nullptr);  // matrix.symmetric()  HostMatrix.C:473
+    int64_t loc = 0, nl = 0;
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {  // count_interface_nnz  :159-178
+        const ogl_interface &itf = ldu.interfaces[i];
+        if (itf.size < 0 || (itf.size > 0 && (!itf.face_cells || !itf.bou_coeffs)))
+            return fail(OGL_ERR_INVALID, "interface %d: bad size or NULL arrays", i);
+        for (ogl_label f = 0; f < itf.size; ++f)
+            if (itf.face_cells[f] < 0 || itf.face_cells[f] >= N)
+                return fail(OGL_ERR_INVALID, "interface %d: faceCell outside [0,%d)", i, N);
+        if (itf.kind == OGL_IFACE_PROCESSOR) {
+            if (itf.neighb_proc < 0)
+                return fail(OGL_ERR_INVALID, "interface %d: negative neighbProcNo", i);
+            nl += itf.size;
+        } else if (itf.kind == OGL_IFACE_CYCLIC) {
+            if (itf.neighb_patch < 0 || itf.neighb_patch >= ldu.n_interfaces ||
+                ldu.interfaces[itf.neighb_patch].size != itf.size)
+                return fail(OGL_ERR_INVALID, "interface %d: cyclic neighbour patch mismatch", i);
+            loc += itf.size;
+        } else {
+            // cyclicAMI / cyclicACMI abort in the reference (HostMatrix.C:339-341, :367-369);
+            // other coupled kinds would corrupt its pattern.
+            return fail(OGL_ERR_UNSUPPORTED, "interface %d: unsupported coupled patch kind %d", i,
+                        itf.kind);
+        }
+    }
+    const int64_t total = (int64_t)N + 2 * (int64_t)F + loc;
+    if (total > INT32_MAX - NNZ_PAD || nl > INT32_MAX - NNZ_PAD)
+        return fail(OGL_ERR_INVALID, "matrix too large for 32-bit labels");
+    p.local_iface_nnz = (ogl_label)loc;
+    p.non_local_nnz = (ogl_label)nl;
+    p.local_nnz = (ogl_label)total;
+
+    // ---- local pattern (init_local_sparsity_pattern, HostMatrix.C:468-589) ----
+    p.rows.resize(total);
+    p.cols.resize(total);
+    p.ldu_mapping.resize(total);
+    init_local_sparsity(N, F, p.symmetric, ldu.upper_addr, ldu.lower_addr, p.rows.data(),
+                        p.cols.data(), p.ldu_mapping.data());
+    if (loc) {
+        // collect_local_interface_indices (:385-410): (interface_idx, row, col) of every cyclic
+        // face; the column is the face cell of the neighbour patch (:324-327)
+        std::vector<std::tuple<ogl_label, ogl_label, ogl_label>> ifc;  // (row, col, idx)
+        ifc.reserve(loc);
+        ogl_label ctr = 0;
+        for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+            const ogl_interface &itf = ldu.interfaces[i];
+            if (itf.kind != OGL_IFACE_CYCLIC) continue;
+            const ogl_label *nbr = ldu.interfaces[itf.neighb_patch].face_cells;
+            for (ogl_label f = 0; f < itf.size; ++f) ifc.emplace_back(itf.face_cells[f], nbr[f], ctr++);
+        }
+        std::stable_sort(ifc.begin(), ifc.end(), [](const auto &a, const auto &b) {  // :510-515
+            return std::tie(std::get<0>(a), std::get<1>(a)) < std::tie(std::get<0>(b), std::get<1>(b));
+        });
+        const int64_t base_nnz = (int64_t)N + 2 * (int64_t)F;
+        const ogl_label iface_base = p.diag_start() + N;  // after_neighbours + nrows_  (:574)
+        std::vector<ogl_label> r2(total), c2(total), m2(total);
+        int64_t cur = 0, tot = 0;
+        for (const auto &[r, c, idx] : ifc) {  // :539-576
+            while (cur < base_nnz && (p.rows[cur] < r || (p.rows[cur] == r && p.cols[cur] <= c))) {
+                r2[tot] = p.rows[cur];
+                c2[tot] = p.cols[cur];
+                m2[tot] = p.ldu_mapping[cur];
+                ++cur;
+                ++tot;
+            }
+            r2[tot] = r;
+            c2[tot] = c;
+            m2[tot] = iface_base + idx;
+            ++tot;
+        }
+        for (; cur < base_nnz; ++cur, ++tot) {  // :580-585
+            r2[tot] = p.rows[cur];
+            c2[tot] = p.cols[cur];
+            m2[tot] = p.ldu_mapping[cur];
+        }
+        p.rows.swap(r2);
+        p.cols.swap(c2);
+        p.ldu_mapping.swap(m2);
+    }
+    p.row_ptrs.assign((size_t)N + 1, 0);
+    for (int64_t e = 0; e < total; ++e) ++p.row_ptrs[p.rows[e] + 1];
+    for (ogl_label r = 0; r < N; ++r) p.row_ptrs[r + 1] += p.row_ptrs[r];
+
+    // ---- non-local pattern (HostMatrix.C:412-466) ----
+    // row = faceCell, col = ldu_mapping = running index over processor-interface faces in
+    // interface order; ordered by row.  The reference's std::sort is keyed on the row only and is
+    // not stable, so the order of entries sharing a row is unspecified there; a stable sort keeps
+    // them in interface order.
+    p.nl_rows.resize(nl);
+    p.nl_cols.resize(nl);
+    p.nl_ldu_mapping.resize(nl);
+    {
+        std::vector<ogl_label> row_of(nl), order(nl);
+        ogl_label k = 0;
+        for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+            const ogl_interface &itf = ldu.interfaces[i];
+            if (itf.kind != OGL_IFACE_PROCESSOR) continue;
+            for (ogl_label f = 0; f < itf.size; ++f) {
+                row_of[k] = itf.face_cells[f];
+                order[k] = k;
+                ++k;
+            }
+        }
+        std::stable_sort(order.begin(), order.end(),
+                         [&](ogl_label a, ogl_label b) { return row_of[a] < row_of[b]; });
+        for (ogl_label e = 0; e < (ogl_label)nl; ++e) {
+            p.nl_rows[e] = row_of[order[e]];
+            p.nl_cols[e] = order[e];
+            p.nl_ldu_mapping[e] = order[e];
+        }
+    }
+
+    // ---- communication pattern (HostMatrix.C:251-306): std::map keyed by neighbour rank ----
+    {
+        std::map<ogl_label, std::vector<ogl_label>> by_rank;
+        for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+            const ogl_interface &itf = ldu.interfaces[i];
+            if (itf.kind != OGL_IFACE_PROCESSOR) continue;
+            auto &v = by_rank[itf.neighb_proc];
+            v.insert(v.end(), itf.face_cells, itf.face_cells + itf.size);
+        }
+        for (const auto &[rank, cells] : by_rank) {
+            p.target_ids.push_back(rank);
+            p.target_sizes.push_back((ogl_label)cells.size());
+            p.send_idxs.insert(p.send_idxs.end(), cells.begin(), cells.end());
+        }
+    }
+    return OGL_OK;
+}
+
+}  // namespace ogl
+
+// ---------------------------------------------------------------------------------------
+// C ABI: pure host logic
+// ---------------------------------------------------------------------------------------
+using namespace ogl;
+
+extern "C" void ogl_host_init_local_sparsity(ogl_label nrows, ogl_label upper_nnz, int is_symmetric,
+                                             const ogl_label *upper, const ogl_label *lower,
+                                             ogl_label *rows, ogl_label *cols, ogl_label *permute)
+{
+    init_local_sparsity(nrows, upper_nnz, is_symmetric != 0, upper, lower, rows, cols, permute);
+}
+
+// HostMatrixFreeFunctions.C:21-30.  In the reference `scale * (pos >= upper_nnz) ? a : b` binds as
+// `(scale * (pos >= upper_nnz)) ? a : b`: scale is a truth value, never a factor.  Kept, so that a
+// case run with reorderOnHost gives the reference's numbers.
+extern "C" void ogl_host_symmetric_update(ogl_label total_nnz, ogl_label upper_nnz,
+                                          const ogl_label *permute, ogl_scalar scale,
+                                          const ogl_scalar *diag, const ogl_scalar *upper,
+                                          ogl_scalar *out)
+{
+    for (ogl_label i = 0; i < total_nnz; ++i) {
+        const ogl_label pos = permute[i];
+        const bool pick_diag = (scale * static_cast<ogl_scalar>(pos >= upper_nnz)) != 0.0;
+        out[i] = pick_diag ? diag[pos - upper_nnz] : upper[pos];
+    }
+}
+
+// HostMatrixFreeFunctions.C:32-56
+extern "C" void ogl_host_symmetric_update_w_interface(ogl_label total_nnz, ogl_label diag_nnz,
+                                                      ogl_label upper_nnz, const ogl_label *permute,
+                                                      ogl_scalar scale, const ogl_scalar *diag,
+                                                      const ogl_scalar *upper,
+                                                      const ogl_scalar *iface, ogl_scalar *out)
+{
+    const ogl_label d0 = upper_nnz, i0 = upper_nnz + diag_nnz;
+    for (ogl_label i = 0; i < total_nnz; ++i) {
+        const ogl_label pos = permute[i];
+        const ogl_scalar v = pos < d0 ? upper[pos] : (pos < i0 ? diag[pos - d0] : iface[pos - i0]);
+        out[i] = scale * v;
+    }
+}
+
+// HostMatrixFreeFunctions.C:58-82
+extern "C" void ogl_host_non_symmetric_update_w_interface(
+    ogl_label total_nnz, ogl_label diag_nnz, ogl_label upper_nnz, const ogl_label *permute,
+    ogl_scalar scale, const ogl_scalar *diag, const ogl_scalar *upper, const ogl_scalar *lower,
+    const ogl_scalar *iface, ogl_scalar *out)
+{
+    const ogl_label l0 = upper_nnz, d0 = 2 * upper_nnz, i0 = 2 * upper_nnz + diag_nnz;
+    for (ogl_label i = 0; i < total_nnz; ++i) {
+        const ogl_label pos = permute[i];
+        const ogl_scalar v = pos < l0   ? upper[pos]
+                             : pos < d0 ? lower[pos - l0]
+                             : pos < i0 ? diag[pos - d0]
+                                        : iface[pos - i0];
+        out[i] = scale * v;
+    }
+}
+
+// HostMatrixFreeFunctions.C:85-102
+extern "C" void ogl_host_non_symmetric_update(ogl_label total_nnz, ogl_label upper_nnz,
+                                              const ogl_label *permute, ogl_scalar scale,
+                                              const ogl_scalar *diag, const ogl_scalar *upper,
+                                              const ogl_scalar *lower, ogl_scalar *out)
+{
+    const ogl_label l0 = upper_nnz, d0 = 2 * upper_nnz;
+    for (ogl_label i = 0; i < total_nnz; ++i) {
+        const ogl_label pos = permute[i];
+        out[i] = scale * (pos < l0 ? upper[pos] : pos < d0 ? lower[pos - l0] : diag[pos - d0]);
+    }
+}
+
+extern "C" int ogl_host_pattern(const ogl_ldu_view *ldu, ogl_matrix_dims *dims,
+                                ogl_label *local_rows, ogl_label *local_cols,
+                                ogl_label *local_ldu_mapping, ogl_label *nl_rows,
+                                ogl_label *nl_cols, ogl_label *nl_ldu_mapping,
+                                ogl_label *target_ids, ogl_label *target_sizes,
+                                ogl_label *send_idxs)
+{
+    if (!ldu || !dims) return fail(OGL_ERR_INVALID, "ldu/dims is NULL");
+    HostPattern p;
+    if (int rc = build_host_pattern(*ldu, p)) return rc;
+    dims->n_rows = p.n_rows;
+    dims->local_nnz = p.local_nnz;
+    dims->non_local_nnz = p.non_local_nnz;
+    dims->n_halo = p.non_local_nnz;
+    dims->n_neighbours = (ogl_label)p.target_ids.size();
+    dims->n_send = (ogl_label)p.send_idxs.size();
+    auto put = [](ogl_label *dst, const std::vector<ogl_label> &src) {
+        if (dst) std::copy(src.begin(), src.end(), dst);
+    };
+    put(local_rows, p.rows);
+    put(local_cols, p.cols);
+    put(local_ldu_mapping, p.ldu_mapping);
+    put(nl_rows, p.nl_rows);
+    put(nl_cols, p.nl_cols);
+    put(nl_ldu_mapping, p.nl_ldu_mapping);
+    put(target_ids, p.target_ids);
+    put(target_sizes, p.target_sizes);
+    put(send_idxs, p.send_idxs);
+    return OGL_OK;
+}
+
+// StoppingCriterion.H:197-209
+extern "C" void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,
+                                         ogl_scalar prev_rel_cost, ogl_label *min_iter,
+                                         ogl_label *frequency)
+{
+    ogl_label mi = cfg->min_iter, fr = cfg->eval_frequency;
+    if (!cfg->export_res && prev_solve_iters > 0 && cfg->adapt_min_iter && prev_rel_cost > 0) {
+        mi = static_cast<ogl_label>(prev_solve_iters * cfg->relaxation_factor);
+        const double alpha =
+            std::sqrt(1.0 / (prev_solve_iters * (1.0 - cfg->relaxation_factor)) * prev_rel_cost);
+        fr = std::min<ogl_label>(cfg->norm_eval_limit,
+                                 std::max<ogl_label>(1, static_cast<ogl_label>(1 / alpha)));
+    }
+    *min_iter = mi;
+    *frequency = fr;
+}
+
+extern "C" void ogl_config_default(ogl_config *c)
+{
+    *c = ogl_config{};
+    c->solver = OGL_SOLVER_CG;
+    c->preconditioner = OGL_PRECOND_NONE;
+    c->max_block_size = 1;
+    c->caching = 0;
+    c->tolerance = 1e-6;
+    c->rel_tol = 1e-6;
+    c->max_iter = 1000;
+    c->min_iter = 0;
+    c->eval_frequency = 1;
+    c->norm_eval_limit = 100;
+    c->relaxation_factor = 0.6;
+    c->adapt_min_iter = 1;
+    c->matrix_format = OGL_FORMAT_COO;
+    c->regenerate = 0;
+    c->update_sys_matrix = 1;
+    c->update_rhs = 1;
+    c->update_init_guess = 0;
+    c->scaling = 1.0;
+    c->reorder_on_host = 0;
+    c->export_res = 0;
+    c->verbose = 0;
+    c->force_host_buffer = 0;
+    c->ranks_per_gpu = 1;
+    c->krylov_dim = 0;
+    c->profile_kernels = 0;
+}

@@ -1,0 +1,676 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the Krylov inner loop.
+//
+// Everything here is HBM-bandwidth bound (SpMV arithmetic intensity 0.134 flop/B), so there is
+// no MFMA: the design rules are coalesced 16-byte-per-lane streams, LDS staging of the SpMV
+// products, 64-lane shuffle reductions and an XCD-aware block -> row-chunk map.
+//
+// Geometry (common.hpp): one 256-thread workgroup (4 wavefronts of 64) owns one chunk of
+// CHUNK_ROWS = 512 consecutive rows; thread t owns rows chunk*512 + 2t, +1.
+//
+// Reductions are deterministic (no atomics): a chunk partial is
+//     thread sums (rows in order)  ->  64-lane xor tree (32,16,8,4,2,1)  ->  wave0+wave1+wave2+wave3
+// and the finaliser sums the partials with the same tree (thread t takes partials t, t+256, ...).
+// oracle/ogl_oracle.c mirrors this tree in its BLOCKED mode so tests can compare bit for bit.
+//
+// Compiled with -ffp-contract=off: every product and every sum rounds once, like the reference
+// executor of Ginkgo on a baseline x86-64 build (no FMA contraction).
+#include "kernels.hpp"
+
+namespace ogl {
+
+namespace {
+
+constexpr int N_WAVES = BLOCK / WAVE;
+constexpr int N_XCD = 8;  // MI355X: 8 XCDs, block b is observed on XCD b % 8 (speed only)
+
+// ------------------------------------------------------------------------------------------
+// reduction tree
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = WAVE / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// Every thread returns the block total.  `slot` = N_WAVES doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *slot)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    if (lane == 0) slot[wave] = v;
+    __syncthreads();
+    double s = slot[0];
+#pragma unroll
+    for (int w = 1; w < N_WAVES; ++w) s += slot[w];
+    __syncthreads();
+    return s;
+}
+
+__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int m, double *slot)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < m; i += BLOCK) s += part[i];
+    return block_sum(s, slot);
+}
+
+// XCD-aware chunk map: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md,
+// "Workgroup dispatch"), each XCD has a private 4 MiB L2.  Give every XCD one contiguous eighth
+// of the rows, walked in dispatch order, so the x-vector window a stencil row touches
+// (+-1, +-nx, +-nx*ny) is re-used inside ONE L2 instead of being fetched by up to 8.
+// Purely a speed choice: results do not depend on placement.
+__device__ __forceinline__ int xcd_chunk(int block, int n_chunks)
+{
+    const int per_xcd = (n_chunks + N_XCD - 1) / N_XCD;
+    return (block % N_XCD) * per_xcd + block / N_XCD;
+}
+inline int xcd_grid(int n_chunks) { return ((n_chunks + N_XCD - 1) / N_XCD) * N_XCD; }
+
+// ------------------------------------------------------------------------------------------
+// CSR-stream SpMV (K2).  A workgroup streams its chunk's non-zeros with 16-byte loads
+// (2 x double2 values + 1 x int4 columns per lane and step, 1 KiB per wave instruction),
+// gathers x (served by L2 / Infinity Cache), parks the products in LDS, and then every thread
+// adds up its own rows left to right -- the same order as the reference executor's row loop,
+// so y is bit-identical to it.
+// ------------------------------------------------------------------------------------------
+template <int MODE, bool FUSE_DOT>
+__global__ __launch_bounds__(BLOCK) void k_spmv_stream(
+    int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const int *__restrict__ cols,
+    const double *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ b,
+    double *__restrict__ y, double *__restrict__ dot_partials, const DevScalars *gate)
+{
+    __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = xcd_chunk(blockIdx.x, n_chunks);
+    if (chunk >= n_chunks) return;
+    const int tid = threadIdx.x;
+    const int r0 = chunk * CHUNK_ROWS;
+    const int r1 = min(r0 + CHUNK_ROWS, n_rows);
+    const int nz0 = row_ptrs[r0];
+    const int nz1 = row_ptrs[r1];
+
+    // this thread's rows
+    const int row = r0 + tid * ROWS_PER_THREAD;
+    int rs[ROWS_PER_THREAD + 1];
+#pragma unroll
+    for (int j = 0; j <= ROWS_PER_THREAD; ++j) rs[j] = row_ptrs[min(row + j, r1)];
+    double acc[ROWS_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_THREAD; ++j)
+        acc[j] = (MODE == SPMV_RESIDUAL && row + j < r1) ? b[row + j] : 0.0;
+
+    constexpr int GROUPS = SPMV_TILE / (BLOCK * 4);
+    for (int t0 = nz0 & ~3; t0 < nz1; t0 += SPMV_TILE) {
+        double2 va[GROUPS], vb[GROUPS];
+        int4 cc[GROUPS];
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const int e = t0 + (g * BLOCK + tid) * 4;
+            const int ec = e < nz1 ? e : t0;  // clamp: stay inside the (padded) arrays
+            va[g] = *reinterpret_cast<const double2 *>(vals + ec);
+            vb[g] = *reinterpret_cast<const double2 *>(vals + ec + 2);
+            cc[g] = *reinterpret_cast<const int4 *>(cols + ec);
+        }
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const double x0 = x[cc[g].x], x1 = x[cc[g].y], x2 = x[cc[g].z], x3 = x[cc[g].w];
+            double2 p0, p1;
+            p0.x = va[g].x * x0;
+            p0.y = va[g].y * x1;
+            p1.x = vb[g].x * x2;
+            p1.y = vb[g].y * x3;
+            const int le = (g * BLOCK + tid) * 4;
+            *reinterpret_cast<double2 *>(prod + le) = p0;
+            *reinterpret_cast<double2 *>(prod + le + 2) = p1;
+        }
+        __syncthreads();
+        const int t1 = t0 + SPMV_TILE;
+#pragma unroll
+        for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+            const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
+            for (int k = kb; k < ke; ++k) {
+                if (MODE == SPMV_RESIDUAL)
+                    acc[j] -= prod[k - t0];
+                else
+                    acc[j] += prod[k - t0];
+            }
+        }
+        __syncthreads();
+    }
+
+    double d = 0.0;
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+        if (row + j < r1) {
+            y[row + j] = acc[j];
+            if (FUSE_DOT) d += x[row + j] * acc[j];
+        }
+    }
+    if (FUSE_DOT) {
+        const double s = block_sum(d, slot);
+        if (tid == 0) dot_partials[chunk] = s;
+    }
+}
+
+// y[row] (+/-)= A_non_local(row,:) * recv, continuing the accumulator the local kernel stored.
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_spmv_non_local(int n_boundary,
+                                                          const int *__restrict__ boundary_rows,
+                                                          const int *__restrict__ entry_ptrs,
+                                                          const int *__restrict__ cols,
+                                                          const double *__restrict__ vals,
+                                                          const double *__restrict__ recv,
+                                                          double *__restrict__ y,
+                                                          const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_boundary) return;
+    const int row = boundary_rows[i];
+    double acc = y[row];
+    for (int k = entry_ptrs[i]; k < entry_ptrs[i + 1]; ++k) {
+        const double t = vals[k] * recv[cols[k]];
+        acc = (MODE == SPMV_RESIDUAL) ? acc - t : acc + t;
+    }
+    y[row] = acc;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pack(int n_send, const int *__restrict__ send_idxs,
+                                                const double *__restrict__ x,
+                                                double *__restrict__ send, const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n_send) send[i] = x[send_idxs[i]];
+}
+
+// ------------------------------------------------------------------------------------------
+// coefficient permutation (K9) and scalar Jacobi generate (K8)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_gather_coeffs(int nnz, const int *__restrict__ map,
+                                                         const double *__restrict__ src,
+                                                         double *__restrict__ out)
+{
+    const int e = (blockIdx.x * BLOCK + threadIdx.x) * 4;
+    if (e + 3 < nnz) {
+        const int4 m = *reinterpret_cast<const int4 *>(map + e);
+        double2 a, c;
+        a.x = src[m.x];
+        a.y = src[m.y];
+        c.x = src[m.z];
+        c.y = src[m.w];
+        *reinterpret_cast<double2 *>(out + e) = a;
+        *reinterpret_cast<double2 *>(out + e + 2) = c;
+    } else {
+        for (int k = e; k < nnz; ++k) out[k] = src[map[k]];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_jacobi_generate(int n_rows,
+                                                           const int *__restrict__ row_ptrs,
+                                                           const int *__restrict__ cols,
+                                                           const double *__restrict__ vals,
+                                                           double *__restrict__ inv_diag)
+{
+    const int row = blockIdx.x * BLOCK + threadIdx.x;
+    if (row >= n_rows) return;
+    double d = 0.0;
+    for (int k = row_ptrs[row]; k < row_ptrs[row + 1]; ++k)
+        if (cols[k] == row) {
+            d = vals[k];
+            break;
+        }
+    inv_diag[row] = 1.0 / d;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scale(int n, double *__restrict__ v, double f)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) v[i] = v[i] * f;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_xbar(int n, double *__restrict__ v,
+                                                     const DevScalars *s)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) v[i] = s->xbar;
+}
+
+// ------------------------------------------------------------------------------------------
+// chunk-shaped vector kernels: thread t of block `chunk` owns rows chunk*512 + 2t, +1
+// ------------------------------------------------------------------------------------------
+struct RowPair {
+    int row;  // first row
+    int n;    // valid rows (0, 1 or 2)
+};
+__device__ __forceinline__ RowPair my_rows(int chunk, int n_rows)
+{
+    RowPair r;
+    r.row = chunk * CHUNK_ROWS + threadIdx.x * ROWS_PER_THREAD;
+    const int left = n_rows - r.row;
+    r.n = left >= ROWS_PER_THREAD ? ROWS_PER_THREAD : (left > 0 ? left : 0);
+    return r;
+}
+__device__ __forceinline__ double2 ld2(const double *__restrict__ p, const RowPair &r)
+{
+    double2 v;
+    if (r.n == 2) {
+        v = *reinterpret_cast<const double2 *>(p + r.row);
+    } else {
+        v.x = r.n == 1 ? p[r.row] : 0.0;
+        v.y = 0.0;
+    }
+    return v;
+}
+__device__ __forceinline__ void st2(double *__restrict__ p, const RowPair &r, double2 v)
+{
+    if (r.n == 2)
+        *reinterpret_cast<double2 *>(p + r.row) = v;
+    else if (r.n == 1)
+        p[r.row] = v.x;
+}
+static_assert(ROWS_PER_THREAD == 2, "vector kernels are written for two rows per thread");
+
+enum PartialOp { P_SUM = 0, P_DOT = 1, P_NORM1 = 2 };
+template <int OP>
+__global__ __launch_bounds__(BLOCK) void k_partials(int n, int n_chunks,
+                                                    const double *__restrict__ a,
+                                                    const double *__restrict__ b,
+                                                    double *__restrict__ part,
+                                                    const DevScalars *gate)
+{
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = blockIdx.x;
+    const RowPair r = my_rows(chunk, n);
+    const double2 va = ld2(a, r);
+    double d = 0.0;
+    if (OP == P_SUM) {
+        if (r.n > 0) d += va.x;
+        if (r.n > 1) d += va.y;
+    } else if (OP == P_NORM1) {
+        if (r.n > 0) d += fabs(va.x);
+        if (r.n > 1) d += fabs(va.y);
+    } else {
+        const double2 vb = ld2(b, r);
+        if (r.n > 0) d += va.x * vb.x;
+        if (r.n > 1) d += va.y * vb.y;
+    }
+    const double s = block_sum(d, slot);
+    if (threadIdx.x == 0) part[chunk] = s;
+    (void)n_chunks;
+}
+
+// StoppingCriterion.C:53-61: t = b - Axref ; e = |t - r| + |t|
+__global__ __launch_bounds__(BLOCK) void k_partials_normfactor(int n, const double *__restrict__ b,
+                                                               const double *__restrict__ w,
+                                                               const double *__restrict__ r,
+                                                               double *__restrict__ part)
+{
+    __shared__ double slot[N_WAVES];
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    const double2 vb = ld2(b, rp), vw = ld2(w, rp), vr = ld2(r, rp);
+    double d = 0.0;
+    if (rp.n > 0) {
+        const double t = vb.x - 1.0 * vw.x;
+        const double p2 = fabs(t);
+        d += fabs(fabs(t - 1.0 * vr.x) + 1.0 * p2);
+    }
+    if (rp.n > 1) {
+        const double t = vb.y - 1.0 * vw.y;
+        const double p2 = fabs(t);
+        d += fabs(fabs(t - 1.0 * vr.y) + 1.0 * p2);
+    }
+    const double s = block_sum(d, slot);
+    if (threadIdx.x == 0) part[chunk] = s;
+}
+
+// z = M^-1 r (scalar Jacobi: r * inv_diag; identity: r), rho partial = sum r z, norm partial = sum |r|
+__global__ __launch_bounds__(BLOCK) void k_cg_rho_norm(int n, const double *__restrict__ r,
+                                                       const double *__restrict__ inv_diag,
+                                                       double *__restrict__ part_rho,
+                                                       double *__restrict__ part_norm,
+                                                       const DevScalars *gate)
+{
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    const double2 vr = ld2(r, rp);
+    double2 vz = vr;
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        vz.x = vr.x * vi.x;
+        vz.y = vr.y * vi.y;
+    }
+    double d = 0.0, a = 0.0;
+    if (rp.n > 0) {
+        d += vr.x * vz.x;
+        a += fabs(vr.x);
+    }
+    if (rp.n > 1) {
+        d += vr.y * vz.y;
+        a += fabs(vr.y);
+    }
+    const double s0 = block_sum(d, slot);
+    const double s1 = block_sum(a, slot);
+    if (threadIdx.x == 0) {
+        part_rho[chunk] = s0;
+        part_norm[chunk] = s1;
+    }
+}
+
+// step_1: p = z + (rho / prev_rho) * p   (tmp = 0 when prev_rho == 0)
+__global__ __launch_bounds__(BLOCK) void k_cg_step1(int n, double *__restrict__ p,
+                                                    const double *__restrict__ r,
+                                                    const double *__restrict__ inv_diag,
+                                                    const DevScalars *s)
+{
+    if (s->stop) return;
+    const double rho = s->rho, prev = s->prev_rho;
+    const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 vz = ld2(r, rp);
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        vz.x = vz.x * vi.x;
+        vz.y = vz.y * vi.y;
+    }
+    double2 vp = ld2(p, rp);
+    vp.x = vz.x + tmp * vp.x;
+    vp.y = vz.y + tmp * vp.y;
+    st2(p, rp, vp);
+}
+
+// step_2: if (beta != 0) { t = rho / beta ; x += t p ; r -= t q } -- then the next turn's
+// z = M^-1 r, rho = r.z and sum|r| partials, fused so r is not re-read (K5+K6+K8).
+__global__ __launch_bounds__(BLOCK) void k_cg_step2(int n, double *__restrict__ x,
+                                                    double *__restrict__ r,
+                                                    const double *__restrict__ p,
+                                                    const double *__restrict__ q,
+                                                    const double *__restrict__ inv_diag,
+                                                    double *__restrict__ part_rho,
+                                                    double *__restrict__ part_norm,
+                                                    const DevScalars *s)
+{
+    __shared__ double slot[N_WAVES];
+    if (s->stop) return;
+    const double rho = s->rho, beta = s->beta;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vr = ld2(r, rp);
+    if (beta != 0.0) {
+        const double t = rho / beta;
+        double2 vx = ld2(x, rp);
+        const double2 vp = ld2(p, rp), vq = ld2(q, rp);
+        vx.x += t * vp.x;
+        vx.y += t * vp.y;
+        vr.x -= t * vq.x;
+        vr.y -= t * vq.y;
+        st2(x, rp, vx);
+        st2(r, rp, vr);
+    }
+    double2 vz = vr;
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        vz.x = vr.x * vi.x;
+        vz.y = vr.y * vi.y;
+    }
+    double d = 0.0, a = 0.0;
+    if (rp.n > 0) {
+        d += vr.x * vz.x;
+        a += fabs(vr.x);
+    }
+    if (rp.n > 1) {
+        d += vr.y * vz.y;
+        a += fabs(vr.y);
+    }
+    const double s0 = block_sum(d, slot);
+    const double s1 = block_sum(a, slot);
+    if (threadIdx.x == 0) {
+        part_rho[chunk] = s0;
+        part_norm[chunk] = s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// finalisers (one workgroup): reduce the per-chunk partials, then the scalar logic
+// ------------------------------------------------------------------------------------------
+
+// StoppingCriterion.C:71-151 on the device.  `norm` is sum|r| over all ranks.
+__device__ void criterion_check(DevScalars *s, const DevCriterion &c, double norm, double *history)
+{
+    const int iter = s->iter;
+    if (iter > 0 && iter < c.min_iter) {  // :77-81
+        s->iter = iter + 1;
+        return;
+    }
+    if (iter % c.frequency != 0) {  // :84-87
+        s->iter = iter + 1;
+        return;
+    }
+    s->n_evals += 1;
+    double res = norm;
+    if (iter == 0) s->init_res = res / s->norm_factor;  // :102-111 (norm_factor set before)
+    res /= s->norm_factor;                              // :113
+    if (c.export_res && history) history[iter] = res;   // :115-117
+    s->res = res;                                       // :119
+    bool stop = false;
+    if (iter >= c.max_iter) stop = true;                                  // :124
+    if (res < c.tolerance) stop = true;                                   // :128
+    if (c.rel_tol > 0 && res < c.rel_tol * s->init_res) stop = true;      // :132-136
+    s->iter = iter + 1;                                                   // :143
+    if (stop) s->stop = 1;
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(BLOCK) void k_finalize(DevScalars *s, FinArgs a)
+{
+    __shared__ double slot[N_WAVES];
+    if (PHASE != FIN_MEAN && PHASE != FIN_NORMFACTOR && PHASE != FIN_RAW && s->stop) return;
+    double v0 = 0.0, v1 = 0.0;
+    if (a.do_reduce) {
+        v0 = reduce_partials(a.part[0], a.n_part, slot);
+        if (a.n_sums > 1) v1 = reduce_partials(a.part[1], a.n_part, slot);
+        if (PHASE == FIN_MEAN) {
+            // distributed compute_mean [UPSTREAM]: local mean, weighted by n_local / n_global
+            v0 /= a.n_local;
+            v0 *= a.n_local / a.n_global;
+        }
+        if (threadIdx.x == 0) {
+            s->sums[0] = v0;
+            s->sums[1] = v1;
+        }
+    }
+    if (!a.do_logic || threadIdx.x != 0) return;
+    if (!a.do_reduce) {
+        v0 = s->sums[0];
+        v1 = s->sums[1];
+    }
+    if (PHASE == FIN_MEAN) {
+        s->xbar = v0;
+    } else if (PHASE == FIN_NORMFACTOR) {
+        s->norm_factor = v0 + 1.0e-15;  // + SMALL, StoppingCriterion.C:68
+    } else if (PHASE == FIN_CG_CHECK) {
+        s->prev_rho = s->rho;  // swap(prev_rho, rho) of the previous turn
+        s->rho = v0;
+        criterion_check(s, a.crit, v1, a.history);
+    } else if (PHASE == FIN_BETA) {
+        s->beta = v0;
+    }
+}
+
+__global__ void k_reset_scalars(DevScalars *s)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    DevScalars z{};
+    z.rho = 1.0;  // becomes prev_rho = 1 at the first check ([UPSTREAM] cg::initialize)
+    z.prev_rho = 1.0;
+    z.alpha = z.omega = z.gamma = z.beta = 1.0;
+    z.norm_factor = 1.0;  // StoppingCriterion.H:136
+    *s = z;
+}
+
+inline int blocks_for(int64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, const double *b,
+                 double *y, double *dot_partials, const DevScalars *gate)
+{
+    if (A.n_rows == 0) return;
+    const int nc = (int)n_chunks(A.n_rows);
+    const dim3 grid(xcd_grid(nc)), block(BLOCK);
+    if (mode == SPMV_RESIDUAL) {
+        hipLaunchKernelGGL((k_spmv_stream<SPMV_RESIDUAL, false>), grid, block, 0, st, A.n_rows, nc,
+                           A.row_ptrs, A.cols, A.vals, x, b, y, nullptr, gate);
+    } else if (dot_partials) {
+        hipLaunchKernelGGL((k_spmv_stream<SPMV_PLAIN, true>), grid, block, 0, st, A.n_rows, nc,
+                           A.row_ptrs, A.cols, A.vals, x, b, y, dot_partials, gate);
+    } else {
+        hipLaunchKernelGGL((k_spmv_stream<SPMV_PLAIN, false>), grid, block, 0, st, A.n_rows, nc,
+                           A.row_ptrs, A.cols, A.vals, x, b, y, nullptr, gate);
+    }
+}
+
+void launch_spmv_non_local(hipStream_t st, const DevHalo &H, int mode, const double *recv,
+                           double *y, const DevScalars *gate)
+{
+    if (H.n_boundary_rows == 0) return;
+    const dim3 grid(blocks_for(H.n_boundary_rows)), block(BLOCK);
+    if (mode == SPMV_RESIDUAL)
+        hipLaunchKernelGGL((k_spmv_non_local<SPMV_RESIDUAL>), grid, block, 0, st,
+                           H.n_boundary_rows, H.boundary_rows, H.entry_ptrs, H.cols, H.vals, recv,
+                           y, gate);
+    else
+        hipLaunchKernelGGL((k_spmv_non_local<SPMV_PLAIN>), grid, block, 0, st, H.n_boundary_rows,
+                           H.boundary_rows, H.entry_ptrs, H.cols, H.vals, recv, y, gate);
+}
+
+void launch_pack(hipStream_t st, const DevHalo &H, const double *x, double *send,
+                 const DevScalars *gate)
+{
+    if (H.n_send == 0) return;
+    hipLaunchKernelGGL(k_pack, dim3(blocks_for(H.n_send)), dim3(BLOCK), 0, st, H.n_send,
+                       H.send_idxs, x, send, gate);
+}
+
+void launch_gather_coeffs(hipStream_t st, int32_t nnz, const int32_t *ldu_mapping,
+                          const double *source, double *coeffs)
+{
+    if (nnz == 0) return;
+    hipLaunchKernelGGL(k_gather_coeffs, dim3(blocks_for(((int64_t)nnz + 3) / 4)), dim3(BLOCK), 0,
+                       st, nnz, ldu_mapping, source, coeffs);
+}
+
+void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag)
+{
+    if (A.n_rows == 0) return;
+    hipLaunchKernelGGL(k_jacobi_generate, dim3(blocks_for(A.n_rows)), dim3(BLOCK), 0, st, A.n_rows,
+                       A.row_ptrs, A.cols, A.vals, inv_diag);
+}
+
+void launch_scale(hipStream_t st, int32_t n, double *v, double factor)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_scale, dim3(blocks_for(n)), dim3(BLOCK), 0, st, n, v, factor);
+}
+
+void launch_fill_xbar(hipStream_t st, int32_t n, double *v, const DevScalars *s)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fill_xbar, dim3(blocks_for(n)), dim3(BLOCK), 0, st, n, v, s);
+}
+
+void launch_partials_sum(hipStream_t st, int32_t n, const double *a, double *part)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL((k_partials<P_SUM>), dim3(nc), dim3(BLOCK), 0, st, n, nc, a, nullptr, part,
+                       nullptr);
+}
+
+void launch_partials_dot(hipStream_t st, int32_t n, const double *a, const double *b, double *part,
+                         const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL((k_partials<P_DOT>), dim3(nc), dim3(BLOCK), 0, st, n, nc, a, b, part, gate);
+}
+
+void launch_partials_norm1(hipStream_t st, int32_t n, const double *a, double *part)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL((k_partials<P_NORM1>), dim3(nc), dim3(BLOCK), 0, st, n, nc, a, nullptr,
+                       part, nullptr);
+}
+
+void launch_partials_normfactor(hipStream_t st, int32_t n, const double *b, const double *w,
+                                const double *r, double *part)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_partials_normfactor, dim3(nc), dim3(BLOCK), 0, st, n, b, w, r, part);
+}
+
+void launch_cg_rho_norm(hipStream_t st, int32_t n, const double *r, const double *inv_diag,
+                        double *part_rho, double *part_norm, const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_cg_rho_norm, dim3(nc), dim3(BLOCK), 0, st, n, r, inv_diag, part_rho,
+                       part_norm, gate);
+}
+
+void launch_cg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *inv_diag,
+                     const DevScalars *s)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_cg_step1, dim3(nc), dim3(BLOCK), 0, st, n, p, r, inv_diag, s);
+}
+
+void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const double *p,
+                     const double *q, const double *inv_diag, double *part_rho, double *part_norm,
+                     const DevScalars *s)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_cg_step2, dim3(nc), dim3(BLOCK), 0, st, n, x, r, p, q, inv_diag, part_rho,
+                       part_norm, s);
+}
+
+void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
+{
+    const dim3 grid(1), block(BLOCK);
+    switch (phase) {
+    case FIN_MEAN:
+        hipLaunchKernelGGL((k_finalize<FIN_MEAN>), grid, block, 0, st, s, a);
+        break;
+    case FIN_NORMFACTOR:
+        hipLaunchKernelGGL((k_finalize<FIN_NORMFACTOR>), grid, block, 0, st, s, a);
+        break;
+    case FIN_CG_CHECK:
+        hipLaunchKernelGGL((k_finalize<FIN_CG_CHECK>), grid, block, 0, st, s, a);
+        break;
+    case FIN_BETA:
+        hipLaunchKernelGGL((k_finalize<FIN_BETA>), grid, block, 0, st, s, a);
+        break;
+    default:
+        hipLaunchKernelGGL((k_finalize<FIN_RAW>), grid, block, 0, st, s, a);
+        break;
+    }
+}
+
+void launch_reset_scalars(hipStream_t st, DevScalars *s)
+{
+    hipLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(64), 0, st, s);
+}
+
+}  // namespace ogl

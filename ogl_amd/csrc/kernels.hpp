@@ -1,0 +1,123 @@
+// kernels.hpp -- launchers of the hand-written gfx950 kernels (kernels.hip).
+// Everything the Krylov loop of the reference delegates to Ginkgo.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace ogl {
+
+// Solver scalars and criterion state, resident in device memory for the whole solve so that the
+// loop never synchronises with the host (the reference syncs D2H on every evaluated check,
+// StoppingCriterion.C:95-97).
+struct DevScalars {
+    double rho, prev_rho, beta;         // CG  ([UPSTREAM] gko::solver::Cg scalars)
+    double alpha, omega, gamma;         // BiCGStab extras
+    double norm_factor;                 // StoppingCriterion.H:136
+    double init_res, res;               // init_normalised_res_norm_, normalised_res_norm_
+    double xbar;                        // mean(x) for the norm factor (StoppingCriterion.C:17-19)
+    double sums[4];                     // rank-local sums staged for the all-reduce
+    int32_t iter;                       // iter_ : number of check_impl calls so far
+    int32_t stop;                       // criterion said stop; later kernels become no-ops
+    int32_t n_evals;                    // checks that evaluated the norm
+    int32_t stop_phase;                 // BiCGStab: 1 = stopped at the mid-step check (finalize x)
+};
+
+// OpenFOAMDistStoppingCriterion parameters (StoppingCriterion.H:32-72)
+struct DevCriterion {
+    double tolerance, rel_tol;
+    int32_t min_iter, max_iter, frequency, export_res;
+};
+
+// Persistent device CSR ("<field>_matrix", CsrMatrixWrapper.H:163-210) + halo part.
+struct DevCsr {
+    int32_t n_rows = 0;
+    int32_t nnz = 0;
+    const int32_t *row_ptrs = nullptr;  // [n_rows + 1]
+    const int32_t *cols = nullptr;      // [nnz + NNZ_PAD]
+    const double *vals = nullptr;       // [nnz + NNZ_PAD]
+};
+
+// Rows that own non-local entries, for "y += A_non_local * recv" (distributed::Matrix::apply).
+struct DevHalo {
+    int32_t n_boundary_rows = 0;            // distinct rows with non-local entries
+    const int32_t *boundary_rows = nullptr; // [n_boundary_rows]
+    const int32_t *entry_ptrs = nullptr;    // [n_boundary_rows + 1] into cols/vals
+    const int32_t *cols = nullptr;          // position in the receive buffer
+    const double *vals = nullptr;           // -bouCoeffs, row-sorted (HostMatrix.C:708-732)
+    int32_t n_send = 0;
+    const int32_t *send_idxs = nullptr;     // rows gathered into the send buffer
+};
+
+enum SpmvMode { SPMV_PLAIN = 0, SPMV_RESIDUAL = 1 };
+
+// y = A x (PLAIN) or y = b - A x (RESIDUAL: accumulator starts at b_i and subtracts the products
+// in stored order, which is what Ginkgo's advanced apply with alpha=-1, beta=1 evaluates).
+// dot_partials != nullptr: also one partial of sum_i x_i*y_i per chunk of CHUNK_ROWS rows.
+// `gate` (may be nullptr): kernel returns immediately when gate->stop is set.
+void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, const double *b,
+                 double *y, double *dot_partials, const DevScalars *gate);
+
+// y[row] (+/-)= sum_k vals[k] * recv[cols[k]] over the boundary rows, continuing y's accumulator.
+void launch_spmv_non_local(hipStream_t st, const DevHalo &H, int mode, const double *recv,
+                           double *y, const DevScalars *gate);
+void launch_pack(hipStream_t st, const DevHalo &H, const double *x, double *send,
+                 const DevScalars *gate);
+
+// coeffs[i] = source[ldu_mapping[i]]   (row_gather, HostMatrix.C:700-703)
+void launch_gather_coeffs(hipStream_t st, int32_t nnz, const int32_t *ldu_mapping,
+                          const double *source, double *coeffs);
+// inv_diag[i] = 1 / A(i,i)   (Jacobi generate with max_block_size 1)
+void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag);
+
+// b *= scaling (lduLduBase.H:244-252)
+void launch_scale(hipStream_t st, int32_t n, double *v, double factor);
+// v[i] = s->xbar
+void launch_fill_xbar(hipStream_t st, int32_t n, double *v, const DevScalars *s);
+
+// --- partial sums, one per chunk ---
+void launch_partials_sum(hipStream_t st, int32_t n, const double *a, double *part);
+void launch_partials_dot(hipStream_t st, int32_t n, const double *a, const double *b, double *part,
+                         const DevScalars *gate);
+void launch_partials_norm1(hipStream_t st, int32_t n, const double *a, double *part);
+// part[c] = sum over chunk of |(b - w) - r| + |b - w|   (StoppingCriterion.C:53-61)
+void launch_partials_normfactor(hipStream_t st, int32_t n, const double *b, const double *w,
+                                const double *r, double *part);
+
+// --- CG steps ([UPSTREAM] cg::initialize / step_1 / step_2) ---
+// partials of rho = sum r_i z_i (z = r * inv_diag, or r when inv_diag == nullptr) and sum |r_i|
+void launch_cg_rho_norm(hipStream_t st, int32_t n, const double *r, const double *inv_diag,
+                        double *part_rho, double *part_norm, const DevScalars *gate);
+// p = z + (rho / prev_rho) p
+void launch_cg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *inv_diag,
+                     const DevScalars *s);
+// x += (rho/beta) p ; r -= (rho/beta) q ; then the partials of the next rho and sum |r|
+void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const double *p,
+                     const double *q, const double *inv_diag, double *part_rho, double *part_norm,
+                     const DevScalars *s);
+
+// --- single-workgroup finalisers: reduce per-chunk partials, then scalar logic -------------
+// phases: what the scalar logic does with the reduced sums.
+enum FinPhase {
+    FIN_MEAN = 0,        // xbar = sum/n * n/global_n (all-reduced)        StoppingCriterion.C:17-19
+    FIN_NORMFACTOR = 1,  // norm_factor = sum + SMALL                      StoppingCriterion.C:62-68
+    FIN_CG_CHECK = 2,    // rho <- sum0, criterion check on sum1           StoppingCriterion.C:71-151
+    FIN_BETA = 3,        // beta <- sum0
+    FIN_RAW = 4          // sums[] only (test / reduce entry point)
+};
+struct FinArgs {
+    const double *part[2] = {nullptr, nullptr};
+    int32_t n_part = 0;     // entries per partial array
+    int32_t n_sums = 1;     // 1 or 2
+    int32_t do_reduce = 1;  // reduce partials -> s->sums
+    int32_t do_logic = 1;   // scalar logic from s->sums (after the all-reduce when multi-rank)
+    double n_local = 0, n_global = 0;  // FIN_MEAN
+    DevCriterion crit{};
+    double *history = nullptr;
+};
+void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a);
+
+// cg::initialize scalars: rho = 0? (unused), prev_rho = 1, iter = 0, stop = 0, norm_factor = 1
+void launch_reset_scalars(hipStream_t st, DevScalars *s);
+
+}  // namespace ogl

@@ -1,0 +1,650 @@
+// solver.cpp -- see solver.hpp.  Citations: reference tree (hpsim/OGL @ 2024-10-16).
+#include "solver.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+
+using namespace ogl;
+
+namespace {
+
+double now_ms()
+{
+    using clk = std::chrono::steady_clock;
+    return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
+}
+
+double *sums_ptr(DevScalars *s)
+{
+    return reinterpret_cast<double *>(reinterpret_cast<char *>(s) + offsetof(DevScalars, sums));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Stager
+// ------------------------------------------------------------------------------------------
+Stager::~Stager()
+{
+    for (int i = 0; i < 2; ++i) {
+        if (pin_[i]) (void)hipHostFree(pin_[i]);
+        if (ev_[i]) (void)hipEventDestroy(ev_[i]);
+    }
+}
+
+int Stager::init(size_t chunk_bytes)
+{
+    if (chunk_) return OGL_OK;
+    for (int i = 0; i < 2; ++i) {
+        OGL_HIP_CHECK(hipHostMalloc(&pin_[i], chunk_bytes, 0));
+        OGL_HIP_CHECK(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
+    }
+    chunk_ = chunk_bytes;
+    return OGL_OK;
+}
+
+int Stager::h2d(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    const char *s = static_cast<const char *>(src);
+    char *d = static_cast<char *>(dst);
+    for (size_t off = 0; off < bytes; off += chunk_) {
+        const size_t len = std::min(chunk_, bytes - off);
+        const int k = next_;
+        next_ ^= 1;
+        if (busy_[k]) OGL_HIP_CHECK(hipEventSynchronize(ev_[k]));
+        std::memcpy(pin_[k], s + off, len);  // the borrowed host array is free again after this
+        OGL_HIP_CHECK(hipMemcpyAsync(d + off, pin_[k], len, hipMemcpyHostToDevice, st));
+        OGL_HIP_CHECK(hipEventRecord(ev_[k], st));
+        busy_[k] = true;
+    }
+    return OGL_OK;
+}
+
+int Stager::d2h(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+    const char *s = static_cast<const char *>(src);
+    char *d = static_cast<char *>(dst);
+    // two chunks in flight: copy chunk i+1 over PCIe while chunk i is memcpy'd out
+    size_t off_prev = 0, len_prev = 0;
+    int k_prev = -1;
+    for (size_t off = 0; off < bytes || k_prev >= 0; off += chunk_) {
+        int k = -1;
+        size_t len = 0;
+        if (off < bytes) {
+            len = std::min(chunk_, bytes - off);
+            k = next_;
+            next_ ^= 1;
+            if (busy_[k]) OGL_HIP_CHECK(hipEventSynchronize(ev_[k]));
+            OGL_HIP_CHECK(hipMemcpyAsync(pin_[k], s + off, len, hipMemcpyDeviceToHost, st));
+            OGL_HIP_CHECK(hipEventRecord(ev_[k], st));
+            busy_[k] = true;
+        }
+        if (k_prev >= 0) {
+            OGL_HIP_CHECK(hipEventSynchronize(ev_[k_prev]));
+            std::memcpy(d + off_prev, pin_[k_prev], len_prev);
+            busy_[k_prev] = false;
+        }
+        k_prev = k;
+        off_prev = off;
+        len_prev = len;
+    }
+    return OGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// registry / solver lifetime
+// ------------------------------------------------------------------------------------------
+ogl_registry::~ogl_registry()
+{
+    if (device >= 0) (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    solvers.clear();
+    comm.reset();
+    cached_precond.release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+ogl_solver::~ogl_solver()
+{
+    if (h_scal) (void)hipHostFree(h_scal);
+    for (auto &e : poll_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : prof_ev)
+        if (e) (void)hipEventDestroy(e);
+}
+
+double ogl_solver::prop(const std::string &key, double dflt) const
+{
+    auto it = props.find(key);
+    return it == props.end() ? dflt : it->second;
+}
+
+DevCsr ogl_solver::csr() const
+{
+    DevCsr A;
+    A.n_rows = pat.n_rows;
+    A.nnz = pat.local_nnz;
+    A.row_ptrs = d_row_ptrs.p;
+    A.cols = d_cols.p;
+    A.vals = d_vals.p;
+    return A;
+}
+
+DevHalo ogl_solver::halo() const
+{
+    DevHalo H;
+    H.n_boundary_rows = (int32_t)boundary_rows.size();
+    H.boundary_rows = d_boundary_rows.p;
+    H.entry_ptrs = d_boundary_ptrs.p;
+    H.cols = d_nl_cols.p;
+    H.vals = d_nl_vals.p;
+    H.n_send = (int32_t)pat.send_idxs.size();
+    H.send_idxs = d_send_idxs.p;
+    return H;
+}
+
+int ogl_solver::upload_vec(DevBuf<double> &dst, const double *src)
+{
+    const size_t n = (size_t)pat.n_rows;
+    if (n == 0) return OGL_OK;
+    if (!src) {
+        OGL_HIP_CHECK(hipMemsetAsync(dst.p, 0, n * sizeof(double), reg->stream));
+        return OGL_OK;
+    }
+    return reg->stager.h2d(dst.p, src, n * sizeof(double), reg->stream);
+}
+
+int ogl_solver::ensure_vectors()
+{
+    hipStream_t st = reg->stream;
+    // +2 so that a trailing double2 access of the last (odd) row stays inside the allocation
+    const size_t n = (size_t)pat.n_rows + 2;
+    const size_t nc = (size_t)n_chunks(pat.n_rows) + 1;
+    OGL_TRY(d_x.alloc(n, st));
+    OGL_TRY(d_b.alloc(n, st));
+    OGL_TRY(d_r.alloc(n, st));
+    OGL_TRY(d_p.alloc(n, st));
+    OGL_TRY(d_q.alloc(n, st));
+    OGL_TRY(d_w.alloc(n, st));
+    OGL_TRY(d_part0.alloc(nc, st));
+    OGL_TRY(d_part1.alloc(nc, st));
+    OGL_TRY(d_scal.alloc(1, st));
+    if (!h_scal) {
+        OGL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 2 * sizeof(DevScalars), 0));
+        for (auto &e : poll_ev) OGL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return OGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// HostMatrixWrapper: pattern once, coefficients every call (HostMatrix.C:15-96)
+// ------------------------------------------------------------------------------------------
+int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
+{
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    hipStream_t st = reg->stream;
+    const double t0 = now_ms();
+    const bool first = !have_pattern || !same_shape(ldu, pat);
+    if (first) {  // :79-87
+        HostPattern np;
+        OGL_TRY(build_host_pattern(ldu, np));
+        pat = std::move(np);
+        have_pattern = true;
+        matrix_set = false;
+        x_resident = b_resident = false;
+        const size_t nnz = (size_t)pat.local_nnz;
+        OGL_TRY(d_row_ptrs.alloc((size_t)pat.n_rows + 1, st));
+        OGL_TRY(d_cols.alloc(nnz + NNZ_PAD, st));
+        OGL_TRY(d_vals.alloc(nnz + NNZ_PAD, st));
+        OGL_TRY(d_ldu_mapping.alloc(nnz + NNZ_PAD, st));
+        OGL_TRY(d_source.alloc((size_t)pat.source_len() + NNZ_PAD, st));
+        OGL_TRY(reg->stager.h2d(d_row_ptrs.p, pat.row_ptrs.data(),
+                                pat.row_ptrs.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_cols.p, pat.cols.data(), nnz * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_ldu_mapping.p, pat.ldu_mapping.data(), nnz * sizeof(int32_t), st));
+
+        // halo: rows owning non-local entries (row-sorted triplets -> one run per row)
+        boundary_rows.clear();
+        boundary_ptrs.clear();
+        for (int32_t e = 0; e < pat.non_local_nnz; ++e) {
+            if (e == 0 || pat.nl_rows[e] != pat.nl_rows[e - 1]) {
+                boundary_rows.push_back(pat.nl_rows[e]);
+                boundary_ptrs.push_back(e);
+            }
+        }
+        boundary_ptrs.push_back(pat.non_local_nnz);
+        const size_t hn = (size_t)pat.non_local_nnz;
+        OGL_TRY(d_boundary_rows.alloc(boundary_rows.size(), st));
+        OGL_TRY(d_boundary_ptrs.alloc(boundary_ptrs.size(), st));
+        OGL_TRY(d_nl_cols.alloc(hn, st));
+        OGL_TRY(d_nl_vals.alloc(hn, st));
+        OGL_TRY(d_send_idxs.alloc(pat.send_idxs.size(), st));
+        OGL_TRY(d_send.alloc(pat.send_idxs.size(), st));
+        OGL_TRY(d_recv.alloc(hn, st));
+        if (hn) {
+            OGL_TRY(reg->stager.h2d(d_boundary_rows.p, boundary_rows.data(),
+                                    boundary_rows.size() * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(d_boundary_ptrs.p, boundary_ptrs.data(),
+                                    boundary_ptrs.size() * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(d_nl_cols.p, pat.nl_cols.data(), hn * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(d_send_idxs.p, pat.send_idxs.data(),
+                                    pat.send_idxs.size() * sizeof(int32_t), st));
+        }
+        neighbours.assign(pat.target_ids.begin(), pat.target_ids.end());
+        counts.assign(pat.target_sizes.begin(), pat.target_sizes.end());
+        if (!neighbours.empty() && !reg->comm->multi())
+            return fail(OGL_ERR_STATE,
+                        "matrix has processor interfaces but the registry has no communicator");
+        // the receive side is assumed to mirror the send side (Partition.H:66-67)
+        if ((size_t)pat.non_local_nnz != pat.send_idxs.size())
+            return fail(OGL_ERR_INVALID, "send/receive sizes differ");
+        OGL_TRY(ensure_vectors());
+    }
+
+    // ---- coefficients (update_local_matrix_data :592-705) ----
+    // MatrixInitFunctor::update only overwrites the matrix values when updateSysMatrix is set
+    // (CsrMatrixWrapper.H:259); the fresh coefficients have no other consumer, so the transfer
+    // is skipped altogether in that case.
+    if (!matrix_set || cfg.update_sys_matrix || cfg.regenerate) {
+        const int32_t N = pat.n_rows, F = pat.upper_nnz;
+        const size_t nnz = (size_t)pat.local_nnz;
+        std::vector<double> iface;
+        if (pat.local_iface_nnz) {
+            iface.resize(pat.local_iface_nnz);
+            collect_interface_coeffs(ldu, true, iface.data());
+        }
+        if (cfg.reorder_on_host) {  // :608-633, scaling applied by the host update functions
+            std::vector<double> sorted(nnz);
+            if (pat.local_iface_nnz) {
+                if (pat.symmetric)
+                    ogl_host_symmetric_update_w_interface(pat.local_nnz, N, F, pat.ldu_mapping.data(),
+                                                          cfg.scaling, ldu.diag, ldu.upper,
+                                                          iface.data(), sorted.data());
+                else
+                    ogl_host_non_symmetric_update_w_interface(
+                        pat.local_nnz, N, F, pat.ldu_mapping.data(), cfg.scaling, ldu.diag,
+                        ldu.upper, ldu.lower, iface.data(), sorted.data());
+            } else if (pat.symmetric) {
+                ogl_host_symmetric_update(pat.local_nnz, F, pat.ldu_mapping.data(), cfg.scaling,
+                                          ldu.diag, ldu.upper, sorted.data());
+            } else {
+                ogl_host_non_symmetric_update(pat.local_nnz, F, pat.ldu_mapping.data(), cfg.scaling,
+                                              ldu.diag, ldu.upper, ldu.lower, sorted.data());
+            }
+            OGL_TRY(reg->stager.h2d(d_vals.p, sorted.data(), nnz * sizeof(double), st));
+        } else {  // :634-704 -- H2D into the unsorted slots, then the device permutation (K9)
+            double *src = d_source.p;
+            OGL_TRY(reg->stager.h2d(src, ldu.upper, (size_t)F * sizeof(double), st));          // :644-650
+            if (!pat.symmetric)
+                OGL_TRY(reg->stager.h2d(src + F, ldu.lower, (size_t)F * sizeof(double), st));  // :653-660
+            OGL_TRY(reg->stager.h2d(src + pat.diag_start(), ldu.diag, (size_t)N * sizeof(double),
+                                    st));                                                     // :663-669
+            if (pat.local_iface_nnz)
+                OGL_TRY(reg->stager.h2d(src + pat.diag_start() + N, iface.data(),
+                                        iface.size() * sizeof(double), st));                  // :672-682
+            launch_gather_coeffs(st, pat.local_nnz, d_ldu_mapping.p, src, d_vals.p);          // :700-703
+        }
+        // ---- non-local coefficients (:708-732): tiny, permuted on the host ----
+        if (pat.non_local_nnz) {
+            std::vector<double> cc(pat.non_local_nnz);
+            collect_interface_coeffs(ldu, false, cc.data());
+            h_nl_vals.resize(pat.non_local_nnz);
+            for (int32_t e = 0; e < pat.non_local_nnz; ++e) h_nl_vals[e] = cc[pat.nl_ldu_mapping[e]];
+            OGL_TRY(reg->stager.h2d(d_nl_vals.p, h_nl_vals.data(),
+                                    h_nl_vals.size() * sizeof(double), st));
+        }
+        matrix_set = true;
+    }
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    t_update_matrix_ms = now_ms() - t0;
+    return OGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Preconditioner::init_preconditioner (Preconditioner.H:353-431) with its caching rules:
+//   * nothing stored yet      -> generate, store, counter := caching
+//   * stored and counter > 0  -> counter -= 1, use the STORED one
+//   * stored and counter == 0 -> counter := caching, generate a fresh one for this solve only;
+//                                the stored object is not replaced (:411-413)
+// The store is registry-wide (one key for all fields, :357), as in the reference.
+// ------------------------------------------------------------------------------------------
+int ogl_solver::init_preconditioner()
+{
+    precond = nullptr;
+    if (cfg.preconditioner == OGL_PRECOND_NONE) return OGL_OK;  // :342
+    if (cfg.preconditioner != OGL_PRECOND_BJ)
+        return fail(OGL_ERR_UNSUPPORTED, "preconditioner kind %d is not built", cfg.preconditioner);
+    if (cfg.max_block_size != 1)
+        return fail(OGL_ERR_UNSUPPORTED, "BJ maxBlockSize %d: only the scalar case is built",
+                    cfg.max_block_size);
+    hipStream_t st = reg->stream;
+    const size_t n = (size_t)pat.n_rows + 2;
+    const int cache = (int)prop("preconditionerCaching", 0);
+    const bool stored = reg->has_cached_precond && reg->cached_precond.n == n;
+    if (stored && cache > 0) {
+        props["preconditionerCaching"] = cache - 1;
+        precond = reg->cached_precond.p;
+        return OGL_OK;
+    }
+    props["preconditionerCaching"] = cfg.caching;
+    if (!stored) {
+        OGL_TRY(reg->cached_precond.alloc(n, st));
+        launch_jacobi_generate(st, csr(), reg->cached_precond.p);
+        reg->has_cached_precond = true;
+        precond = reg->cached_precond.p;
+    } else {
+        OGL_TRY(d_inv_diag.alloc(n, st));
+        launch_jacobi_generate(st, csr(), d_inv_diag.p);
+        precond = d_inv_diag.p;
+    }
+    return OGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// distributed::Matrix::apply: y = A_local x (+ dot partials), then y += A_non_local recv
+// ------------------------------------------------------------------------------------------
+int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y, double *dot_part,
+                          const DevScalars *gate)
+{
+    hipStream_t st = reg->stream;
+    const bool has_halo = pat.non_local_nnz > 0;
+    if (has_halo) {
+        launch_pack(st, halo(), x, d_send.p, gate);
+        OGL_TRY(reg->comm->exchange(d_send.p, d_recv.p, neighbours, counts, st));
+    }
+    launch_spmv(st, csr(), mode, x, b, y, has_halo ? nullptr : dot_part, gate);
+    if (has_halo) {
+        launch_spmv_non_local(st, halo(), mode, d_recv.p, y, gate);
+        if (dot_part) launch_partials_dot(st, pat.n_rows, x, y, dot_part, gate);
+    }
+    return OGL_OK;
+}
+
+int ogl_solver::finalize(int phase, FinArgs &a)
+{
+    hipStream_t st = reg->stream;
+    if (!reg->comm->multi()) {
+        a.do_reduce = 1;
+        a.do_logic = 1;
+        launch_finalize(st, phase, d_scal.p, a);
+        return OGL_OK;
+    }
+    a.do_reduce = 1;
+    a.do_logic = 0;
+    launch_finalize(st, phase, d_scal.p, a);
+    OGL_TRY(reg->comm->allreduce(sums_ptr(d_scal.p), a.n_sums, st));
+    a.do_reduce = 0;
+    a.do_logic = 1;
+    launch_finalize(st, phase, d_scal.p, a);
+    return OGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// GKOCG: gko::solver::Cg step order ([UPSTREAM]) with the OpenFOAM criterion
+// evaluated on the device.  Per turn:
+//   (z = M^-1 r, rho = r.z, sum|r|)  -> check -> p = z + (rho/prev_rho) p -> q = A p, beta = p.q
+//   -> x += (rho/beta) p, r -= (rho/beta) q
+// The host only enqueues; it looks at the stop flag one batch late, and kernels enqueued after
+// the stop are no-ops, so x, r and the counters are exactly those of the stopping turn.
+// ------------------------------------------------------------------------------------------
+int ogl_solver::run_cg(ogl_perf *perf)
+{
+    hipStream_t st = reg->stream;
+    const int n = pat.n_rows;
+    DevScalars *s = d_scal.p;
+    const int nc = (int)n_chunks(n);
+
+    // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
+    const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
+    const int prev_iters = (int)prop(is_final ? "prevSolveIters_final" : "prevSolveIters", 1);
+    const double prev_cost = prop("_prev_solve", 0.0);
+    DevCriterion crit{};
+    crit.tolerance = cfg.tolerance;
+    crit.rel_tol = cfg.rel_tol;
+    crit.max_iter = cfg.max_iter;
+    crit.export_res = cfg.export_res;
+    ogl_host_adapt_criterion(&cfg, prev_iters, prev_cost, &crit.min_iter, &crit.frequency);
+    if (crit.frequency < 1) return fail(OGL_ERR_INVALID, "evalFrequency must be >= 1");
+    const int max_steps = crit.max_iter + crit.frequency + 1;
+    OGL_TRY(d_history.alloc((size_t)max_steps + 2, st));
+    if (cfg.export_res)
+        OGL_HIP_CHECK(hipMemsetAsync(d_history.p, 0, d_history.n * sizeof(double), st));
+
+    // profile_kernels: one event pair per in-loop SpMV
+    const int prof_cap = cfg.profile_kernels ? std::min(max_steps, 4096) : 0;
+    while ((int)prof_ev.size() < 2 * prof_cap) {
+        hipEvent_t e;
+        OGL_HIP_CHECK(hipEventCreate(&e));
+        prof_ev.push_back(e);
+    }
+    hipEvent_t ev_chk[2] = {nullptr, nullptr};
+    OGL_HIP_CHECK(hipEventCreate(&ev_chk[0]));
+    OGL_HIP_CHECK(hipEventCreate(&ev_chk[1]));
+
+    const double t_start = now_ms();
+    launch_reset_scalars(st, s);
+
+    FinArgs fa;
+    // norm factor, part 1: xbar = mean(x) (StoppingCriterion.C:17-19)
+    launch_partials_sum(st, n, d_x.p, d_part0.p);
+    fa = FinArgs{};
+    fa.part[0] = d_part0.p;
+    fa.n_part = nc;
+    fa.n_sums = 1;
+    fa.n_local = (double)n;
+    fa.n_global = (double)n;
+    if (reg->comm->multi()) {
+        // global row count (Partition.H:118-121), via the same device all-reduce
+        double nn = (double)n;
+        OGL_HIP_CHECK(hipMemcpyAsync(sums_ptr(s), &nn, sizeof(double), hipMemcpyHostToDevice, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        OGL_TRY(reg->comm->allreduce(sums_ptr(s), 1, st));
+        OGL_HIP_CHECK(hipMemcpyAsync(&nn, sums_ptr(s), sizeof(double), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        fa.n_global = nn;
+    }
+    OGL_TRY(finalize(FIN_MEAN, fa));
+    // Axref = A * (xbar 1) (:24-29) into q
+    launch_fill_xbar(st, n, d_w.p, s);
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_w.p, nullptr, d_q.p, nullptr, nullptr));
+    // r = b - A x  ([UPSTREAM] r = b; r = -1*A*x + 1*r)
+    OGL_TRY(dist_spmv(SPMV_RESIDUAL, d_x.p, d_b.p, d_r.p, nullptr, nullptr));
+    // norm factor, part 2 (:53-68)
+    launch_partials_normfactor(st, n, d_b.p, d_q.p, d_r.p, d_part0.p);
+    fa = FinArgs{};
+    fa.part[0] = d_part0.p;
+    fa.n_part = nc;
+    fa.n_sums = 1;
+    OGL_TRY(finalize(FIN_NORMFACTOR, fa));
+    // p = q = 0 ([UPSTREAM] cg::initialize); z is never materialised (z = r * inv_diag on the fly)
+    OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, (size_t)n * sizeof(double), st));
+
+    // turn 0: rho, sum|r|, check -- timed once as "time per residual norm calculation"
+    launch_cg_rho_norm(st, n, d_r.p, precond, d_part0.p, d_part1.p, s);
+    FinArgs chk{};
+    chk.part[0] = d_part0.p;
+    chk.part[1] = d_part1.p;
+    chk.n_part = nc;
+    chk.n_sums = 2;
+    chk.crit = crit;
+    chk.history = d_history.p;
+    OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
+    OGL_TRY(finalize(FIN_CG_CHECK, chk));
+    OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+
+    FinArgs fb{};
+    fb.part[0] = d_part0.p;
+    fb.n_part = nc;
+    fb.n_sums = 1;
+
+    int enq = 0;
+    auto enqueue_steps = [&](int count) -> int {
+        for (int i = 0; i < count; ++i, ++enq) {
+            launch_cg_step1(st, n, d_p.p, d_r.p, precond, s);
+            const bool prof = enq < prof_cap;
+            if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+            OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, d_part0.p, s));
+            if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+            OGL_TRY(finalize(FIN_BETA, fb));
+            launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, precond, d_part0.p, d_part1.p, s);
+            OGL_TRY(finalize(FIN_CG_CHECK, chk));
+        }
+        return OGL_OK;
+    };
+    auto poll_record = [&](int slot) -> int {
+        OGL_HIP_CHECK(hipMemcpyAsync(&h_scal[slot], s, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipEventRecord(poll_ev[slot], st));
+        return OGL_OK;
+    };
+
+    const int batch = 16;
+    OGL_TRY(enqueue_steps(std::min(batch, max_steps - enq)));
+    OGL_TRY(poll_record(0));
+    for (int k = 0;; ++k) {
+        const bool more = enq < max_steps;
+        if (more) {
+            OGL_TRY(enqueue_steps(std::min(batch, max_steps - enq)));
+            OGL_TRY(poll_record((k + 1) & 1));
+        }
+        OGL_HIP_CHECK(hipEventSynchronize(poll_ev[k & 1]));
+        if (h_scal[k & 1].stop) break;
+        if (!more) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
+    }
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    const double t_solve = now_ms() - t_start;
+
+    DevScalars fin;
+    OGL_HIP_CHECK(hipMemcpy(&fin, s, sizeof(fin), hipMemcpyDeviceToHost));
+    history.clear();
+    if (cfg.export_res) {
+        history.resize(fin.iter);
+        OGL_HIP_CHECK(hipMemcpy(history.data(), d_history.p, (size_t)fin.iter * sizeof(double),
+                                hipMemcpyDeviceToHost));
+    }
+    float chk_ms = 0.f;
+    OGL_HIP_CHECK(hipEventElapsedTime(&chk_ms, ev_chk[0], ev_chk[1]));
+    (void)hipEventDestroy(ev_chk[0]);
+    (void)hipEventDestroy(ev_chk[1]);
+
+    perf->initial_residual = fin.init_res;   // lduLduBase.H:283
+    perf->final_residual = fin.res;          // :284
+    perf->n_iterations = fin.iter;           // :285, GKOCG.H:105-108
+    perf->n_norm_evals = fin.n_evals;
+    perf->norm_factor = fin.norm_factor;
+    perf->t_solve_ms = t_solve;
+    const int steps_done = std::max(0, fin.iter - 1);
+    perf->spmv_avg_ms = 0;
+    perf->spmv_launches = 0;
+    if (prof_cap) {
+        double acc = 0;
+        const int m = std::min(steps_done, prof_cap);
+        for (int i = 0; i < m; ++i) {
+            float ms = 0.f;
+            OGL_HIP_CHECK(hipEventElapsedTime(&ms, prof_ev[2 * i], prof_ev[2 * i + 1]));
+            acc += ms;
+        }
+        perf->spmv_launches = m;
+        perf->spmv_avg_ms = m ? acc / m : 0.0;
+    }
+
+    // store_number_of_iterations + relative residual-evaluation cost (lduLduBase.H:286-293);
+    // both are stored as labels, i.e. truncated (common.C:75-76,117-123)
+    props[is_final ? "prevSolveIters_final" : "prevSolveIters"] = fin.iter;
+    const double time_per_iter = t_solve * 1e3 / std::max(fin.iter, 1);
+    const double res_norm_time = std::max(1e-3, (double)chk_ms * 1e3);
+    double rel_cost = time_per_iter / res_norm_time;
+    if (reg->comm->multi()) {  // broadcast from rank 0 (:291-292) so every rank adapts alike
+        double v = reg->comm->rank == 0 ? rel_cost : 0.0;
+        OGL_HIP_CHECK(hipMemcpy(sums_ptr(s), &v, sizeof(double), hipMemcpyHostToDevice));
+        OGL_TRY(reg->comm->allreduce(sums_ptr(s), 1, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        OGL_HIP_CHECK(hipMemcpy(&rel_cost, sums_ptr(s), sizeof(double), hipMemcpyDeviceToHost));
+    }
+    props["_prev_solve"] = std::floor(rel_cost);
+    return OGL_OK;
+}
+
+int ogl_solver::run_bicgstab(ogl_perf *)
+{
+    return fail(OGL_ERR_UNSUPPORTED, "GKOBiCGStab is not built yet");
+}
+
+// solver->apply(b, x) on the resident vectors (lduLduBase.H:254-276)
+int ogl_solver::apply_resident(ogl_perf *perf)
+{
+    if (!matrix_set) return fail(OGL_ERR_STATE, "solve before set_matrix");
+    if (!x_resident || !b_resident) return fail(OGL_ERR_STATE, "rhs/solution not resident");
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    ogl_perf local{};
+    if (!perf) perf = &local;
+    OGL_TRY(init_preconditioner());
+    switch (cfg.solver) {
+    case OGL_SOLVER_CG:
+        return run_cg(perf);
+    case OGL_SOLVER_BICGSTAB:
+        return run_bicgstab(perf);
+    default:
+        return fail(OGL_ERR_UNSUPPORTED, "solver kind %d is not built", cfg.solver);
+    }
+}
+
+// lduLduBase::solve_multi_gpu_impl (lduLduBase.H:189-308)
+int ogl_solver::solve(const double *source, double *psi, ogl_perf *perf)
+{
+    if (!matrix_set) return fail(OGL_ERR_STATE, "solve before set_matrix");
+    if (!source || !psi) return fail(OGL_ERR_INVALID, "source/psi is NULL");
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    hipStream_t st = reg->stream;
+    ogl_perf local{};
+    if (!perf) perf = &local;
+    *perf = ogl_perf{};
+    const double t0 = now_ms();
+    if (!b_resident || cfg.update_rhs) {  // :217-226
+        OGL_TRY(upload_vec(d_b, source));
+        b_resident = true;
+    }
+    if (!x_resident || cfg.update_init_guess) {  // :228-237
+        OGL_TRY(upload_vec(d_x, psi));
+        x_resident = true;
+    }
+    if (cfg.scaling != 1.0) launch_scale(st, pat.n_rows, d_b.p, cfg.scaling);  // :242-252
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    perf->t_upload_ms = now_ms() - t0;
+    perf->t_update_matrix_ms = t_update_matrix_ms;
+    OGL_TRY(apply_resident(perf));
+    const double t1 = now_ms();
+    OGL_TRY(reg->stager.d2h(psi, d_x.p, (size_t)pat.n_rows * sizeof(double), st));  // :278-279
+    perf->t_copy_back_ms = now_ms() - t1;
+    return OGL_OK;
+}
+
+// `repeats` in-loop SpMVs (q = A b, fused dot) timed with HIP events on the solver's stream
+int ogl_solver::time_spmv(int repeats, double *avg_ms)
+{
+    if (!matrix_set) return fail(OGL_ERR_STATE, "time_spmv before set_matrix");
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    hipStream_t st = reg->stream;
+    hipEvent_t e0, e1;
+    OGL_HIP_CHECK(hipEventCreate(&e0));
+    OGL_HIP_CHECK(hipEventCreate(&e1));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_b.p, nullptr, d_q.p, d_part0.p, nullptr));  // warm-up
+    OGL_HIP_CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < repeats; ++i) {
+        // alternate the input so consecutive launches do not read what the last one wrote
+        const double *x = (i & 1) ? d_r.p : d_b.p;
+        OGL_TRY(dist_spmv(SPMV_PLAIN, x, nullptr, d_q.p, d_part0.p, nullptr));
+    }
+    OGL_HIP_CHECK(hipEventRecord(e1, st));
+    OGL_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OGL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = repeats > 0 ? (double)ms / repeats : 0.0;
+    return OGL_OK;
+}

@@ -1,0 +1,151 @@
+// solver.hpp -- persistent per-(rank, field) device state and the Krylov drivers.
+// Re-implements the reference's L2-L4: DevicePersistent/*, HostMatrixWrapper's
+// device half, Preconditioner caching, StoppingCriterion policy and lduLduBase orchestration.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "comm.hpp"
+#include "common.hpp"
+#include "host_matrix.hpp"
+#include "kernels.hpp"
+
+namespace ogl {
+
+#define OGL_HIP_CHECK(expr)                                                                \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return ::ogl::fail(OGL_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+#define OGL_TRY(expr)                 \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != OGL_OK) return rc_; \
+    } while (0)
+
+// PersistentArray<T> (DevicePersistent/Array/Array.H:91-229): a named device array that lives as
+// long as its registry.
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    // (re)allocate `count` elements, zero-filled
+    int alloc(size_t count, hipStream_t st)
+    {
+        if (count == n && p) return OGL_OK;
+        release();
+        if (count == 0) return OGL_OK;
+        OGL_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        OGL_HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(T), st));
+        n = count;
+        return OGL_OK;
+    }
+};
+
+// Pinned double-buffered staging for pageable host arrays (K10/K12: "pinned async copies").
+class Stager {
+public:
+    ~Stager();
+    int init(size_t chunk_bytes);
+    int h2d(void *dst, const void *src, size_t bytes, hipStream_t st);
+    int d2h(void *dst, const void *src, size_t bytes, hipStream_t st);  // returns after completion
+
+private:
+    void *pin_[2] = {nullptr, nullptr};
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+    bool busy_[2] = {false, false};
+    size_t chunk_ = 0;
+    int next_ = 0;
+};
+
+}  // namespace ogl
+
+struct ogl_solver;
+
+// objectRegistry analogue (DevicePersistent/Base/Base.H:53-137) + ExecutorHandler
+struct ogl_registry {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::unique_ptr<ogl::Comm> comm;
+    std::map<std::string, std::unique_ptr<ogl_solver>> solvers;
+    ogl::Stager stager;
+    // "Cached_preconditinoner" (sic) -- one registry-wide slot (Preconditioner.H:357)
+    ogl::DevBuf<double> cached_precond;
+    bool has_cached_precond = false;
+    ~ogl_registry();
+};
+
+struct ogl_solver {
+    ogl_registry *reg = nullptr;
+    std::string field;
+    ogl_config cfg{};
+
+    // ---- HostMatrixWrapper state ----
+    ogl::HostPattern pat;
+    bool have_pattern = false;
+    bool matrix_set = false;
+    ogl::DevBuf<int32_t> d_row_ptrs, d_cols, d_ldu_mapping;  // "<field>_local_*"
+    ogl::DevBuf<double> d_vals;                              // "<field>_matrix" values
+    ogl::DevBuf<double> d_source;                            // unsorted [upper|lower|diag|iface]
+    // halo part
+    std::vector<int32_t> boundary_rows, boundary_ptrs;
+    ogl::DevBuf<int32_t> d_boundary_rows, d_boundary_ptrs, d_nl_cols, d_send_idxs;
+    ogl::DevBuf<double> d_nl_vals, d_send, d_recv;
+    std::vector<double> h_nl_vals;
+    std::vector<int> neighbours, counts;
+
+    // ---- vectors: "<field>_rhs", "<field>_solution" + Krylov work vectors ----
+    ogl::DevBuf<double> d_x, d_b, d_r, d_p, d_q, d_w, d_inv_diag;
+    ogl::DevBuf<double> d_v, d_s, d_t, d_y, d_z, d_rr;  // BiCGStab
+    ogl::DevBuf<double> d_part0, d_part1;
+    ogl::DevBuf<ogl::DevScalars> d_scal;
+    ogl::DevBuf<double> d_history;
+    ogl::DevScalars *h_scal = nullptr;  // pinned, 2 slots
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    bool x_resident = false, b_resident = false;
+    const double *precond = nullptr;  // device inverse diagonal in use, or nullptr (identity)
+
+    // ---- per-field properties (common/common.C:75-146) ----
+    std::map<std::string, double> props;
+
+    // ---- last solve ----
+    std::vector<double> history;
+    double t_update_matrix_ms = 0;
+    // profile_kernels
+    std::vector<hipEvent_t> prof_ev;
+
+    ~ogl_solver();
+
+    int set_matrix(const ogl_ldu_view &ldu);
+    int solve(const double *source, double *psi, ogl_perf *perf);
+    int apply_resident(ogl_perf *perf);
+    int upload_vec(ogl::DevBuf<double> &dst, const double *src);
+    int ensure_vectors();
+    int init_preconditioner();
+    int dist_spmv(int mode, const double *x, const double *b, double *y, double *dot_part,
+                  const ogl::DevScalars *gate);
+    int finalize(int phase, ogl::FinArgs &a);
+    int run_cg(ogl_perf *perf);
+    int run_bicgstab(ogl_perf *perf);
+    int time_spmv(int repeats, double *avg_ms);
+    ogl::DevCsr csr() const;
+    ogl::DevHalo halo() const;
+    double prop(const std::string &key, double dflt) const;
+};

@@ -412,8 +412,11 @@ void orc_set_reduction(int mode, orc_label chunk_rows) {
 }
 
 /* The fixed reduction tree of the HIP kernels (ogl_amd/csrc/kernels.hip, block_reduce):
- * 256 threads; thread t owns elements t, t+256, ... of the chunk, summed in order from 0;
- * 64-lane xor tree (offsets 32,16,8,4,2,1); the 4 wave sums are added left to right. */
+ * a chunk is chunk_rows consecutive rows handled by 256 threads; thread t owns the
+ * chunk_rows/256 consecutive rows starting at t*chunk_rows/256, summed in order from 0;
+ * 64-lane xor tree (offsets 32,16,8,4,2,1); the 4 wave sums are added left to right.  The
+ * per-chunk partials are then summed by one block: thread t takes partials t, t+256, ...
+ * in order, followed by the same tree. */
 #define ORC_BLOCK 256
 #define ORC_WAVE 64
 static orc_scalar block_tree(orc_scalar *acc /* [ORC_BLOCK] */) {
@@ -465,10 +468,11 @@ static orc_scalar reduce_terms(orc_label n, const orc_scalar *a, const orc_scala
     orc_scalar *part = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)(n_chunks ? n_chunks : 1));
     for (orc_label c = 0; c < n_chunks; ++c) {
         orc_scalar acc[ORC_BLOCK];
+        const orc_label rpt = R / ORC_BLOCK; /* consecutive rows owned by one thread */
         for (int t = 0; t < ORC_BLOCK; ++t) {
             orc_scalar s = 0.0;
-            for (orc_label j = t; j < R; j += ORC_BLOCK) {
-                const int64_t i = (int64_t)c * R + j;
+            for (orc_label j = 0; j < rpt; ++j) {
+                const int64_t i = (int64_t)c * R + (int64_t)t * rpt + j;
                 if (i < n) s += f(a, b, (orc_label)i);
             }
             acc[t] = s;
@@ -637,7 +641,10 @@ void orc_jacobi_generate_scalar(orc_label n, const orc_label *rowptr, const orc_
     for (orc_label row = 0; row < n; ++row) {
         orc_scalar d = 0.0;
         for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k)
-            if (cols[k] == row) d = vals[k];
+            if (cols[k] == row) {
+                d = vals[k]; /* first match, like Csr::extract_diagonal [UPSTREAM] */
+                break;
+            }
         inv_diag[row] = 1.0 / d;
     }
 }
