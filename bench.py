@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on synthetic input, one JSON line on rank 0.
+
+Workload (BASELINE.json configs[1]): 7-point Poisson lduMatrix on a 216^3 box per GPU
+(10,077,696 rows / 70,263,936 nnz), GKOCG + block-Jacobi (maxBlockSize 1), fp64 values + int32
+indices, persistent device CSR.  One "step" = one solver->apply(b, x) (what the reference times
+as delta_t_solve, lduLduBase.H:275-276) of a fixed number of CG iterations from x0 = 0, with the
+matrix, b and x already resident in HBM.
+
+  value     = CG iterations per second; at N GPUs the global box is 216 x 216 x (216 N), cut into
+              N z-slabs (weak scaling: 10M rows per GPU, halo exchange + scalar all-reduces over
+              RCCL), and value counts 10M-row block iterations: N * iterations / time.
+  roofline  = the in-loop CSR SpMV: algorithmic bytes 12 nnz + 20 N + 4 over the
+              kernel's mean duration, measured with HIP events on the solver's stream inside the
+              timed steps (profile_kernels=1), against 8 TB/s.
+  cpu_baseline = the oracle (sequential restatement, 1 core, "port") on the same matrix for a
+              bounded number of iterations; plus its OpenMP variant as `cpu_baseline_omp`.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+         --master-port 29500 bench.py --gpus 8 --steps 5 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBPS = 6290.0        # measured float4-copy ceiling, same guide
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=216, help="box edge per GPU (216 = configs[1])")
+    ap.add_argument("--iters", type=int, default=100, help="CG iterations per step")
+    ap.add_argument("--precond", default="BJ", choices=["BJ", "none"])
+    ap.add_argument("--cpu-iters", type=int, default=-1,
+                    help="oracle iterations for cpu_baseline (-1: sized for ~15 s, 0: skip)")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="do not event-time the in-loop SpMV (roofline then comes from a "
+                         "separate back-to-back SpMV loop)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        args.gpus = world
+
+    import numpy as np
+    import torch  # plumbing only: device sync, barrier, max-over-ranks
+    import torch.distributed as dist
+
+    from ogl_amd import capi, synthetic
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path in libogl_amd")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    n = args.n
+    case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
+    N, nnz = case.n_cells, case.nnz
+    # any smooth right-hand side will do for a fixed-iteration run; x0 = 0
+    b = synthetic.x_star(case.global_index, case.global_n) + 0.5
+
+    reg = capi.Registry(device_id=local_rank, hip_stream=torch.cuda.current_stream().cuda_stream)
+    if world > 1:
+        uid = [capi.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        reg.init_rccl(rank, world, uid[0])
+    precond = capi.PRECOND_BJ if args.precond == "BJ" else capi.PRECOND_NONE
+    cfg = capi.default_config(solver=capi.SOLVER_CG, preconditioner=precond, max_block_size=1,
+                              tolerance=0.0, rel_tol=0.0, max_iter=args.iters, min_iter=0,
+                              eval_frequency=1, adapt_min_iter=0, matrix_format=capi.FORMAT_CSR,
+                              export_res=0, profile_kernels=0 if args.no_profile else 1)
+    s = reg.solver("p", cfg)
+    t0 = time.perf_counter()
+    s.set_matrix(case)                       # pattern + H2D + device permutation (not timed below)
+    t_first_matrix = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    s.set_matrix(case)                       # values-only refresh, as every later time step
+    t_refresh_matrix = time.perf_counter() - t0
+    s.upload_rhs(b)
+    s.upload_solution(None)
+
+    def step():
+        s.upload_solution(None)              # x0 = 0, device memset
+        return s.apply_resident()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    perfs = [step() for _ in range(args.steps)]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    iters = sum(p.n_iterations - 1 for p in perfs)        # CG steps (checks - 1)
+    assert all(p.n_iterations == args.iters + 1 for p in perfs), [p.n_iterations for p in perfs]
+    value = world * iters / elapsed
+
+    # ---- roofline of the dominant kernel: the in-loop CSR SpMV -------------------------------
+    b_spmv = 12 * nnz + 20 * N + 4
+    if args.no_profile:
+        spmv_ms = s.time_spmv(100)
+        spmv_src = "100 back-to-back launches, HIP events"
+    else:
+        launches = sum(p.spmv_launches for p in perfs)
+        spmv_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in perfs) / max(1, launches)
+        spmv_src = f"{launches} in-loop launches of the timed steps, HIP event pairs"
+    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
+    b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
+    # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
+    t0 = time.perf_counter()
+    s.set_matrix(case)
+    _, p_e2e = s.solve(b, np.zeros_like(b))
+    t_e2e = time.perf_counter() - t0
+
+    out = {
+        "metric": "cg_iters_per_sec", "value": value, "unit": "iter/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix, GKOCG + "
+                        f"{'BJ(maxBlockSize 1)' if precond else 'no preconditioner'}, "
+                        "fp64/int32 persistent device CSR (BASELINE.json configs[1])",
+            "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
+            "parallelism": f"rows sharded into {world} z-slab(s), RCCL halo + all-reduce"
+                           if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "kernel": "k_spmv_stream<PLAIN, fused p.q>", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
+            "traffic": None, "algorithmic_bytes_per_launch": b_spmv,
+            "avg_kernel_ms": spmv_ms, "timing": spmv_src,
+        },
+        "cg_iteration": {
+            "algorithmic_bytes": b_cg, "ms": 1e3 * elapsed / max(1, iters),
+            "achieved_GBps": b_cg * iters / elapsed / 1e9,
+            "frac_of_peak": b_cg * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
+        },
+        "boundary": {
+            "first_set_matrix_s": t_first_matrix, "refresh_set_matrix_s": t_refresh_matrix,
+            "solve_incl_pcie_s": t_e2e,
+            "iters_per_sec_incl_pcie": (p_e2e.n_iterations - 1) / t_e2e,
+        },
+    }
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle on the same matrix ----------------------
+    if rank == 0 and world == 1 and args.cpu_iters != 0:
+        from oracle import oracle as orc
+        orc.build()
+        t0 = time.perf_counter()
+        rows, cols, perm = orc.init_local_sparsity(N, case.upper_addr, case.lower_addr, True)
+        vals = orc.update_local_matrix_data(case.diag, case.upper, None, [], perm)
+        rowptr = orc.rowptr_from_rows(N, rows)
+        A = orc.DistMatrix(rowptr, cols, vals)
+        inv = orc.jacobi_generate_scalar(rowptr, cols, vals) if precond else None
+        t_build = time.perf_counter() - t0
+        cpu_iters = args.cpu_iters
+        if cpu_iters < 0:                      # ~15 s of sequential work: probe with 2 iterations
+            t0 = time.perf_counter()
+            orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=2,
+                   export_res=False)
+            per_it = (time.perf_counter() - t0) / 3.0
+            cpu_iters = int(max(3, min(args.iters, 15.0 / max(per_it, 1e-6))))
+        t0 = time.perf_counter()
+        r = orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=cpu_iters,
+                   export_res=False)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": (r.n_iterations - 1) / t_cpu, "unit": "iter/s", "cores": 1, "kind": "port",
+            "sample": f"{r.n_iterations - 1} CG iterations of the same {n}^3 system, oracle "
+                      f"(sequential reference-executor restatement), {t_cpu:.1f} s "
+                      f"(+{t_build:.1f} s LDU->CSR)",
+        }
+        threads = orc.omp_max_threads()
+        omp_iters = min(args.iters, max(3, cpu_iters * min(threads, 8)))
+        t0 = time.perf_counter()
+        r = orc.cg_omp(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=omp_iters,
+                       export_res=False, threads=threads)
+        t_omp = time.perf_counter() - t0
+        out["cpu_baseline_omp"] = {
+            "value": (r.n_iterations - 1) / t_omp, "unit": "iter/s", "cores": threads,
+            "kind": "port", "sample": f"{r.n_iterations - 1} iterations, OpenMP variant, {t_omp:.1f} s",
+        }
+
+    reg.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
