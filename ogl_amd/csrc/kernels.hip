@@ -9,7 +9,8 @@
 //
 // Reductions are deterministic (no atomics): a chunk partial is
 //     thread sums (rows in order)  ->  64-lane xor tree (32,16,8,4,2,1)  ->  wave0+wave1+wave2+wave3
-// and the finaliser sums the partials with the same tree (thread t takes partials t, t+256, ...).
+// and the finaliser (one 1024-thread workgroup) sums the partials: thread t takes partials
+// t, t+1024, ... in order, xor tree per wave, then the 16 wave sums left to right.
 // oracle/ogl_oracle.c mirrors this tree in its BLOCKED mode so tests can compare bit for bit.
 //
 // Compiled with -ffp-contract=off: every product and every sum rounds once, like the reference
@@ -47,24 +48,71 @@ __device__ __forceinline__ double block_sum(double v, double *slot)
     return s;
 }
 
-__device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int m, double *slot)
+// Finaliser tree (one workgroup of FIN_BLOCK = 1024 threads = 16 wavefronts): thread t adds
+// partials t, t+1024, ... in that order, then the 64-lane xor tree, then the 16 wave sums left to
+// right.  The loads of a batch are issued together (they are independent) and only the adds stay
+// ordered, so a 10M-row vector (19,683 partials) costs about one memory latency.
+constexpr int FIN_BLOCK = 1024;
+constexpr int FIN_WAVES = FIN_BLOCK / WAVE;
+constexpr int FIN_BATCH = 8;
+
+__device__ __forceinline__ double fin_block_sum(double v, double *slot)
 {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < m; i += BLOCK) s += part[i];
-    return block_sum(s, slot);
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    if (lane == 0) slot[wave] = v;
+    __syncthreads();
+    double s = slot[0];
+#pragma unroll
+    for (int w = 1; w < FIN_WAVES; ++w) s += slot[w];
+    __syncthreads();
+    return s;
 }
 
-// XCD-aware chunk map: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md,
-// "Workgroup dispatch"), each XCD has a private 4 MiB L2.  Give every XCD one contiguous eighth
-// of the rows, walked in dispatch order, so the x-vector window a stencil row touches
-// (+-1, +-nx, +-nx*ny) is re-used inside ONE L2 instead of being fetched by up to 8.
-// Purely a speed choice: results do not depend on placement.
-__device__ __forceinline__ int xcd_chunk(int block, int n_chunks)
+// Reduces one or two partial arrays at once (loads of both in flight together).
+template <int K>
+__device__ __forceinline__ void reduce_partials(const double *const (&part)[2], int m, double *slot,
+                                                double (&out)[2])
 {
-    const int per_xcd = (n_chunks + N_XCD - 1) / N_XCD;
-    return (block % N_XCD) * per_xcd + block / N_XCD;
+    double s[2] = {0.0, 0.0};
+    for (int i0 = threadIdx.x; i0 < m; i0 += FIN_BLOCK * FIN_BATCH) {
+        double v[2][FIN_BATCH];
+#pragma unroll
+        for (int k = 0; k < FIN_BATCH; ++k) {
+            const int i = i0 + k * FIN_BLOCK;
+#pragma unroll
+            for (int a = 0; a < K; ++a) v[a][k] = i < m ? part[a][i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < FIN_BATCH; ++k)
+            if (i0 + k * FIN_BLOCK < m) {
+#pragma unroll
+                for (int a = 0; a < K; ++a) s[a] += v[a][k];
+            }
+    }
+    out[0] = fin_block_sum(s[0], slot);
+    out[1] = K > 1 ? fin_block_sum(s[1], slot) : 0.0;
 }
-inline int xcd_grid(int n_chunks) { return ((n_chunks + N_XCD - 1) / N_XCD) * N_XCD; }
+
+// XCD-aware chunk map.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md,
+// "Workgroup dispatch"); each XCD has a private 4 MiB L2.  Measured on the 216^3 case
+// (tools/spmv_tune.hip, profiles/spmv_tune_r01.txt):
+//   * one contiguous eighth of the rows per XCD  -> 208 us  (8 separate DRAM fronts)
+//   * plain chunk = block                        -> 193 us
+//   * groups of 4 consecutive chunks per XCD, all XCDs advancing on ONE front -> 190 us
+// so neighbouring rows (the +-1 / +-nx stencil legs) share an L2 while HBM still sees a single
+// streaming front.  Purely a speed choice: results do not depend on placement.
+constexpr int XCD_GROUP = 4;
+__device__ __forceinline__ int xcd_chunk(int block)
+{
+    const int slot = block / N_XCD, xcd = block % N_XCD;
+    return (slot / XCD_GROUP) * (N_XCD * XCD_GROUP) + xcd * XCD_GROUP + slot % XCD_GROUP;
+}
+inline int xcd_grid(int n_chunks)
+{
+    constexpr int Q = N_XCD * XCD_GROUP;
+    return ((n_chunks + Q - 1) / Q) * Q;
+}
 
 // ------------------------------------------------------------------------------------------
 // CSR-stream SpMV (K2).  A workgroup streams its chunk's non-zeros with 16-byte loads
@@ -82,7 +130,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
     __shared__ double slot[N_WAVES];
     if (gate && gate->stop) return;
-    const int chunk = xcd_chunk(blockIdx.x, n_chunks);
+    const int chunk = xcd_chunk(blockIdx.x);
     if (chunk >= n_chunks) return;
     const int tid = threadIdx.x;
     const int r0 = chunk * CHUNK_ROWS;
@@ -466,14 +514,20 @@ __device__ void criterion_check(DevScalars *s, const DevCriterion &c, double nor
 }
 
 template <int PHASE>
-__global__ __launch_bounds__(BLOCK) void k_finalize(DevScalars *s, FinArgs a)
+__global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a)
 {
-    __shared__ double slot[N_WAVES];
+    __shared__ double slot[FIN_WAVES];
     if (PHASE != FIN_MEAN && PHASE != FIN_NORMFACTOR && PHASE != FIN_RAW && s->stop) return;
     double v0 = 0.0, v1 = 0.0;
     if (a.do_reduce) {
-        v0 = reduce_partials(a.part[0], a.n_part, slot);
-        if (a.n_sums > 1) v1 = reduce_partials(a.part[1], a.n_part, slot);
+        const double *const parts[2] = {a.part[0], a.part[1]};
+        double r[2];
+        if (a.n_sums > 1)
+            reduce_partials<2>(parts, a.n_part, slot, r);
+        else
+            reduce_partials<1>(parts, a.n_part, slot, r);
+        v0 = r[0];
+        v1 = r[1];
         if (PHASE == FIN_MEAN) {
             // distributed compute_mean [UPSTREAM]: local mean, weighted by n_local / n_global
             v0 /= a.n_local;
@@ -648,7 +702,7 @@ void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const doub
 
 void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
 {
-    const dim3 grid(1), block(BLOCK);
+    const dim3 grid(1), block(FIN_BLOCK);
     switch (phase) {
     case FIN_MEAN:
         hipLaunchKernelGGL((k_finalize<FIN_MEAN>), grid, block, 0, st, s, a);

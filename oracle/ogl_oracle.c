@@ -415,8 +415,8 @@ void orc_set_reduction(int mode, orc_label chunk_rows) {
  * a chunk is chunk_rows consecutive rows handled by 256 threads; thread t owns the
  * chunk_rows/256 consecutive rows starting at t*chunk_rows/256, summed in order from 0;
  * 64-lane xor tree (offsets 32,16,8,4,2,1); the 4 wave sums are added left to right.  The
- * per-chunk partials are then summed by one block: thread t takes partials t, t+256, ...
- * in order, followed by the same tree. */
+ * per-chunk partials are then summed by one block of 1024 threads: thread t takes partials
+ * t, t+1024, ... in order, xor tree per wave, then the 16 wave sums left to right. */
 #define ORC_BLOCK 256
 #define ORC_WAVE 64
 static orc_scalar block_tree(orc_scalar *acc /* [ORC_BLOCK] */) {
@@ -447,14 +447,26 @@ static orc_scalar term_id(const orc_scalar *a, const orc_scalar *b, orc_label i)
     return a[i];
 }
 
+/* finaliser: one block of ORC_FIN_BLOCK threads (16 waves of 64) */
+#define ORC_FIN_BLOCK 1024
 static orc_scalar reduce_blocked_partials(orc_label m, const orc_scalar *part) {
-    orc_scalar acc[ORC_BLOCK];
-    for (int t = 0; t < ORC_BLOCK; ++t) {
+    orc_scalar acc[ORC_FIN_BLOCK], wsum[ORC_FIN_BLOCK / ORC_WAVE];
+    for (int t = 0; t < ORC_FIN_BLOCK; ++t) {
         orc_scalar s = 0.0;
-        for (orc_label i = t; i < m; i += ORC_BLOCK) s += part[i];
+        for (orc_label i = t; i < m; i += ORC_FIN_BLOCK) s += part[i];
         acc[t] = s;
     }
-    return block_tree(acc);
+    for (int w = 0; w < ORC_FIN_BLOCK / ORC_WAVE; ++w) {
+        orc_scalar *v = acc + w * ORC_WAVE, t[ORC_WAVE];
+        for (int off = ORC_WAVE / 2; off >= 1; off >>= 1) {
+            for (int l = 0; l < ORC_WAVE; ++l) t[l] = v[l] + v[l ^ off];
+            memcpy(v, t, sizeof(t));
+        }
+        wsum[w] = v[0];
+    }
+    orc_scalar s = wsum[0];
+    for (int w = 1; w < ORC_FIN_BLOCK / ORC_WAVE; ++w) s += wsum[w];
+    return s;
 }
 
 static orc_scalar reduce_terms(orc_label n, const orc_scalar *a, const orc_scalar *b, term_fn f) {

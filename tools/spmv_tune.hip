@@ -1,0 +1,348 @@
+// spmv_tune.hip -- development harness (not product): times variants of the CSR-stream SpMV on the
+// 216^3 7-point Poisson CSR so the product kernel can adopt the fastest one.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/spmv_tune.hip -o tools/spmv_tune
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                               \
+        }                                                                          \
+    } while (0)
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+constexpr int BLOCK = 256;
+constexpr int WAVE = 64;
+constexpr int N_WAVES = 4;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v, double *slot)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x / 64;
+    if (lane == 0) slot[wave] = v;
+    __syncthreads();
+    double s = slot[0];
+    for (int w = 1; w < N_WAVES; ++w) s += slot[w];
+    __syncthreads();
+    return s;
+}
+
+template <bool NT, class T>
+__device__ __forceinline__ T ldg(const T *p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// LAYOUT 0: 4 contiguous non-zeros per lane and step (2 x double2 + int4)
+// LAYOUT 1: 2 contiguous non-zeros per lane and step (double2 + int2)
+// LAYOUT 2: 1 non-zero per lane and step (lane-strided: best gather locality, 8-byte loads)
+template <int CHUNK_ROWS, int TILE, int LAYOUT, bool NT, int XCD, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void k_spmv(int n_rows, int n_chunks,
+                                                      const int *__restrict__ row_ptrs,
+                                                      const int *__restrict__ cols,
+                                                      const double *__restrict__ vals,
+                                                      const double *__restrict__ x,
+                                                      double *__restrict__ y,
+                                                      double *__restrict__ dot_partials)
+{
+    constexpr int RPT = CHUNK_ROWS / BLOCK;
+    __shared__ __attribute__((aligned(16))) double prod[TILE];
+    __shared__ double slot[N_WAVES];
+    int chunk = blockIdx.x;
+    if (XCD == 1) {
+        const int per = (n_chunks + 7) / 8;
+        chunk = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    } else if (XCD > 1) {  // groups of G = XCD consecutive chunks per XCD, all XCDs on one front
+        constexpr int G = XCD;
+        const int b = blockIdx.x, slot = b / 8, xcd = b % 8;
+        chunk = (slot / G) * (8 * G) + xcd * G + slot % G;
+    }
+    if (chunk >= n_chunks) return;
+    const int tid = threadIdx.x;
+    const int r0 = chunk * CHUNK_ROWS;
+    const int r1 = min(r0 + CHUNK_ROWS, n_rows);
+    const int nz0 = row_ptrs[r0], nz1 = row_ptrs[r1];
+    const int row = r0 + tid * RPT;
+    int rs[RPT + 1];
+#pragma unroll
+    for (int j = 0; j <= RPT; ++j) rs[j] = row_ptrs[min(row + j, r1)];
+    double acc[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) acc[j] = 0.0;
+
+    constexpr int EPL = LAYOUT == 0 ? 4 : (LAYOUT == 1 ? 2 : 1);  // elements per lane per step
+    constexpr int STEPS = TILE / (BLOCK * EPL);
+    for (int t0 = nz0 & ~3; t0 < nz1; t0 += TILE) {
+        if (LAYOUT == 0) {
+            d2 va[STEPS], vb[STEPS];
+            i4 cc[STEPS];
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) {
+                const int e = t0 + (g * BLOCK + tid) * 4;
+                const int ec = e < nz1 ? e : t0;
+                va[g] = ldg<NT>(reinterpret_cast<const d2 *>(vals + ec));
+                vb[g] = ldg<NT>(reinterpret_cast<const d2 *>(vals + ec + 2));
+                cc[g] = ldg<NT>(reinterpret_cast<const i4 *>(cols + ec));
+            }
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) {
+                const double x0 = x[cc[g].x], x1 = x[cc[g].y], x2 = x[cc[g].z], x3 = x[cc[g].w];
+                d2 p0, p1;
+                p0.x = va[g].x * x0;
+                p0.y = va[g].y * x1;
+                p1.x = vb[g].x * x2;
+                p1.y = vb[g].y * x3;
+                const int le = (g * BLOCK + tid) * 4;
+                *reinterpret_cast<d2 *>(prod + le) = p0;
+                *reinterpret_cast<d2 *>(prod + le + 2) = p1;
+            }
+        } else if (LAYOUT == 1) {
+            d2 va[STEPS];
+            i2 cc[STEPS];
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) {
+                const int e = t0 + (g * BLOCK + tid) * 2;
+                const int ec = e < nz1 ? e : t0;
+                va[g] = ldg<NT>(reinterpret_cast<const d2 *>(vals + ec));
+                cc[g] = ldg<NT>(reinterpret_cast<const i2 *>(cols + ec));
+            }
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) {
+                const double x0 = x[cc[g].x], x1 = x[cc[g].y];
+                d2 p0;
+                p0.x = va[g].x * x0;
+                p0.y = va[g].y * x1;
+                *reinterpret_cast<d2 *>(prod + (g * BLOCK + tid) * 2) = p0;
+            }
+        } else {
+            double va[STEPS];
+            int cc[STEPS];
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) {
+                const int e = t0 + g * BLOCK + tid;
+                const int ec = e < nz1 ? e : t0;
+                va[g] = ldg<NT>(vals + ec);
+                cc[g] = ldg<NT>(cols + ec);
+            }
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) prod[g * BLOCK + tid] = va[g] * x[cc[g]];
+        }
+        __syncthreads();
+        const int t1 = t0 + TILE;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
+            for (int k = kb; k < ke; ++k) acc[j] += prod[k - t0];
+        }
+        __syncthreads();
+    }
+    double d = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+        if (row + j < r1) {
+            y[row + j] = acc[j];
+            d += x[row + j] * acc[j];
+        }
+    const double s = block_sum(d, slot);
+    if (tid == 0) dot_partials[chunk] = s;
+}
+
+// plain streaming reference points: copy (read+write) and read-only sum, 16 B per lane
+__global__ __launch_bounds__(256) void k_copy(const double2 *__restrict__ a, double2 *__restrict__ b, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) b[i] = a[i];
+}
+__global__ __launch_bounds__(256) void k_read(const double2 *__restrict__ a, double *__restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    double s = 0;
+    for (; i < n; i += stride) {
+        const double2 v = a[i];
+        s += v.x + v.y;
+    }
+    if (s == 123.456) out[0] = s;
+}
+
+struct Csr {
+    int n, nnz;
+    std::vector<int> rp, cols;
+    std::vector<double> vals;
+};
+
+static Csr poisson(int n)
+{
+    Csr A;
+    const long N = (long)n * n * n;
+    A.n = (int)N;
+    A.rp.resize(N + 1);
+    A.cols.reserve(7 * N);
+    A.vals.reserve(7 * N);
+    long e = 0;
+    for (long c = 0; c < N; ++c) {
+        const int i = c % n, j = (c / n) % n, k = c / ((long)n * n);
+        A.rp[c] = (int)e;
+        int nb = 0;
+        auto add = [&](long col, double v) {
+            A.cols.push_back((int)col);
+            A.vals.push_back(v);
+            ++e;
+        };
+        if (k > 0) { add(c - (long)n * n, -1.0); ++nb; }
+        if (j > 0) { add(c - n, -1.0); ++nb; }
+        if (i > 0) { add(c - 1, -1.0); ++nb; }
+        const long dpos = e;
+        add(c, 0.0);
+        if (i < n - 1) { add(c + 1, -1.0); ++nb; }
+        if (j < n - 1) { add(c + n, -1.0); ++nb; }
+        if (k < n - 1) { add(c + (long)n * n, -1.0); ++nb; }
+        A.vals[dpos] = nb + 1e-3 * (1.0 + (c % 7) / 7.0);
+    }
+    A.rp[N] = (int)e;
+    A.nnz = (int)e;
+    return A;
+}
+
+template <int CHUNK_ROWS, int TILE, int LAYOUT, bool NT, int XCD, int MINW>
+static void run(const char *name, const Csr &A, const int *d_rp, const int *d_cols, const double *d_vals,
+                double *d_x0, double *d_x1, double *d_y, double *d_part, const std::vector<double> &yref,
+                int reps)
+{
+    const int nc = (A.n + CHUNK_ROWS - 1) / CHUNK_ROWS;
+    const int grid = XCD == 0 ? nc : (XCD == 1 ? ((nc + 7) / 8) * 8 : ((nc + 8 * XCD - 1) / (8 * XCD)) * 8 * XCD);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto launch = [&](const double *x) {
+        hipLaunchKernelGGL((k_spmv<CHUNK_ROWS, TILE, LAYOUT, NT, XCD, MINW>), dim3(grid), dim3(BLOCK), 0, 0,
+                           A.n, nc, d_rp, d_cols, d_vals, x, d_y, d_part);
+    };
+    launch(d_x0);
+    CK(hipDeviceSynchronize());
+    std::vector<double> y(A.n);
+    CK(hipMemcpy(y.data(), d_y, sizeof(double) * A.n, hipMemcpyDeviceToHost));
+    long bad = 0;
+    for (int i = 0; i < A.n; ++i) bad += (y[i] != yref[i]);
+    for (int i = 0; i < 5; ++i) launch(i & 1 ? d_x1 : d_x0);
+    float best = 1e30f, tot = 0;
+    // per-launch timing, alternate inputs
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(e0));
+        launch(i & 1 ? d_x1 : d_x0);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        tot += ms;
+        if (ms < best) best = ms;
+    }
+    // back-to-back
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch(i & 1 ? d_x1 : d_x0);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float b2b;
+    CK(hipEventElapsedTime(&b2b, e0, e1));
+    b2b /= reps;
+    const double bytes = 12.0 * A.nnz + 20.0 * A.n + 4;
+    printf("%-44s avg %7.1f us  best %7.1f us  b2b %7.1f us  -> %6.0f GB/s (b2b)  %5.1f%% of 8TB/s  mismatches %ld\n",
+           name, 1e3 * tot / reps, 1e3 * best, 1e3 * b2b, bytes / (b2b * 1e-3) / 1e9,
+           100.0 * bytes / (b2b * 1e-3) / 8e12, bad);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 216;
+    const int reps = argc > 2 ? atoi(argv[2]) : 50;
+    Csr A = poisson(n);
+    printf("poisson %d^3: rows %d nnz %d\n", n, A.n, A.nnz);
+    std::vector<double> x0(A.n), x1(A.n), yref(A.n);
+    for (int i = 0; i < A.n; ++i) {
+        x0[i] = sin(0.001 * i) + 0.5;
+        x1[i] = cos(0.002 * i) - 0.25;
+    }
+    for (int r = 0; r < A.n; ++r) {
+        double s = 0;
+        for (int k = A.rp[r]; k < A.rp[r + 1]; ++k) s += A.vals[k] * x0[A.cols[k]];
+        yref[r] = s;
+    }
+    int *d_rp, *d_cols;
+    double *d_vals, *d_x0, *d_x1, *d_y, *d_part;
+    CK(hipMalloc(&d_rp, sizeof(int) * (A.n + 1)));
+    CK(hipMalloc(&d_cols, sizeof(int) * (A.nnz + 16)));
+    CK(hipMalloc(&d_vals, sizeof(double) * (A.nnz + 16)));
+    CK(hipMalloc(&d_x0, sizeof(double) * (A.n + 2)));
+    CK(hipMalloc(&d_x1, sizeof(double) * (A.n + 2)));
+    CK(hipMalloc(&d_y, sizeof(double) * (A.n + 2)));
+    CK(hipMalloc(&d_part, sizeof(double) * (A.n / 128 + 16)));
+    CK(hipMemset(d_cols, 0, sizeof(int) * (A.nnz + 16)));
+    CK(hipMemset(d_vals, 0, sizeof(double) * (A.nnz + 16)));
+    CK(hipMemcpy(d_rp, A.rp.data(), sizeof(int) * (A.n + 1), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_cols, A.cols.data(), sizeof(int) * A.nnz, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_vals, A.vals.data(), sizeof(double) * A.nnz, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_x0, x0.data(), sizeof(double) * A.n, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_x1, x1.data(), sizeof(double) * A.n, hipMemcpyHostToDevice));
+
+    // streaming reference points on the value array (562 MB)
+    {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const size_t n2 = (size_t)A.nnz / 2;
+        double2 *d_tmp;
+        CK(hipMalloc(&d_tmp, sizeof(double2) * n2));
+        for (int grid : {2048, 4096, 16384}) {
+            k_copy<<<grid, 256>>>((const double2 *)d_vals, d_tmp, n2);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 20; ++i) k_copy<<<grid, 256>>>((const double2 *)d_vals, d_tmp, n2);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("copy  grid %5d: %6.0f GB/s (read+write)\n", grid, 2.0 * n2 * 16 / (ms / 20 * 1e-3) / 1e9);
+            k_read<<<grid, 256>>>((const double2 *)d_vals, d_y, n2);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 20; ++i) k_read<<<grid, 256>>>((const double2 *)d_vals, d_y, n2);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("read  grid %5d: %6.0f GB/s (read only)\n", grid, 1.0 * n2 * 16 / (ms / 20 * 1e-3) / 1e9);
+        }
+        CK(hipFree(d_tmp));
+    }
+
+#define RUN(CR, TILE, LAY, NT, XCD, MINW) \
+    run<CR, TILE, LAY, NT, XCD, MINW>("chunk" #CR " tile" #TILE " lay" #LAY " nt" #NT " xcd" #XCD " minw" #MINW, A, \
+                                      d_rp, d_cols, d_vals, d_x0, d_x1, d_y, d_part, yref, reps)
+    RUN(512, 4096, 0, false, 1, 1);   // product kernel today
+    RUN(512, 4096, 0, false, 0, 1);
+    RUN(512, 4096, 0, false, 2, 1);
+    RUN(512, 4096, 0, false, 4, 1);
+    RUN(512, 4096, 0, false, 8, 1);
+    RUN(512, 4096, 0, false, 16, 1);
+    RUN(512, 4096, 0, false, 64, 1);
+    RUN(512, 4096, 1, true, 0, 1);
+    RUN(512, 4096, 1, true, 4, 1);
+    RUN(512, 4096, 1, true, 16, 1);
+    RUN(512, 4096, 0, false, 0, 1);
+    return 0;
+}
