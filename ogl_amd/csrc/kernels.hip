@@ -518,6 +518,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
 {
     __shared__ double slot[FIN_WAVES];
     if (PHASE != FIN_MEAN && PHASE != FIN_NORMFACTOR && PHASE != FIN_RAW && s->stop) return;
+    // thread 0 fetches the scalar block up front (its latency hides behind the partial loads),
+    // does the logic in registers and stores the block once: the criterion's dependent global
+    // round trips would otherwise cost more than the reduction itself
+    DevScalars L;
+    if (threadIdx.x == 0 && a.do_logic) L = *s;
     double v0 = 0.0, v1 = 0.0;
     if (a.do_reduce) {
         const double *const parts[2] = {a.part[0], a.part[1]};
@@ -533,27 +538,31 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
             v0 /= a.n_local;
             v0 *= a.n_local / a.n_global;
         }
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && !a.do_logic) {
             s->sums[0] = v0;
             s->sums[1] = v1;
         }
     }
     if (!a.do_logic || threadIdx.x != 0) return;
     if (!a.do_reduce) {
-        v0 = s->sums[0];
-        v1 = s->sums[1];
+        v0 = L.sums[0];
+        v1 = L.sums[1];
+    } else {
+        L.sums[0] = v0;
+        L.sums[1] = v1;
     }
     if (PHASE == FIN_MEAN) {
-        s->xbar = v0;
+        L.xbar = v0;
     } else if (PHASE == FIN_NORMFACTOR) {
-        s->norm_factor = v0 + 1.0e-15;  // + SMALL, StoppingCriterion.C:68
+        L.norm_factor = v0 + 1.0e-15;  // + SMALL, StoppingCriterion.C:68
     } else if (PHASE == FIN_CG_CHECK) {
-        s->prev_rho = s->rho;  // swap(prev_rho, rho) of the previous turn
-        s->rho = v0;
-        criterion_check(s, a.crit, v1, a.history);
+        L.prev_rho = L.rho;  // swap(prev_rho, rho) of the previous turn
+        L.rho = v0;
+        criterion_check(&L, a.crit, v1, a.history);
     } else if (PHASE == FIN_BETA) {
-        s->beta = v0;
+        L.beta = v0;
     }
+    *s = L;
 }
 
 __global__ void k_reset_scalars(DevScalars *s)

@@ -1,0 +1,181 @@
+"""One rank of a multi-process run of the sharded path (launched by test_distributed.py through
+torch.distributed.run, gloo rendezvous on 127.0.0.1).
+
+modes
+  oracle    CPU only: the oracle's distributed CG (halo exchange + all-reduce through gloo)
+            against the single-rank oracle on the assembled global system, plus the product's
+            host-side pattern (ogl_host_pattern) against the oracle's per rank.
+  gpu-host  every rank drives libogl_amd on the (shared) GPU with the host-buffer transport
+            (forceHostBuffer: callbacks -> gloo) and must reproduce the distributed oracle run in
+            the device's reduction order bit for bit.
+  gpu-rccl  same through RCCL (needs one GPU per rank).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from ogl_amd import synthetic  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from helpers import blocked, orc_ifaces, oracle_csr  # noqa: E402
+
+
+def make_exchange(neigh_of_patch):
+    """Blocked neighbour exchange over gloo: (neighbours, counts, send) -> recv."""
+    def exchange(neighbours, counts, send):
+        recv = np.zeros_like(send)
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+        reqs, bufs = [], []
+        for i, nb in enumerate(neighbours):
+            s = torch.from_numpy(np.ascontiguousarray(send[offs[i]:offs[i + 1]]))
+            r = torch.zeros(int(counts[i]), dtype=torch.float64)
+            reqs.append(dist.isend(s, int(nb)))
+            reqs.append(dist.irecv(r, int(nb)))
+            bufs.append((i, r, s))
+        for q in reqs:
+            q.wait()
+        for i, r, _ in bufs:
+            recv[offs[i]:offs[i + 1]] = r.numpy()
+        return recv
+    return exchange
+
+
+def allreduce(a):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()
+
+
+def oracle_dist_matrix(case):
+    ifs = orc_ifaces(orc, case)
+    rp, cols, vals = oracle_csr(orc, case)
+    nl_rows, nl_cols, nl_perm = orc.init_non_local_sparsity(ifs)
+    nl_vals = orc.update_non_local_matrix_data(ifs, nl_perm)
+    ids, sizes, send_idxs = orc.create_communication_pattern(ifs)
+    nl_rp = orc.rowptr_from_rows(case.n_cells, nl_rows)
+    ex = make_exchange(None)
+    A = orc.DistMatrix(rp, cols, vals, nl_rp, nl_cols, nl_vals, send_idxs, n_halo=nl_rows.size,
+                       exchange=lambda s: ex(ids, sizes, s), allreduce=allreduce,
+                       global_n=case.global_n)
+    return A, (rp, cols, vals), (nl_rows, nl_cols, nl_perm, nl_vals), (ids, sizes, send_idxs)
+
+
+def gather_global(case, x):
+    """Assemble the global vector on every rank (test plumbing)."""
+    out = np.zeros(case.global_n)
+    out[case.global_index] = x
+    return allreduce(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", required=True)
+    ap.add_argument("--shape", default="8,8,8")
+    ap.add_argument("--procs", default="1,1,2")
+    ap.add_argument("--precond", type=int, default=1)
+    ap.add_argument("--asym", type=int, default=0)
+    args = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gx, gy, gz = map(int, args.shape.split(","))
+    px, py, pz = map(int, args.procs.split(","))
+    assert px * py * pz == world
+    kw = dict(symmetric=not args.asym)
+    if args.asym:
+        kw.update(off_upper=-0.9, off_lower=-1.1)
+    case = synthetic.poisson_block(gx, gy, gz, px, py, pz, rank, **kw)
+    glob = synthetic.poisson_block(gx, gy, gz, **kw)
+    xs_g = synthetic.x_star(glob.global_index, glob.global_n)
+    b_g = synthetic.apply_case(glob, xs_g)
+    b = b_g[case.global_index]
+    skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
+
+    A, (rp, cols, vals), nl, comm = oracle_dist_matrix(case)
+    inv = orc.jacobi_generate_scalar(rp, cols, vals) if args.precond else None
+
+    # ---- product host logic per rank vs the oracle (pure host, no GPU) ----
+    from ogl_amd import capi
+    d, loc, pnl, pcomm = capi.host_pattern(case)
+    assert d.n_neighbours == comm[0].size and d.n_send == comm[2].size
+    for a_, b_ in zip(pnl, nl[:3]):
+        np.testing.assert_array_equal(a_, b_)
+    for a_, b_ in zip(pcomm, comm):
+        np.testing.assert_array_equal(a_, b_)
+
+    # ---- distributed SpMV vs the global operator ----
+    rng = np.random.default_rng(20241016)
+    xg = rng.uniform(-1, 1, glob.n_cells)
+    y = A.apply(xg[case.global_index])
+    np.testing.assert_allclose(gather_global(case, y), synthetic.apply_case(glob, xg), rtol=1e-13,
+                               atol=1e-13)
+
+    solve = orc.bicgstab if args.asym else orc.cg
+    if args.mode == "oracle":
+        res = solve(A, b, np.zeros_like(b), inv, **skw)
+        g_rp, g_cols, g_vals = oracle_csr(orc, glob)
+        G = orc.DistMatrix(g_rp, g_cols, g_vals)
+        g_inv = orc.jacobi_generate_scalar(g_rp, g_cols, g_vals) if args.precond else None
+        ref = solve(G, b_g, np.zeros_like(b_g), g_inv, **skw)
+        xg_sol = gather_global(case, res.x)
+        np.testing.assert_allclose(xg_sol, ref.x, atol=1e-9, rtol=0)
+        np.testing.assert_allclose(xg_sol, xs_g, atol=1e-8, rtol=0)
+        assert abs(res.n_iterations - ref.n_iterations) <= 2, (res.n_iterations, ref.n_iterations)
+        m = min(20, res.history.size, ref.history.size)
+        np.testing.assert_allclose(res.history[:m], ref.history[:m], rtol=1e-10)
+        assert res.norm_factor == ref.norm_factor or abs(res.norm_factor / ref.norm_factor - 1) < 1e-13
+        # every rank saw the same (all-reduced) history
+        h = allreduce(res.history / world)
+        np.testing.assert_allclose(h, res.history, rtol=1e-15)
+    else:
+        n_dev = torch.cuda.device_count()
+        dev = rank % max(1, n_dev)
+        reg = capi.Registry(device_id=dev)
+        if args.mode == "gpu-host":
+            ex = make_exchange(None)
+            reg.set_host_comm(rank, world, allreduce, lambda nb, ct, s: ex(nb, ct, s))
+        else:
+            uid = [capi.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            reg.init_rccl(rank, world, uid[0])
+        cfg = capi.default_config(
+            solver=capi.SOLVER_BICGSTAB if args.asym else capi.SOLVER_CG,
+            preconditioner=capi.PRECOND_BJ if args.precond else capi.PRECOND_NONE,
+            tolerance=1e-11, rel_tol=0.0, max_iter=300, export_res=1, adapt_min_iter=0,
+            matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode == "gpu-host"))
+        s = reg.solver("p", cfg).set_matrix(case)
+        # device halo matrix == oracle's
+        r_, c_, m_, v_ = s.non_local_matrix()
+        np.testing.assert_array_equal(r_, nl[0])
+        np.testing.assert_array_equal(c_, nl[1])
+        np.testing.assert_array_equal(v_, nl[3])
+        np.testing.assert_array_equal(s.spmv(xg[case.global_index]), y)
+        x, perf = s.solve(b, np.zeros_like(b))
+        hist = s.history()
+        with blocked(orc, capi.lib().ogl_reduction_chunk_rows()):
+            ref = solve(A, b, np.zeros_like(b), inv, **skw)
+        if args.mode == "gpu-host":
+            # same local trees, same 2-operand gloo sum: bit-identical
+            assert perf.n_iterations == (ref.n_iterations // 2 if args.asym else ref.n_iterations)
+            np.testing.assert_array_equal(hist, ref.history)
+            np.testing.assert_array_equal(x, ref.x)
+        else:
+            m = min(hist.size, ref.history.size, 30)
+            np.testing.assert_allclose(hist[:m], ref.history[:m], rtol=1e-10)
+            np.testing.assert_allclose(x, ref.x, atol=1e-9, rtol=0)
+        np.testing.assert_allclose(gather_global(case, x), xs_g, atol=1e-8, rtol=0)
+        reg.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: {args.mode} ok")
+
+
+if __name__ == "__main__":
+    main()
