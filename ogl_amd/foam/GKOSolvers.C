@@ -1,0 +1,87 @@
+// GKOSolvers.C -- the one translation unit an OpenFOAM tree compiles to get libOGL.so backed by
+// libogl_amd.so.  NOT built in this repository's image (no OpenFOAM here); it is the adapter of
+// ogl_amd/host/OGLAdapter.H compiled against the real headers instead of MiniFoam.H.
+//
+//   wmake libso ogl_amd/foam          (needs FOAM_SRC; see Make/options)
+//   controlDict:  libs ("libOGL.so");           (README.md:63-65 of the reference)
+//   fvSolution:   p { solver GKOCG; preconditioner BJ; executor hip; ... }
+//
+// Replaces: Solver/CG/GKOCG.C:14-17, Solver/BiCGStab/GKOBiCGStab.C:14-20,
+//           Solver/GMRES/GKOGMRES.C:14-20 (registration) and everything they pull in.
+#include "fvCFD.H"
+#include "lduMatrix.H"
+#include "processorFvPatch.H"
+#include "processorLduInterface.H"
+#include "cyclicFvPatch.H"
+#include "cyclicAMIFvPatch.H"
+#include "regIOobject.H"
+#include "Pstream.H"
+#include "PstreamReduceOps.H"
+
+// OpenFOAM spells these differently from the stand-in:
+#define OGL_ABORT_FATAL Foam::abort(Foam::FatalError)
+
+#include "OGLAdapter.H"
+
+namespace Foam {
+
+// Communicator for decomposed runs (ExecutorHandler.H:140-144,167-172).
+//  * default: RCCL over xGMI -- rank 0 creates the unique id, Pstream broadcasts the 128 bytes;
+//  * forceHostBuffer true: the library stages halo/scalars through pinned host memory and these
+//    callbacks move them with OpenFOAM's own message passing.
+namespace {
+
+void ogl_allreduce_sum(void *, double *v, int32_t n)
+{
+    for (int32_t i = 0; i < n; ++i) reduce(v[i], sumOp<scalar>());
+}
+
+void ogl_neighbour_exchange(void *, int32_t n_nbr, const int32_t *ranks, const int32_t *counts,
+                            const double *send, double *recv)
+{
+    label off = 0;
+    PstreamBuffers bufs(Pstream::commsTypes::nonBlocking);
+    for (int32_t i = 0; i < n_nbr; ++i) {
+        UOPstream os(ranks[i], bufs);
+        os.write(reinterpret_cast<const char *>(send + off), counts[i] * sizeof(double));
+        off += counts[i];
+    }
+    bufs.finishedSends();
+    off = 0;
+    for (int32_t i = 0; i < n_nbr; ++i) {
+        UIPstream is(ranks[i], bufs);
+        is.read(reinterpret_cast<char *>(recv + off), counts[i] * sizeof(double));
+        off += counts[i];
+    }
+}
+
+struct InstallCommHook {
+    InstallCommHook()
+    {
+        OGLDeviceRegistry::commHook() = [](ogl_registry *reg, const dictionary &controls) {
+            const bool host = controls.lookupOrDefault<Switch>("forceHostBuffer", false);
+            int rc;
+            if (host) {
+                rc = ogl_registry_set_host_comm(reg, Pstream::myProcNo(), Pstream::nProcs(),
+                                                ogl_allreduce_sum, ogl_neighbour_exchange, nullptr);
+            } else {
+                List<char> id(OGL_RCCL_ID_BYTES, '\0');
+                if (Pstream::master() && ogl_rccl_unique_id(id.begin()) != OGL_OK)
+                    FatalErrorInFunction << ogl_last_error() << abort(FatalError);
+                Pstream::scatter(id);
+                rc = ogl_registry_init_rccl(reg, Pstream::myProcNo(), Pstream::nProcs(), id.begin());
+            }
+            if (rc != OGL_OK) FatalErrorInFunction << ogl_last_error() << abort(FatalError);
+        };
+    }
+} installCommHook_;
+
+}  // namespace
+
+defineTypeNameAndDebug(GKOCG, 0);
+defineTypeNameAndDebug(GKOBiCGStab, 0);
+defineTypeNameAndDebug(GKOGMRES, 0);
+
+}  // namespace Foam
+
+OGL_REGISTER_SOLVERS

@@ -1,0 +1,29 @@
+"""Runs the C++ plug-in surface tests (tests/cpp/test_host_plugin.cpp): the lduMatrix::solver
+classes GKOCG / GKOBiCGStab / GKOGMRES of ogl_amd/host/OGLAdapter.H over the MiniFoam stand-in."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_host_plugin")
+
+
+def _run(which):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    p = subprocess.run([EXE, which], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "0 failure(s)" in p.stdout
+    return p.stdout
+
+
+def test_cpp_plugin_surface_cpu():
+    out = _run("cpu")
+    assert out.count("[  OK  ]") >= 6
+
+
+@pytest.mark.gpu
+def test_cpp_plugin_surface_gpu():
+    out = _run("gpu")
+    assert out.count("[  OK  ]") >= 3
