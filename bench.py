@@ -50,6 +50,25 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes of this same command
+    (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs).  Units and the
+    gfx950 correction per MI355X_MICROARCH.md "HBM": counters are KiB, FETCH_SIZE reads half the
+    bytes of a wide coalesced stream (calibrated here on k_cg_step1: 2 x 118,111 KiB = 241.9 MB
+    measured vs 24 N = 241.9 MB algorithmic)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    k = d.get(kernel)
+    if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+        return None, None
+    total = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
+    return total, os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE) KiB, separate passes"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -133,6 +152,7 @@ def main():
         spmv_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in perfs) / max(1, launches)
         spmv_src = f"{launches} in-loop launches of the timed steps, HIP event pairs"
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic("k_spmv_stream<0, true>") if n == 216 else (None, None)
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
     # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
     t0 = time.perf_counter()
@@ -158,7 +178,8 @@ def main():
             "kernel": "k_spmv_stream<PLAIN, fused p.q>", "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
-            "traffic": None, "algorithmic_bytes_per_launch": b_spmv,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": b_spmv,
             "avg_kernel_ms": spmv_ms, "timing": spmv_src,
         },
         "cg_iteration": {

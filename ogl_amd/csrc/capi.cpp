@@ -214,7 +214,7 @@ extern "C" int ogl_solver_spmv(ogl_solver *s, const ogl_scalar *x, ogl_scalar *y
     hipStream_t st = s->reg->stream;
     const size_t bytes = (size_t)s->pat.n_rows * sizeof(double);
     OGL_TRY(s->reg->stager.h2d(s->d_w.p, x, bytes, st));
-    OGL_TRY(s->dist_spmv(SPMV_PLAIN, s->d_w.p, nullptr, s->d_q.p, nullptr, nullptr));
+    OGL_TRY(s->dist_spmv(SPMV_PLAIN, s->d_w.p, nullptr, s->d_q.p, SpmvDots{}, nullptr));
     OGL_TRY(s->reg->stager.d2h(y, s->d_q.p, bytes, st));
     OGL_HIP_CHECK(hipGetLastError());
     return OGL_OK;

@@ -121,11 +121,14 @@ inline int xcd_grid(int n_chunks)
 // adds up its own rows left to right -- the same order as the reference executor's row loop,
 // so y is bit-identical to it.
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool FUSE_DOT>
+// NDOT = 1: partials of sum_i w_i*y_i (w = x for CG's p.q, w = rr or s for BiCGStab);
+// NDOT = 2: additionally partials of sum_i y_i*y_i (BiCGStab's t.t).
+template <int MODE, int NDOT>
 __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ b,
-    double *__restrict__ y, double *__restrict__ dot_partials, const DevScalars *gate)
+    double *__restrict__ y, const double *__restrict__ w, double *__restrict__ dot_partials,
+    double *__restrict__ dot2_partials, const DevScalars *gate)
 {
     __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
     __shared__ double slot[N_WAVES];
@@ -187,17 +190,22 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
         __syncthreads();
     }
 
-    double d = 0.0;
+    double d = 0.0, d2 = 0.0;
 #pragma unroll
     for (int j = 0; j < ROWS_PER_THREAD; ++j) {
         if (row + j < r1) {
             y[row + j] = acc[j];
-            if (FUSE_DOT) d += x[row + j] * acc[j];
+            if (NDOT >= 1) d += w[row + j] * acc[j];
+            if (NDOT >= 2) d2 += acc[j] * acc[j];
         }
     }
-    if (FUSE_DOT) {
+    if (NDOT >= 1) {
         const double s = block_sum(d, slot);
         if (tid == 0) dot_partials[chunk] = s;
+    }
+    if (NDOT >= 2) {
+        const double s = block_sum(d2, slot);
+        if (tid == 0) dot2_partials[chunk] = s;
     }
 }
 
@@ -484,6 +492,134 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2(int n, double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// BiCGStab steps ([UPSTREAM] bicgstab::step_1 / step_2 / step_3 / finalize)
+// ------------------------------------------------------------------------------------------
+// step_1: p = r + (rho/prev_rho * alpha/omega) (p - omega v)   [p = r when prev_rho*omega == 0];
+// then y = M^-1 p (scalar Jacobi; with the identity y aliases p and is not written)
+__global__ __launch_bounds__(BLOCK) void k_bicg_step1(int n, double *__restrict__ p,
+                                                      const double *__restrict__ r,
+                                                      const double *__restrict__ v,
+                                                      const double *__restrict__ inv_diag,
+                                                      double *__restrict__ y, const DevScalars *s)
+{
+    if (s->stop) return;
+    const double rho = s->rho, prev = s->prev_rho, alpha = s->alpha, omega = s->omega;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    const double2 vr = ld2(r, rp);
+    double2 vp = vr;
+    if (prev * omega != 0.0) {
+        const double tmp = rho / prev * alpha / omega;
+        const double2 po = ld2(p, rp), vv = ld2(v, rp);
+        vp.x = vr.x + tmp * (po.x - omega * vv.x);
+        vp.y = vr.y + tmp * (po.y - omega * vv.y);
+    }
+    st2(p, rp, vp);
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        double2 vy;
+        vy.x = vp.x * vi.x;
+        vy.y = vp.y * vi.y;
+        st2(y, rp, vy);
+    }
+}
+
+// step_2: s = r - alpha v (alpha = rho/beta from the finaliser; s = r when beta == 0); z = M^-1 s;
+// partial of sum|s| for the mid-turn criterion check
+__global__ __launch_bounds__(BLOCK) void k_bicg_step2(int n, const double *__restrict__ r,
+                                                      const double *__restrict__ v,
+                                                      double *__restrict__ sv,
+                                                      const double *__restrict__ inv_diag,
+                                                      double *__restrict__ z,
+                                                      double *__restrict__ part_norm,
+                                                      const DevScalars *s)
+{
+    __shared__ double slot[N_WAVES];
+    if (s->stop) return;
+    const double alpha = s->alpha, beta = s->beta;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vs = ld2(r, rp);
+    if (beta != 0.0) {
+        const double2 vv = ld2(v, rp);
+        vs.x = vs.x - alpha * vv.x;
+        vs.y = vs.y - alpha * vv.y;
+    }
+    st2(sv, rp, vs);
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        double2 vz;
+        vz.x = vs.x * vi.x;
+        vz.y = vs.y * vi.y;
+        st2(z, rp, vz);
+    }
+    double a = 0.0;
+    if (rp.n > 0) a += fabs(vs.x);
+    if (rp.n > 1) a += fabs(vs.y);
+    const double s1 = block_sum(a, slot);
+    if (threadIdx.x == 0) part_norm[chunk] = s1;
+}
+
+// step_3: x += alpha y + omega z ; r = s - omega t ; then the partials of the next turn's
+// rho = rr.r and of sum|r|
+__global__ __launch_bounds__(BLOCK) void k_bicg_step3(int n, double *__restrict__ x,
+                                                      double *__restrict__ r,
+                                                      const double *__restrict__ sv,
+                                                      const double *__restrict__ t,
+                                                      const double *__restrict__ y,
+                                                      const double *__restrict__ z,
+                                                      const double *__restrict__ rr,
+                                                      double *__restrict__ part_rho,
+                                                      double *__restrict__ part_norm,
+                                                      const DevScalars *s)
+{
+    __shared__ double slot[N_WAVES];
+    if (s->stop) return;
+    const double alpha = s->alpha, omega = s->omega;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vx = ld2(x, rp);
+    const double2 vy = ld2(y, rp), vz = ld2(z, rp), vs = ld2(sv, rp), vt = ld2(t, rp),
+                  vrr = ld2(rr, rp);
+    vx.x += alpha * vy.x + omega * vz.x;
+    vx.y += alpha * vy.y + omega * vz.y;
+    double2 vr;
+    vr.x = vs.x - omega * vt.x;
+    vr.y = vs.y - omega * vt.y;
+    st2(x, rp, vx);
+    st2(r, rp, vr);
+    double d = 0.0, a = 0.0;
+    if (rp.n > 0) {
+        d += vrr.x * vr.x;
+        a += fabs(vr.x);
+    }
+    if (rp.n > 1) {
+        d += vrr.y * vr.y;
+        a += fabs(vr.y);
+    }
+    const double s0 = block_sum(d, slot);
+    const double s1 = block_sum(a, slot);
+    if (threadIdx.x == 0) {
+        part_rho[chunk] = s0;
+        part_norm[chunk] = s1;
+    }
+}
+
+// bicgstab::finalize: x += alpha y, only on the turn whose mid-step check stopped the solver
+__global__ __launch_bounds__(BLOCK) void k_bicg_finalize_x(int n, double *__restrict__ x,
+                                                           const double *__restrict__ y,
+                                                           const DevScalars *s, int turn)
+{
+    if (!(s->stop && s->stop_phase == 1 && s->stop_turn == turn)) return;
+    const double alpha = s->alpha;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 vx = ld2(x, rp);
+    const double2 vy = ld2(y, rp);
+    vx.x += alpha * vy.x;
+    vx.y += alpha * vy.y;
+    st2(x, rp, vx);
+}
+
+// ------------------------------------------------------------------------------------------
 // finalisers (one workgroup): reduce the per-chunk partials, then the scalar logic
 // ------------------------------------------------------------------------------------------
 
@@ -561,6 +697,19 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
         criterion_check(&L, a.crit, v1, a.history);
     } else if (PHASE == FIN_BETA) {
         L.beta = v0;
+    } else if (PHASE == FIN_BICG_ALPHA) {  // beta = rr.v ; alpha = rho / beta (0 when beta == 0)
+        L.beta = v0;
+        L.alpha = (v0 != 0.0) ? L.rho / v0 : 0.0;
+    } else if (PHASE == FIN_BICG_CHECK2) {  // mid-turn check on s
+        criterion_check(&L, a.crit, v0, a.history);
+        if (L.stop) {
+            L.stop_phase = 1;
+            L.stop_turn = a.turn;
+        }
+    } else if (PHASE == FIN_BICG_OMEGA) {  // gamma = s.t ; beta = t.t ; omega = gamma / beta
+        L.gamma = v0;
+        L.beta = v1;
+        L.omega = (v1 != 0.0) ? v0 / v1 : 0.0;
     }
     *s = L;
 }
@@ -584,21 +733,24 @@ inline int blocks_for(int64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 // launchers
 // ------------------------------------------------------------------------------------------
 void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, const double *b,
-                 double *y, double *dot_partials, const DevScalars *gate)
+                 double *y, const SpmvDots &dots, const DevScalars *gate)
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
+#define OGL_SPMV(MODE, NDOT)                                                                       \
+    hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
+                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
     if (mode == SPMV_RESIDUAL) {
-        hipLaunchKernelGGL((k_spmv_stream<SPMV_RESIDUAL, false>), grid, block, 0, st, A.n_rows, nc,
-                           A.row_ptrs, A.cols, A.vals, x, b, y, nullptr, gate);
-    } else if (dot_partials) {
-        hipLaunchKernelGGL((k_spmv_stream<SPMV_PLAIN, true>), grid, block, 0, st, A.n_rows, nc,
-                           A.row_ptrs, A.cols, A.vals, x, b, y, dot_partials, gate);
+        OGL_SPMV(SPMV_RESIDUAL, 0);
+    } else if (dots.part && dots.part_yy) {
+        OGL_SPMV(SPMV_PLAIN, 2);
+    } else if (dots.part) {
+        OGL_SPMV(SPMV_PLAIN, 1);
     } else {
-        hipLaunchKernelGGL((k_spmv_stream<SPMV_PLAIN, false>), grid, block, 0, st, A.n_rows, nc,
-                           A.row_ptrs, A.cols, A.vals, x, b, y, nullptr, gate);
+        OGL_SPMV(SPMV_PLAIN, 0);
     }
+#undef OGL_SPMV
 }
 
 void launch_spmv_non_local(hipStream_t st, const DevHalo &H, int mode, const double *recv,
@@ -709,6 +861,41 @@ void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const doub
                        part_norm, s);
 }
 
+void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,
+                       const double *inv_diag, double *y, const DevScalars *s)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_bicg_step1, dim3(nc), dim3(BLOCK), 0, st, n, p, r, v, inv_diag, y, s);
+}
+
+void launch_bicg_step2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv,
+                       const double *inv_diag, double *z, double *part_norm, const DevScalars *s)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_bicg_step2, dim3(nc), dim3(BLOCK), 0, st, n, r, v, sv, inv_diag, z,
+                       part_norm, s);
+}
+
+void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const double *sv,
+                       const double *t, const double *y, const double *z, const double *rr,
+                       double *part_rho, double *part_norm, const DevScalars *s)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_bicg_step3, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr,
+                       part_rho, part_norm, s);
+}
+
+void launch_bicg_finalize_x(hipStream_t st, int32_t n, double *x, const double *y,
+                            const DevScalars *s, int turn)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_bicg_finalize_x, dim3(nc), dim3(BLOCK), 0, st, n, x, y, s, turn);
+}
+
 void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
 {
     const dim3 grid(1), block(FIN_BLOCK);
@@ -724,6 +911,15 @@ void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
         break;
     case FIN_BETA:
         hipLaunchKernelGGL((k_finalize<FIN_BETA>), grid, block, 0, st, s, a);
+        break;
+    case FIN_BICG_ALPHA:
+        hipLaunchKernelGGL((k_finalize<FIN_BICG_ALPHA>), grid, block, 0, st, s, a);
+        break;
+    case FIN_BICG_CHECK2:
+        hipLaunchKernelGGL((k_finalize<FIN_BICG_CHECK2>), grid, block, 0, st, s, a);
+        break;
+    case FIN_BICG_OMEGA:
+        hipLaunchKernelGGL((k_finalize<FIN_BICG_OMEGA>), grid, block, 0, st, s, a);
         break;
     default:
         hipLaunchKernelGGL((k_finalize<FIN_RAW>), grid, block, 0, st, s, a);

@@ -21,6 +21,8 @@ struct DevScalars {
     int32_t stop;                       // criterion said stop; later kernels become no-ops
     int32_t n_evals;                    // checks that evaluated the norm
     int32_t stop_phase;                 // BiCGStab: 1 = stopped at the mid-step check (finalize x)
+    int32_t stop_turn;                  // BiCGStab: turn index of that stop
+    int32_t pad_;
 };
 
 // OpenFOAMDistStoppingCriterion parameters (StoppingCriterion.H:32-72)
@@ -53,10 +55,15 @@ enum SpmvMode { SPMV_PLAIN = 0, SPMV_RESIDUAL = 1 };
 
 // y = A x (PLAIN) or y = b - A x (RESIDUAL: accumulator starts at b_i and subtracts the products
 // in stored order, which is what Ginkgo's advanced apply with alpha=-1, beta=1 evaluates).
-// dot_partials != nullptr: also one partial of sum_i x_i*y_i per chunk of CHUNK_ROWS rows.
+// dots.part != nullptr: also one partial of sum_i w_i*y_i (and y_i*y_i) per chunk of CHUNK_ROWS rows.
 // `gate` (may be nullptr): kernel returns immediately when gate->stop is set.
+struct SpmvDots {
+    const double *with = nullptr;  // w in sum_i w_i*y_i (CG: x itself; BiCGStab: rr or s)
+    double *part = nullptr;        // per-chunk partials of w.y, or nullptr
+    double *part_yy = nullptr;     // per-chunk partials of y.y (needs `part`), or nullptr
+};
 void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, const double *b,
-                 double *y, double *dot_partials, const DevScalars *gate);
+                 double *y, const SpmvDots &dots, const DevScalars *gate);
 
 // y[row] (+/-)= sum_k vals[k] * recv[cols[k]] over the boundary rows, continuing y's accumulator.
 void launch_spmv_non_local(hipStream_t st, const DevHalo &H, int mode, const double *recv,
@@ -96,6 +103,17 @@ void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const doub
                      const double *q, const double *inv_diag, double *part_rho, double *part_norm,
                      const DevScalars *s);
 
+// --- BiCGStab steps ([UPSTREAM] bicgstab::step_1/2/3, finalize) ---
+void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,
+                       const double *inv_diag, double *y, const DevScalars *s);
+void launch_bicg_step2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv,
+                       const double *inv_diag, double *z, double *part_norm, const DevScalars *s);
+void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const double *sv,
+                       const double *t, const double *y, const double *z, const double *rr,
+                       double *part_rho, double *part_norm, const DevScalars *s);
+void launch_bicg_finalize_x(hipStream_t st, int32_t n, double *x, const double *y,
+                            const DevScalars *s, int turn);
+
 // --- single-workgroup finalisers: reduce per-chunk partials, then scalar logic -------------
 // phases: what the scalar logic does with the reduced sums.
 enum FinPhase {
@@ -103,7 +121,10 @@ enum FinPhase {
     FIN_NORMFACTOR = 1,  // norm_factor = sum + SMALL                      StoppingCriterion.C:62-68
     FIN_CG_CHECK = 2,    // rho <- sum0, criterion check on sum1           StoppingCriterion.C:71-151
     FIN_BETA = 3,        // beta <- sum0
-    FIN_RAW = 4          // sums[] only (test / reduce entry point)
+    FIN_RAW = 4,         // sums[] only (test / reduce entry point)
+    FIN_BICG_ALPHA = 5,  // beta <- sum0 ; alpha = rho / beta
+    FIN_BICG_CHECK2 = 6, // mid-turn criterion check on sum0 = sum|s|
+    FIN_BICG_OMEGA = 7   // gamma <- sum0 ; beta <- sum1 ; omega = gamma / beta
 };
 struct FinArgs {
     const double *part[2] = {nullptr, nullptr};
@@ -114,6 +135,7 @@ struct FinArgs {
     double n_local = 0, n_global = 0;  // FIN_MEAN
     DevCriterion crit{};
     double *history = nullptr;
+    int32_t turn = 0;  // BiCGStab turn index (FIN_BICG_CHECK2)
 };
 void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a);
 

@@ -347,8 +347,8 @@ int ogl_solver::init_preconditioner()
 // ------------------------------------------------------------------------------------------
 // distributed::Matrix::apply: y = A_local x (+ dot partials), then y += A_non_local recv
 // ------------------------------------------------------------------------------------------
-int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y, double *dot_part,
-                          const DevScalars *gate)
+int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
+                          const SpmvDots &dots, const DevScalars *gate)
 {
     hipStream_t st = reg->stream;
     const bool has_halo = pat.non_local_nnz > 0;
@@ -356,10 +356,13 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
         launch_pack(st, halo(), x, d_send.p, gate);
         OGL_TRY(reg->comm->exchange(d_send.p, d_recv.p, neighbours, counts, st));
     }
-    launch_spmv(st, csr(), mode, x, b, y, has_halo ? nullptr : dot_part, gate);
+    // with a halo the fused partials would miss the non-local part of the boundary rows: the dots
+    // are taken in a separate pass after "y += A_non_local recv" (+16 N bytes each)
+    launch_spmv(st, csr(), mode, x, b, y, has_halo ? SpmvDots{} : dots, gate);
     if (has_halo) {
         launch_spmv_non_local(st, halo(), mode, d_recv.p, y, gate);
-        if (dot_part) launch_partials_dot(st, pat.n_rows, x, y, dot_part, gate);
+        if (dots.part) launch_partials_dot(st, pat.n_rows, dots.with, y, dots.part, gate);
+        if (dots.part_yy) launch_partials_dot(st, pat.n_rows, y, y, dots.part_yy, gate);
     }
     return OGL_OK;
 }
@@ -391,12 +394,26 @@ int ogl_solver::finalize(int phase, FinArgs &a)
 // The host only enqueues; it looks at the stop flag one batch late, and kernels enqueued after
 // the stop are no-ops, so x, r and the counters are exactly those of the stopping turn.
 // ------------------------------------------------------------------------------------------
-int ogl_solver::run_cg(ogl_perf *perf)
+int ogl_solver::run_cg(ogl_perf *perf) { return run_krylov(perf); }
+int ogl_solver::run_bicgstab(ogl_perf *perf) { return run_krylov(perf); }
+
+// One driver for GKOCG and GKOBiCGStab: criterion set-up, initial residual + norm factor, the
+// solver-specific turn, the batched enqueue / late stop-poll, result collection.
+//
+// GKOBiCGStab ([UPSTREAM] gko::solver::Bicgstab), per turn:
+//   rho = rr.r, sum|r| -> check#1 -> p = r + (rho/prev_rho * alpha/omega)(p - omega v) -> y = M^-1 p
+//   -> v = A y, beta = rr.v -> alpha = rho/beta, s = r - alpha v, sum|s| -> check#2 (x += alpha y
+//   when it stops) -> z = M^-1 s -> t = A z, gamma = s.t, beta = t.t -> omega = gamma/beta,
+//   x += alpha y + omega z, r = s - omega t.
+// Two checks per turn: maxIter is doubled (StoppingCriterion.H:188) and the reported count halved
+// (GKOBiCGStab.H:114).
+int ogl_solver::run_krylov(ogl_perf *perf)
 {
     hipStream_t st = reg->stream;
     const int n = pat.n_rows;
     DevScalars *s = d_scal.p;
     const int nc = (int)n_chunks(n);
+    const bool bicg = cfg.solver == OGL_SOLVER_BICGSTAB;
 
     // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
     const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
@@ -405,17 +422,29 @@ int ogl_solver::run_cg(ogl_perf *perf)
     DevCriterion crit{};
     crit.tolerance = cfg.tolerance;
     crit.rel_tol = cfg.rel_tol;
-    crit.max_iter = cfg.max_iter;
+    crit.max_iter = bicg ? 2 * cfg.max_iter : cfg.max_iter;  // :188
     crit.export_res = cfg.export_res;
     ogl_host_adapt_criterion(&cfg, prev_iters, prev_cost, &crit.min_iter, &crit.frequency);
     if (crit.frequency < 1) return fail(OGL_ERR_INVALID, "evalFrequency must be >= 1");
-    const int max_steps = crit.max_iter + crit.frequency + 1;
-    OGL_TRY(d_history.alloc((size_t)max_steps + 2, st));
+    const int max_checks = crit.max_iter + crit.frequency + 1;  // the check count never exceeds this
+    const int max_turns = bicg ? max_checks / 2 + 1 : max_checks;
+    OGL_TRY(d_history.alloc((size_t)max_checks + 4, st));
     if (cfg.export_res)
         OGL_HIP_CHECK(hipMemsetAsync(d_history.p, 0, d_history.n * sizeof(double), st));
+    if (bicg) {
+        const size_t nv = (size_t)n + 2;
+        OGL_TRY(d_v.alloc(nv, st));
+        OGL_TRY(d_s.alloc(nv, st));
+        OGL_TRY(d_t.alloc(nv, st));
+        OGL_TRY(d_rr.alloc(nv, st));
+        if (precond) {
+            OGL_TRY(d_y.alloc(nv, st));
+            OGL_TRY(d_z.alloc(nv, st));
+        }
+    }
 
-    // profile_kernels: one event pair per in-loop SpMV
-    const int prof_cap = cfg.profile_kernels ? std::min(max_steps, 4096) : 0;
+    // profile_kernels: one event pair per in-loop SpMV (the first of a BiCGStab turn)
+    const int prof_cap = cfg.profile_kernels ? std::min(max_turns, 4096) : 0;
     while ((int)prof_ev.size() < 2 * prof_cap) {
         hipEvent_t e;
         OGL_HIP_CHECK(hipEventCreate(&e));
@@ -450,9 +479,9 @@ int ogl_solver::run_cg(ogl_perf *perf)
     OGL_TRY(finalize(FIN_MEAN, fa));
     // Axref = A * (xbar 1) (:24-29) into q
     launch_fill_xbar(st, n, d_w.p, s);
-    OGL_TRY(dist_spmv(SPMV_PLAIN, d_w.p, nullptr, d_q.p, nullptr, nullptr));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_w.p, nullptr, d_q.p, SpmvDots{}, nullptr));
     // r = b - A x  ([UPSTREAM] r = b; r = -1*A*x + 1*r)
-    OGL_TRY(dist_spmv(SPMV_RESIDUAL, d_x.p, d_b.p, d_r.p, nullptr, nullptr));
+    OGL_TRY(dist_spmv(SPMV_RESIDUAL, d_x.p, d_b.p, d_r.p, SpmvDots{}, nullptr));
     // norm factor, part 2 (:53-68)
     launch_partials_normfactor(st, n, d_b.p, d_q.p, d_r.p, d_part0.p);
     fa = FinArgs{};
@@ -460,11 +489,20 @@ int ogl_solver::run_cg(ogl_perf *perf)
     fa.n_part = nc;
     fa.n_sums = 1;
     OGL_TRY(finalize(FIN_NORMFACTOR, fa));
-    // p = q = 0 ([UPSTREAM] cg::initialize); z is never materialised (z = r * inv_diag on the fly)
-    OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, (size_t)n * sizeof(double), st));
 
-    // turn 0: rho, sum|r|, check -- timed once as "time per residual norm calculation"
-    launch_cg_rho_norm(st, n, d_r.p, precond, d_part0.p, d_part1.p, s);
+    // solver initialisation + turn 0: rho, sum|r|, check (timed once as "time per residual norm
+    // calculation", lduLduBase.H:287)
+    OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, (size_t)n * sizeof(double), st));
+    if (bicg) {
+        // rr = r ; p = v = 0 ([UPSTREAM] bicgstab::initialize); rho = rr.r = r.r
+        OGL_HIP_CHECK(hipMemcpyAsync(d_rr.p, d_r.p, (size_t)n * sizeof(double),
+                                     hipMemcpyDeviceToDevice, st));
+        OGL_HIP_CHECK(hipMemsetAsync(d_v.p, 0, (size_t)n * sizeof(double), st));
+        launch_cg_rho_norm(st, n, d_r.p, nullptr, d_part0.p, d_part1.p, s);
+    } else {
+        // p = q = 0 ([UPSTREAM] cg::initialize); z is never materialised (z = r * inv_diag on the fly)
+        launch_cg_rho_norm(st, n, d_r.p, precond, d_part0.p, d_part1.p, s);
+    }
     FinArgs chk{};
     chk.part[0] = d_part0.p;
     chk.part[1] = d_part1.p;
@@ -476,22 +514,50 @@ int ogl_solver::run_cg(ogl_perf *perf)
     OGL_TRY(finalize(FIN_CG_CHECK, chk));
     OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
 
-    FinArgs fb{};
-    fb.part[0] = d_part0.p;
-    fb.n_part = nc;
-    fb.n_sums = 1;
+    FinArgs f1{};  // one partial array
+    f1.part[0] = d_part0.p;
+    f1.n_part = nc;
+    f1.n_sums = 1;
+    f1.crit = crit;
+    f1.history = d_history.p;
+    FinArgs f2 = f1;  // two partial arrays
+    f2.part[1] = d_part1.p;
+    f2.n_sums = 2;
+
+    double *y = precond ? d_y.p : d_p.p;  // identity preconditioner: y aliases p, z aliases s
+    double *z = precond ? d_z.p : d_s.p;
 
     int enq = 0;
-    auto enqueue_steps = [&](int count) -> int {
+    auto enqueue_turns = [&](int count) -> int {
         for (int i = 0; i < count; ++i, ++enq) {
-            launch_cg_step1(st, n, d_p.p, d_r.p, precond, s);
             const bool prof = enq < prof_cap;
-            if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
-            OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, d_part0.p, s));
-            if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
-            OGL_TRY(finalize(FIN_BETA, fb));
-            launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, precond, d_part0.p, d_part1.p, s);
-            OGL_TRY(finalize(FIN_CG_CHECK, chk));
+            if (!bicg) {
+                launch_cg_step1(st, n, d_p.p, d_r.p, precond, s);
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
+                                  SpmvDots{d_p.p, d_part0.p, nullptr}, s));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                OGL_TRY(finalize(FIN_BETA, f1));
+                launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, precond, d_part0.p, d_part1.p, s);
+                OGL_TRY(finalize(FIN_CG_CHECK, chk));
+            } else {
+                launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p,
+                                  SpmvDots{d_rr.p, d_part0.p, nullptr}, s));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                OGL_TRY(finalize(FIN_BICG_ALPHA, f1));
+                launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part0.p, s);
+                f1.turn = enq;
+                OGL_TRY(finalize(FIN_BICG_CHECK2, f1));
+                launch_bicg_finalize_x(st, n, d_x.p, y, s, enq);
+                OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
+                                  SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
+                OGL_TRY(finalize(FIN_BICG_OMEGA, f2));
+                launch_bicg_step3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p,
+                                  d_part1.p, s);
+                OGL_TRY(finalize(FIN_CG_CHECK, chk));
+            }
         }
         return OGL_OK;
     };
@@ -501,13 +567,16 @@ int ogl_solver::run_cg(ogl_perf *perf)
         return OGL_OK;
     };
 
-    const int batch = 16;
-    OGL_TRY(enqueue_steps(std::min(batch, max_steps - enq)));
+    // The host never waits for the turn it has just enqueued: it looks at the stop flag of batch k
+    // only after batch k+1 is in the queue.  Every rank sees the same flags (the norms are
+    // all-reduced), hence enqueues the same number of batches and of RCCL calls.
+    const int batch = bicg ? 8 : 16;
+    OGL_TRY(enqueue_turns(std::min(batch, max_turns - enq)));
     OGL_TRY(poll_record(0));
     for (int k = 0;; ++k) {
-        const bool more = enq < max_steps;
+        const bool more = enq < max_turns;
         if (more) {
-            OGL_TRY(enqueue_steps(std::min(batch, max_steps - enq)));
+            OGL_TRY(enqueue_turns(std::min(batch, max_turns - enq)));
             OGL_TRY(poll_record((k + 1) & 1));
         }
         OGL_HIP_CHECK(hipEventSynchronize(poll_ev[k & 1]));
@@ -531,18 +600,18 @@ int ogl_solver::run_cg(ogl_perf *perf)
     (void)hipEventDestroy(ev_chk[0]);
     (void)hipEventDestroy(ev_chk[1]);
 
-    perf->initial_residual = fin.init_res;   // lduLduBase.H:283
-    perf->final_residual = fin.res;          // :284
-    perf->n_iterations = fin.iter;           // :285, GKOCG.H:105-108
+    perf->initial_residual = fin.init_res;                  // lduLduBase.H:283
+    perf->final_residual = fin.res;                         // :284
+    perf->n_iterations = bicg ? fin.iter / 2 : fin.iter;    // :285, GKOCG.H:105-108, GKOBiCGStab.H:114
     perf->n_norm_evals = fin.n_evals;
     perf->norm_factor = fin.norm_factor;
     perf->t_solve_ms = t_solve;
-    const int steps_done = std::max(0, fin.iter - 1);
+    const int turns_done = bicg ? fin.iter / 2 : std::max(0, fin.iter - 1);
     perf->spmv_avg_ms = 0;
     perf->spmv_launches = 0;
     if (prof_cap) {
         double acc = 0;
-        const int m = std::min(steps_done, prof_cap);
+        const int m = std::min(turns_done, prof_cap);
         for (int i = 0; i < m; ++i) {
             float ms = 0.f;
             OGL_HIP_CHECK(hipEventElapsedTime(&ms, prof_ev[2 * i], prof_ev[2 * i + 1]));
@@ -553,9 +622,10 @@ int ogl_solver::run_cg(ogl_perf *perf)
     }
 
     // store_number_of_iterations + relative residual-evaluation cost (lduLduBase.H:286-293);
-    // both are stored as labels, i.e. truncated (common.C:75-76,117-123)
+    // both are stored as labels, i.e. truncated (common.C:75-76,117-123).  The stored count is the
+    // raw number of checks for every solver (GKOBiCGStab.H:98-103).
     props[is_final ? "prevSolveIters_final" : "prevSolveIters"] = fin.iter;
-    const double time_per_iter = t_solve * 1e3 / std::max(fin.iter, 1);
+    const double time_per_iter = t_solve * 1e3 / std::max(perf->n_iterations, 1);
     const double res_norm_time = std::max(1e-3, (double)chk_ms * 1e3);
     double rel_cost = time_per_iter / res_norm_time;
     if (reg->comm->multi()) {  // broadcast from rank 0 (:291-292) so every rank adapts alike
@@ -567,11 +637,6 @@ int ogl_solver::run_cg(ogl_perf *perf)
     }
     props["_prev_solve"] = std::floor(rel_cost);
     return OGL_OK;
-}
-
-int ogl_solver::run_bicgstab(ogl_perf *)
-{
-    return fail(OGL_ERR_UNSUPPORTED, "GKOBiCGStab is not built yet");
 }
 
 // solver->apply(b, x) on the resident vectors (lduLduBase.H:254-276)
@@ -632,12 +697,12 @@ int ogl_solver::time_spmv(int repeats, double *avg_ms)
     hipEvent_t e0, e1;
     OGL_HIP_CHECK(hipEventCreate(&e0));
     OGL_HIP_CHECK(hipEventCreate(&e1));
-    OGL_TRY(dist_spmv(SPMV_PLAIN, d_b.p, nullptr, d_q.p, d_part0.p, nullptr));  // warm-up
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_b.p, nullptr, d_q.p, SpmvDots{d_b.p, d_part0.p, nullptr}, nullptr));  // warm-up
     OGL_HIP_CHECK(hipEventRecord(e0, st));
     for (int i = 0; i < repeats; ++i) {
         // alternate the input so consecutive launches do not read what the last one wrote
         const double *x = (i & 1) ? d_r.p : d_b.p;
-        OGL_TRY(dist_spmv(SPMV_PLAIN, x, nullptr, d_q.p, d_part0.p, nullptr));
+        OGL_TRY(dist_spmv(SPMV_PLAIN, x, nullptr, d_q.p, SpmvDots{x, d_part0.p, nullptr}, nullptr));
     }
     OGL_HIP_CHECK(hipEventRecord(e1, st));
     OGL_HIP_CHECK(hipEventSynchronize(e1));

@@ -139,11 +139,12 @@ struct ogl_solver {
     int upload_vec(ogl::DevBuf<double> &dst, const double *src);
     int ensure_vectors();
     int init_preconditioner();
-    int dist_spmv(int mode, const double *x, const double *b, double *y, double *dot_part,
+    int dist_spmv(int mode, const double *x, const double *b, double *y, const ogl::SpmvDots &dots,
                   const ogl::DevScalars *gate);
     int finalize(int phase, ogl::FinArgs &a);
     int run_cg(ogl_perf *perf);
     int run_bicgstab(ogl_perf *perf);
+    int run_krylov(ogl_perf *perf);
     int time_spmv(int repeats, double *avg_ms);
     ogl::DevCsr csr() const;
     ogl::DevHalo halo() const;

@@ -58,5 +58,10 @@ def test_gpu_host_buffer_transport(shape, procs, n, precond):
 
 
 @pytest.mark.gpu
+def test_gpu_host_buffer_transport_bicgstab():
+    run_ranks(2, "--mode", "gpu-host", "--shape", "12,12,12", "--procs", "1,1,2", "--asym", "1")
+
+
+@pytest.mark.gpu
 def test_gpu_rccl_single_rank():
     run_ranks(1, "--mode", "gpu-rccl", "--shape", "12,12,12", "--procs", "1,1,1")

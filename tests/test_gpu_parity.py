@@ -285,3 +285,63 @@ def test_empty_system(reg):
     s = reg.solver("empty", cg_cfg(max_iter=3)).set_matrix(case)
     x, perf = s.solve(np.zeros(0), np.zeros(0))
     assert x.size == 0 and perf.n_iterations >= 1
+
+
+# ---------------------------------------------------------------------------- GKOBiCGStab
+
+@pytest.mark.parametrize("precond", [capi.PRECOND_NONE, capi.PRECOND_BJ], ids=["none", "BJ"])
+@pytest.mark.parametrize("sym", [False, True], ids=["asym", "sym"])
+@pytest.mark.parametrize("tol", [1e-3, 1e-6, 1e-9, 1e-12])
+def test_bicgstab_history(reg, oracle, chunk_rows, precond, sym, tol):
+    """Both criterion checks of a turn (on r, then on s) are exercised by sweeping the tolerance:
+    the stop lands on either; a mid-turn stop must apply x += alpha y (bicgstab::finalize)."""
+    case = synthetic.poisson_case(12, symmetric=sym)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    cfg = cg_cfg(solver=capi.SOLVER_BICGSTAB, preconditioner=precond, max_iter=300, tolerance=tol)
+    s = reg.solver(f"bicg_{precond}_{sym}", cfg).set_matrix(case)
+    s.upload_solution(None)
+    x, perf = s.solve(b, np.zeros_like(b))
+    hist = s.history()
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    inv = oracle.jacobi_generate_scalar(rp, cols, vals) if precond else None
+    with blocked(oracle, chunk_rows):
+        ref = oracle.bicgstab(A, b, np.zeros_like(b), inv, tolerance=tol, rel_tol=0.0, max_iter=300)
+    assert perf.n_iterations == ref.n_iterations // 2        # GKOBiCGStab.H:114
+    np.testing.assert_array_equal(hist, ref.history)
+    np.testing.assert_array_equal(x, ref.x)
+    assert perf.final_residual == ref.final_residual < tol
+    ref_s = oracle.bicgstab(A, b, np.zeros_like(b), inv, tolerance=tol, rel_tol=0.0, max_iter=300)
+    # sequential-order oracle: both satisfy the same residual bar, so they agree to ~cond * tol
+    np.testing.assert_allclose(x, ref_s.x, atol=max(1e-8, 1e3 * tol), rtol=0)
+
+
+def test_bicgstab_stops_on_both_checks(oracle):
+    # make sure the sweep above really covers an odd (check on r) and an even (check on s) stop
+    case = synthetic.poisson_case(12, symmetric=False)
+    b = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
+    A, _ = oracle_matrix(oracle, case)
+    parities = set()
+    for tol in (1e-3, 1e-6, 1e-9, 1e-12, 1e-2, 1e-4, 1e-5, 1e-7):
+        ref = oracle.bicgstab(A, b, np.zeros_like(b), None, tolerance=tol, rel_tol=0.0, max_iter=300)
+        parities.add(ref.n_iterations % 2)
+    assert parities == {0, 1}
+
+
+def test_bicgstab_max_iter_is_doubled(reg, oracle):
+    case = synthetic.poisson_case(8, symmetric=False)
+    b = np.ones(case.n_cells)
+    s = reg.solver("bicg_max", cg_cfg(solver=capi.SOLVER_BICGSTAB, max_iter=7)).set_matrix(case)
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, _ = oracle_matrix(oracle, case)
+    ref = oracle.bicgstab(A, b, np.zeros_like(b), None, tolerance=0.0, rel_tol=0.0, max_iter=7)
+    assert ref.n_iterations == 15 and perf.n_iterations == 7      # 2*7 checks + 1, halved
+    assert s.get_property("prevSolveIters_final") == 15           # raw count is what is stored
+
+
+def test_gmres_is_refused_for_now(reg):
+    case = synthetic.poisson_case(4)
+    s = reg.solver("gm", cg_cfg(solver=capi.SOLVER_GMRES)).set_matrix(case)
+    with pytest.raises(capi.OglError) as e:
+        s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
+    assert e.value.status == capi.ERR_UNSUPPORTED

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 --pmc counter_collection CSVs (one pass per counter set) into one JSON:
+per kernel, the mean counter value over the dispatches that did real work (the solver enqueues a
+few gated no-op launches after the stop; they are dropped by a 5 %-of-max threshold).
+
+  pmc_summary.py OUT.json DIR [DIR ...]       (each DIR holds one pass)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    vals = collections.defaultdict(list)
+    for d in dirs:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    vals[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
+    res = collections.defaultdict(dict)
+    for (k, c), v in vals.items():
+        mx = max(v)
+        real = [x for x in v if x > 0.05 * mx] if mx > 0 else v
+        short = k.split("namespace)::")[-1].split("(")[0]
+        res[short][c] = {"mean": sum(real) / len(real), "dispatches": len(real),
+                         "dropped_noop_dispatches": len(v) - len(real)}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    for k in sorted(res):
+        print(k, {c: round(x["mean"], 1) for c, x in res[k].items()})
+
+
+if __name__ == "__main__":
+    main()
