@@ -82,6 +82,45 @@ void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *o
     }
 }
 
+void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
+                        std::vector<ogl_label> &block_ptrs, std::vector<ogl_label> &row_block)
+{
+    const ogl_label n = p.n_rows;
+    block_ptrs.assign(1, 0);
+    row_block.assign(n, 0);
+    if (n == 0) return;
+    auto same_pattern = [&](ogl_label a, ogl_label b) {
+        const ogl_label la = p.row_ptrs[a + 1] - p.row_ptrs[a], lb = p.row_ptrs[b + 1] - p.row_ptrs[b];
+        if (la != lb) return false;
+        return std::equal(p.cols.begin() + p.row_ptrs[a], p.cols.begin() + p.row_ptrs[a + 1],
+                          p.cols.begin() + p.row_ptrs[b]);
+    };
+    std::vector<ogl_label> nat{0};  // natural blocks
+    ogl_label cur = 1;
+    for (ogl_label i = 1; i < n; ++i) {
+        if (same_pattern(i - 1, i) && cur < max_block_size) {
+            ++cur;
+        } else {
+            nat.push_back(i);
+            cur = 1;
+        }
+    }
+    nat.push_back(n);
+    cur = nat[1] - nat[0];  // agglomerate
+    for (size_t i = 1; i + 1 < nat.size(); ++i) {
+        const ogl_label bs = nat[i + 1] - nat[i];
+        if (cur + bs <= max_block_size) {
+            cur += bs;
+        } else {
+            block_ptrs.push_back(nat[i]);
+            cur = bs;
+        }
+    }
+    block_ptrs.push_back(n);
+    for (size_t b = 0; b + 1 < block_ptrs.size(); ++b)
+        for (ogl_label r = block_ptrs[b]; r < block_ptrs[b + 1]; ++r) row_block[r] = (ogl_label)b;
+}
+
 bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p)
 {
     if (ldu.n_cells != p.n_rows || ldu.n_faces != p.upper_nnz) return false;

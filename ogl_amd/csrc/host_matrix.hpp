@@ -49,6 +49,12 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p);
 // ("For now we assume columns and rows to be constant", HostMatrix.H:33).
 bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p);
 
+// Jacobi block pointers for maxBlockSize > 1 ([UPSTREAM] gko::preconditioner::Jacobi
+// find_blocks): natural blocks = runs of consecutive rows with identical column pattern (capped at
+// max_block_size), adjacent natural blocks agglomerated while the merged size <= max_block_size.
+void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
+                        std::vector<ogl_label> &block_ptrs, std::vector<ogl_label> &row_block);
+
 // HostMatrix.C:180-207: concatenated bouCoeffs of the (non-)processor interfaces, times -1.
 void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *out);
 

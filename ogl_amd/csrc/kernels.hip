@@ -280,6 +280,82 @@ __global__ __launch_bounds__(BLOCK) void k_jacobi_generate(int n_rows,
     inv_diag[row] = 1.0 / d;
 }
 
+// Block Jacobi generate: one thread inverts one diagonal block in place (global memory; runs
+// once per preconditioner generation).  Same operation order as oracle/ogl_oracle.c invert_block:
+// Gauss-Jordan, partial (row) pivoting, pivot row scaled first, then the other rows eliminated,
+// finally the row swaps undone as a column permutation.
+__global__ __launch_bounds__(BLOCK) void k_bj_generate(int n_blocks,
+                                                       const int *__restrict__ block_ptrs,
+                                                       const int *__restrict__ row_ptrs,
+                                                       const int *__restrict__ cols,
+                                                       const double *__restrict__ vals,
+                                                       double *__restrict__ blocks, int ld)
+{
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= n_blocks) return;
+    const int r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
+    double *a = blocks + (size_t)b * ld * ld;
+    for (int i = 0; i < ld * ld; ++i) a[i] = 0.0;
+    for (int i = 0; i < bs; ++i)
+        for (int k = row_ptrs[r0 + i]; k < row_ptrs[r0 + i + 1]; ++k) {
+            const int c = cols[k] - r0;
+            if (c >= 0 && c < bs) a[i * ld + c] = vals[k];
+        }
+    int perm[MAX_JACOBI_BLOCK];
+    for (int k = 0; k < bs; ++k) perm[k] = k;
+    for (int k = 0; k < bs; ++k) {
+        int piv = k;
+        double best = fabs(a[k * ld + k]);
+        for (int i = k + 1; i < bs; ++i)
+            if (fabs(a[i * ld + k]) > best) {
+                best = fabs(a[i * ld + k]);
+                piv = i;
+            }
+        if (piv != k) {
+            for (int j = 0; j < bs; ++j) {
+                const double t = a[k * ld + j];
+                a[k * ld + j] = a[piv * ld + j];
+                a[piv * ld + j] = t;
+            }
+            const int t = perm[k];
+            perm[k] = perm[piv];
+            perm[piv] = t;
+        }
+        const double d = a[k * ld + k];
+        a[k * ld + k] = 1.0;
+        for (int j = 0; j < bs; ++j) a[k * ld + j] /= d;
+        for (int i = 0; i < bs; ++i) {
+            if (i == k) continue;
+            const double f = a[i * ld + k];
+            a[i * ld + k] = 0.0;
+            for (int j = 0; j < bs; ++j) a[i * ld + j] -= f * a[k * ld + j];
+        }
+    }
+    double row[MAX_JACOBI_BLOCK];
+    for (int i = 0; i < bs; ++i) {
+        for (int j = 0; j < bs; ++j) row[perm[j]] = a[i * ld + j];
+        for (int j = 0; j < bs; ++j) a[i * ld + j] = row[j];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bj_apply(int n_rows, const int *__restrict__ block_ptrs,
+                                                    const int *__restrict__ row_block,
+                                                    const double *__restrict__ blocks, int ld,
+                                                    const double *__restrict__ in,
+                                                    double *__restrict__ out,
+                                                    const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const int row = blockIdx.x * BLOCK + threadIdx.x;
+    if (row >= n_rows) return;
+    const int b = row_block[row];
+    const int r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
+    const double *a = blocks + (size_t)b * ld * ld + (size_t)(row - r0) * ld;
+    double sum = 0.0;
+    for (int j = 0; j < bs; ++j) sum += a[j] * in[r0 + j];
+    out[row] = sum;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_scale(int n, double *__restrict__ v, double f)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -788,6 +864,21 @@ void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag)
     if (A.n_rows == 0) return;
     hipLaunchKernelGGL(k_jacobi_generate, dim3(blocks_for(A.n_rows)), dim3(BLOCK), 0, st, A.n_rows,
                        A.row_ptrs, A.cols, A.vals, inv_diag);
+}
+
+void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J)
+{
+    if (J.n_blocks == 0) return;
+    hipLaunchKernelGGL(k_bj_generate, dim3(blocks_for(J.n_blocks)), dim3(BLOCK), 0, st, J.n_blocks,
+                       J.block_ptrs, A.row_ptrs, A.cols, A.vals, J.blocks, J.stride);
+}
+
+void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
+                     const DevScalars *gate)
+{
+    if (J.n_rows == 0) return;
+    hipLaunchKernelGGL(k_bj_apply, dim3(blocks_for(J.n_rows)), dim3(BLOCK), 0, st, J.n_rows,
+                       J.block_ptrs, J.row_block, J.blocks, J.stride, in, out, gate);
 }
 
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor)

@@ -77,6 +77,23 @@ void launch_gather_coeffs(hipStream_t st, int32_t nnz, const int32_t *ldu_mappin
 // inv_diag[i] = 1 / A(i,i)   (Jacobi generate with max_block_size 1)
 void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag);
 
+// Block Jacobi with maxBlockSize k > 1 (Preconditioner.H:91-105): inverted diagonal blocks,
+// row-major, `stride` x `stride` doubles per block.
+struct DevBlockJacobi {
+    int32_t n_rows = 0;
+    int32_t n_blocks = 0;
+    int32_t stride = 0;                  // = maxBlockSize
+    const int32_t *block_ptrs = nullptr; // [n_blocks + 1] first row of each block
+    const int32_t *row_block = nullptr;  // [n_rows] block of each row
+    double *blocks = nullptr;            // [n_blocks * stride * stride]
+};
+constexpr int MAX_JACOBI_BLOCK = 32;
+// blocks[b] = inverse of A(block b, block b) by Gauss-Jordan with partial pivoting
+void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J);
+// out = M^-1 in : per row, the block row times the block's slice of `in`, summed left to right
+void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
+                     const DevScalars *gate);
+
 // b *= scaling (lduLduBase.H:244-252)
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor);
 // v[i] = s->xbar

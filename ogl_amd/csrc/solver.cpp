@@ -103,7 +103,9 @@ ogl_registry::~ogl_registry()
     if (stream) (void)hipStreamSynchronize(stream);
     solvers.clear();
     comm.reset();
-    cached_precond.release();
+    cached_precond.values.release();
+    cached_precond.block_ptrs.release();
+    cached_precond.row_block.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -312,35 +314,79 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
 //                                the stored object is not replaced (:411-413)
 // The store is registry-wide (one key for all fields, :357), as in the reference.
 // ------------------------------------------------------------------------------------------
+int ogl_solver::generate_preconditioner(PrecondData &P)
+{
+    hipStream_t st = reg->stream;
+    const size_t n = (size_t)pat.n_rows;
+    if (cfg.max_block_size == 1) {  // scalar Jacobi: 1 / diag
+        OGL_TRY(P.values.alloc(n + 2, st));
+        launch_jacobi_generate(st, csr(), P.values.p);
+        P.kind = 1;
+        P.stride = 0;
+    } else {
+        // Jacobi factory with max_block_size = maxBlockSize, skip_sorting (Preconditioner.H:100-104)
+        std::vector<int32_t> ptrs, row_block;
+        find_jacobi_blocks(pat, cfg.max_block_size, ptrs, row_block);
+        P.n_blocks = (int32_t)ptrs.size() - 1;
+        const size_t k = (size_t)cfg.max_block_size;
+        OGL_TRY(P.block_ptrs.alloc(ptrs.size(), st));
+        OGL_TRY(P.row_block.alloc(std::max<size_t>(1, row_block.size()), st));
+        OGL_TRY(P.values.alloc(std::max<size_t>(1, (size_t)P.n_blocks * k * k), st));
+        OGL_TRY(reg->stager.h2d(P.block_ptrs.p, ptrs.data(), ptrs.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(P.row_block.p, row_block.data(), row_block.size() * sizeof(int32_t), st));
+        DevBlockJacobi J;
+        J.n_rows = pat.n_rows;
+        J.n_blocks = P.n_blocks;
+        J.stride = cfg.max_block_size;
+        J.block_ptrs = P.block_ptrs.p;
+        J.row_block = P.row_block.p;
+        J.blocks = P.values.p;
+        launch_bj_generate(st, csr(), J);
+        P.kind = 2;
+        P.stride = cfg.max_block_size;
+    }
+    P.n_rows = n;
+    return OGL_OK;
+}
+
+void ogl_solver::apply_preconditioner(const double *in, double *out, const DevScalars *gate)
+{
+    DevBlockJacobi J;
+    J.n_rows = pat.n_rows;
+    J.n_blocks = precond_data->n_blocks;
+    J.stride = precond_data->stride;
+    J.block_ptrs = precond_data->block_ptrs.p;
+    J.row_block = precond_data->row_block.p;
+    J.blocks = precond_data->values.p;
+    launch_bj_apply(reg->stream, J, in, out, gate);
+}
+
 int ogl_solver::init_preconditioner()
 {
     precond = nullptr;
+    precond_data = nullptr;
     if (cfg.preconditioner == OGL_PRECOND_NONE) return OGL_OK;  // :342
     if (cfg.preconditioner != OGL_PRECOND_BJ)
         return fail(OGL_ERR_UNSUPPORTED, "preconditioner kind %d is not built", cfg.preconditioner);
-    if (cfg.max_block_size != 1)
-        return fail(OGL_ERR_UNSUPPORTED, "BJ maxBlockSize %d: only the scalar case is built",
-                    cfg.max_block_size);
-    hipStream_t st = reg->stream;
-    const size_t n = (size_t)pat.n_rows + 2;
+    if (cfg.max_block_size < 1 || cfg.max_block_size > MAX_JACOBI_BLOCK)
+        return fail(OGL_ERR_INVALID, "BJ maxBlockSize %d outside [1, %d]", cfg.max_block_size,
+                    MAX_JACOBI_BLOCK);
+    const int kind = cfg.max_block_size == 1 ? 1 : 2;
+    const int stride = kind == 2 ? cfg.max_block_size : 0;
     const int cache = (int)prop("preconditionerCaching", 0);
-    const bool stored = reg->has_cached_precond && reg->cached_precond.n == n;
+    const bool stored =
+        reg->has_cached_precond && reg->cached_precond.matches(kind, (size_t)pat.n_rows, stride);
     if (stored && cache > 0) {
         props["preconditionerCaching"] = cache - 1;
-        precond = reg->cached_precond.p;
-        return OGL_OK;
-    }
-    props["preconditionerCaching"] = cfg.caching;
-    if (!stored) {
-        OGL_TRY(reg->cached_precond.alloc(n, st));
-        launch_jacobi_generate(st, csr(), reg->cached_precond.p);
-        reg->has_cached_precond = true;
-        precond = reg->cached_precond.p;
+        precond_data = &reg->cached_precond;
     } else {
-        OGL_TRY(d_inv_diag.alloc(n, st));
-        launch_jacobi_generate(st, csr(), d_inv_diag.p);
-        precond = d_inv_diag.p;
+        props["preconditionerCaching"] = cfg.caching;
+        PrecondData &P = stored ? own_precond : reg->cached_precond;
+        OGL_TRY(generate_preconditioner(P));
+        if (!stored) reg->has_cached_precond = true;
+        precond_data = &P;
     }
+    if (precond_data->kind == 1) precond = precond_data->values.p;
     return OGL_OK;
 }
 
@@ -414,6 +460,9 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     DevScalars *s = d_scal.p;
     const int nc = (int)n_chunks(n);
     const bool bicg = cfg.solver == OGL_SOLVER_BICGSTAB;
+    // block Jacobi (maxBlockSize > 1): z = M^-1 r is materialised by its own kernel; the scalar
+    // case stays fused into the step kernels
+    const bool generic = precond_data && precond_data->kind == 2;
 
     // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
     const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
@@ -437,10 +486,12 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         OGL_TRY(d_s.alloc(nv, st));
         OGL_TRY(d_t.alloc(nv, st));
         OGL_TRY(d_rr.alloc(nv, st));
-        if (precond) {
+        if (precond || generic) {
             OGL_TRY(d_y.alloc(nv, st));
             OGL_TRY(d_z.alloc(nv, st));
         }
+    } else if (generic) {
+        OGL_TRY(d_z.alloc((size_t)n + 2, st));
     }
 
     // profile_kernels: one event pair per in-loop SpMV (the first of a BiCGStab turn)
@@ -502,6 +553,10 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     } else {
         // p = q = 0 ([UPSTREAM] cg::initialize); z is never materialised (z = r * inv_diag on the fly)
         launch_cg_rho_norm(st, n, d_r.p, precond, d_part0.p, d_part1.p, s);
+        if (generic) {  // rho = r . (M^-1 r) with the block preconditioner
+            apply_preconditioner(d_r.p, d_z.p, s);
+            launch_partials_dot(st, n, d_r.p, d_z.p, d_part0.p, s);
+        }
     }
     FinArgs chk{};
     chk.part[0] = d_part0.p;
@@ -524,14 +579,25 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     f2.part[1] = d_part1.p;
     f2.n_sums = 2;
 
-    double *y = precond ? d_y.p : d_p.p;  // identity preconditioner: y aliases p, z aliases s
-    double *z = precond ? d_z.p : d_s.p;
+    double *y = (precond || generic) ? d_y.p : d_p.p;  // identity: y aliases p, z aliases s
+    double *z = (precond || generic) ? d_z.p : d_s.p;
 
     int enq = 0;
     auto enqueue_turns = [&](int count) -> int {
         for (int i = 0; i < count; ++i, ++enq) {
             const bool prof = enq < prof_cap;
-            if (!bicg) {
+            if (!bicg && generic) {
+                launch_cg_step1(st, n, d_p.p, d_z.p, nullptr, s);  // p = z + (rho/prev_rho) p
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
+                                  SpmvDots{d_p.p, d_part0.p, nullptr}, s));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                OGL_TRY(finalize(FIN_BETA, f1));
+                launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, nullptr, d_part0.p, d_part1.p, s);
+                apply_preconditioner(d_r.p, d_z.p, s);
+                launch_partials_dot(st, n, d_r.p, d_z.p, d_part0.p, s);
+                OGL_TRY(finalize(FIN_CG_CHECK, chk));
+            } else if (!bicg) {
                 launch_cg_step1(st, n, d_p.p, d_r.p, precond, s);
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
@@ -542,12 +608,14 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else {
                 launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
+                if (generic) apply_preconditioner(d_p.p, y, s);
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p,
                                   SpmvDots{d_rr.p, d_part0.p, nullptr}, s));
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
                 OGL_TRY(finalize(FIN_BICG_ALPHA, f1));
                 launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part0.p, s);
+                if (generic) apply_preconditioner(d_s.p, z, s);
                 f1.turn = enq;
                 OGL_TRY(finalize(FIN_BICG_CHECK2, f1));
                 launch_bicg_finalize_x(st, n, d_x.p, y, s, enq);

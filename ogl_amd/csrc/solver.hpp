@@ -74,6 +74,17 @@ private:
     int next_ = 0;
 };
 
+// A generated preconditioner ("Cached_preconditinoner" holds one of these, Preconditioner.H:357)
+struct PrecondData {
+    int kind = 0;  // 0 none, 1 scalar Jacobi (inverse diagonal), 2 block Jacobi
+    size_t n_rows = 0;
+    int stride = 0;  // block Jacobi: maxBlockSize
+    int32_t n_blocks = 0;
+    DevBuf<double> values;  // inverse diagonal (n_rows + 2) or inverted blocks
+    DevBuf<int32_t> block_ptrs, row_block;
+    bool matches(int k, size_t n, int st) const { return kind == k && n_rows == n && stride == st; }
+};
+
 }  // namespace ogl
 
 struct ogl_solver;
@@ -87,7 +98,7 @@ struct ogl_registry {
     std::map<std::string, std::unique_ptr<ogl_solver>> solvers;
     ogl::Stager stager;
     // "Cached_preconditinoner" (sic) -- one registry-wide slot (Preconditioner.H:357)
-    ogl::DevBuf<double> cached_precond;
+    ogl::PrecondData cached_precond;
     bool has_cached_precond = false;
     ~ogl_registry();
 };
@@ -120,7 +131,9 @@ struct ogl_solver {
     ogl::DevScalars *h_scal = nullptr;  // pinned, 2 slots
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
     bool x_resident = false, b_resident = false;
-    const double *precond = nullptr;  // device inverse diagonal in use, or nullptr (identity)
+    ogl::PrecondData own_precond;              // regenerated-for-this-solve preconditioner
+    const ogl::PrecondData *precond_data = nullptr;  // the one in use (own or the registry's)
+    const double *precond = nullptr;  // scalar Jacobi: inverse diagonal (fused path); else nullptr
 
     // ---- per-field properties (common/common.C:75-146) ----
     std::map<std::string, double> props;
@@ -139,6 +152,8 @@ struct ogl_solver {
     int upload_vec(ogl::DevBuf<double> &dst, const double *src);
     int ensure_vectors();
     int init_preconditioner();
+    int generate_preconditioner(ogl::PrecondData &P);
+    void apply_preconditioner(const double *in, double *out, const ogl::DevScalars *gate);
     int dist_spmv(int mode, const double *x, const double *b, double *y, const ogl::SpmvDots &dots,
                   const ogl::DevScalars *gate);
     int finalize(int phase, ogl::FinArgs &a);

@@ -661,13 +661,129 @@ void orc_jacobi_generate_scalar(orc_label n, const orc_label *rowptr, const orc_
     }
 }
 
-/* Schwarz-wrapped local solver (Preconditioner.H:47-64): purely local apply. */
-static void precond_apply(orc_label n, const orc_scalar *inv_diag, const orc_scalar *r,
-                          orc_scalar *z) {
-    if (inv_diag)
-        for (orc_label i = 0; i < n; ++i) z[i] = r[i] * inv_diag[i];
-    else
+/* ---- block Jacobi, max_block_size > 1 ([UPSTREAM] gko::preconditioner::Jacobi) ----------
+ * find_blocks: natural blocks = runs of consecutive rows with the same column pattern (capped
+ * at max_block_size), then adjacent natural blocks are agglomerated while the merged size stays
+ * <= max_block_size.  Each diagonal block is inverted by Gauss-Jordan elimination with partial
+ * (row) pivoting; apply is a dense block mat-vec, rows summed left to right from 0. */
+static int same_pattern(const orc_label *rowptr, const orc_label *cols, orc_label a, orc_label b) {
+    const orc_label la = rowptr[a + 1] - rowptr[a], lb = rowptr[b + 1] - rowptr[b];
+    if (la != lb) return 0;
+    for (orc_label k = 0; k < la; ++k)
+        if (cols[rowptr[a] + k] != cols[rowptr[b] + k]) return 0;
+    return 1;
+}
+
+orc_label orc_jacobi_find_blocks(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                                 orc_label max_block_size, orc_label *block_ptrs) {
+    if (n == 0) {
+        block_ptrs[0] = 0;
+        return 0;
+    }
+    /* natural blocks */
+    orc_label *nat = (orc_label *)xmalloc(sizeof(orc_label) * ((size_t)n + 1));
+    orc_label n_nat = 1, cur = 1;
+    nat[0] = 0;
+    for (orc_label i = 1; i < n; ++i) {
+        if (same_pattern(rowptr, cols, i - 1, i) && cur < max_block_size) {
+            ++cur;
+        } else {
+            nat[n_nat++] = i;
+            cur = 1;
+        }
+    }
+    nat[n_nat] = n;
+    /* agglomerate */
+    orc_label nb = 1;
+    block_ptrs[0] = 0;
+    cur = nat[1] - nat[0];
+    for (orc_label i = 1; i < n_nat; ++i) {
+        const orc_label bs = nat[i + 1] - nat[i];
+        if (cur + bs <= max_block_size) {
+            cur += bs;
+        } else {
+            block_ptrs[nb++] = nat[i];
+            cur = bs;
+        }
+    }
+    block_ptrs[nb] = n;
+    free(nat);
+    return nb;
+}
+
+/* In-place inverse of the bs x bs row-major block `a` (leading dimension ld). */
+static void invert_block(orc_label bs, orc_scalar *a, orc_label ld) {
+    orc_label perm[64];
+    for (orc_label k = 0; k < bs; ++k) perm[k] = k;
+    for (orc_label k = 0; k < bs; ++k) {
+        orc_label piv = k;
+        orc_scalar best = fabs(a[k * ld + k]);
+        for (orc_label i = k + 1; i < bs; ++i)
+            if (fabs(a[i * ld + k]) > best) {
+                best = fabs(a[i * ld + k]);
+                piv = i;
+            }
+        if (piv != k) {
+            for (orc_label j = 0; j < bs; ++j) {
+                const orc_scalar t = a[k * ld + j];
+                a[k * ld + j] = a[piv * ld + j];
+                a[piv * ld + j] = t;
+            }
+            const orc_label t = perm[k];
+            perm[k] = perm[piv];
+            perm[piv] = t;
+        }
+        const orc_scalar d = a[k * ld + k];
+        a[k * ld + k] = 1.0;
+        for (orc_label j = 0; j < bs; ++j) a[k * ld + j] /= d; /* pivot row; a_kk = 1/d */
+        for (orc_label i = 0; i < bs; ++i) {
+            if (i == k) continue;
+            const orc_scalar f = a[i * ld + k];
+            a[i * ld + k] = 0.0;
+            for (orc_label j = 0; j < bs; ++j) a[i * ld + j] -= f * a[k * ld + j];
+        }
+    }
+    /* undo the row swaps: column perm[k] of the inverse is column k computed above */
+    orc_scalar tmp[64 * 64];
+    for (orc_label i = 0; i < bs; ++i)
+        for (orc_label j = 0; j < bs; ++j) tmp[i * bs + perm[j]] = a[i * ld + j];
+    for (orc_label i = 0; i < bs; ++i)
+        for (orc_label j = 0; j < bs; ++j) a[i * ld + j] = tmp[i * bs + j];
+}
+
+void orc_jacobi_generate_blocks(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                                const orc_scalar *vals, orc_label n_blocks,
+                                const orc_label *block_ptrs, orc_label stride, orc_scalar *blocks) {
+    (void)n;
+    for (orc_label b = 0; b < n_blocks; ++b) {
+        const orc_label r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
+        orc_scalar *a = blocks + (size_t)b * stride * stride;
+        for (orc_label i = 0; i < stride * stride; ++i) a[i] = 0.0;
+        for (orc_label i = 0; i < bs; ++i)
+            for (orc_label k = rowptr[r0 + i]; k < rowptr[r0 + i + 1]; ++k) {
+                const orc_label c = cols[k] - r0;
+                if (c >= 0 && c < bs) a[i * stride + c] = vals[k];
+            }
+        invert_block(bs, a, stride);
+    }
+}
+
+static void precond_apply(orc_label n, const orc_precond *P, const orc_scalar *r, orc_scalar *z) {
+    if (!P || P->kind == ORC_PRECOND_NONE) {
         memcpy(z, r, sizeof(orc_scalar) * (size_t)n); /* identity: copy */
+    } else if (P->kind == ORC_PRECOND_SCALAR) {
+        for (orc_label i = 0; i < n; ++i) z[i] = r[i] * P->inv_diag[i];
+    } else {
+        for (orc_label b = 0; b < P->n_blocks; ++b) {
+            const orc_label r0 = P->block_ptrs[b], bs = P->block_ptrs[b + 1] - r0;
+            const orc_scalar *a = P->blocks + (size_t)b * P->stride * P->stride;
+            for (orc_label i = 0; i < bs; ++i) {
+                orc_scalar sum = 0.0;
+                for (orc_label j = 0; j < bs; ++j) sum += a[i * P->stride + j] * r[r0 + j];
+                z[r0 + i] = sum;
+            }
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -676,6 +792,13 @@ static void precond_apply(orc_label n, const orc_scalar *inv_diag, const orc_sca
 orc_label orc_cg(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                  const orc_scalar *inv_diag, const orc_criterion *crit,
                  orc_criterion_state *st) {
+    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0};
+    return orc_cg_p(A, b, x, &P, crit, st);
+}
+
+orc_label orc_cg_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                   const orc_precond *inv_diag, const orc_criterion *crit,
+                   orc_criterion_state *st) {
     const orc_label n = A->n;
     const size_t bytes = sizeof(orc_scalar) * (size_t)n;
     orc_scalar *r = (orc_scalar *)xmalloc(bytes), *z = (orc_scalar *)calloc(n ? n : 1, sizeof(orc_scalar));
@@ -720,6 +843,13 @@ orc_label orc_cg(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
 orc_label orc_bicgstab(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                        const orc_scalar *inv_diag, const orc_criterion *crit,
                        orc_criterion_state *st) {
+    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0};
+    return orc_bicgstab_p(A, b, x, &P, crit, st);
+}
+
+orc_label orc_bicgstab_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                         const orc_precond *inv_diag, const orc_criterion *crit,
+                         orc_criterion_state *st) {
     const orc_label n = A->n;
     const size_t cnt = n ? (size_t)n : 1;
     orc_scalar *r = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));

@@ -227,6 +227,24 @@ orc_scalar orc_compute_normfactor(const orc_dist_matrix *A, const orc_scalar *r,
 void orc_jacobi_generate_scalar(orc_label n, const orc_label *rowptr, const orc_label *cols,
                                 const orc_scalar *vals, orc_scalar *inv_diag);
 
+/* max_block_size > 1: block pointers (returns the number of blocks; block_ptrs needs n+1
+ * entries), then the inverted diagonal blocks, row-major, `stride` x `stride` doubles each. */
+orc_label orc_jacobi_find_blocks(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                                 orc_label max_block_size, orc_label *block_ptrs);
+void orc_jacobi_generate_blocks(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                                const orc_scalar *vals, orc_label n_blocks,
+                                const orc_label *block_ptrs, orc_label stride, orc_scalar *blocks);
+
+enum { ORC_PRECOND_NONE = 0, ORC_PRECOND_SCALAR = 1, ORC_PRECOND_BLOCK = 2 };
+typedef struct {
+    int kind;
+    const orc_scalar *inv_diag;   /* SCALAR */
+    orc_label n_blocks;           /* BLOCK  */
+    const orc_label *block_ptrs;
+    const orc_scalar *blocks;
+    orc_label stride;
+} orc_precond;
+
 /* ------------------------------------------------------------------ */
 /* Solvers ([UPSTREAM] gko::solver::Cg / Bicgstab, lduLduBase.H:272-276) */
 /* ------------------------------------------------------------------ */
@@ -239,6 +257,13 @@ orc_label orc_cg(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
 orc_label orc_bicgstab(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                        const orc_scalar *inv_diag, const orc_criterion *crit,
                        orc_criterion_state *st);
+
+/* same with a general preconditioner object (NULL = identity) */
+orc_label orc_cg_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                   const orc_precond *P, const orc_criterion *crit, orc_criterion_state *st);
+orc_label orc_bicgstab_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                         const orc_precond *P, const orc_criterion *crit,
+                         orc_criterion_state *st);
 
 /* "omp executor" baseline: row-parallel SpMV, parallel AXPYs and reductions, single rank.
  * Same step order as orc_cg; reductions are OpenMP tree sums (not bit-comparable).

@@ -69,7 +69,7 @@ def _load(name):
     lib.orc_create_communication_pattern.restype = C.c_int32
     for f in ("orc_dot", "orc_norm1", "orc_sum", "orc_compute_normfactor"):
         getattr(lib, f).restype = C.c_double
-    for f in ("orc_cg", "orc_bicgstab", "orc_cg_omp"):
+    for f in ("orc_cg", "orc_bicgstab", "orc_cg_omp", "orc_cg_p", "orc_bicgstab_p"):
         getattr(lib, f).restype = C.c_int32
     lib.orc_omp_max_threads.restype = C.c_int
     return lib
@@ -310,6 +310,38 @@ def jacobi_generate_scalar(rowptr, cols, vals):
     return out
 
 
+class _CPrecond(C.Structure):
+    _fields_ = [("kind", C.c_int), ("inv_diag", _SP), ("n_blocks", C.c_int32),
+                ("block_ptrs", _LP), ("blocks", _SP), ("stride", C.c_int32)]
+
+
+class Precond:
+    """Jacobi preconditioner object: scalar (maxBlockSize 1) or block (maxBlockSize k > 1)."""
+
+    def __init__(self, rowptr, cols, vals, max_block_size=1):
+        rowptr, prp = _l(rowptr)
+        cols, pc = _l(cols)
+        vals, pv = _s(vals)
+        n = rowptr.size - 1
+        self.max_block_size = int(max_block_size)
+        if self.max_block_size == 1:
+            self.inv_diag = jacobi_generate_scalar(rowptr, cols, vals)
+            self.c = _CPrecond(1, self.inv_diag.ctypes.data_as(_SP), 0, None, None, 0)
+        else:
+            k = self.max_block_size
+            bp = np.zeros(n + 1, label)
+            lib().orc_jacobi_find_blocks.restype = C.c_int32
+            nb = lib().orc_jacobi_find_blocks(C.c_int32(n), prp, pc, C.c_int32(k),
+                                              bp.ctypes.data_as(_LP))
+            self.block_ptrs = np.ascontiguousarray(bp[:nb + 1])
+            self.blocks = np.zeros(nb * k * k, scalar)
+            lib().orc_jacobi_generate_blocks(C.c_int32(n), prp, pc, pv, C.c_int32(nb),
+                                             self.block_ptrs.ctypes.data_as(_LP), C.c_int32(k),
+                                             self.blocks.ctypes.data_as(_SP))
+            self.c = _CPrecond(2, None, nb, self.block_ptrs.ctypes.data_as(_LP),
+                               self.blocks.ctypes.data_as(_SP), k)
+
+
 class DistMatrix:
     """local CSR (+ optional non-local CSR, halo exchange and all-reduce callbacks)."""
 
@@ -388,7 +420,10 @@ def _solve(fn_name, A, b, x0, inv_diag, tolerance, rel_tol, min_iter, max_iter, 
     b, pb = _s(b)
     x = np.array(x0, dtype=scalar, copy=True)
     pinv = None
-    if inv_diag is not None:
+    if isinstance(inv_diag, Precond):
+        fn_name += "_p"
+        pinv = C.byref(inv_diag.c)
+    elif inv_diag is not None:
         inv_diag, pinv = _s(inv_diag)
     crit = _CCriterion(tolerance, rel_tol, min_iter, max_iter, frequency, int(bool(export_res)))
     hist = np.zeros(max_iter + 2, scalar)
