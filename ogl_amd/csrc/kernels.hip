@@ -696,6 +696,124 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_finalize_x(int n, double *__rest
 }
 
 // ------------------------------------------------------------------------------------------
+// GMRES vector kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_gmres_scale(int n, double *__restrict__ out,
+                                                       const double *__restrict__ in,
+                                                       const double *__restrict__ denom,
+                                                       const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const double d = *denom;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 v = ld2(in, rp);
+    v.x = v.x / d;
+    v.y = v.y / d;
+    st2(out, rp, v);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gmres_mgs(int n, double *__restrict__ w,
+                                                     const double *__restrict__ vprev,
+                                                     const double *__restrict__ hprev,
+                                                     const double *__restrict__ vdot,
+                                                     double *__restrict__ part,
+                                                     const DevScalars *gate)
+{
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vw = ld2(w, rp);
+    if (vprev) {
+        const double h = *hprev;
+        const double2 vp = ld2(vprev, rp);
+        vw.x -= h * vp.x;
+        vw.y -= h * vp.y;
+        st2(w, rp, vw);
+    }
+    const double2 vd = vdot ? ld2(vdot, rp) : vw;
+    double d = 0.0;
+    if (rp.n > 0) d += vw.x * vd.x;
+    if (rp.n > 1) d += vw.y * vd.y;
+    const double s0 = block_sum(d, slot);
+    if (threadIdx.x == 0) part[chunk] = s0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gmres_update_x(int n, const double *__restrict__ V,
+                                                          long ld, const double *__restrict__ y,
+                                                          int it, const double *__restrict__ inv_diag,
+                                                          double *__restrict__ x,
+                                                          double *__restrict__ before,
+                                                          const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 sum;
+    sum.x = 0.0;
+    sum.y = 0.0;
+    for (int j = 0; j < it; ++j) {
+        const double yj = y[j];
+        const double2 v = ld2(V + (size_t)j * ld, rp);
+        sum.x += v.x * yj;
+        sum.y += v.y * yj;
+    }
+    if (before) {
+        st2(before, rp, sum);
+        return;
+    }
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        sum.x = sum.x * vi.x;
+        sum.y = sum.y * vi.y;
+    }
+    double2 vx = ld2(x, rp);
+    vx.x += sum.x;
+    vx.y += sum.y;
+    st2(x, rp, vx);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_mul(int n, double *__restrict__ out,
+                                               const double *__restrict__ in,
+                                               const double *__restrict__ inv_diag,
+                                               const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 v = ld2(in, rp);
+    const double2 vi = ld2(inv_diag, rp);
+    v.x = v.x * vi.x;
+    v.y = v.y * vi.y;
+    st2(out, rp, v);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_add(int n, double *__restrict__ x,
+                                               const double *__restrict__ a, const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 vx = ld2(x, rp);
+    const double2 va = ld2(a, rp);
+    vx.x += va.x;
+    vx.y += va.y;
+    st2(x, rp, vx);
+}
+
+// GMRES dense-state accessors (layout: kernels.hpp gmres_state_len)
+struct GmresState {
+    double *H, *gs, *gc, *rnc, *y;
+    int m;
+    __device__ GmresState(double *base, int m_) : m(m_)
+    {
+        H = base;
+        gs = H + (size_t)(m + 1) * m;
+        gc = gs + m;
+        rnc = gc + m;
+        y = rnc + (m + 1);
+    }
+    __device__ double &h(int i, int j) const { return H[(size_t)j * (m + 1) + i]; }
+};
+
+// ------------------------------------------------------------------------------------------
 // finalisers (one workgroup): reduce the per-chunk partials, then the scalar logic
 // ------------------------------------------------------------------------------------------
 
@@ -729,7 +847,9 @@ template <int PHASE>
 __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a)
 {
     __shared__ double slot[FIN_WAVES];
-    if (PHASE != FIN_MEAN && PHASE != FIN_NORMFACTOR && PHASE != FIN_RAW && s->stop) return;
+    if (PHASE != FIN_MEAN && PHASE != FIN_NORMFACTOR && PHASE != FIN_RAW &&
+        PHASE != FIN_GMRES_SOLVE && s->stop)
+        return;
     // thread 0 fetches the scalar block up front (its latency hides behind the partial loads),
     // does the logic in registers and stores the block once: the criterion's dependent global
     // round trips would otherwise cost more than the reduction itself
@@ -786,6 +906,49 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
         L.gamma = v0;
         L.beta = v1;
         L.omega = (v1 != 0.0) ? v0 / v1 : 0.0;
+    } else if (PHASE == FIN_GMRES_RESTART) {  // gmres::restart
+        GmresState g(a.gm, a.m);
+        const double rn = sqrt(v0);
+        g.rnc[0] = rn;
+        L.beta = rn;  // V_0 = r / rn
+        L.stale_norm = v1;
+    } else if (PHASE == FIN_GMRES_H) {  // finish_arnoldi: H(k, it)
+        GmresState g(a.gm, a.m);
+        g.h(a.k, a.turn) = v0;
+    } else if (PHASE == FIN_GMRES_COL) {  // norm of the new basis vector, then givens_rotation
+        GmresState g(a.gm, a.m);
+        const int it = a.turn;
+        const double hn = sqrt(v0);
+        g.h(it + 1, it) = hn;
+        L.beta = hn;  // V_{it+1} /= hn
+        for (int j = 0; j < it; ++j) {
+            const double t = g.gc[j] * g.h(j, it) + g.gs[j] * g.h(j + 1, it);
+            g.h(j + 1, it) = -g.gs[j] * g.h(j, it) + g.gc[j] * g.h(j + 1, it);
+            g.h(j, it) = t;
+        }
+        if (g.h(it, it) == 0.0) {
+            g.gc[it] = 0.0;
+            g.gs[it] = 1.0;
+        } else {
+            const double scale = fabs(g.h(it, it)) + fabs(g.h(it + 1, it));
+            const double a0 = g.h(it, it) / scale, a1 = g.h(it + 1, it) / scale;
+            const double hyp = scale * sqrt(a0 * a0 + a1 * a1);
+            g.gc[it] = g.h(it, it) / hyp;
+            g.gs[it] = g.h(it + 1, it) / hyp;
+        }
+        g.h(it, it) = g.gc[it] * g.h(it, it) + g.gs[it] * g.h(it + 1, it);
+        g.h(it + 1, it) = 0.0;
+        g.rnc[it + 1] = -g.gs[it] * g.rnc[it];
+        g.rnc[it] = g.gc[it] * g.rnc[it];
+    } else if (PHASE == FIN_GMRES_CHECK) {
+        criterion_check(&L, a.crit, L.stale_norm, a.history);
+    } else if (PHASE == FIN_GMRES_SOLVE) {  // solve_upper_triangular over `turn` columns
+        GmresState g(a.gm, a.m);
+        for (int i = a.turn - 1; i >= 0; --i) {
+            double t = g.rnc[i];
+            for (int j = i + 1; j < a.turn; ++j) t -= g.h(i, j) * g.y[j];
+            g.y[i] = t / g.h(i, i);
+        }
     }
     *s = L;
 }
@@ -987,6 +1150,48 @@ void launch_bicg_finalize_x(hipStream_t st, int32_t n, double *x, const double *
     hipLaunchKernelGGL(k_bicg_finalize_x, dim3(nc), dim3(BLOCK), 0, st, n, x, y, s, turn);
 }
 
+void launch_gmres_scale(hipStream_t st, int32_t n, double *out, const double *in,
+                        const double *denom, const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_gmres_scale, dim3(nc), dim3(BLOCK), 0, st, n, out, in, denom, gate);
+}
+
+void launch_gmres_mgs(hipStream_t st, int32_t n, double *w, const double *vprev,
+                      const double *hprev, const double *vdot, double *part,
+                      const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_gmres_mgs, dim3(nc), dim3(BLOCK), 0, st, n, w, vprev, hprev, vdot, part, gate);
+}
+
+void launch_gmres_update_x(hipStream_t st, int32_t n, const double *V, int64_t ld, const double *y,
+                           int32_t it, const double *inv_diag, double *x, double *before,
+                           const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_gmres_update_x, dim3(nc), dim3(BLOCK), 0, st, n, V, (long)ld, y, it,
+                       inv_diag, x, before, gate);
+}
+
+void launch_mul(hipStream_t st, int32_t n, double *out, const double *in, const double *inv_diag,
+                const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_mul, dim3(nc), dim3(BLOCK), 0, st, n, out, in, inv_diag, gate);
+}
+
+void launch_add(hipStream_t st, int32_t n, double *x, const double *a, const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_add, dim3(nc), dim3(BLOCK), 0, st, n, x, a, gate);
+}
+
 void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
 {
     const dim3 grid(1), block(FIN_BLOCK);
@@ -1011,6 +1216,21 @@ void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
         break;
     case FIN_BICG_OMEGA:
         hipLaunchKernelGGL((k_finalize<FIN_BICG_OMEGA>), grid, block, 0, st, s, a);
+        break;
+    case FIN_GMRES_RESTART:
+        hipLaunchKernelGGL((k_finalize<FIN_GMRES_RESTART>), grid, block, 0, st, s, a);
+        break;
+    case FIN_GMRES_H:
+        hipLaunchKernelGGL((k_finalize<FIN_GMRES_H>), grid, block, 0, st, s, a);
+        break;
+    case FIN_GMRES_COL:
+        hipLaunchKernelGGL((k_finalize<FIN_GMRES_COL>), grid, block, 0, st, s, a);
+        break;
+    case FIN_GMRES_CHECK:
+        hipLaunchKernelGGL((k_finalize<FIN_GMRES_CHECK>), grid, block, 0, st, s, a);
+        break;
+    case FIN_GMRES_SOLVE:
+        hipLaunchKernelGGL((k_finalize<FIN_GMRES_SOLVE>), grid, block, 0, st, s, a);
         break;
     default:
         hipLaunchKernelGGL((k_finalize<FIN_RAW>), grid, block, 0, st, s, a);

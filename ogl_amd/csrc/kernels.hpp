@@ -23,6 +23,7 @@ struct DevScalars {
     int32_t stop_phase;                 // BiCGStab: 1 = stopped at the mid-step check (finalize x)
     int32_t stop_turn;                  // BiCGStab: turn index of that stop
     int32_t pad_;
+    double stale_norm;                  // GMRES: sum|r| of the last restart (what the criterion sees)
 };
 
 // OpenFOAMDistStoppingCriterion parameters (StoppingCriterion.H:32-72)
@@ -131,6 +132,24 @@ void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const do
 void launch_bicg_finalize_x(hipStream_t st, int32_t n, double *x, const double *y,
                             const DevScalars *s, int turn);
 
+// --- GMRES vector kernels ([UPSTREAM] gmres::restart / finish_arnoldi / solve_krylov) ---
+// out = in / *denom
+void launch_gmres_scale(hipStream_t st, int32_t n, double *out, const double *in,
+                        const double *denom, const DevScalars *gate);
+// modified Gram-Schmidt link: if (vprev) w -= (*hprev) * vprev ; partial of w . vdot (vdot == nullptr: w . w)
+void launch_gmres_mgs(hipStream_t st, int32_t n, double *w, const double *vprev,
+                      const double *hprev, const double *vdot, double *part,
+                      const DevScalars *gate);
+// t_i = sum_{j < it} V_j[i] * y[j] ; with `before` != nullptr the sum is stored there, otherwise
+// x_i += t_i * inv_diag_i (inv_diag == nullptr: x_i += t_i)
+void launch_gmres_update_x(hipStream_t st, int32_t n, const double *V, int64_t ld, const double *y,
+                           int32_t it, const double *inv_diag, double *x, double *before,
+                           const DevScalars *gate);
+// out = in * inv_diag (scalar Jacobi apply), x += a
+void launch_mul(hipStream_t st, int32_t n, double *out, const double *in, const double *inv_diag,
+                const DevScalars *gate);
+void launch_add(hipStream_t st, int32_t n, double *x, const double *a, const DevScalars *gate);
+
 // --- single-workgroup finalisers: reduce per-chunk partials, then scalar logic -------------
 // phases: what the scalar logic does with the reduced sums.
 enum FinPhase {
@@ -141,8 +160,16 @@ enum FinPhase {
     FIN_RAW = 4,         // sums[] only (test / reduce entry point)
     FIN_BICG_ALPHA = 5,  // beta <- sum0 ; alpha = rho / beta
     FIN_BICG_CHECK2 = 6, // mid-turn criterion check on sum0 = sum|s|
-    FIN_BICG_OMEGA = 7   // gamma <- sum0 ; beta <- sum1 ; omega = gamma / beta
+    FIN_BICG_OMEGA = 7,  // gamma <- sum0 ; beta <- sum1 ; omega = gamma / beta
+    FIN_GMRES_RESTART = 8,  // rn = sqrt(sum0) -> rnc[0], beta ; stale_norm = sum1   (gmres::restart)
+    FIN_GMRES_H = 9,        // H(k, it) = sum0                                        (finish_arnoldi)
+    FIN_GMRES_COL = 10,     // H(it+1, it) = sqrt(sum0) -> beta ; Givens ; rnc        (givens_rotation)
+    FIN_GMRES_CHECK = 11,   // criterion check on stale_norm
+    FIN_GMRES_SOLVE = 12    // y = R^-1 rnc for `turn` columns                        (solve_krylov)
 };
+// GMRES small dense state in one device array of doubles:
+//   H[(m+1) x m] column-major | givens_sin[m] | givens_cos[m] | rnc[m+1] | y[m]
+inline size_t gmres_state_len(int m) { return (size_t)(m + 1) * m + 2 * (size_t)m + (m + 1) + m; }
 struct FinArgs {
     const double *part[2] = {nullptr, nullptr};
     int32_t n_part = 0;     // entries per partial array
@@ -152,7 +179,10 @@ struct FinArgs {
     double n_local = 0, n_global = 0;  // FIN_MEAN
     DevCriterion crit{};
     double *history = nullptr;
-    int32_t turn = 0;  // BiCGStab turn index (FIN_BICG_CHECK2)
+    int32_t turn = 0;  // BiCGStab turn index (FIN_BICG_CHECK2); GMRES: column `it`
+    double *gm = nullptr;  // GMRES dense state
+    int32_t m = 0;         // GMRES krylov_dim
+    int32_t k = 0;         // GMRES row of H (FIN_GMRES_H)
 };
 void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a);
 

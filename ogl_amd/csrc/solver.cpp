@@ -416,6 +416,12 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
 int ogl_solver::finalize(int phase, FinArgs &a)
 {
     hipStream_t st = reg->stream;
+    if (a.n_sums == 0) {  // nothing to reduce: scalar logic only (identical on every rank)
+        a.do_reduce = 0;
+        a.do_logic = 1;
+        launch_finalize(st, phase, d_scal.p, a);
+        return OGL_OK;
+    }
     if (!reg->comm->multi()) {
         a.do_reduce = 1;
         a.do_logic = 1;
@@ -460,6 +466,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     DevScalars *s = d_scal.p;
     const int nc = (int)n_chunks(n);
     const bool bicg = cfg.solver == OGL_SOLVER_BICGSTAB;
+    const bool gmres = cfg.solver == OGL_SOLVER_GMRES;
+    // Ginkgo's default Krylov dimension is 100; the reference has no keyword for it
+    // (GKOGMRES.H:46-63), `krylovDim` is this build's addition
+    const int m = cfg.krylov_dim > 0 ? cfg.krylov_dim : 100;
+    const int64_t ldv = (int64_t)n + 2;  // leading dimension of the Krylov bases
     // block Jacobi (maxBlockSize > 1): z = M^-1 r is materialised by its own kernel; the scalar
     // case stays fused into the step kernels
     const bool generic = precond_data && precond_data->kind == 2;
@@ -476,7 +487,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     ogl_host_adapt_criterion(&cfg, prev_iters, prev_cost, &crit.min_iter, &crit.frequency);
     if (crit.frequency < 1) return fail(OGL_ERR_INVALID, "evalFrequency must be >= 1");
     const int max_checks = crit.max_iter + crit.frequency + 1;  // the check count never exceeds this
-    const int max_turns = bicg ? max_checks / 2 + 1 : max_checks;
+    const int max_turns = bicg ? max_checks / 2 + 1 : max_checks;  // CG and GMRES: one check per turn
     OGL_TRY(d_history.alloc((size_t)max_checks + 4, st));
     if (cfg.export_res)
         OGL_HIP_CHECK(hipMemsetAsync(d_history.p, 0, d_history.n * sizeof(double), st));
@@ -490,6 +501,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             OGL_TRY(d_y.alloc(nv, st));
             OGL_TRY(d_z.alloc(nv, st));
         }
+    } else if (gmres) {
+        OGL_TRY(d_V.alloc((size_t)(m + 1) * (size_t)ldv, st));
+        OGL_TRY(d_gm.alloc(gmres_state_len(m), st));
+        OGL_HIP_CHECK(hipMemsetAsync(d_gm.p, 0, gmres_state_len(m) * sizeof(double), st));
+        if (generic) OGL_TRY(d_z.alloc((size_t)n + 2, st));
     } else if (generic) {
         OGL_TRY(d_z.alloc((size_t)n + 2, st));
     }
@@ -544,7 +560,46 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // solver initialisation + turn 0: rho, sum|r|, check (timed once as "time per residual norm
     // calculation", lduLduBase.H:287)
     OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, (size_t)n * sizeof(double), st));
-    if (bicg) {
+    FinArgs fg{};  // GMRES finaliser arguments
+    fg.part[0] = d_part0.p;
+    fg.part[1] = d_part1.p;
+    fg.n_part = nc;
+    fg.crit = crit;
+    fg.history = d_history.p;
+    fg.gm = d_gm.p;
+    fg.m = m;
+    const double *beta_ptr =
+        reinterpret_cast<const double *>(reinterpret_cast<const char *>(s) + offsetof(DevScalars, beta));
+    auto gm_h = [&](int i, int j) { return d_gm.p + (size_t)j * (m + 1) + i; };
+    double *gm_y = d_gm.p + (size_t)(m + 1) * m + 2 * (size_t)m + (m + 1);
+    // gmres::restart: rn = ||r||, rnc[0] = rn, V_0 = r / rn; the criterion keeps sum|r| of this r
+    auto gmres_restart = [&](const DevScalars *gate) -> int {
+        launch_cg_rho_norm(st, n, d_r.p, nullptr, d_part0.p, d_part1.p, gate);  // r.r and sum|r|
+        fg.n_sums = 2;
+        OGL_TRY(finalize(FIN_GMRES_RESTART, fg));
+        launch_gmres_scale(st, n, d_V.p, d_r.p, beta_ptr, gate);
+        return OGL_OK;
+    };
+    // solve_krylov + x += M^-1 (V y) over `cols` columns of the cycle
+    auto gmres_update_x = [&](int cols, const DevScalars *gate) -> int {
+        if (cols <= 0) return OGL_OK;
+        fg.n_sums = 0;
+        fg.turn = cols;
+        OGL_TRY(finalize(FIN_GMRES_SOLVE, fg));
+        if (generic) {
+            launch_gmres_update_x(st, n, d_V.p, ldv, gm_y, cols, nullptr, d_x.p, d_w.p, gate);
+            apply_preconditioner(d_w.p, d_z.p, gate);
+            launch_add(st, n, d_x.p, d_z.p, gate);
+        } else {
+            launch_gmres_update_x(st, n, d_V.p, ldv, gm_y, cols, precond, d_x.p, nullptr, gate);
+        }
+        return OGL_OK;
+    };
+    if (gmres) {
+        OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
+        OGL_TRY(gmres_restart(nullptr));
+        OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+    } else if (bicg) {
         // rr = r ; p = v = 0 ([UPSTREAM] bicgstab::initialize); rho = rr.r = r.r
         OGL_HIP_CHECK(hipMemcpyAsync(d_rr.p, d_r.p, (size_t)n * sizeof(double),
                                      hipMemcpyDeviceToDevice, st));
@@ -565,9 +620,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     chk.n_sums = 2;
     chk.crit = crit;
     chk.history = d_history.p;
-    OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
-    OGL_TRY(finalize(FIN_CG_CHECK, chk));
-    OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+    if (!gmres) {
+        OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
+        OGL_TRY(finalize(FIN_CG_CHECK, chk));
+        OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+    }
 
     FinArgs f1{};  // one partial array
     f1.part[0] = d_part0.p;
@@ -586,7 +643,43 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     auto enqueue_turns = [&](int count) -> int {
         for (int i = 0; i < count; ++i, ++enq) {
             const bool prof = enq < prof_cap;
-            if (!bicg && generic) {
+            if (gmres) {
+                // [UPSTREAM] Gmres loop: check (on the residual of the last restart), restart
+                // when the cycle is full, then one Arnoldi step
+                fg.n_sums = 0;
+                OGL_TRY(finalize(FIN_GMRES_CHECK, fg));
+                if (enq > 0 && enq % m == 0) {
+                    OGL_TRY(gmres_update_x(m, s));
+                    OGL_TRY(dist_spmv(SPMV_RESIDUAL, d_x.p, d_b.p, d_r.p, SpmvDots{}, s));
+                    OGL_TRY(gmres_restart(s));
+                }
+                const int it = enq % m;
+                double *v_it = d_V.p + (size_t)it * ldv, *nx = d_V.p + (size_t)(it + 1) * ldv;
+                const double *w = v_it;  // identity preconditioner: w aliases V_it
+                if (generic) {
+                    apply_preconditioner(v_it, d_w.p, s);
+                    w = d_w.p;
+                } else if (precond) {
+                    launch_mul(st, n, d_w.p, v_it, precond, s);
+                    w = d_w.p;
+                }
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                OGL_TRY(dist_spmv(SPMV_PLAIN, w, nullptr, nx, SpmvDots{}, s));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                // finish_arnoldi (modified Gram-Schmidt): H(k,it) = nx.V_k ; nx -= H(k,it) V_k
+                fg.turn = it;
+                fg.n_sums = 1;
+                for (int k = 0; k <= it; ++k) {
+                    launch_gmres_mgs(st, n, nx, k > 0 ? d_V.p + (size_t)(k - 1) * ldv : nullptr,
+                                     k > 0 ? gm_h(k - 1, it) : nullptr, d_V.p + (size_t)k * ldv,
+                                     d_part0.p, s);
+                    fg.k = k;
+                    OGL_TRY(finalize(FIN_GMRES_H, fg));
+                }
+                launch_gmres_mgs(st, n, nx, v_it, gm_h(it, it), nullptr, d_part0.p, s);
+                OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
+                launch_gmres_scale(st, n, nx, nx, beta_ptr, s);
+            } else if (!bicg && generic) {
                 launch_cg_step1(st, n, d_p.p, d_z.p, nullptr, s);  // p = z + (rho/prev_rho) p
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
@@ -653,10 +746,17 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     }
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
-    const double t_solve = now_ms() - t_start;
-
     DevScalars fin;
     OGL_HIP_CHECK(hipMemcpy(&fin, s, sizeof(fin), hipMemcpyDeviceToHost));
+    if (gmres) {
+        // final solve_krylov on the (partial) cycle: Arnoldi steps done since the last restart
+        const int steps = fin.iter - 1;
+        const int cols = steps <= 0 ? 0 : (steps - 1) % m + 1;
+        OGL_TRY(gmres_update_x(cols, nullptr));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        OGL_HIP_CHECK(hipGetLastError());
+    }
+    const double t_solve = now_ms() - t_start;
     history.clear();
     if (cfg.export_res) {
         history.resize(fin.iter);
@@ -721,6 +821,8 @@ int ogl_solver::apply_resident(ogl_perf *perf)
         return run_cg(perf);
     case OGL_SOLVER_BICGSTAB:
         return run_bicgstab(perf);
+    case OGL_SOLVER_GMRES:
+        return run_krylov(perf);
     default:
         return fail(OGL_ERR_UNSUPPORTED, "solver kind %d is not built", cfg.solver);
     }

@@ -907,6 +907,121 @@ orc_label orc_bicgstab_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scal
 }
 
 /* ------------------------------------------------------------------ */
+/* GMRES ([UPSTREAM] gko::solver::Gmres::apply_dense_impl, restarted,   */
+/* right-preconditioned; reference kernels restart / finish_arnoldi     */
+/* (modified Gram-Schmidt) / givens_rotation / solve_krylov).           */
+/* The criterion receives the residual VECTOR of the last restart (the  */
+/* solver only hands the implicit norm forward inside a cycle), so      */
+/* OGL's L1 check sees a new value only after a restart (*/
+/* unpinned).  krylov_dim <= 0 selects Ginkgo's default, 100.           */
+/* ------------------------------------------------------------------ */
+static orc_scalar dist_norm2(const orc_dist_matrix *A, const orc_scalar *a) {
+    orc_scalar s = orc_dot(A->n, a, a);
+    global_sum(A, &s, 1);
+    return sqrt(s);
+}
+
+orc_label orc_gmres_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                      const orc_precond *P, const orc_criterion *crit, orc_criterion_state *st,
+                      orc_label krylov_dim) {
+    const orc_label n = A->n, m = krylov_dim > 0 ? krylov_dim : 100;
+    const size_t cnt = n ? (size_t)n : 1;
+    orc_scalar *V = (orc_scalar *)calloc(cnt * ((size_t)m + 1), sizeof(orc_scalar));
+    orc_scalar *H = (orc_scalar *)calloc(((size_t)m + 1) * (size_t)m, sizeof(orc_scalar));
+    orc_scalar *gs = (orc_scalar *)calloc((size_t)m, sizeof(orc_scalar));
+    orc_scalar *gc = (orc_scalar *)calloc((size_t)m, sizeof(orc_scalar));
+    orc_scalar *rnc = (orc_scalar *)calloc((size_t)m + 1, sizeof(orc_scalar));
+    orc_scalar *y = (orc_scalar *)calloc((size_t)m, sizeof(orc_scalar));
+    orc_scalar *r = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *w = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    orc_scalar *u = (orc_scalar *)calloc(cnt, sizeof(orc_scalar));
+    if (!V || !H || !gs || !gc || !rnc || !y || !r || !w || !u) abort();
+#define HH(i, j) H[(size_t)(j) * ((size_t)m + 1) + (size_t)(i)]
+#define VV(k) (V + (size_t)(k) * cnt)
+    criterion_reset(st);
+    orc_label it = 0;
+    for (int restart = 1;; restart = 0) {
+        if (restart) { /* residual + restart kernel */
+            dist_residual(A, b, x, r);
+            const orc_scalar rn = dist_norm2(A, r);
+            rnc[0] = rn;
+            for (orc_label i = 0; i < n; ++i) VV(0)[i] = r[i] / rn;
+            it = 0;
+        }
+        if (criterion_check(A, crit, st, r, x, b)) break;
+        if (it == m) { /* update x with the cycle's solution, then restart */
+            for (orc_label i = m - 1; i >= 0; --i) { /* solve_upper_triangular */
+                orc_scalar t = rnc[i];
+                for (orc_label j = i + 1; j < m; ++j) t -= HH(i, j) * y[j];
+                y[i] = t / HH(i, i);
+            }
+            for (orc_label i = 0; i < n; ++i) { /* calculate_qy */
+                orc_scalar sum = 0.0;
+                for (orc_label j = 0; j < m; ++j) sum += VV(j)[i] * y[j];
+                w[i] = sum;
+            }
+            precond_apply(n, P, w, u);
+            for (orc_label i = 0; i < n; ++i) x[i] += u[i];
+            dist_residual(A, b, x, r);
+            const orc_scalar rn = dist_norm2(A, r);
+            rnc[0] = rn;
+            for (orc_label i = 0; i < n; ++i) VV(0)[i] = r[i] / rn;
+            it = 0;
+        }
+        /* Arnoldi step */
+        precond_apply(n, P, VV(it), w);
+        orc_dist_spmv(A, w, VV(it + 1));
+        orc_scalar *nx = VV(it + 1);
+        for (orc_label k = 0; k <= it; ++k) { /* finish_arnoldi: modified Gram-Schmidt */
+            const orc_scalar h = dist_dot(A, nx, VV(k));
+            HH(k, it) = h;
+            for (orc_label i = 0; i < n; ++i) nx[i] -= h * VV(k)[i];
+        }
+        const orc_scalar hn = dist_norm2(A, nx);
+        HH(it + 1, it) = hn;
+        for (orc_label i = 0; i < n; ++i) nx[i] /= hn;
+        for (orc_label j = 0; j < it; ++j) { /* givens_rotation: previous rotations */
+            const orc_scalar t = gc[j] * HH(j, it) + gs[j] * HH(j + 1, it);
+            HH(j + 1, it) = -gs[j] * HH(j, it) + gc[j] * HH(j + 1, it);
+            HH(j, it) = t;
+        }
+        if (HH(it, it) == 0.0) { /* calculate_sin_and_cos */
+            gc[it] = 0.0;
+            gs[it] = 1.0;
+        } else {
+            const orc_scalar scale = fabs(HH(it, it)) + fabs(HH(it + 1, it));
+            const orc_scalar a0 = HH(it, it) / scale, a1 = HH(it + 1, it) / scale;
+            const orc_scalar hyp = scale * sqrt(a0 * a0 + a1 * a1);
+            gc[it] = HH(it, it) / hyp;
+            gs[it] = HH(it + 1, it) / hyp;
+        }
+        HH(it, it) = gc[it] * HH(it, it) + gs[it] * HH(it + 1, it);
+        HH(it + 1, it) = 0.0;
+        rnc[it + 1] = -gs[it] * rnc[it]; /* calculate_next_residual_norm */
+        rnc[it] = gc[it] * rnc[it];
+        ++it;
+    }
+    if (it > 0) { /* final solve_krylov on the partial cycle */
+        for (orc_label i = it - 1; i >= 0; --i) {
+            orc_scalar t = rnc[i];
+            for (orc_label j = i + 1; j < it; ++j) t -= HH(i, j) * y[j];
+            y[i] = t / HH(i, i);
+        }
+        for (orc_label i = 0; i < n; ++i) {
+            orc_scalar sum = 0.0;
+            for (orc_label j = 0; j < it; ++j) sum += VV(j)[i] * y[j];
+            w[i] = sum;
+        }
+        precond_apply(n, P, w, u);
+        for (orc_label i = 0; i < n; ++i) x[i] += u[i];
+    }
+#undef HH
+#undef VV
+    free(V); free(H); free(gs); free(gc); free(rnc); free(y); free(r); free(w); free(u);
+    return st->iter;
+}
+
+/* ------------------------------------------------------------------ */
 /* "omp executor" baseline (single rank)                                */
 /* ------------------------------------------------------------------ */
 int orc_omp_max_threads(void) {

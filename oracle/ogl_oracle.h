@@ -265,6 +265,11 @@ orc_label orc_bicgstab_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scal
                          const orc_precond *P, const orc_criterion *crit,
                          orc_criterion_state *st);
 
+/* GKOGMRES: restarted GMRES(krylov_dim), krylov_dim <= 0 -> Ginkgo's default 100 */
+orc_label orc_gmres_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                      const orc_precond *P, const orc_criterion *crit, orc_criterion_state *st,
+                      orc_label krylov_dim);
+
 /* "omp executor" baseline: row-parallel SpMV, parallel AXPYs and reductions, single rank.
  * Same step order as orc_cg; reductions are OpenMP tree sums (not bit-comparable).
  * Only built when compiled with -fopenmp; returns -1 otherwise. */

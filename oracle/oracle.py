@@ -454,6 +454,22 @@ def bicgstab(A, b, x0, inv_diag=None, tolerance=1e-6, rel_tol=1e-6, min_iter=0, 
                   frequency, export_res)
 
 
+def gmres(A, b, x0, precond=None, tolerance=1e-6, rel_tol=1e-6, min_iter=0, max_iter=1000,
+          frequency=1, export_res=True, krylov_dim=0):
+    """GKOGMRES semantics; precond is a Precond object or None."""
+    b, pb = _s(b)
+    x = np.array(x0, dtype=scalar, copy=True)
+    crit = _CCriterion(tolerance, rel_tol, min_iter, max_iter, frequency, int(bool(export_res)))
+    hist = np.zeros(max_iter + frequency + 4, scalar)
+    st = _CState()
+    st.history = hist.ctypes.data_as(_SP)
+    lib().orc_gmres_p.restype = C.c_int32
+    lib().orc_gmres_p(C.byref(A.c), pb, x.ctypes.data_as(_SP),
+                      C.byref(precond.c) if precond is not None else None, C.byref(crit),
+                      C.byref(st), C.c_int32(krylov_dim))
+    return Result(x, st, hist, export_res)
+
+
 def cg_omp(A, b, x0, inv_diag=None, tolerance=1e-6, rel_tol=1e-6, min_iter=0, max_iter=1000,
            frequency=1, export_res=True, threads=0):
     return _solve("orc_cg_omp", A, b, x0, inv_diag, tolerance, rel_tol, min_iter, max_iter,

@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--procs", default="1,1,2")
     ap.add_argument("--precond", type=int, default=1)
     ap.add_argument("--asym", type=int, default=0)
+    ap.add_argument("--gmres", type=int, default=0)
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -118,11 +119,17 @@ def main():
                                atol=1e-13)
 
     solve = orc.bicgstab if args.asym else orc.cg
+    if args.gmres:
+        P = orc.Precond(rp, cols, vals, 1) if args.precond else None
+        inv = P
+        solve = lambda A_, b_, x_, P_, **kw: orc.gmres(A_, b_, x_, P_, krylov_dim=args.gmres, **kw)
     if args.mode == "oracle":
         res = solve(A, b, np.zeros_like(b), inv, **skw)
         g_rp, g_cols, g_vals = oracle_csr(orc, glob)
         G = orc.DistMatrix(g_rp, g_cols, g_vals)
         g_inv = orc.jacobi_generate_scalar(g_rp, g_cols, g_vals) if args.precond else None
+        if args.gmres and args.precond:
+            g_inv = orc.Precond(g_rp, g_cols, g_vals, 1)
         ref = solve(G, b_g, np.zeros_like(b_g), g_inv, **skw)
         xg_sol = gather_global(case, res.x)
         np.testing.assert_allclose(xg_sol, ref.x, atol=1e-9, rtol=0)
@@ -146,7 +153,8 @@ def main():
             dist.broadcast_object_list(uid, src=0)
             reg.init_rccl(rank, world, uid[0])
         cfg = capi.default_config(
-            solver=capi.SOLVER_BICGSTAB if args.asym else capi.SOLVER_CG,
+            solver=capi.SOLVER_GMRES if args.gmres else
+            (capi.SOLVER_BICGSTAB if args.asym else capi.SOLVER_CG), krylov_dim=args.gmres,
             preconditioner=capi.PRECOND_BJ if args.precond else capi.PRECOND_NONE,
             tolerance=1e-11, rel_tol=0.0, max_iter=300, export_res=1, adapt_min_iter=0,
             matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode == "gpu-host"))
@@ -163,7 +171,8 @@ def main():
             ref = solve(A, b, np.zeros_like(b), inv, **skw)
         if args.mode == "gpu-host":
             # same local trees, same 2-operand gloo sum: bit-identical
-            assert perf.n_iterations == (ref.n_iterations // 2 if args.asym else ref.n_iterations)
+            assert perf.n_iterations == (ref.n_iterations // 2 if (args.asym and not args.gmres)
+                                         else ref.n_iterations)
             np.testing.assert_array_equal(hist, ref.history)
             np.testing.assert_array_equal(x, ref.x)
         else:

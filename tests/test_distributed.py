@@ -63,5 +63,14 @@ def test_gpu_host_buffer_transport_bicgstab():
 
 
 @pytest.mark.gpu
+def test_gpu_host_buffer_transport_gmres():
+    run_ranks(2, "--mode", "gpu-host", "--shape", "10,10,10", "--procs", "1,1,2", "--gmres", "20")
+
+
+def test_oracle_two_ranks_gmres():
+    run_ranks(2, "--mode", "oracle", "--shape", "8,8,8", "--procs", "1,1,2", "--gmres", "20")
+
+
+@pytest.mark.gpu
 def test_gpu_rccl_single_rank():
     run_ranks(1, "--mode", "gpu-rccl", "--shape", "12,12,12", "--procs", "1,1,1")

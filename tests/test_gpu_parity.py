@@ -339,12 +339,46 @@ def test_bicgstab_max_iter_is_doubled(reg, oracle):
     assert s.get_property("prevSolveIters_final") == 15           # raw count is what is stored
 
 
-def test_gmres_is_refused_for_now(reg):
-    case = synthetic.poisson_case(4)
-    s = reg.solver("gm", cg_cfg(solver=capi.SOLVER_GMRES)).set_matrix(case)
-    with pytest.raises(capi.OglError) as e:
-        s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
-    assert e.value.status == capi.ERR_UNSUPPORTED
+# ---------------------------------------------------------------------------- GKOGMRES
+
+@pytest.mark.parametrize("sym", [True, False], ids=["sym", "asym"])
+@pytest.mark.parametrize("precond,k", [(capi.PRECOND_NONE, 1), (capi.PRECOND_BJ, 1), (capi.PRECOND_BJ, 4)],
+                         ids=["none", "BJ1", "BJ4"])
+@pytest.mark.parametrize("kdim", [5, 30, 0])
+def test_gmres_history(reg, oracle, chunk_rows, sym, precond, k, kdim):
+    """Restarted, right-preconditioned GMRES (krylovDim 0 = Ginkgo's default 100).  The criterion
+    sees the residual vector of the last restart, so its value only moves at restarts."""
+    case = synthetic.poisson_case(10, symmetric=sym)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    cfg = cg_cfg(solver=capi.SOLVER_GMRES, preconditioner=precond, max_block_size=k, max_iter=250,
+                 tolerance=1e-10, krylov_dim=kdim)
+    s = reg.solver(f"gmres_{sym}_{precond}_{k}_{kdim}", cfg).set_matrix(case)
+    x, perf = s.solve(b, np.zeros_like(b))
+    hist = s.history()
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    P = oracle.Precond(rp, cols, vals, k) if precond else None
+    with blocked(oracle, chunk_rows):
+        ref = oracle.gmres(A, b, np.zeros_like(b), P, tolerance=1e-10, rel_tol=0.0, max_iter=250,
+                           krylov_dim=kdim)
+    assert perf.n_iterations == ref.n_iterations
+    np.testing.assert_array_equal(hist, ref.history)
+    np.testing.assert_array_equal(x, ref.x)
+    m = kdim or 100
+    # stale residual inside a cycle: the recorded value is constant between restarts
+    for c in range(0, hist.size - 1, m):
+        seg = hist[c + 1:c + m + 1]
+        assert np.all(seg == seg[0])
+    if perf.final_residual < 1e-10:
+        np.testing.assert_allclose(x, xs, atol=1e-6, rtol=0)
+
+
+def test_gmres_first_check_stops(reg, oracle):
+    case = synthetic.poisson_case(6)
+    b = np.ones(case.n_cells)
+    s = reg.solver("gmres0", cg_cfg(solver=capi.SOLVER_GMRES, tolerance=2.0, krylov_dim=7)).set_matrix(case)
+    x, perf = s.solve(b, np.zeros_like(b))
+    assert perf.n_iterations == 1 and np.all(x == 0.0)
 
 
 # ---------------------------------------------------------------------------- block Jacobi, maxBlockSize > 1
