@@ -197,6 +197,16 @@ int ogl_solver_solve(ogl_solver *s, const ogl_scalar *source, ogl_scalar *psi, o
  * status.  Entry i = normalised residual at criterion check i. */
 int ogl_solver_history(ogl_solver *s, double *out, int32_t capacity);
 
+/* `debug true` at a write time (lduLduBase.H:259-264): MatrixMarket dump of the persistent system
+ * as the DEVICE holds it, into `directory` (the reference uses processor?/<time>/):
+ *   <field>_A_local.mtx, <field>_A_non_local.mtx   coordinate real general, 1-based, row-major,
+ *                                                  15 significant digits (common.C:31-58,
+ *                                                  CsrMatrixWrapper.H:273-290)
+ *   <field>_rhs_b_.mtx                              array real general (Vector.H:173-176)
+ *   <field>_res_norms.mtx                           residual history of the last solve when `export`
+ *                                                  was set (the reference records it, never writes it) */
+int ogl_solver_export_system(ogl_solver *s, const char *directory);
+
 /* Per-field solver properties kept between solves (common/common.C:75-146):
  * prevSolveIters(_final), _prev_solve (relative residual-evaluation cost), preconditionerCaching. */
 int ogl_solver_get_property(ogl_solver *s, const char *key, double *value);

@@ -71,7 +71,8 @@ EXPORTED_SYMBOLS = [
     "ogl_last_error", "ogl_abi_version", "ogl_config_default", "ogl_registry_create",
     "ogl_registry_destroy", "ogl_registry_set_host_comm", "ogl_rccl_unique_id",
     "ogl_registry_init_rccl", "ogl_solver_get_or_create", "ogl_solver_set_matrix",
-    "ogl_solver_solve", "ogl_solver_history", "ogl_solver_get_property",
+    "ogl_solver_solve", "ogl_solver_history", "ogl_solver_export_system",
+    "ogl_solver_get_property",
     "ogl_solver_set_property", "ogl_solver_apply_resident", "ogl_solver_upload_solution",
     "ogl_solver_upload_rhs", "ogl_solver_download_solution", "ogl_solver_spmv",
     "ogl_solver_time_spmv", "ogl_solver_reduce", "ogl_reduction_chunk_rows",
@@ -240,6 +241,10 @@ class Solver:
         out = np.zeros(capacity, np.float64)
         n = _check(lib().ogl_solver_history(self._h, _ps(out), capacity))
         return out[:n].copy()
+
+    def export_system(self, directory):
+        os.makedirs(directory, exist_ok=True)
+        _check(lib().ogl_solver_export_system(self._h, directory.encode()))
 
     def get_property(self, key):
         v = C.c_double()

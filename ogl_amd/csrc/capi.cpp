@@ -1,7 +1,10 @@
 // capi.cpp -- extern "C" entry points of include/ogl_amd.h.  No exception crosses this file.
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
+#include <vector>
 
 #include "solver.hpp"
 
@@ -86,6 +89,13 @@ extern "C" int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n
     OGL_GUARD_END
 }
 
+template <class T>
+static int fetch(ogl_solver *s, T *dst, const T *dev, size_t count)
+{
+    if (!dst || count == 0) return OGL_OK;
+    return s->reg->stager.d2h(dst, dev, count * sizeof(T), s->reg->stream);
+}
+
 static int check_config(const ogl_config &c)
 {
     if (c.solver < OGL_SOLVER_CG || c.solver > OGL_SOLVER_GMRES)
@@ -140,6 +150,56 @@ extern "C" int ogl_solver_history(ogl_solver *s, double *out, int32_t capacity)
     const int n = std::min<int>(capacity, (int)s->history.size());
     std::copy(s->history.begin(), s->history.begin() + n, out);
     return n;
+}
+
+// MatrixMarket export (common.C:31-58): what test/data_validation.py of the reference inspects
+extern "C" int ogl_solver_export_system(ogl_solver *s, const char *directory)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !directory) return fail(OGL_ERR_INVALID, "NULL argument");
+    if (!s->matrix_set) return fail(OGL_ERR_STATE, "no matrix yet");
+    OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    const HostPattern &p = s->pat;
+    const std::string base = std::string(directory) + "/" + s->field;
+    std::vector<double> vals((size_t)p.local_nnz), nl((size_t)p.non_local_nnz), b((size_t)p.n_rows);
+    OGL_TRY(fetch(s, vals.data(), s->d_vals.p, vals.size()));
+    OGL_TRY(fetch(s, nl.data(), s->d_nl_vals.p, nl.size()));
+    if (s->b_resident) OGL_TRY(fetch(s, b.data(), s->d_b.p, b.size()));
+    auto open = [&](const std::string &fn) -> FILE * {
+        FILE *f = std::fopen(fn.c_str(), "w");
+        if (!f) fail(OGL_ERR_INVALID, "cannot write %s", fn.c_str());
+        return f;
+    };
+    FILE *f = open(base + "_A_local.mtx");
+    if (!f) return OGL_ERR_INVALID;
+    std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n", p.n_rows, p.n_rows,
+                 p.local_nnz);
+    for (int32_t e = 0; e < p.local_nnz; ++e)
+        std::fprintf(f, "%d %d %.15g\n", p.rows[e] + 1, p.cols[e] + 1, vals[e]);
+    std::fclose(f);
+    f = open(base + "_A_non_local.mtx");
+    if (!f) return OGL_ERR_INVALID;
+    std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n", p.n_rows,
+                 p.non_local_nnz, p.non_local_nnz);  // N x H, CsrMatrixWrapper.H:185-188
+    for (int32_t e = 0; e < p.non_local_nnz; ++e)
+        std::fprintf(f, "%d %d %.15g\n", p.nl_rows[e] + 1, p.nl_cols[e] + 1, nl[e]);
+    std::fclose(f);
+    if (s->b_resident) {
+        f = open(base + "_rhs_b_.mtx");
+        if (!f) return OGL_ERR_INVALID;
+        std::fprintf(f, "%%%%MatrixMarket matrix array real general\n%d 1\n", p.n_rows);
+        for (double v : b) std::fprintf(f, "%.15g\n", v);
+        std::fclose(f);
+    }
+    if (!s->history.empty()) {
+        f = open(base + "_res_norms.mtx");
+        if (!f) return OGL_ERR_INVALID;
+        std::fprintf(f, "%%%%MatrixMarket matrix array real general\n%zu 1\n", s->history.size());
+        for (double v : s->history) std::fprintf(f, "%.17g\n", v);
+        std::fclose(f);
+    }
+    return OGL_OK;
+    OGL_GUARD_END
 }
 
 extern "C" int ogl_solver_get_property(ogl_solver *s, const char *key, double *value)
@@ -277,13 +337,6 @@ extern "C" int ogl_solver_matrix_dims(ogl_solver *s, ogl_matrix_dims *d)
     d->n_neighbours = (ogl_label)s->pat.target_ids.size();
     d->n_send = (ogl_label)s->pat.send_idxs.size();
     return OGL_OK;
-}
-
-template <class T>
-static int fetch(ogl_solver *s, T *dst, const T *dev, size_t count)
-{
-    if (!dst || count == 0) return OGL_OK;
-    return s->reg->stager.d2h(dst, dev, count * sizeof(T), s->reg->stream);
 }
 
 extern "C" int ogl_solver_get_local_matrix(ogl_solver *s, ogl_label *row_ptrs, ogl_label *cols,

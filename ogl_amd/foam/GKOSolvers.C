@@ -20,6 +20,9 @@
 
 // OpenFOAM spells these differently from the stand-in:
 #define OGL_ABORT_FATAL Foam::abort(Foam::FatalError)
+// `debug true`: export at write times into processor?/<time>/ (lduLduBase.H:259-264, common.C:31-45)
+#define OGL_EXPORT_NOW(db) ((db).time().writeTime())
+#define OGL_EXPORT_DIR(db) (Foam::mkDir((db).time().timePath()), std::string((db).time().timePath()))
 
 #include "OGLAdapter.H"
 

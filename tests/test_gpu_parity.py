@@ -444,3 +444,40 @@ def test_block_jacobi_bad_size(reg):
     with pytest.raises(capi.OglError) as e:
         s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
     assert e.value.status == capi.ERR_INVALID
+
+
+# ---------------------------------------------------------------------------- MatrixMarket export
+
+def test_mtx_export(reg, oracle, tmp_path):
+    """common.C:31-58 / test/data_validation.py of the reference: files exist, coordinate format,
+    row-major order, Poisson sign pattern, differ when the coefficients change."""
+    import hashlib
+    import scipy.io
+    case = synthetic.poisson_block(6, 5, 4, periodic_x=True)
+    b = np.linspace(-1, 1, case.n_cells)
+    s = reg.solver("pmtx", cg_cfg(max_iter=5)).set_matrix(case)
+    s.solve(b, np.zeros_like(b))
+    d1 = str(tmp_path / "0.05")
+    s.export_system(d1)
+    A = scipy.io.mmread(f"{d1}/pmtx_A_local.mtx").tocsr()
+    rp, cols, vals = oracle_csr(oracle, case)
+    np.testing.assert_array_equal(A.indptr, rp)
+    np.testing.assert_array_equal(A.indices, cols)
+    np.testing.assert_allclose(A.data, vals, rtol=1e-14)
+    lines = open(f"{d1}/pmtx_A_local.mtx").read().splitlines()
+    assert lines[0] == "%%MatrixMarket matrix coordinate real general"
+    ent = [ln.split(" ") for ln in lines[2:]]
+    keys = [(int(r), int(c)) for r, c, _ in ent]
+    assert keys == sorted(keys)                                   # row-major (data_validation.py)
+    for r, c, v in ent:                                           # sign bounds, Poisson analogue
+        assert (float(v) > 0) if r == c else (float(v) < 0)
+    np.testing.assert_allclose(scipy.io.mmread(f"{d1}/pmtx_rhs_b_.mtx").ravel(), b, rtol=1e-14)
+    hist = scipy.io.mmread(f"{d1}/pmtx_res_norms.mtx").ravel()
+    np.testing.assert_array_equal(hist, s.history())
+    assert open(f"{d1}/pmtx_A_non_local.mtx").read().splitlines()[1] == f"{case.n_cells} 0 0"
+    case.diag = case.diag * 1.25
+    s.set_matrix(case)
+    d2 = str(tmp_path / "0.5")
+    s.export_system(d2)
+    md5 = [hashlib.md5(open(f"{d}/pmtx_A_local.mtx", "rb").read()).hexdigest() for d in (d1, d2)]
+    assert md5[0] != md5[1]                                       # matrices differ between times
