@@ -106,6 +106,12 @@ ogl_registry::~ogl_registry()
     cached_precond.values.release();
     cached_precond.block_ptrs.release();
     cached_precond.row_block.release();
+    if (comm_stream) {
+        (void)hipStreamSynchronize(comm_stream);
+        (void)hipStreamDestroy(comm_stream);
+        (void)hipEventDestroy(ev_packed);
+        (void)hipEventDestroy(ev_received);
+    }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -399,13 +405,24 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     hipStream_t st = reg->stream;
     const bool has_halo = pat.non_local_nnz > 0;
     if (has_halo) {
+        // pack on the compute stream, exchange on the communication stream: the neighbour copies
+        // fly while the local SpMV below runs; the non-local kernel waits for their arrival
+        if (!reg->comm_stream) {
+            OGL_HIP_CHECK(hipStreamCreateWithFlags(&reg->comm_stream, hipStreamNonBlocking));
+            OGL_HIP_CHECK(hipEventCreateWithFlags(&reg->ev_packed, hipEventDisableTiming));
+            OGL_HIP_CHECK(hipEventCreateWithFlags(&reg->ev_received, hipEventDisableTiming));
+        }
         launch_pack(st, halo(), x, d_send.p, gate);
-        OGL_TRY(reg->comm->exchange(d_send.p, d_recv.p, neighbours, counts, st));
+        OGL_HIP_CHECK(hipEventRecord(reg->ev_packed, st));
+        OGL_HIP_CHECK(hipStreamWaitEvent(reg->comm_stream, reg->ev_packed, 0));
+        OGL_TRY(reg->comm->exchange(d_send.p, d_recv.p, neighbours, counts, reg->comm_stream));
+        OGL_HIP_CHECK(hipEventRecord(reg->ev_received, reg->comm_stream));
     }
     // with a halo the fused partials would miss the non-local part of the boundary rows: the dots
     // are taken in a separate pass after "y += A_non_local recv" (+16 N bytes each)
     launch_spmv(st, csr(), mode, x, b, y, has_halo ? SpmvDots{} : dots, gate);
     if (has_halo) {
+        OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
         launch_spmv_non_local(st, halo(), mode, d_recv.p, y, gate);
         if (dots.part) launch_partials_dot(st, pat.n_rows, dots.with, y, dots.part, gate);
         if (dots.part_yy) launch_partials_dot(st, pat.n_rows, y, y, dots.part_yy, gate);

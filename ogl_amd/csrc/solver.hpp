@@ -94,6 +94,9 @@ struct ogl_registry {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // halo exchange runs on its own stream so that it overlaps the local SpMV (K3)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_received = nullptr;
     std::unique_ptr<ogl::Comm> comm;
     std::map<std::string, std::unique_ptr<ogl_solver>> solvers;
     ogl::Stager stager;
