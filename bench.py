@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--n", type=int, default=216, help="box edge per GPU (216 = configs[1])")
     ap.add_argument("--iters", type=int, default=100, help="CG iterations per step")
     ap.add_argument("--precond", default="BJ", choices=["BJ", "none"])
+    ap.add_argument("--format", default="Csr", choices=["Csr", "Ell"],
+                    help="matrixFormat (Csr = the headline; Ell = configs[4]'s comparison)")
     ap.add_argument("--cpu-iters", type=int, default=-1,
                     help="oracle iterations for cpu_baseline (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-profile", action="store_true",
@@ -110,7 +112,8 @@ def main():
     precond = capi.PRECOND_BJ if args.precond == "BJ" else capi.PRECOND_NONE
     cfg = capi.default_config(solver=capi.SOLVER_CG, preconditioner=precond, max_block_size=1,
                               tolerance=0.0, rel_tol=0.0, max_iter=args.iters, min_iter=0,
-                              eval_frequency=1, adapt_min_iter=0, matrix_format=capi.FORMAT_CSR,
+                              eval_frequency=1, adapt_min_iter=0,
+                              matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
                               export_res=0, profile_kernels=0 if args.no_profile else 1)
     s = reg.solver("p", cfg)
     t0 = time.perf_counter()
@@ -143,7 +146,9 @@ def main():
     value = world * iters / elapsed
 
     # ---- roofline of the dominant kernel: the in-loop CSR SpMV -------------------------------
-    b_spmv = 12 * nnz + 20 * N + 4
+    b_spmv = 12 * nnz + 20 * N + 4            # CSR: values + columns + row pointers + x + y
+    if args.format == "Ell":                  # 7 slots/row -> 84 N + 16 N
+        b_spmv = (12 * 7 + 16) * N
     if args.no_profile:
         spmv_ms = s.time_spmv(100)
         spmv_src = "100 back-to-back launches, HIP events"
@@ -152,7 +157,8 @@ def main():
         spmv_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in perfs) / max(1, launches)
         spmv_src = f"{launches} in-loop launches of the timed steps, HIP event pairs"
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic("k_spmv_stream<0, true>") if n == 216 else (None, None)
+    traffic, traffic_src = (pmc_traffic("k_spmv_stream<0, 1>") if (n == 216 and args.format == "Csr")
+                            else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
     # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
     t0 = time.perf_counter()
@@ -175,7 +181,8 @@ def main():
                            if world > 1 else "single GPU",
         },
         "roofline": {
-            "kernel": "k_spmv_stream<PLAIN, fused p.q>", "bound": "hbm",
+            "kernel": ("k_spmv_ell" if args.format == "Ell" else "k_spmv_stream") + "<PLAIN, fused p.q>",
+            "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
             "traffic": traffic, "traffic_source": traffic_src,

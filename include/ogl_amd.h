@@ -57,8 +57,9 @@ typedef enum {
 } ogl_precond_kind;
 
 typedef enum { OGL_FORMAT_COO = 0, OGL_FORMAT_CSR = 1, OGL_FORMAT_ELL = 2 } ogl_matrix_format;
-/* CsrMatrixWrapper.H:138-161.  All three select the same persistent device CSR here: the
- * reference executor's Coo/Csr/Ell products accumulate a row in the same stored order. */
+/* CsrMatrixWrapper.H:138-161.  Coo and Csr select the persistent device CSR (row-sorted triplets
+ * and CSR accumulate a row in the same stored order in the reference executor); Ell adds a
+ * slot-major padded copy and its own SpMV kernel.  All three give bit-identical products. */
 
 typedef struct ogl_config {
     int32_t solver;             /* ogl_solver_kind                               "solver"            */

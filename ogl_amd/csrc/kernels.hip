@@ -568,6 +568,100 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2(int n, double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// ELL SpMV (matrixFormat Ell).  Slot-major planes: every load is a 16-byte (values) / 8-byte
+// (columns) coalesced access over the chunk's rows, no LDS, no row pointers; a thread owns rows
+// 2t, 2t+1 and adds the slots in order (= stored column order; padding slots are skipped), so the
+// result and the fused dot partials are bit-identical to the CSR kernel's.
+// ------------------------------------------------------------------------------------------
+template <int MODE, int NDOT>
+__global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, int width, long stride,
+                                                    const int *__restrict__ cols,
+                                                    const double *__restrict__ vals,
+                                                    const double *__restrict__ x,
+                                                    const double *__restrict__ b,
+                                                    double *__restrict__ y,
+                                                    const double *__restrict__ w,
+                                                    double *__restrict__ dot_partials,
+                                                    double *__restrict__ dot2_partials,
+                                                    const DevScalars *gate)
+{
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = xcd_chunk(blockIdx.x);
+    if (chunk >= n_chunks) return;
+    const RowPair rp = my_rows(chunk, n_rows);
+    double2 acc;
+    acc.x = acc.y = 0.0;
+    if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
+    // the planes are padded to an even stride (+2), so the pair load of the last odd row is in bounds
+    const long r = rp.n > 0 ? rp.row : 0;
+    constexpr int BATCH = 8;
+    for (int i0 = 0; i0 < width; i0 += BATCH) {
+        double2 v[BATCH];
+        int2 c[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int i = min(i0 + k, width - 1);  // clamp: always a valid plane
+            v[k] = *reinterpret_cast<const double2 *>(vals + (long)i * stride + r);
+            c[k] = *reinterpret_cast<const int2 *>(cols + (long)i * stride + r);
+            if (i0 + k >= width) c[k].x = c[k].y = -1;
+        }
+        double xv0[BATCH], xv1[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            xv0[k] = c[k].x >= 0 ? x[c[k].x] : 0.0;
+            xv1[k] = c[k].y >= 0 ? x[c[k].y] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            if (c[k].x >= 0) {
+                const double t = v[k].x * xv0[k];
+                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - t : acc.x + t;
+            }
+            if (c[k].y >= 0) {
+                const double t = v[k].y * xv1[k];
+                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - t : acc.y + t;
+            }
+        }
+    }
+    st2(y, rp, acc);
+    if (NDOT >= 1) {
+        const double2 vw = ld2(w, rp);
+        double d = 0.0, d2 = 0.0;
+        if (rp.n > 0) {
+            d += vw.x * acc.x;
+            d2 += acc.x * acc.x;
+        }
+        if (rp.n > 1) {
+            d += vw.y * acc.y;
+            d2 += acc.y * acc.y;
+        }
+        const double s = block_sum(d, slot);
+        if (threadIdx.x == 0) dot_partials[chunk] = s;
+        if (NDOT >= 2) {
+            const double s2 = block_sum(d2, slot);
+            if (threadIdx.x == 0) dot2_partials[chunk] = s2;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gather_coeffs_masked(long n, const int *__restrict__ map,
+                                                                const double *__restrict__ src,
+                                                                double *__restrict__ out)
+{
+    const long i = ((long)blockIdx.x * BLOCK + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        const int2 m = *reinterpret_cast<const int2 *>(map + i);
+        double2 v;
+        v.x = m.x >= 0 ? src[m.x] : 0.0;
+        v.y = m.y >= 0 ? src[m.y] : 0.0;
+        *reinterpret_cast<double2 *>(out + i) = v;
+    } else if (i < n) {
+        out[i] = map[i] >= 0 ? src[map[i]] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // BiCGStab steps ([UPSTREAM] bicgstab::step_1 / step_2 / step_3 / finalize)
 // ------------------------------------------------------------------------------------------
 // step_1: p = r + (rho/prev_rho * alpha/omega) (p - omega v)   [p = r when prev_rho*omega == 0];
@@ -990,6 +1084,35 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
         OGL_SPMV(SPMV_PLAIN, 0);
     }
 #undef OGL_SPMV
+}
+
+void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,
+                     double *y, const SpmvDots &dots, const DevScalars *gate)
+{
+    if (A.n_rows == 0) return;
+    const int nc = (int)n_chunks(A.n_rows);
+    const dim3 grid(xcd_grid(nc)), block(BLOCK);
+#define OGL_ELL(MODE, NDOT)                                                                      \
+    hipLaunchKernelGGL((k_spmv_ell<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.width,      \
+                       (long)A.stride, A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+    if (mode == SPMV_RESIDUAL) {
+        OGL_ELL(SPMV_RESIDUAL, 0);
+    } else if (dots.part && dots.part_yy) {
+        OGL_ELL(SPMV_PLAIN, 2);
+    } else if (dots.part) {
+        OGL_ELL(SPMV_PLAIN, 1);
+    } else {
+        OGL_ELL(SPMV_PLAIN, 0);
+    }
+#undef OGL_ELL
+}
+
+void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,
+                                 double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_gather_coeffs_masked, dim3(blocks_for((n + 1) / 2)), dim3(BLOCK), 0, st,
+                       (long)n, map, source, out);
 }
 
 void launch_spmv_non_local(hipStream_t st, const DevHalo &H, int mode, const double *recv,

@@ -66,6 +66,22 @@ struct SpmvDots {
 void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, const double *b,
                  double *y, const SpmvDots &dots, const DevScalars *gate);
 
+// matrixFormat Ell (CsrMatrixWrapper.H:146-149): `width` slots per row, slot-major (column-major in
+// Ginkgo's terms) with leading dimension `stride` >= n_rows; padding slots carry column -1 and are
+// skipped, so a row is summed in the same stored order as in the CSR kernel (bit-identical y).
+struct DevEll {
+    int32_t n_rows = 0;
+    int32_t width = 0;
+    int64_t stride = 0;
+    const int32_t *cols = nullptr;  // [width * stride]
+    const double *vals = nullptr;   // [width * stride]
+};
+void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,
+                     double *y, const SpmvDots &dots, const DevScalars *gate);
+// out[i] = map[i] >= 0 ? source[map[i]] : 0   (coefficient permutation into the padded ELL slots)
+void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,
+                                 double *out);
+
 // y[row] (+/-)= sum_k vals[k] * recv[cols[k]] over the boundary rows, continuing y's accumulator.
 void launch_spmv_non_local(hipStream_t st, const DevHalo &H, int mode, const double *recv,
                            double *y, const DevScalars *gate);

@@ -141,6 +141,45 @@ DevCsr ogl_solver::csr() const
     return A;
 }
 
+DevEll ogl_solver::ell() const
+{
+    DevEll E;
+    E.n_rows = pat.n_rows;
+    E.width = ell_width;
+    E.stride = ell_stride;
+    E.cols = d_ell_cols.p;
+    E.vals = d_ell_vals.p;
+    return E;
+}
+
+// matrixFormat Ell (CsrMatrixWrapper.H:146-149): `width` = longest row; slot i of row r lives at
+// i * stride + r.  ell_map holds the CSR position of each slot (-1 = padding), so the values are
+// refreshed from the freshly permuted CSR values whatever path produced them.
+int ogl_solver::build_ell()
+{
+    hipStream_t st = reg->stream;
+    const int32_t N = pat.n_rows;
+    int32_t width = 0;
+    for (int32_t r = 0; r < N; ++r) width = std::max(width, pat.row_ptrs[r + 1] - pat.row_ptrs[r]);
+    const int64_t stride = ((int64_t)N + 1) / 2 * 2 + 2;  // even, and the pair load of the last row fits
+    const size_t len = (size_t)width * (size_t)stride;
+    std::vector<int32_t> cols(len, -1), map(len, -1);
+    for (int32_t r = 0; r < N; ++r)
+        for (int32_t k = pat.row_ptrs[r], i = 0; k < pat.row_ptrs[r + 1]; ++k, ++i) {
+            cols[(size_t)i * stride + r] = pat.cols[k];
+            map[(size_t)i * stride + r] = k;
+        }
+    OGL_TRY(d_ell_cols.alloc(len + 2, st));
+    OGL_TRY(d_ell_map.alloc(len + 2, st));
+    OGL_TRY(d_ell_vals.alloc(len + 2, st));
+    OGL_TRY(reg->stager.h2d(d_ell_cols.p, cols.data(), len * sizeof(int32_t), st));
+    OGL_TRY(reg->stager.h2d(d_ell_map.p, map.data(), len * sizeof(int32_t), st));
+    ell_width = width;
+    ell_stride = stride;
+    ell_ready = true;
+    return OGL_OK;
+}
+
 DevHalo ogl_solver::halo() const
 {
     DevHalo H;
@@ -202,6 +241,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         pat = std::move(np);
         have_pattern = true;
         matrix_set = false;
+        ell_ready = false;
         x_resident = b_resident = false;
         const size_t nnz = (size_t)pat.local_nnz;
         OGL_TRY(d_row_ptrs.alloc((size_t)pat.n_rows + 1, st));
@@ -305,6 +345,15 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
                                     h_nl_vals.size() * sizeof(double), st));
         }
         matrix_set = true;
+        ell_values_stale = true;
+    }
+    if (cfg.matrix_format == OGL_FORMAT_ELL) {
+        if (!ell_ready) OGL_TRY(build_ell());
+        if (ell_values_stale) {
+            launch_gather_coeffs_masked(st, (int64_t)ell_width * ell_stride, d_ell_map.p, d_vals.p,
+                                        d_ell_vals.p);
+            ell_values_stale = false;
+        }
     }
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
@@ -420,7 +469,10 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     }
     // with a halo the fused partials would miss the non-local part of the boundary rows: the dots
     // are taken in a separate pass after "y += A_non_local recv" (+16 N bytes each)
-    launch_spmv(st, csr(), mode, x, b, y, has_halo ? SpmvDots{} : dots, gate);
+    if (cfg.matrix_format == OGL_FORMAT_ELL && ell_ready && !ell_values_stale)
+        launch_spmv_ell(st, ell(), mode, x, b, y, has_halo ? SpmvDots{} : dots, gate);
+    else
+        launch_spmv(st, csr(), mode, x, b, y, has_halo ? SpmvDots{} : dots, gate);
     if (has_halo) {
         OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
         launch_spmv_non_local(st, halo(), mode, d_recv.p, y, gate);

@@ -118,6 +118,14 @@ struct ogl_solver {
     ogl::DevBuf<int32_t> d_row_ptrs, d_cols, d_ldu_mapping;  // "<field>_local_*"
     ogl::DevBuf<double> d_vals;                              // "<field>_matrix" values
     ogl::DevBuf<double> d_source;                            // unsorted [upper|lower|diag|iface]
+    // matrixFormat Ell: slot-major copy of the local matrix (built on demand, refreshed from vals)
+    ogl::DevBuf<int32_t> d_ell_cols, d_ell_map;
+    ogl::DevBuf<double> d_ell_vals;
+    int32_t ell_width = 0;
+    int64_t ell_stride = 0;
+    bool ell_ready = false, ell_values_stale = true;
+    int build_ell();
+    ogl::DevEll ell() const;
     // halo part
     std::vector<int32_t> boundary_rows, boundary_ptrs;
     ogl::DevBuf<int32_t> d_boundary_rows, d_boundary_ptrs, d_nl_cols, d_send_idxs;

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
+#include <cmath>
 
 #define CK(x)                                                                      \
     do {                                                                           \
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_spmv(int n_rows, int n_chunks,
                                                       const double *__restrict__ vals,
                                                       const double *__restrict__ x,
                                                       double *__restrict__ y,
-                                                      double *__restrict__ dot_partials)
+                                                      double *__restrict__ dot_partials,
+                                                      const int *__restrict__ order)
 {
     constexpr int RPT = CHUNK_ROWS / BLOCK;
     __shared__ __attribute__((aligned(16))) double prod[TILE];
@@ -68,6 +71,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_spmv(int n_rows, int n_chunks,
     if (XCD == 1) {
         const int per = (n_chunks + 7) / 8;
         chunk = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    } else if (XCD == 100) {  // host-computed order: chunks c and c +- (far band / 512) share an XCD
+        chunk = order[blockIdx.x];
+        if (chunk < 0) return;
     } else if (XCD > 1) {  // groups of G = XCD consecutive chunks per XCD, all XCDs on one front
         constexpr int G = XCD;
         const int b = blockIdx.x, slot = b / 8, xcd = b % 8;
@@ -182,11 +188,109 @@ __global__ __launch_bounds__(256) void k_read(const double2 *__restrict__ a, dou
     if (s == 123.456) out[0] = s;
 }
 
+
+struct Csr;
+// ---- ablations of the product kernel (results are wrong on purpose where noted) ----
+// ABL 0: stream values + columns, no gather (x := 1), products to LDS, row sums, y write
+// ABL 1: stream + gather, but no LDS/row phase: each thread writes the sum of its own 16 products
+// ABL 2: stream only: per-thread sum of values and columns, one write per thread
+template <int ABL>
+__global__ __launch_bounds__(BLOCK) void k_abl(int n_rows, int n_chunks, const int *__restrict__ row_ptrs,
+                                               const int *__restrict__ cols,
+                                               const double *__restrict__ vals,
+                                               const double *__restrict__ x, double *__restrict__ y)
+{
+    constexpr int CHUNK_ROWS = 512, TILE = 4096, RPT = 2, STEPS = 4;
+    __shared__ __attribute__((aligned(16))) double prod[TILE];
+    const int slot = blockIdx.x / 8, xcd = blockIdx.x % 8;
+    const int chunk = (slot / 4) * 32 + xcd * 4 + slot % 4;
+    if (chunk >= n_chunks) return;
+    const int tid = threadIdx.x;
+    const int r0 = chunk * CHUNK_ROWS;
+    const int r1 = min(r0 + CHUNK_ROWS, n_rows);
+    const int nz0 = row_ptrs[r0], nz1 = row_ptrs[r1];
+    const int row = r0 + tid * RPT;
+    int rs[RPT + 1];
+    for (int j = 0; j <= RPT; ++j) rs[j] = row_ptrs[min(row + j, r1)];
+    double acc[RPT] = {0.0, 0.0};
+    double tsum = 0.0;
+    for (int t0 = nz0 & ~3; t0 < nz1; t0 += TILE) {
+        d2 va[STEPS], vb[STEPS];
+        i4 cc[STEPS];
+#pragma unroll
+        for (int g = 0; g < STEPS; ++g) {
+            const int e = t0 + (g * BLOCK + tid) * 4;
+            const int ec = e < nz1 ? e : t0;
+            va[g] = *reinterpret_cast<const d2 *>(vals + ec);
+            vb[g] = *reinterpret_cast<const d2 *>(vals + ec + 2);
+            cc[g] = *reinterpret_cast<const i4 *>(cols + ec);
+        }
+#pragma unroll
+        for (int g = 0; g < STEPS; ++g) {
+            double x0, x1, x2, x3;
+            if (ABL == 1) {
+                x0 = x[cc[g].x]; x1 = x[cc[g].y]; x2 = x[cc[g].z]; x3 = x[cc[g].w];
+            } else if (ABL == 3) {  // same gather instruction count, but x confined to 32 KB (L1/L2 hits)
+                x0 = x[cc[g].x & 4095]; x1 = x[cc[g].y & 4095]; x2 = x[cc[g].z & 4095]; x3 = x[cc[g].w & 4095];
+            } else if (ABL == 4) {  // x confined to 2 MB (L2 hits, L1 misses)
+                x0 = x[cc[g].x & 262143]; x1 = x[cc[g].y & 262143]; x2 = x[cc[g].z & 262143]; x3 = x[cc[g].w & 262143];
+            } else {
+                x0 = (double)cc[g].x; x1 = (double)cc[g].y; x2 = (double)cc[g].z; x3 = (double)cc[g].w;
+            }
+            d2 p0, p1;
+            p0.x = va[g].x * x0; p0.y = va[g].y * x1; p1.x = vb[g].x * x2; p1.y = vb[g].y * x3;
+            if (ABL == 0) {
+                const int le = (g * BLOCK + tid) * 4;
+                *reinterpret_cast<d2 *>(prod + le) = p0;
+                *reinterpret_cast<d2 *>(prod + le + 2) = p1;
+            } else {
+                tsum += p0.x + p0.y + p1.x + p1.y;
+            }
+        }
+        if (ABL == 0) {
+            __syncthreads();
+            const int t1 = t0 + TILE;
+            for (int j = 0; j < RPT; ++j) {
+                const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
+                for (int k = kb; k < ke; ++k) acc[j] += prod[k - t0];
+            }
+            __syncthreads();
+        }
+    }
+    if (ABL == 0) {
+        for (int j = 0; j < RPT; ++j)
+            if (row + j < r1) y[row + j] = acc[j];
+    } else {
+        if (row < r1) y[row] = tsum;
+        if (row + 1 < r1) y[row + 1] = tsum;
+    }
+}
+
+
 struct Csr {
     int n, nnz;
     std::vector<int> rp, cols;
     std::vector<double> vals;
 };
+
+template <int ABL>
+static void run_abl(const char *name, const Csr &A, const int *d_rp, const int *d_cols, const double *d_vals,
+                    double *d_x0, double *d_y, int reps)
+{
+    const int nc = (A.n + 511) / 512;
+    const int grid = ((nc + 31) / 32) * 32;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_abl<ABL>), dim3(grid), dim3(BLOCK), 0, 0, A.n, nc, d_rp, d_cols, d_vals, d_x0, d_y);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_abl<ABL>), dim3(grid), dim3(BLOCK), 0, 0, A.n, nc, d_rp, d_cols, d_vals, d_x0, d_y);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-60s b2b %7.1f us\n", name, 1e3 * ms / reps);
+}
 
 static Csr poisson(int n)
 {
@@ -224,16 +328,36 @@ static Csr poisson(int n)
 template <int CHUNK_ROWS, int TILE, int LAYOUT, bool NT, int XCD, int MINW>
 static void run(const char *name, const Csr &A, const int *d_rp, const int *d_cols, const double *d_vals,
                 double *d_x0, double *d_x1, double *d_y, double *d_part, const std::vector<double> &yref,
-                int reps)
+                int reps, double band = 0)
 {
     const int nc = (A.n + CHUNK_ROWS - 1) / CHUNK_ROWS;
-    const int grid = XCD == 0 ? nc : (XCD == 1 ? ((nc + 7) / 8) * 8 : ((nc + 8 * XCD - 1) / (8 * XCD)) * 8 * XCD);
+    int grid = XCD == 0 ? nc : (XCD == 1 ? ((nc + 7) / 8) * 8 : ((nc + 8 * XCD - 1) / (8 * XCD)) * 8 * XCD);
+    int *d_order = nullptr;
+    if (XCD == 100) {
+        // XCD of chunk c = floor(frac(c * CHUNK_ROWS / band) * 8); per-XCD lists ascending; block b
+        // (XCD b % 8) takes entry b / 8 of its list
+        std::vector<std::vector<int>> lists(8);
+        for (int c = 0; c < nc; ++c) {
+            const double ph = (double)c * CHUNK_ROWS / band;
+            int x = (int)((ph - floor(ph)) * 8.0);
+            if (x > 7) x = 7;
+            lists[x].push_back(c);
+        }
+        size_t mx = 0;
+        for (auto &l : lists) mx = std::max(mx, l.size());
+        std::vector<int> order(mx * 8, -1);
+        for (int x = 0; x < 8; ++x)
+            for (size_t i = 0; i < lists[x].size(); ++i) order[i * 8 + x] = lists[x][i];
+        grid = (int)order.size();
+        CK(hipMalloc(&d_order, sizeof(int) * order.size()));
+        CK(hipMemcpy(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     auto launch = [&](const double *x) {
         hipLaunchKernelGGL((k_spmv<CHUNK_ROWS, TILE, LAYOUT, NT, XCD, MINW>), dim3(grid), dim3(BLOCK), 0, 0,
-                           A.n, nc, d_rp, d_cols, d_vals, x, d_y, d_part);
+                           A.n, nc, d_rp, d_cols, d_vals, x, d_y, d_part, d_order);
     };
     launch(d_x0);
     CK(hipDeviceSynchronize());
@@ -333,16 +457,24 @@ int main(int argc, char **argv)
 #define RUN(CR, TILE, LAY, NT, XCD, MINW) \
     run<CR, TILE, LAY, NT, XCD, MINW>("chunk" #CR " tile" #TILE " lay" #LAY " nt" #NT " xcd" #XCD " minw" #MINW, A, \
                                       d_rp, d_cols, d_vals, d_x0, d_x1, d_y, d_part, yref, reps)
-    RUN(512, 4096, 0, false, 1, 1);   // product kernel today
+#define RUNB(CR, TILE, LAY, NT, BAND) \
+    run<CR, TILE, LAY, NT, 100, 1>("chunk" #CR " tile" #TILE " lay" #LAY " nt" #NT " band-aware " #BAND, A, \
+                                      d_rp, d_cols, d_vals, d_x0, d_x1, d_y, d_part, yref, reps, BAND)
+    run_abl<0>("abl0: stream + LDS row phase, no gather", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
+    run_abl<1>("abl1: stream + gather, no LDS/row phase", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
+    run_abl<2>("abl2: stream only", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
+    run_abl<3>("abl3: stream + gather confined to 32 KB of x, no LDS", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
+    run_abl<4>("abl4: stream + gather confined to 2 MB of x, no LDS", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
+    const double n2 = (double)n * n;
+    RUN(512, 4096, 0, false, 4, 1);   // product kernel today
     RUN(512, 4096, 0, false, 0, 1);
-    RUN(512, 4096, 0, false, 2, 1);
+    RUNB(512, 4096, 0, false, n2);
+    RUNB(512, 4096, 0, false, 2 * n2);
+    RUNB(512, 4096, 0, false, n2 / 2);
+    RUNB(512, 4096, 0, false, n2 / 3);
+    RUNB(512, 4096, 0, true, n2);
+    RUNB(512, 4096, 1, true, n2);
+    RUNB(256, 2048, 0, false, n2);
     RUN(512, 4096, 0, false, 4, 1);
-    RUN(512, 4096, 0, false, 8, 1);
-    RUN(512, 4096, 0, false, 16, 1);
-    RUN(512, 4096, 0, false, 64, 1);
-    RUN(512, 4096, 1, true, 0, 1);
-    RUN(512, 4096, 1, true, 4, 1);
-    RUN(512, 4096, 1, true, 16, 1);
-    RUN(512, 4096, 0, false, 0, 1);
     return 0;
 }
