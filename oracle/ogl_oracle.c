@@ -1047,8 +1047,32 @@ orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *
     orc_scalar *z = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
     orc_scalar *p = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
     orc_scalar *q = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
-    const orc_label *rowptr = A->rowptr, *cols = A->cols;
-    const orc_scalar *vals = A->vals;
+    /* First-touch placement: the caller's arrays were allocated (and touched) by one thread, i.e.
+     * on one NUMA node.  Every thread copies the slice it will stream later (same static
+     * schedule), so a multi-socket host serves the loop from all of its memory controllers. */
+    const orc_label nnz_all = A->rowptr[n];
+    orc_label *rowptr = (orc_label *)xmalloc(sizeof(orc_label) * (cnt + 1));
+    orc_label *cols = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)(nnz_all ? nnz_all : 1));
+    orc_scalar *vals = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)(nnz_all ? nnz_all : 1));
+    orc_scalar *bb = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
+    orc_scalar *xx = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
+    orc_scalar *inv_copy = inv_diag ? (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt) : 0;
+#pragma omp parallel for schedule(static)
+    for (orc_label row = 0; row < n; ++row) {
+        rowptr[row] = A->rowptr[row];
+        for (orc_label k = A->rowptr[row]; k < A->rowptr[row + 1]; ++k) {
+            cols[k] = A->cols[k];
+            vals[k] = A->vals[k];
+        }
+        bb[row] = b[row];
+        xx[row] = x[row];
+        if (inv_copy) inv_copy[row] = inv_diag[row];
+    }
+    rowptr[n] = nnz_all;
+    orc_scalar *x_out = x;
+    b = bb;
+    x = xx;
+    if (inv_copy) inv_diag = inv_copy;
     orc_scalar rho = 0.0, prev_rho = 1.0, beta = 0.0, norm = 0.0;
     criterion_reset(st);
 #pragma omp parallel for schedule(static)
@@ -1109,7 +1133,9 @@ orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *
         }
         prev_rho = rho;
     }
+    memcpy(x_out, x, sizeof(orc_scalar) * (size_t)n);
     free(r); free(z); free(p); free(q);
+    free(rowptr); free(cols); free(vals); free(bb); free(xx); free(inv_copy);
     return st->iter;
 #endif
 }

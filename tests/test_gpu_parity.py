@@ -481,3 +481,40 @@ def test_mtx_export(reg, oracle, tmp_path):
     s.export_system(d2)
     md5 = [hashlib.md5(open(f"{d}/pmtx_A_local.mtx", "rb").read()).hexdigest() for d in (d1, d2)]
     assert md5[0] != md5[1]                                       # matrices differ between times
+
+
+# ---------------------------------------------------------------------------- adaptive policy
+
+def test_adaptive_min_iter_and_frequency_between_solves(oracle, chunk_rows):
+    """StoppingCriterion.H:199-209 + common.C:104-146: the second solve of a field skips the checks
+    below relaxationFactor * prevSolveIters and evaluates every `frequency` turns; both come from
+    the per-field properties the first solve stored."""
+    case = synthetic.poisson_case(12)
+    b = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
+    reg = capi.Registry()
+    try:
+        cfg = cg_cfg(adapt_min_iter=1, export_res=0, tolerance=1e-9, max_iter=300)
+        s = reg.solver("adapt", cfg).set_matrix(case)
+        x1, p1 = s.solve(b, np.zeros_like(b))
+        prev_iters = int(s.get_property("prevSolveIters_final"))
+        assert prev_iters == p1.n_iterations
+        s.set_property("_prev_solve", 9.0)            # pin the (timing-derived) relative cost
+        mi, fr = capi.host_adapt_criterion(cfg, prev_iters, 9.0)
+        assert mi == int(prev_iters * 0.6) and fr >= 1
+        s.upload_solution(None)
+        x2, p2 = s.solve(b, np.zeros_like(b))
+        A, _ = oracle_matrix(oracle, case)
+        with blocked(oracle, chunk_rows):
+            ref = oracle.cg(A, b, np.zeros_like(b), None, tolerance=1e-9, rel_tol=0.0, max_iter=300,
+                            min_iter=mi, frequency=fr, export_res=False)
+        assert (p2.n_iterations, p2.n_norm_evals) == (ref.n_iterations, ref.n_evals)
+        assert p2.n_norm_evals < p1.n_norm_evals
+        np.testing.assert_array_equal(x2, ref.x)
+        # `export true` switches the adaptation off (StoppingCriterion.H:201)
+        s3 = reg.solver("adapt", cg_cfg(adapt_min_iter=1, export_res=1, tolerance=1e-9, max_iter=300))
+        s3.set_matrix(case)
+        s3.upload_solution(None)
+        x3, p3 = s3.solve(b, np.zeros_like(b))
+        assert p3.n_norm_evals == p3.n_iterations
+    finally:
+        reg.close()
