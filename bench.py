@@ -39,7 +39,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=216, help="box edge per GPU (216 = configs[1])")
+    # (--edge, not --n: torch.distributed.run abbreviates its own options and would swallow --n)
+    ap.add_argument("--edge", "--n", dest="n", type=int, default=216,
+                    help="box edge per GPU (216 = configs[1])")
     ap.add_argument("--iters", type=int, default=100, help="CG iterations per step")
     ap.add_argument("--precond", default="BJ", choices=["BJ", "none"])
     ap.add_argument("--format", default="Csr", choices=["Csr", "Ell"],
@@ -89,6 +91,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in libogl_amd")
+    # one rank per GPU; on a box with fewer GPUs than ranks (development only) ranks share devices
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -105,10 +109,52 @@ def main():
     b = synthetic.x_star(case.global_index, case.global_n) + 0.5
 
     reg = capi.Registry(device_id=local_rank, hip_stream=torch.cuda.current_stream().cuda_stream)
+    transport = "single GPU"
     if world > 1:
-        uid = [capi.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        reg.init_rccl(rank, world, uid[0])
+        # device transport: RCCL over xGMI.  If the communicator cannot be built on this node the
+        # ranks agree (over gloo) to fall back to the host-buffer transport -- slower, but the
+        # sharded path still runs and the JSON line says which transport was measured.
+        ok = 1
+        try:
+            if os.environ.get("OGL_BENCH_TRANSPORT", "rccl") != "rccl":
+                raise capi.OglError(capi.ERR_COMM, "host transport requested")
+            uid = [capi.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            reg.init_rccl(rank, world, uid[0])
+        except capi.OglError as e:
+            ok = 0
+            if rank == 0:
+                print(f"bench.py: RCCL unavailable ({e}); using the host-buffer transport",
+                      file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        transport = "RCCL halo + all-reduce"
+        if int(flag.item()) == 0:
+            transport = "host-buffer (gloo) halo + all-reduce"
+
+            def _allreduce(a):
+                t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return t.numpy()
+
+            def _exchange(neighbours, counts, send):
+                recv = np.zeros_like(send)
+                offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+                reqs, bufs = [], []
+                for i, nb in enumerate(neighbours):
+                    s_t = torch.from_numpy(np.ascontiguousarray(send[offs[i]:offs[i + 1]]))
+                    r_t = torch.zeros(int(counts[i]), dtype=torch.float64)
+                    reqs += [dist.isend(s_t, int(nb)), dist.irecv(r_t, int(nb))]
+                    bufs.append((i, r_t, s_t))
+                for q in reqs:
+                    q.wait()
+                for i, r_t, _ in bufs:
+                    recv[offs[i]:offs[i + 1]] = r_t.numpy()
+                return recv
+
+            reg.close()
+            reg = capi.Registry(device_id=local_rank)
+            reg.set_host_comm(rank, world, _allreduce, _exchange)
     precond = capi.PRECOND_BJ if args.precond == "BJ" else capi.PRECOND_NONE
     cfg = capi.default_config(solver=capi.SOLVER_CG, preconditioner=precond, max_block_size=1,
                               tolerance=0.0, rel_tol=0.0, max_iter=args.iters, min_iter=0,
@@ -177,7 +223,7 @@ def main():
                         f"{'BJ(maxBlockSize 1)' if precond else 'no preconditioner'}, "
                         "fp64/int32 persistent device CSR (BASELINE.json configs[1])",
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
-            "parallelism": f"rows sharded into {world} z-slab(s), RCCL halo + all-reduce"
+            "parallelism": f"rows sharded into {world} z-slab(s), {transport}"
                            if world > 1 else "single GPU",
         },
         "roofline": {

@@ -10,7 +10,7 @@ python -c "import torch; torch.cuda.init(); import __graft_entry__ as g; g.smoke
 tail -3 gpurun_out/smoke_notorch.log gpurun_out/smoke_torch.log
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -25 gpurun_out/pytest_gpu.log
-timeout 600 python bench.py --n 64 --steps 3 --warmup 1 --iters 50 > gpurun_out/bench_n64.json 2> gpurun_out/bench_n64.err; echo "bench64 rc=$?"
+timeout 600 python bench.py --edge 64 --steps 3 --warmup 1 --iters 50 > gpurun_out/bench_n64.json 2> gpurun_out/bench_n64.err; echo "bench64 rc=$?"
 cat gpurun_out/bench_n64.json; tail -5 gpurun_out/bench_n64.err
 timeout 900 python bench.py --steps 3 --warmup 1 > gpurun_out/bench_n216.json 2> gpurun_out/bench_n216.err; echo "bench216 rc=$?"
 cat gpurun_out/bench_n216.json; tail -5 gpurun_out/bench_n216.err
