@@ -53,7 +53,9 @@ typedef enum { OGL_SOLVER_CG = 0, OGL_SOLVER_BICGSTAB = 1, OGL_SOLVER_GMRES = 2 
 
 typedef enum {
     OGL_PRECOND_NONE = 0, /* Preconditioner.H:342 */
-    OGL_PRECOND_BJ = 1    /* Preconditioner.H:91-105 (Schwarz-wrapped Jacobi on the local matrix) */
+    OGL_PRECOND_BJ = 1,   /* Preconditioner.H:91-105 (Schwarz-wrapped Jacobi on the local matrix) */
+    OGL_PRECOND_ISAI = 2, /* Preconditioner.H:225-241  isai_type::spd     (M^-1 = W^T W)           */
+    OGL_PRECOND_GISAI = 3 /* Preconditioner.H:242-258  isai_type::general (M^-1 = W)               */
 } ogl_precond_kind;
 
 typedef enum { OGL_FORMAT_COO = 0, OGL_FORMAT_CSR = 1, OGL_FORMAT_ELL = 2 } ogl_matrix_format;
@@ -86,6 +88,7 @@ typedef struct ogl_config {
     int32_t force_host_buffer;  /* 0     ExecutorHandler.H:136-139               "forceHostBuffer"   */
     int32_t ranks_per_gpu;      /* 1     ExecutorHandler.H:135 (only 1 works)    "ranksPerGPU"       */
     int32_t krylov_dim;         /* 0 = Ginkgo default (100); GMRES only; NOT a reference keyword   */
+    int32_t sparsity_power;     /* 1     Preconditioner.H:227 (only 1 is built)  "sparsityPower"     */
     int32_t profile_kernels;    /* 0; 1 = hipEvent-time the in-loop SpMV (bench.py roofline leg)    */
 } ogl_config;
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libogl_amd.so")
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_COMM, ERR_STATE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 SOLVER_CG, SOLVER_BICGSTAB, SOLVER_GMRES = 0, 1, 2
-PRECOND_NONE, PRECOND_BJ = 0, 1
+PRECOND_NONE, PRECOND_BJ, PRECOND_ISAI, PRECOND_GISAI = 0, 1, 2, 3
 FORMAT_COO, FORMAT_CSR, FORMAT_ELL = 0, 1, 2
 IFACE_PROCESSOR, IFACE_CYCLIC = 0, 1
 RCCL_ID_BYTES = 128
@@ -34,7 +34,8 @@ class Config(C.Structure):
         ("update_sys_matrix", C.c_int32), ("update_rhs", C.c_int32),
         ("update_init_guess", C.c_int32), ("scaling", C.c_double), ("reorder_on_host", C.c_int32),
         ("export_res", C.c_int32), ("verbose", C.c_int32), ("force_host_buffer", C.c_int32),
-        ("ranks_per_gpu", C.c_int32), ("krylov_dim", C.c_int32), ("profile_kernels", C.c_int32),
+        ("ranks_per_gpu", C.c_int32), ("krylov_dim", C.c_int32), ("sparsity_power", C.c_int32),
+        ("profile_kernels", C.c_int32),
     ]
 
 

@@ -427,5 +427,6 @@ extern "C" void ogl_config_default(ogl_config *c)
     c->force_host_buffer = 0;
     c->ranks_per_gpu = 1;
     c->krylov_dim = 0;
+    c->sparsity_power = 1;
     c->profile_kernels = 0;
 }

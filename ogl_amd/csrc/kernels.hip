@@ -356,6 +356,71 @@ __global__ __launch_bounds__(BLOCK) void k_bj_apply(int n_rows, const int *__res
     out[row] = sum;
 }
 
+// ISAI generate: same operation order as oracle/ogl_oracle.c (csr_entry, solve_dense)
+__device__ double csr_entry(const int *__restrict__ row_ptrs, const int *__restrict__ cols,
+                            const double *__restrict__ vals, int r, int c)
+{
+    for (int k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k)
+        if (cols[k] == c) return vals[k];
+    return 0.0;
+}
+
+__global__ __launch_bounds__(64) void k_isai_generate(int n_rows, const int *__restrict__ row_ptrs,
+                                                      const int *__restrict__ cols,
+                                                      const double *__restrict__ vals, int spd,
+                                                      const int *__restrict__ w_row_ptrs,
+                                                      const int *__restrict__ w_cols,
+                                                      double *__restrict__ w_vals)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_rows) return;
+    constexpr int LD = MAX_ISAI_ROW;
+    const int w0 = w_row_ptrs[i], bs = w_row_ptrs[i + 1] - w0;
+    int J[LD], pos = -1;
+    for (int r = 0; r < bs; ++r) {
+        J[r] = w_cols[w0 + r];
+        if (J[r] == i) pos = r;
+    }
+    double a[LD * LD], rhs[LD];
+    for (int r = 0; r < bs; ++r) {
+        for (int c = 0; c < bs; ++c)
+            a[r * LD + c] = spd ? csr_entry(row_ptrs, cols, vals, J[r], J[c])
+                                : csr_entry(row_ptrs, cols, vals, J[c], J[r]);
+        rhs[r] = (r == pos) ? 1.0 : 0.0;
+    }
+    for (int k = 0; k < bs; ++k) {
+        int piv = k;
+        double best = fabs(a[k * LD + k]);
+        for (int r = k + 1; r < bs; ++r)
+            if (fabs(a[r * LD + k]) > best) {
+                best = fabs(a[r * LD + k]);
+                piv = r;
+            }
+        if (piv != k) {
+            for (int j = 0; j < bs; ++j) {
+                const double t = a[k * LD + j];
+                a[k * LD + j] = a[piv * LD + j];
+                a[piv * LD + j] = t;
+            }
+            const double t = rhs[k];
+            rhs[k] = rhs[piv];
+            rhs[piv] = t;
+        }
+        for (int r = k + 1; r < bs; ++r) {
+            const double f = a[r * LD + k] / a[k * LD + k];
+            for (int j = k + 1; j < bs; ++j) a[r * LD + j] -= f * a[k * LD + j];
+            rhs[r] -= f * rhs[k];
+        }
+    }
+    for (int r = bs - 1; r >= 0; --r) {
+        double t = rhs[r];
+        for (int j = r + 1; j < bs; ++j) t -= a[r * LD + j] * rhs[j];
+        rhs[r] = t / a[r * LD + r];
+    }
+    const double scale = spd ? sqrt(rhs[pos]) : 1.0;
+    for (int r = 0; r < bs; ++r) w_vals[w0 + r] = spd ? rhs[r] / scale : rhs[r];
+}
+
 __global__ __launch_bounds__(BLOCK) void k_scale(int n, double *__restrict__ v, double f)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -1165,6 +1230,14 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
     if (J.n_rows == 0) return;
     hipLaunchKernelGGL(k_bj_apply, dim3(blocks_for(J.n_rows)), dim3(BLOCK), 0, st, J.n_rows,
                        J.block_ptrs, J.row_block, J.blocks, J.stride, in, out, gate);
+}
+
+void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
+                          const int32_t *w_cols, double *w_vals)
+{
+    if (A.n_rows == 0) return;
+    hipLaunchKernelGGL(k_isai_generate, dim3((A.n_rows + 63) / 64), dim3(64), 0, st, A.n_rows,
+                       A.row_ptrs, A.cols, A.vals, spd, w_row_ptrs, w_cols, w_vals);
 }
 
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor)

@@ -111,6 +111,14 @@ void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
                      const DevScalars *gate);
 
+// ISAI / GISAI with sparsityPower 1 (Preconditioner.H:225-258): row i of the approximate inverse W
+// solves a dense system over its own pattern (<= 32 entries), one thread per row, Gaussian
+// elimination with partial pivoting.  spd: pattern tril(A), A(J,J) y = e_i, W(i,J) = y / sqrt(y_i);
+// general: pattern of A, A(J,J)^T y = e_i, W(i,J) = y.
+constexpr int MAX_ISAI_ROW = 32;
+void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
+                          const int32_t *w_cols, double *w_vals);
+
 // b *= scaling (lduLduBase.H:244-252)
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor);
 // v[i] = s->xbar

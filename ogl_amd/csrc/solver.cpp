@@ -373,7 +373,53 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
 {
     hipStream_t st = reg->stream;
     const size_t n = (size_t)pat.n_rows;
-    if (cfg.max_block_size == 1) {  // scalar Jacobi: 1 / diag
+    if (cfg.preconditioner == OGL_PRECOND_ISAI || cfg.preconditioner == OGL_PRECOND_GISAI) {
+        // Isai<spd|general> with sparsity_power 1 and skip_sorting (Preconditioner.H:225-258).
+        // Pattern of W on the host (tril(A) for spd, A for general), its transpose + map for spd,
+        // values on the device (one dense solve per row).
+        const bool spd = cfg.preconditioner == OGL_PRECOND_ISAI;
+        const int32_t N = pat.n_rows;
+        std::vector<int32_t> wrp((size_t)N + 1, 0), wc;
+        wc.reserve((size_t)pat.local_nnz);
+        for (int32_t r = 0; r < N; ++r) {
+            for (int32_t k = pat.row_ptrs[r]; k < pat.row_ptrs[r + 1]; ++k)
+                if (!spd || pat.cols[k] <= r) wc.push_back(pat.cols[k]);
+            wrp[r + 1] = (int32_t)wc.size();
+            if (wrp[r + 1] - wrp[r] > MAX_ISAI_ROW)
+                return fail(OGL_ERR_UNSUPPORTED, "ISAI: row %d has more than %d pattern entries", r,
+                            MAX_ISAI_ROW);
+        }
+        const size_t wn = wc.size();
+        OGL_TRY(P.w_row_ptrs.alloc((size_t)N + 1, st));
+        OGL_TRY(P.w_cols.alloc(wn + NNZ_PAD, st));
+        OGL_TRY(P.w_vals.alloc(wn + NNZ_PAD, st));
+        OGL_TRY(reg->stager.h2d(P.w_row_ptrs.p, wrp.data(), wrp.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(P.w_cols.p, wc.data(), wn * sizeof(int32_t), st));
+        launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p);
+        if (spd) {  // W^T: counting transpose keeps every row sorted by column
+            std::vector<int32_t> trp((size_t)N + 1, 0), tc(wn), tmap(wn);
+            for (size_t k = 0; k < wn; ++k) ++trp[wc[k] + 1];
+            for (int32_t r = 0; r < N; ++r) trp[r + 1] += trp[r];
+            std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
+            for (int32_t r = 0; r < N; ++r)
+                for (int32_t k = wrp[r]; k < wrp[r + 1]; ++k) {
+                    const int32_t e = fill[wc[k]]++;
+                    tc[e] = r;
+                    tmap[e] = k;
+                }
+            OGL_TRY(P.wt_row_ptrs.alloc((size_t)N + 1, st));
+            OGL_TRY(P.wt_cols.alloc(wn + NNZ_PAD, st));
+            OGL_TRY(P.wt_map.alloc(wn + NNZ_PAD, st));
+            OGL_TRY(P.wt_vals.alloc(wn + NNZ_PAD, st));
+            OGL_TRY(reg->stager.h2d(P.wt_row_ptrs.p, trp.data(), trp.size() * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(P.wt_cols.p, tc.data(), wn * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(P.wt_map.p, tmap.data(), wn * sizeof(int32_t), st));
+            launch_gather_coeffs(st, (int32_t)wn, P.wt_map.p, P.w_vals.p, P.wt_vals.p);
+        }
+        P.w_nnz = (int32_t)wn;
+        P.kind = spd ? 3 : 4;
+        P.stride = 0;
+    } else if (cfg.max_block_size == 1) {  // scalar Jacobi: 1 / diag
         OGL_TRY(P.values.alloc(n + 2, st));
         launch_jacobi_generate(st, csr(), P.values.p);
         P.kind = 1;
@@ -406,6 +452,25 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
 
 void ogl_solver::apply_preconditioner(const double *in, double *out, const DevScalars *gate)
 {
+    if (precond_data->kind == 3 || precond_data->kind == 4) {  // ISAI: one or two SpMVs
+        DevCsr W;
+        W.n_rows = pat.n_rows;
+        W.nnz = precond_data->w_nnz;
+        W.row_ptrs = precond_data->w_row_ptrs.p;
+        W.cols = precond_data->w_cols.p;
+        W.vals = precond_data->w_vals.p;
+        if (precond_data->kind == 4) {
+            launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, out, SpmvDots{}, gate);
+            return;
+        }
+        DevCsr WT = W;
+        WT.row_ptrs = precond_data->wt_row_ptrs.p;
+        WT.cols = precond_data->wt_cols.p;
+        WT.vals = precond_data->wt_vals.p;
+        launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, d_isai_tmp.p, SpmvDots{}, gate);
+        launch_spmv(reg->stream, WT, SPMV_PLAIN, d_isai_tmp.p, nullptr, out, SpmvDots{}, gate);
+        return;
+    }
     DevBlockJacobi J;
     J.n_rows = pat.n_rows;
     J.n_blocks = precond_data->n_blocks;
@@ -421,12 +486,18 @@ int ogl_solver::init_preconditioner()
     precond = nullptr;
     precond_data = nullptr;
     if (cfg.preconditioner == OGL_PRECOND_NONE) return OGL_OK;  // :342
-    if (cfg.preconditioner != OGL_PRECOND_BJ)
+    const bool isai = cfg.preconditioner == OGL_PRECOND_ISAI || cfg.preconditioner == OGL_PRECOND_GISAI;
+    if (cfg.preconditioner != OGL_PRECOND_BJ && !isai)
         return fail(OGL_ERR_UNSUPPORTED, "preconditioner kind %d is not built", cfg.preconditioner);
-    if (cfg.max_block_size < 1 || cfg.max_block_size > MAX_JACOBI_BLOCK)
+    if (isai && cfg.sparsity_power != 1)
+        return fail(OGL_ERR_UNSUPPORTED, "ISAI sparsityPower %d: only 1 is built", cfg.sparsity_power);
+    if (!isai && (cfg.max_block_size < 1 || cfg.max_block_size > MAX_JACOBI_BLOCK))
         return fail(OGL_ERR_INVALID, "BJ maxBlockSize %d outside [1, %d]", cfg.max_block_size,
                     MAX_JACOBI_BLOCK);
-    const int kind = cfg.max_block_size == 1 ? 1 : 2;
+    if (cfg.preconditioner == OGL_PRECOND_ISAI)
+        OGL_TRY(d_isai_tmp.alloc((size_t)pat.n_rows + 2, reg->stream));
+    const int kind = isai ? (cfg.preconditioner == OGL_PRECOND_ISAI ? 3 : 4)
+                          : (cfg.max_block_size == 1 ? 1 : 2);
     const int stride = kind == 2 ? cfg.max_block_size : 0;
     const int cache = (int)prop("preconditionerCaching", 0);
     const bool stored =
@@ -542,7 +613,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     const int64_t ldv = (int64_t)n + 2;  // leading dimension of the Krylov bases
     // block Jacobi (maxBlockSize > 1): z = M^-1 r is materialised by its own kernel; the scalar
     // case stays fused into the step kernels
-    const bool generic = precond_data && precond_data->kind == 2;
+    const bool generic = precond_data && precond_data->kind >= 2;  // block Jacobi, ISAI, GISAI
 
     // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
     const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242

@@ -82,6 +82,12 @@ struct PrecondData {
     int32_t n_blocks = 0;
     DevBuf<double> values;  // inverse diagonal (n_rows + 2) or inverted blocks
     DevBuf<int32_t> block_ptrs, row_block;
+    // ISAI (kind 3: spd, M^-1 = W^T W; kind 4: general, M^-1 = W): CSR arrays padded like the
+    // system matrix so the CSR-stream SpMV kernel applies them; wt_map = position in W of every
+    // entry of W^T
+    DevBuf<int32_t> w_row_ptrs, w_cols, wt_row_ptrs, wt_cols, wt_map;
+    DevBuf<double> w_vals, wt_vals;
+    int32_t w_nnz = 0;
     bool matches(int k, size_t n, int st) const { return kind == k && n_rows == n && stride == st; }
 };
 
@@ -137,6 +143,7 @@ struct ogl_solver {
     ogl::DevBuf<double> d_x, d_b, d_r, d_p, d_q, d_w, d_inv_diag;
     ogl::DevBuf<double> d_v, d_s, d_t, d_y, d_z, d_rr;  // BiCGStab
     ogl::DevBuf<double> d_V, d_gm;                      // GMRES: Krylov bases, dense state
+    ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T
     ogl::DevBuf<double> d_part0, d_part1;
     ogl::DevBuf<ogl::DevScalars> d_scal;
     ogl::DevBuf<double> d_history;

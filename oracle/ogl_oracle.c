@@ -768,7 +768,113 @@ void orc_jacobi_generate_blocks(orc_label n, const orc_label *rowptr, const orc_
     }
 }
 
+/* ---- ISAI ([UPSTREAM] gko::preconditioner::Isai, sparsity power 1) ------------------------- */
+static orc_scalar csr_entry(const orc_label *rowptr, const orc_label *cols, const orc_scalar *vals,
+                            orc_label r, orc_label c) {
+    for (orc_label k = rowptr[r]; k < rowptr[r + 1]; ++k)
+        if (cols[k] == c) return vals[k];
+    return 0.0;
+}
+
+/* Gaussian elimination with partial pivoting + back substitution; solution returned in rhs. */
+static void solve_dense(orc_label bs, orc_scalar *a, orc_label ld, orc_scalar *rhs) {
+    for (orc_label k = 0; k < bs; ++k) {
+        orc_label piv = k;
+        orc_scalar best = fabs(a[k * ld + k]);
+        for (orc_label i = k + 1; i < bs; ++i)
+            if (fabs(a[i * ld + k]) > best) {
+                best = fabs(a[i * ld + k]);
+                piv = i;
+            }
+        if (piv != k) {
+            for (orc_label j = 0; j < bs; ++j) {
+                const orc_scalar t = a[k * ld + j];
+                a[k * ld + j] = a[piv * ld + j];
+                a[piv * ld + j] = t;
+            }
+            const orc_scalar t = rhs[k];
+            rhs[k] = rhs[piv];
+            rhs[piv] = t;
+        }
+        for (orc_label i = k + 1; i < bs; ++i) {
+            const orc_scalar f = a[i * ld + k] / a[k * ld + k];
+            for (orc_label j = k + 1; j < bs; ++j) a[i * ld + j] -= f * a[k * ld + j];
+            rhs[i] -= f * rhs[k];
+        }
+    }
+    for (orc_label i = bs - 1; i >= 0; --i) {
+        orc_scalar t = rhs[i];
+        for (orc_label j = i + 1; j < bs; ++j) t -= a[i * ld + j] * rhs[j];
+        rhs[i] = t / a[i * ld + i];
+    }
+}
+
+orc_label orc_isai_generate(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                            const orc_scalar *vals, int spd, orc_label *w_rowptr, orc_label *w_cols,
+                            orc_scalar *w_vals) {
+    w_rowptr[0] = 0;
+    for (orc_label i = 0; i < n; ++i) {
+        orc_label cnt = 0;
+        for (orc_label k = rowptr[i]; k < rowptr[i + 1]; ++k)
+            if (!spd || cols[k] <= i) ++cnt;
+        if (cnt > 32) return -1;
+        w_rowptr[i + 1] = w_rowptr[i] + cnt;
+    }
+    if (!w_vals) return w_rowptr[n];
+    for (orc_label i = 0; i < n; ++i) {
+        orc_label J[32], bs = 0, pos = -1;
+        for (orc_label k = rowptr[i]; k < rowptr[i + 1]; ++k)
+            if (!spd || cols[k] <= i) {
+                if (cols[k] == i) pos = bs;
+                J[bs++] = cols[k];
+            }
+        orc_scalar a[32 * 32], rhs[32];
+        for (orc_label r = 0; r < bs; ++r) {
+            for (orc_label c = 0; c < bs; ++c)
+                a[r * 32 + c] = spd ? csr_entry(rowptr, cols, vals, J[r], J[c])
+                                    : csr_entry(rowptr, cols, vals, J[c], J[r]);
+            rhs[r] = (r == pos) ? 1.0 : 0.0;
+        }
+        solve_dense(bs, a, 32, rhs);
+        const orc_scalar scale = spd ? sqrt(rhs[pos]) : 1.0;
+        for (orc_label r = 0; r < bs; ++r) {
+            w_cols[w_rowptr[i] + r] = J[r];
+            w_vals[w_rowptr[i] + r] = spd ? rhs[r] / scale : rhs[r];
+        }
+    }
+    return w_rowptr[n];
+}
+
+void orc_csr_transpose(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                       const orc_scalar *vals, orc_label *t_rowptr, orc_label *t_cols,
+                       orc_scalar *t_vals) {
+    const orc_label nnz = rowptr[n];
+    for (orc_label r = 0; r <= n; ++r) t_rowptr[r] = 0;
+    for (orc_label k = 0; k < nnz; ++k) t_rowptr[cols[k] + 1]++;
+    for (orc_label r = 0; r < n; ++r) t_rowptr[r + 1] += t_rowptr[r];
+    orc_label *fill = (orc_label *)xmalloc(sizeof(orc_label) * ((size_t)n + 1));
+    memcpy(fill, t_rowptr, sizeof(orc_label) * ((size_t)n + 1));
+    for (orc_label r = 0; r < n; ++r)
+        for (orc_label k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+            const orc_label e = fill[cols[k]]++;
+            t_cols[e] = r;
+            t_vals[e] = vals[k];
+        }
+    free(fill);
+}
+
 static void precond_apply(orc_label n, const orc_precond *P, const orc_scalar *r, orc_scalar *z) {
+    if (P && P->kind == ORC_PRECOND_ISAI_GENERAL) {
+        orc_spmv(n, P->w_rowptr, P->w_cols, P->w_vals, r, z);
+        return;
+    }
+    if (P && P->kind == ORC_PRECOND_ISAI_SPD) { /* z = W^T (W r) */
+        orc_scalar *t = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)(n ? n : 1));
+        orc_spmv(n, P->w_rowptr, P->w_cols, P->w_vals, r, t);
+        orc_spmv(n, P->wt_rowptr, P->wt_cols, P->wt_vals, t, z);
+        free(t);
+        return;
+    }
     if (!P || P->kind == ORC_PRECOND_NONE) {
         memcpy(z, r, sizeof(orc_scalar) * (size_t)n); /* identity: copy */
     } else if (P->kind == ORC_PRECOND_SCALAR) {
@@ -792,7 +898,7 @@ static void precond_apply(orc_label n, const orc_precond *P, const orc_scalar *r
 orc_label orc_cg(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                  const orc_scalar *inv_diag, const orc_criterion *crit,
                  orc_criterion_state *st) {
-    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0};
+    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return orc_cg_p(A, b, x, &P, crit, st);
 }
 
@@ -843,7 +949,7 @@ orc_label orc_cg_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
 orc_label orc_bicgstab(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                        const orc_scalar *inv_diag, const orc_criterion *crit,
                        orc_criterion_state *st) {
-    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0};
+    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return orc_bicgstab_p(A, b, x, &P, crit, st);
 }
 

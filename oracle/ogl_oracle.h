@@ -235,7 +235,8 @@ void orc_jacobi_generate_blocks(orc_label n, const orc_label *rowptr, const orc_
                                 const orc_scalar *vals, orc_label n_blocks,
                                 const orc_label *block_ptrs, orc_label stride, orc_scalar *blocks);
 
-enum { ORC_PRECOND_NONE = 0, ORC_PRECOND_SCALAR = 1, ORC_PRECOND_BLOCK = 2 };
+enum { ORC_PRECOND_NONE = 0, ORC_PRECOND_SCALAR = 1, ORC_PRECOND_BLOCK = 2,
+       ORC_PRECOND_ISAI_SPD = 3, ORC_PRECOND_ISAI_GENERAL = 4 };
 typedef struct {
     int kind;
     const orc_scalar *inv_diag;   /* SCALAR */
@@ -243,7 +244,25 @@ typedef struct {
     const orc_label *block_ptrs;
     const orc_scalar *blocks;
     orc_label stride;
+    /* ISAI (Preconditioner.H:225-258): approximate inverse W in CSR; SPD: z = W^T (W r) */
+    const orc_label *w_rowptr, *w_cols;
+    const orc_scalar *w_vals;
+    const orc_label *wt_rowptr, *wt_cols;
+    const orc_scalar *wt_vals;
 } orc_precond;
+
+/* ISAI with sparsityPower 1 ([UPSTREAM] gko::preconditioner::Isai).  spd != 0: W has the pattern
+ * of tril(A); row i solves A(J,J) y = e_i and stores y / sqrt(y_i) (FSAI), M^-1 = W^T W.
+ * spd == 0 (GISAI): W has A's pattern; row i solves A(J,J)^T y = e_i, M^-1 = W.
+ * Step 1 (vals == NULL): returns nnz(W) and fills w_rowptr[n+1]; step 2: fills w_cols / w_vals.
+ * Rows with more than 32 pattern entries are not handled (returns -1). */
+orc_label orc_isai_generate(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                            const orc_scalar *vals, int spd, orc_label *w_rowptr, orc_label *w_cols,
+                            orc_scalar *w_vals);
+/* CSR transpose (pattern + values), rows of the result sorted by column */
+void orc_csr_transpose(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                       const orc_scalar *vals, orc_label *t_rowptr, orc_label *t_cols,
+                       orc_scalar *t_vals);
 
 /* ------------------------------------------------------------------ */
 /* Solvers ([UPSTREAM] gko::solver::Cg / Bicgstab, lduLduBase.H:272-276) */

@@ -312,21 +312,47 @@ def jacobi_generate_scalar(rowptr, cols, vals):
 
 class _CPrecond(C.Structure):
     _fields_ = [("kind", C.c_int), ("inv_diag", _SP), ("n_blocks", C.c_int32),
-                ("block_ptrs", _LP), ("blocks", _SP), ("stride", C.c_int32)]
+                ("block_ptrs", _LP), ("blocks", _SP), ("stride", C.c_int32),
+                ("w_rowptr", _LP), ("w_cols", _LP), ("w_vals", _SP),
+                ("wt_rowptr", _LP), ("wt_cols", _LP), ("wt_vals", _SP)]
 
 
 class Precond:
     """Jacobi preconditioner object: scalar (maxBlockSize 1) or block (maxBlockSize k > 1)."""
 
-    def __init__(self, rowptr, cols, vals, max_block_size=1):
+    def __init__(self, rowptr, cols, vals, max_block_size=1, isai=None):
+        """isai: None (Jacobi), "spd" (keyword ISAI) or "general" (keyword GISAI)."""
         rowptr, prp = _l(rowptr)
         cols, pc = _l(cols)
         vals, pv = _s(vals)
         n = rowptr.size - 1
         self.max_block_size = int(max_block_size)
-        if self.max_block_size == 1:
+        if isai is not None:
+            spd = C.c_int(isai == "spd")
+            lib().orc_isai_generate.restype = C.c_int32
+            self.w_rowptr = np.zeros(n + 1, label)
+            nnz = lib().orc_isai_generate(C.c_int32(n), prp, pc, pv, spd,
+                                          self.w_rowptr.ctypes.data_as(_LP), None, None)
+            if nnz < 0:
+                raise ValueError("ISAI row wider than 32")
+            self.w_cols, self.w_vals = np.zeros(max(1, nnz), label), np.zeros(max(1, nnz), scalar)
+            lib().orc_isai_generate(C.c_int32(n), prp, pc, pv, spd, self.w_rowptr.ctypes.data_as(_LP),
+                                    self.w_cols.ctypes.data_as(_LP), self.w_vals.ctypes.data_as(_SP))
+            self.wt_rowptr = np.zeros(n + 1, label)
+            self.wt_cols, self.wt_vals = np.zeros_like(self.w_cols), np.zeros_like(self.w_vals)
+            lib().orc_csr_transpose(C.c_int32(n), self.w_rowptr.ctypes.data_as(_LP),
+                                    self.w_cols.ctypes.data_as(_LP), self.w_vals.ctypes.data_as(_SP),
+                                    self.wt_rowptr.ctypes.data_as(_LP),
+                                    self.wt_cols.ctypes.data_as(_LP),
+                                    self.wt_vals.ctypes.data_as(_SP))
+            self.c = _CPrecond(3 if isai == "spd" else 4, None, 0, None, None, 0,
+                               self.w_rowptr.ctypes.data_as(_LP), self.w_cols.ctypes.data_as(_LP),
+                               self.w_vals.ctypes.data_as(_SP), self.wt_rowptr.ctypes.data_as(_LP),
+                               self.wt_cols.ctypes.data_as(_LP), self.wt_vals.ctypes.data_as(_SP))
+        elif self.max_block_size == 1:
             self.inv_diag = jacobi_generate_scalar(rowptr, cols, vals)
-            self.c = _CPrecond(1, self.inv_diag.ctypes.data_as(_SP), 0, None, None, 0)
+            self.c = _CPrecond(1, self.inv_diag.ctypes.data_as(_SP), 0, None, None, 0, None, None,
+                               None, None, None, None)
         else:
             k = self.max_block_size
             bp = np.zeros(n + 1, label)
@@ -339,7 +365,7 @@ class Precond:
                                              self.block_ptrs.ctypes.data_as(_LP), C.c_int32(k),
                                              self.blocks.ctypes.data_as(_SP))
             self.c = _CPrecond(2, None, nb, self.block_ptrs.ctypes.data_as(_LP),
-                               self.blocks.ctypes.data_as(_SP), k)
+                               self.blocks.ctypes.data_as(_SP), k, None, None, None, None, None, None)
 
 
 class DistMatrix:

@@ -518,3 +518,54 @@ def test_adaptive_min_iter_and_frequency_between_solves(oracle, chunk_rows):
         assert p3.n_norm_evals == p3.n_iterations
     finally:
         reg.close()
+
+
+# ---------------------------------------------------------------------------- ISAI / GISAI
+
+@pytest.mark.parametrize("precond,kind,sym,solver", [
+    (capi.PRECOND_ISAI, "spd", True, "cg"),
+    (capi.PRECOND_GISAI, "general", True, "cg"),
+    (capi.PRECOND_GISAI, "general", False, "bicgstab"),
+    (capi.PRECOND_GISAI, "general", False, "gmres"),
+    (capi.PRECOND_ISAI, "spd", True, "bicgstab"),
+], ids=["ISAI-cg", "GISAI-cg", "GISAI-bicgstab", "GISAI-gmres", "ISAI-bicgstab"])
+def test_isai(reg, oracle, chunk_rows, precond, kind, sym, solver):
+    """Preconditioner.H:225-258 (sparsityPower 1): W generated row by row on the device (dense
+    solves over the row's own pattern), applied as one (GISAI) or two (ISAI: W^T W) SpMVs."""
+    case = synthetic.poisson_block(11, 9, 8, symmetric=sym, periodic_x=True, off_upper=-0.9,
+                                   off_lower=-0.9 if sym else -1.1)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    sk = {"cg": capi.SOLVER_CG, "bicgstab": capi.SOLVER_BICGSTAB, "gmres": capi.SOLVER_GMRES}[solver]
+    cfg = cg_cfg(solver=sk, preconditioner=precond, max_iter=300, tolerance=1e-11, krylov_dim=25)
+    s = reg.solver(f"isai_{kind}_{sym}_{solver}", cfg).set_matrix(case)
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    P = oracle.Precond(rp, cols, vals, isai=kind)
+    kw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
+    with blocked(oracle, chunk_rows):
+        if solver == "cg":
+            ref = oracle.cg(A, b, np.zeros_like(b), P, **kw)
+        elif solver == "bicgstab":
+            ref = oracle.bicgstab(A, b, np.zeros_like(b), P, **kw)
+        else:
+            ref = oracle.gmres(A, b, np.zeros_like(b), P, krylov_dim=25, **kw)
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x)
+    if perf.final_residual < 1e-11:
+        np.testing.assert_allclose(x, xs, atol=1e-7, rtol=0)
+    # the preconditioner pays: fewer checks than the unpreconditioned run of the same solver
+    if solver != "gmres":
+        s0 = reg.solver(f"isai0_{sym}_{solver}", cg_cfg(solver=sk, max_iter=300, tolerance=1e-11))
+        s0.set_matrix(case)
+        s0.upload_solution(None)           # the field may hold an earlier parametrisation's x
+        _, perf0 = s0.solve(b, np.zeros_like(b))
+        assert perf.n_iterations < perf0.n_iterations
+
+
+def test_isai_unsupported_power(reg):
+    case = synthetic.poisson_case(4)
+    s = reg.solver("isai_p2", cg_cfg(preconditioner=capi.PRECOND_ISAI, sparsity_power=2)).set_matrix(case)
+    with pytest.raises(capi.OglError) as e:
+        s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
+    assert e.value.status == capi.ERR_UNSUPPORTED
