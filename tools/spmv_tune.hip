@@ -292,6 +292,99 @@ static void run_abl(const char *name, const Csr &A, const int *d_rp, const int *
     printf("%-60s b2b %7.1f us\n", name, 1e3 * ms / reps);
 }
 
+
+// ---- persistent variant: NB blocks, block b owns chunks vmap(b), vmap(b)+NB, ... (candidate for
+// the product: per-block ordered accumulation of the chunk partials) ----
+template <int NB>
+__global__ __launch_bounds__(BLOCK) void k_spmv_persist(int n_rows, int n_chunks,
+                                                        const int *__restrict__ row_ptrs,
+                                                        const int *__restrict__ cols,
+                                                        const double *__restrict__ vals,
+                                                        const double *__restrict__ x,
+                                                        double *__restrict__ y,
+                                                        double *__restrict__ acc_out)
+{
+    constexpr int CHUNK_ROWS = 512, TILE = 4096, RPT = 2, STEPS = 4;
+    __shared__ __attribute__((aligned(16))) double prod[TILE];
+    __shared__ double slot[N_WAVES];
+    const int slot_i = blockIdx.x / 8, xcd = blockIdx.x % 8;
+    const int v = (slot_i / 4) * 32 + xcd * 4 + slot_i % 4;
+    const int tid = threadIdx.x;
+    double block_acc = 0.0;
+    for (int chunk = v; chunk < n_chunks; chunk += NB) {
+        const int r0 = chunk * CHUNK_ROWS;
+        const int r1 = min(r0 + CHUNK_ROWS, n_rows);
+        const int nz0 = row_ptrs[r0], nz1 = row_ptrs[r1];
+        const int row = r0 + tid * RPT;
+        int rs[RPT + 1];
+        for (int j = 0; j <= RPT; ++j) rs[j] = row_ptrs[min(row + j, r1)];
+        double acc[RPT] = {0.0, 0.0};
+        for (int t0 = nz0 & ~3; t0 < nz1; t0 += TILE) {
+            d2 va[STEPS], vb[STEPS];
+            i4 cc[STEPS];
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) {
+                const int e = t0 + (g * BLOCK + tid) * 4;
+                const int ec = e < nz1 ? e : t0;
+                va[g] = *reinterpret_cast<const d2 *>(vals + ec);
+                vb[g] = *reinterpret_cast<const d2 *>(vals + ec + 2);
+                cc[g] = *reinterpret_cast<const i4 *>(cols + ec);
+            }
+#pragma unroll
+            for (int g = 0; g < STEPS; ++g) {
+                d2 p0, p1;
+                p0.x = va[g].x * x[cc[g].x]; p0.y = va[g].y * x[cc[g].y];
+                p1.x = vb[g].x * x[cc[g].z]; p1.y = vb[g].y * x[cc[g].w];
+                const int le = (g * BLOCK + tid) * 4;
+                *reinterpret_cast<d2 *>(prod + le) = p0;
+                *reinterpret_cast<d2 *>(prod + le + 2) = p1;
+            }
+            __syncthreads();
+            const int t1 = t0 + TILE;
+            for (int j = 0; j < RPT; ++j) {
+                const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
+                for (int k = kb; k < ke; ++k) acc[j] += prod[k - t0];
+            }
+            __syncthreads();
+        }
+        double d = 0.0;
+        for (int j = 0; j < RPT; ++j)
+            if (row + j < r1) {
+                y[row + j] = acc[j];
+                d += x[row + j] * acc[j];
+            }
+        block_acc += block_sum(d, slot);
+    }
+    if (tid == 0) acc_out[v] = block_acc;
+}
+
+template <int NB>
+static void run_persist(const char *name, const Csr &A, const int *d_rp, const int *d_cols, const double *d_vals,
+                        double *d_x0, double *d_x1, double *d_y, double *d_part, const std::vector<double> &yref, int reps)
+{
+    const int nc = (A.n + 511) / 512;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto launch = [&](const double *x) {
+        hipLaunchKernelGGL((k_spmv_persist<NB>), dim3(NB), dim3(BLOCK), 0, 0, A.n, nc, d_rp, d_cols, d_vals, x, d_y, d_part);
+    };
+    launch(d_x0);
+    CK(hipDeviceSynchronize());
+    std::vector<double> y(A.n);
+    CK(hipMemcpy(y.data(), d_y, sizeof(double) * A.n, hipMemcpyDeviceToHost));
+    long bad = 0;
+    for (int i = 0; i < A.n; ++i) bad += (y[i] != yref[i]);
+    for (int i = 0; i < 3; ++i) launch(i & 1 ? d_x1 : d_x0);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch(i & 1 ? d_x1 : d_x0);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-60s b2b %7.1f us  mismatches %ld\n", name, 1e3 * ms / reps, bad);
+}
+
 static Csr poisson(int n)
 {
     Csr A;
@@ -460,6 +553,9 @@ int main(int argc, char **argv)
 #define RUNB(CR, TILE, LAY, NT, BAND) \
     run<CR, TILE, LAY, NT, 100, 1>("chunk" #CR " tile" #TILE " lay" #LAY " nt" #NT " band-aware " #BAND, A, \
                                       d_rp, d_cols, d_vals, d_x0, d_x1, d_y, d_part, yref, reps, BAND)
+    run_persist<1024>("persistent 1024 blocks", A, d_rp, d_cols, d_vals, d_x0, d_x1, d_y, d_part, yref, reps);
+    run_persist<1280>("persistent 1280 blocks", A, d_rp, d_cols, d_vals, d_x0, d_x1, d_y, d_part, yref, reps);
+    run_persist<2048>("persistent 2048 blocks", A, d_rp, d_cols, d_vals, d_x0, d_x1, d_y, d_part, yref, reps);
     run_abl<0>("abl0: stream + LDS row phase, no gather", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
     run_abl<1>("abl1: stream + gather, no LDS/row phase", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
     run_abl<2>("abl2: stream only", A, d_rp, d_cols, d_vals, d_x0, d_y, reps);
