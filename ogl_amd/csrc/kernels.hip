@@ -54,7 +54,7 @@ __device__ __forceinline__ double block_sum(double v, double *slot)
 // ordered, so a 10M-row vector (19,683 partials) costs about one memory latency.
 constexpr int FIN_BLOCK = 1024;
 constexpr int FIN_WAVES = FIN_BLOCK / WAVE;
-constexpr int FIN_BATCH = 8;
+constexpr int FIN_BATCH = 8;  // (20 = one batch for 10M rows measured no faster)
 
 __device__ __forceinline__ double fin_block_sum(double v, double *slot)
 {
@@ -475,11 +475,14 @@ __global__ __launch_bounds__(BLOCK) void k_partials(int n, int n_chunks,
                                                     const double *__restrict__ a,
                                                     const double *__restrict__ b,
                                                     double *__restrict__ part,
-                                                    const DevScalars *gate)
+                                                    const DevScalars *gate,
+                                                    const int *__restrict__ chunk_list)
 {
     __shared__ double slot[N_WAVES];
     if (gate && gate->stop) return;
-    const int chunk = blockIdx.x;
+    // chunk_list: only these chunks (the ones holding boundary rows, whose fused partials of the
+    // local SpMV are stale once the non-local part has been added)
+    const int chunk = chunk_list ? chunk_list[blockIdx.x] : (int)blockIdx.x;
     const RowPair r = my_rows(chunk, n);
     const double2 va = ld2(a, r);
     double d = 0.0;
@@ -1257,7 +1260,7 @@ void launch_partials_sum(hipStream_t st, int32_t n, const double *a, double *par
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
     hipLaunchKernelGGL((k_partials<P_SUM>), dim3(nc), dim3(BLOCK), 0, st, n, nc, a, nullptr, part,
-                       nullptr);
+                       nullptr, nullptr);
 }
 
 void launch_partials_dot(hipStream_t st, int32_t n, const double *a, const double *b, double *part,
@@ -1265,7 +1268,17 @@ void launch_partials_dot(hipStream_t st, int32_t n, const double *a, const doubl
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL((k_partials<P_DOT>), dim3(nc), dim3(BLOCK), 0, st, n, nc, a, b, part, gate);
+    hipLaunchKernelGGL((k_partials<P_DOT>), dim3(nc), dim3(BLOCK), 0, st, n, nc, a, b, part, gate,
+                       nullptr);
+}
+
+void launch_partials_dot_chunks(hipStream_t st, int32_t n, const double *a, const double *b,
+                                double *part, const DevScalars *gate, const int32_t *chunk_list,
+                                int32_t count)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL((k_partials<P_DOT>), dim3(count), dim3(BLOCK), 0, st, n, (int)n_chunks(n), a, b,
+                       part, gate, chunk_list);
 }
 
 void launch_partials_norm1(hipStream_t st, int32_t n, const double *a, double *part)
@@ -1273,7 +1286,7 @@ void launch_partials_norm1(hipStream_t st, int32_t n, const double *a, double *p
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
     hipLaunchKernelGGL((k_partials<P_NORM1>), dim3(nc), dim3(BLOCK), 0, st, n, nc, a, nullptr,
-                       part, nullptr);
+                       part, nullptr, nullptr);
 }
 
 void launch_partials_normfactor(hipStream_t st, int32_t n, const double *b, const double *w,

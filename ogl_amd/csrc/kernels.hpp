@@ -128,6 +128,10 @@ void launch_fill_xbar(hipStream_t st, int32_t n, double *v, const DevScalars *s)
 void launch_partials_sum(hipStream_t st, int32_t n, const double *a, double *part);
 void launch_partials_dot(hipStream_t st, int32_t n, const double *a, const double *b, double *part,
                          const DevScalars *gate);
+// same for the listed chunks only (multi-rank: the chunks that hold boundary rows)
+void launch_partials_dot_chunks(hipStream_t st, int32_t n, const double *a, const double *b,
+                                double *part, const DevScalars *gate, const int32_t *chunk_list,
+                                int32_t count);
 void launch_partials_norm1(hipStream_t st, int32_t n, const double *a, double *part);
 // part[c] = sum over chunk of |(b - w) - r| + |b - w|   (StoppingCriterion.C:53-61)
 void launch_partials_normfactor(hipStream_t st, int32_t n, const double *b, const double *w,

@@ -265,6 +265,15 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         }
         boundary_ptrs.push_back(pat.non_local_nnz);
         const size_t hn = (size_t)pat.non_local_nnz;
+        {  // chunks whose fused dot partials must be redone after the non-local part was added
+            std::vector<int32_t> bc;
+            for (int32_t r : boundary_rows)
+                if (bc.empty() || bc.back() != r / CHUNK_ROWS) bc.push_back(r / CHUNK_ROWS);
+            n_boundary_chunks = (int32_t)bc.size();
+            OGL_TRY(d_boundary_chunks.alloc(bc.size(), st));
+            if (!bc.empty())
+                OGL_TRY(reg->stager.h2d(d_boundary_chunks.p, bc.data(), bc.size() * sizeof(int32_t), st));
+        }
         OGL_TRY(d_boundary_rows.alloc(boundary_rows.size(), st));
         OGL_TRY(d_boundary_ptrs.alloc(boundary_ptrs.size(), st));
         OGL_TRY(d_nl_cols.alloc(hn, st));
@@ -538,17 +547,22 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
         OGL_TRY(reg->comm->exchange(d_send.p, d_recv.p, neighbours, counts, reg->comm_stream));
         OGL_HIP_CHECK(hipEventRecord(reg->ev_received, reg->comm_stream));
     }
-    // with a halo the fused partials would miss the non-local part of the boundary rows: the dots
-    // are taken in a separate pass after "y += A_non_local recv" (+16 N bytes each)
+    // The fused dot partials of the local kernel are final for every chunk without boundary rows;
+    // the few chunks that hold boundary rows are redone after "y += A_non_local recv" (same
+    // per-chunk tree, so the sums are bit-identical to a dot over the finished y).
     if (cfg.matrix_format == OGL_FORMAT_ELL && ell_ready && !ell_values_stale)
-        launch_spmv_ell(st, ell(), mode, x, b, y, has_halo ? SpmvDots{} : dots, gate);
+        launch_spmv_ell(st, ell(), mode, x, b, y, dots, gate);
     else
-        launch_spmv(st, csr(), mode, x, b, y, has_halo ? SpmvDots{} : dots, gate);
+        launch_spmv(st, csr(), mode, x, b, y, dots, gate);
     if (has_halo) {
         OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
         launch_spmv_non_local(st, halo(), mode, d_recv.p, y, gate);
-        if (dots.part) launch_partials_dot(st, pat.n_rows, dots.with, y, dots.part, gate);
-        if (dots.part_yy) launch_partials_dot(st, pat.n_rows, y, y, dots.part_yy, gate);
+        if (dots.part)
+            launch_partials_dot_chunks(st, pat.n_rows, dots.with, y, dots.part, gate,
+                                       d_boundary_chunks.p, n_boundary_chunks);
+        if (dots.part_yy)
+            launch_partials_dot_chunks(st, pat.n_rows, y, y, dots.part_yy, gate,
+                                       d_boundary_chunks.p, n_boundary_chunks);
     }
     return OGL_OK;
 }

@@ -135,6 +135,8 @@ struct ogl_solver {
     // halo part
     std::vector<int32_t> boundary_rows, boundary_ptrs;
     ogl::DevBuf<int32_t> d_boundary_rows, d_boundary_ptrs, d_nl_cols, d_send_idxs;
+    ogl::DevBuf<int32_t> d_boundary_chunks;  // chunks (of CHUNK_ROWS rows) that hold boundary rows
+    int32_t n_boundary_chunks = 0;
     ogl::DevBuf<double> d_nl_vals, d_send, d_recv;
     std::vector<double> h_nl_vals;
     std::vector<int> neighbours, counts;
