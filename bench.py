@@ -43,7 +43,12 @@ def parse():
     ap.add_argument("--edge", "--n", dest="n", type=int, default=216,
                     help="box edge per GPU (216 = configs[1])")
     ap.add_argument("--iters", type=int, default=100, help="CG iterations per step")
-    ap.add_argument("--precond", default="BJ", choices=["BJ", "none"])
+    ap.add_argument("--precond", default="BJ", choices=["BJ", "none", "ISAI", "GISAI"])
+    ap.add_argument("--solver", default="GKOCG", choices=["GKOCG", "GKOBiCGStab", "GKOGMRES"],
+                    help="GKOCG = the headline; the others measure configs[2]/[4]-style runs")
+    ap.add_argument("--block-size", type=int, default=1, help="BJ maxBlockSize")
+    ap.add_argument("--krylov-dim", type=int, default=30, help="GKOGMRES restart length")
+    ap.add_argument("--asym", action="store_true", help="non-symmetric coefficients (momentum-like)")
     ap.add_argument("--format", default="Csr", choices=["Csr", "Ell"],
                     help="matrixFormat (Csr = the headline; Ell = configs[4]'s comparison)")
     ap.add_argument("--cpu-iters", type=int, default=-1,
@@ -103,7 +108,11 @@ def main():
             dist.barrier()
 
     n = args.n
-    case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
+    if args.asym:
+        case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank, symmetric=False,
+                                       off_upper=-0.9, off_lower=-1.1)
+    else:
+        case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
     N, nnz = case.n_cells, case.nnz
     # any smooth right-hand side will do for a fixed-iteration run; x0 = 0
     b = synthetic.x_star(case.global_index, case.global_n) + 0.5
@@ -155,8 +164,12 @@ def main():
             reg.close()
             reg = capi.Registry(device_id=local_rank)
             reg.set_host_comm(rank, world, _allreduce, _exchange)
-    precond = capi.PRECOND_BJ if args.precond == "BJ" else capi.PRECOND_NONE
-    cfg = capi.default_config(solver=capi.SOLVER_CG, preconditioner=precond, max_block_size=1,
+    precond = {"BJ": capi.PRECOND_BJ, "none": capi.PRECOND_NONE, "ISAI": capi.PRECOND_ISAI,
+               "GISAI": capi.PRECOND_GISAI}[args.precond]
+    solver_kind = {"GKOCG": capi.SOLVER_CG, "GKOBiCGStab": capi.SOLVER_BICGSTAB,
+                   "GKOGMRES": capi.SOLVER_GMRES}[args.solver]
+    cfg = capi.default_config(solver=solver_kind, preconditioner=precond,
+                              max_block_size=args.block_size, krylov_dim=args.krylov_dim,
                               tolerance=0.0, rel_tol=0.0, max_iter=args.iters, min_iter=0,
                               eval_frequency=1, adapt_min_iter=0,
                               matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
@@ -187,8 +200,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    iters = sum(p.n_iterations - 1 for p in perfs)        # CG steps (checks - 1)
-    assert all(p.n_iterations == args.iters + 1 for p in perfs), [p.n_iterations for p in perfs]
+    # turns actually done: CG / GMRES report checks (= turns + 1), BiCGStab reports checks / 2
+    bicg = args.solver == "GKOBiCGStab"
+    iters = sum(p.n_iterations - (0 if bicg else 1) for p in perfs)
+    expect = args.iters if bicg else args.iters + 1
+    assert all(p.n_iterations == expect for p in perfs), [p.n_iterations for p in perfs]
     value = world * iters / elapsed
 
     # ---- roofline of the dominant kernel: the in-loop CSR SpMV -------------------------------
@@ -206,6 +222,8 @@ def main():
     traffic, traffic_src = (pmc_traffic("k_spmv_stream<0, 1>") if (n == 216 and args.format == "Csr")
                             else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
+    if args.solver != "GKOCG" or precond not in (capi.PRECOND_BJ, capi.PRECOND_NONE) or args.block_size != 1:
+        b_cg = None              # the per-iteration byte model of SURVEY.md §8d is for CG only
     # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
     t0 = time.perf_counter()
     s.set_matrix(case)
@@ -219,8 +237,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix, GKOCG + "
-                        f"{'BJ(maxBlockSize 1)' if precond else 'no preconditioner'}, "
+            "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix"
+                        f"{' (non-symmetric)' if args.asym else ''}, {args.solver}"
+                        f"{'(' + str(args.krylov_dim) + ')' if args.solver == 'GKOGMRES' else ''} + "
+                        f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
                         "fp64/int32 persistent device CSR (BASELINE.json configs[1])",
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "parallelism": f"rows sharded into {world} z-slab(s), {transport}"
@@ -237,8 +257,8 @@ def main():
         },
         "cg_iteration": {
             "algorithmic_bytes": b_cg, "ms": 1e3 * elapsed / max(1, iters),
-            "achieved_GBps": b_cg * iters / elapsed / 1e9,
-            "frac_of_peak": b_cg * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
+            "achieved_GBps": None if b_cg is None else b_cg * iters / elapsed / 1e9,
+            "frac_of_peak": None if b_cg is None else b_cg * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
         },
         "boundary": {
             "first_set_matrix_s": t_first_matrix, "refresh_set_matrix_s": t_refresh_matrix,
@@ -248,7 +268,9 @@ def main():
     }
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle on the same matrix ----------------------
-    if rank == 0 and world == 1 and args.cpu_iters != 0:
+    headline = (args.solver == "GKOCG" and args.precond in ("BJ", "none") and args.block_size == 1
+                and not args.asym)
+    if rank == 0 and world == 1 and args.cpu_iters != 0 and headline:
         from oracle import oracle as orc
         orc.build()
         t0 = time.perf_counter()

@@ -284,57 +284,62 @@ __global__ __launch_bounds__(BLOCK) void k_jacobi_generate(int n_rows,
 // once per preconditioner generation).  Same operation order as oracle/ogl_oracle.c invert_block:
 // Gauss-Jordan, partial (row) pivoting, pivot row scaled first, then the other rows eliminated,
 // finally the row swaps undone as a column permutation.
-__global__ __launch_bounds__(BLOCK) void k_bj_generate(int n_blocks,
-                                                       const int *__restrict__ block_ptrs,
-                                                       const int *__restrict__ row_ptrs,
-                                                       const int *__restrict__ cols,
-                                                       const double *__restrict__ vals,
-                                                       double *__restrict__ blocks, int ld)
+// The block lives in a per-thread array of the smallest power-of-two leading dimension LD that
+// holds maxBlockSize (scratch of 8*LD*LD bytes per thread: 128 B for LD = 4), not in global memory,
+// and is written out once.
+template <int LD>
+__global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__restrict__ block_ptrs,
+                                                    const int *__restrict__ row_ptrs,
+                                                    const int *__restrict__ cols,
+                                                    const double *__restrict__ vals,
+                                                    double *__restrict__ blocks, int ld)
 {
-    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_blocks) return;
     const int r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
-    double *a = blocks + (size_t)b * ld * ld;
-    for (int i = 0; i < ld * ld; ++i) a[i] = 0.0;
+    double a[LD * LD];
+    for (int i = 0; i < LD * LD; ++i) a[i] = 0.0;
     for (int i = 0; i < bs; ++i)
         for (int k = row_ptrs[r0 + i]; k < row_ptrs[r0 + i + 1]; ++k) {
             const int c = cols[k] - r0;
-            if (c >= 0 && c < bs) a[i * ld + c] = vals[k];
+            if (c >= 0 && c < bs) a[i * LD + c] = vals[k];
         }
-    int perm[MAX_JACOBI_BLOCK];
+    int perm[LD];
     for (int k = 0; k < bs; ++k) perm[k] = k;
     for (int k = 0; k < bs; ++k) {
         int piv = k;
-        double best = fabs(a[k * ld + k]);
+        double best = fabs(a[k * LD + k]);
         for (int i = k + 1; i < bs; ++i)
-            if (fabs(a[i * ld + k]) > best) {
-                best = fabs(a[i * ld + k]);
+            if (fabs(a[i * LD + k]) > best) {
+                best = fabs(a[i * LD + k]);
                 piv = i;
             }
         if (piv != k) {
             for (int j = 0; j < bs; ++j) {
-                const double t = a[k * ld + j];
-                a[k * ld + j] = a[piv * ld + j];
-                a[piv * ld + j] = t;
+                const double t = a[k * LD + j];
+                a[k * LD + j] = a[piv * LD + j];
+                a[piv * LD + j] = t;
             }
             const int t = perm[k];
             perm[k] = perm[piv];
             perm[piv] = t;
         }
-        const double d = a[k * ld + k];
-        a[k * ld + k] = 1.0;
-        for (int j = 0; j < bs; ++j) a[k * ld + j] /= d;
+        const double d = a[k * LD + k];
+        a[k * LD + k] = 1.0;
+        for (int j = 0; j < bs; ++j) a[k * LD + j] /= d;
         for (int i = 0; i < bs; ++i) {
             if (i == k) continue;
-            const double f = a[i * ld + k];
-            a[i * ld + k] = 0.0;
-            for (int j = 0; j < bs; ++j) a[i * ld + j] -= f * a[k * ld + j];
+            const double f = a[i * LD + k];
+            a[i * LD + k] = 0.0;
+            for (int j = 0; j < bs; ++j) a[i * LD + j] -= f * a[k * LD + j];
         }
     }
-    double row[MAX_JACOBI_BLOCK];
+    double *out = blocks + (size_t)b * ld * ld;
+    for (int i = 0; i < ld * ld; ++i) out[i] = 0.0;
+    double row[LD];
     for (int i = 0; i < bs; ++i) {
-        for (int j = 0; j < bs; ++j) row[perm[j]] = a[i * ld + j];
-        for (int j = 0; j < bs; ++j) a[i * ld + j] = row[j];
+        for (int j = 0; j < bs; ++j) row[perm[j]] = a[i * LD + j];
+        for (int j = 0; j < bs; ++j) out[i * ld + j] = row[j];
     }
 }
 
@@ -365,6 +370,7 @@ __device__ double csr_entry(const int *__restrict__ row_ptrs, const int *__restr
     return 0.0;
 }
 
+template <int LD>
 __global__ __launch_bounds__(64) void k_isai_generate(int n_rows, const int *__restrict__ row_ptrs,
                                                       const int *__restrict__ cols,
                                                       const double *__restrict__ vals, int spd,
@@ -374,7 +380,6 @@ __global__ __launch_bounds__(64) void k_isai_generate(int n_rows, const int *__r
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_rows) return;
-    constexpr int LD = MAX_ISAI_ROW;
     const int w0 = w_row_ptrs[i], bs = w_row_ptrs[i + 1] - w0;
     int J[LD], pos = -1;
     for (int r = 0; r < bs; ++r) {
@@ -1223,8 +1228,21 @@ void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag)
 void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J)
 {
     if (J.n_blocks == 0) return;
-    hipLaunchKernelGGL(k_bj_generate, dim3(blocks_for(J.n_blocks)), dim3(BLOCK), 0, st, J.n_blocks,
-                       J.block_ptrs, A.row_ptrs, A.cols, A.vals, J.blocks, J.stride);
+    const dim3 grid((J.n_blocks + 63) / 64), block(64);
+#define OGL_BJ(LD)                                                                              \
+    hipLaunchKernelGGL((k_bj_generate<LD>), grid, block, 0, st, J.n_blocks, J.block_ptrs,        \
+                       A.row_ptrs, A.cols, A.vals, J.blocks, J.stride)
+    if (J.stride <= 2)
+        OGL_BJ(2);
+    else if (J.stride <= 4)
+        OGL_BJ(4);
+    else if (J.stride <= 8)
+        OGL_BJ(8);
+    else if (J.stride <= 16)
+        OGL_BJ(16);
+    else
+        OGL_BJ(32);
+#undef OGL_BJ
 }
 
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
@@ -1236,11 +1254,20 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
 }
 
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
-                          const int32_t *w_cols, double *w_vals)
+                          const int32_t *w_cols, double *w_vals, int32_t max_row)
 {
     if (A.n_rows == 0) return;
-    hipLaunchKernelGGL(k_isai_generate, dim3((A.n_rows + 63) / 64), dim3(64), 0, st, A.n_rows,
-                       A.row_ptrs, A.cols, A.vals, spd, w_row_ptrs, w_cols, w_vals);
+    const dim3 grid((A.n_rows + 63) / 64), block(64);
+#define OGL_ISAI(LD)                                                                             \
+    hipLaunchKernelGGL((k_isai_generate<LD>), grid, block, 0, st, A.n_rows, A.row_ptrs, A.cols,   \
+                       A.vals, spd, w_row_ptrs, w_cols, w_vals)
+    if (max_row <= 8)
+        OGL_ISAI(8);
+    else if (max_row <= 16)
+        OGL_ISAI(16);
+    else
+        OGL_ISAI(32);
+#undef OGL_ISAI
 }
 
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor)

@@ -116,8 +116,9 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
 // elimination with partial pivoting.  spd: pattern tril(A), A(J,J) y = e_i, W(i,J) = y / sqrt(y_i);
 // general: pattern of A, A(J,J)^T y = e_i, W(i,J) = y.
 constexpr int MAX_ISAI_ROW = 32;
+// max_row = longest row of W (selects the per-thread scratch size: 8, 16 or 32)
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
-                          const int32_t *w_cols, double *w_vals);
+                          const int32_t *w_cols, double *w_vals, int32_t max_row);
 
 // b *= scaling (lduLduBase.H:244-252)
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor);

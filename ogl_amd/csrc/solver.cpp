@@ -240,6 +240,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         OGL_TRY(build_host_pattern(ldu, np));
         pat = std::move(np);
         have_pattern = true;
+        static uint64_t pattern_counter = 0;
+        pat_id = ++pattern_counter;
         matrix_set = false;
         ell_ready = false;
         x_resident = b_resident = false;
@@ -388,44 +390,55 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         // values on the device (one dense solve per row).
         const bool spd = cfg.preconditioner == OGL_PRECOND_ISAI;
         const int32_t N = pat.n_rows;
-        std::vector<int32_t> wrp((size_t)N + 1, 0), wc;
-        wc.reserve((size_t)pat.local_nnz);
-        for (int32_t r = 0; r < N; ++r) {
-            for (int32_t k = pat.row_ptrs[r]; k < pat.row_ptrs[r + 1]; ++k)
-                if (!spd || pat.cols[k] <= r) wc.push_back(pat.cols[k]);
-            wrp[r + 1] = (int32_t)wc.size();
-            if (wrp[r + 1] - wrp[r] > MAX_ISAI_ROW)
-                return fail(OGL_ERR_UNSUPPORTED, "ISAI: row %d has more than %d pattern entries", r,
-                            MAX_ISAI_ROW);
+        const int kind = spd ? 3 : 4;
+        if (!P.has_structure(pat_id, kind, 0)) {
+            P.struct_pat_id = 0;
+            std::vector<int32_t> wrp((size_t)N + 1, 0), wc;
+            wc.reserve((size_t)pat.local_nnz);
+            int32_t max_row = 0;
+            for (int32_t r = 0; r < N; ++r) {
+                for (int32_t k = pat.row_ptrs[r]; k < pat.row_ptrs[r + 1]; ++k)
+                    if (!spd || pat.cols[k] <= r) wc.push_back(pat.cols[k]);
+                wrp[r + 1] = (int32_t)wc.size();
+                max_row = std::max(max_row, wrp[r + 1] - wrp[r]);
+                if (wrp[r + 1] - wrp[r] > MAX_ISAI_ROW)
+                    return fail(OGL_ERR_UNSUPPORTED, "ISAI: row %d has more than %d pattern entries",
+                                r, MAX_ISAI_ROW);
+            }
+            const size_t wn = wc.size();
+            OGL_TRY(P.w_row_ptrs.alloc((size_t)N + 1, st));
+            OGL_TRY(P.w_cols.alloc(wn + NNZ_PAD, st));
+            OGL_TRY(P.w_vals.alloc(wn + NNZ_PAD, st));
+            OGL_TRY(reg->stager.h2d(P.w_row_ptrs.p, wrp.data(), wrp.size() * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(P.w_cols.p, wc.data(), wn * sizeof(int32_t), st));
+            if (spd) {  // W^T: counting transpose keeps every row sorted by column
+                std::vector<int32_t> trp((size_t)N + 1, 0), tc(wn), tmap(wn);
+                for (size_t k = 0; k < wn; ++k) ++trp[wc[k] + 1];
+                for (int32_t r = 0; r < N; ++r) trp[r + 1] += trp[r];
+                std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
+                for (int32_t r = 0; r < N; ++r)
+                    for (int32_t k = wrp[r]; k < wrp[r + 1]; ++k) {
+                        const int32_t e = fill[wc[k]]++;
+                        tc[e] = r;
+                        tmap[e] = k;
+                    }
+                OGL_TRY(P.wt_row_ptrs.alloc((size_t)N + 1, st));
+                OGL_TRY(P.wt_cols.alloc(wn + NNZ_PAD, st));
+                OGL_TRY(P.wt_map.alloc(wn + NNZ_PAD, st));
+                OGL_TRY(P.wt_vals.alloc(wn + NNZ_PAD, st));
+                OGL_TRY(reg->stager.h2d(P.wt_row_ptrs.p, trp.data(), trp.size() * sizeof(int32_t), st));
+                OGL_TRY(reg->stager.h2d(P.wt_cols.p, tc.data(), wn * sizeof(int32_t), st));
+                OGL_TRY(reg->stager.h2d(P.wt_map.p, tmap.data(), wn * sizeof(int32_t), st));
+            }
+            P.w_nnz = (int32_t)wn;
+            P.w_max_row = max_row;
+            P.struct_pat_id = pat_id;
+            P.struct_kind = kind;
+            P.struct_stride = 0;
         }
-        const size_t wn = wc.size();
-        OGL_TRY(P.w_row_ptrs.alloc((size_t)N + 1, st));
-        OGL_TRY(P.w_cols.alloc(wn + NNZ_PAD, st));
-        OGL_TRY(P.w_vals.alloc(wn + NNZ_PAD, st));
-        OGL_TRY(reg->stager.h2d(P.w_row_ptrs.p, wrp.data(), wrp.size() * sizeof(int32_t), st));
-        OGL_TRY(reg->stager.h2d(P.w_cols.p, wc.data(), wn * sizeof(int32_t), st));
-        launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p);
-        if (spd) {  // W^T: counting transpose keeps every row sorted by column
-            std::vector<int32_t> trp((size_t)N + 1, 0), tc(wn), tmap(wn);
-            for (size_t k = 0; k < wn; ++k) ++trp[wc[k] + 1];
-            for (int32_t r = 0; r < N; ++r) trp[r + 1] += trp[r];
-            std::vector<int32_t> fill(trp.begin(), trp.end() - 1);
-            for (int32_t r = 0; r < N; ++r)
-                for (int32_t k = wrp[r]; k < wrp[r + 1]; ++k) {
-                    const int32_t e = fill[wc[k]]++;
-                    tc[e] = r;
-                    tmap[e] = k;
-                }
-            OGL_TRY(P.wt_row_ptrs.alloc((size_t)N + 1, st));
-            OGL_TRY(P.wt_cols.alloc(wn + NNZ_PAD, st));
-            OGL_TRY(P.wt_map.alloc(wn + NNZ_PAD, st));
-            OGL_TRY(P.wt_vals.alloc(wn + NNZ_PAD, st));
-            OGL_TRY(reg->stager.h2d(P.wt_row_ptrs.p, trp.data(), trp.size() * sizeof(int32_t), st));
-            OGL_TRY(reg->stager.h2d(P.wt_cols.p, tc.data(), wn * sizeof(int32_t), st));
-            OGL_TRY(reg->stager.h2d(P.wt_map.p, tmap.data(), wn * sizeof(int32_t), st));
-            launch_gather_coeffs(st, (int32_t)wn, P.wt_map.p, P.w_vals.p, P.wt_vals.p);
-        }
-        P.w_nnz = (int32_t)wn;
+        launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p,
+                             P.w_max_row);
+        if (spd) launch_gather_coeffs(st, P.w_nnz, P.wt_map.p, P.w_vals.p, P.wt_vals.p);
         P.kind = spd ? 3 : 4;
         P.stride = 0;
     } else if (cfg.max_block_size == 1) {  // scalar Jacobi: 1 / diag
@@ -435,15 +448,22 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         P.stride = 0;
     } else {
         // Jacobi factory with max_block_size = maxBlockSize, skip_sorting (Preconditioner.H:100-104)
-        std::vector<int32_t> ptrs, row_block;
-        find_jacobi_blocks(pat, cfg.max_block_size, ptrs, row_block);
-        P.n_blocks = (int32_t)ptrs.size() - 1;
         const size_t k = (size_t)cfg.max_block_size;
-        OGL_TRY(P.block_ptrs.alloc(ptrs.size(), st));
-        OGL_TRY(P.row_block.alloc(std::max<size_t>(1, row_block.size()), st));
-        OGL_TRY(P.values.alloc(std::max<size_t>(1, (size_t)P.n_blocks * k * k), st));
-        OGL_TRY(reg->stager.h2d(P.block_ptrs.p, ptrs.data(), ptrs.size() * sizeof(int32_t), st));
-        OGL_TRY(reg->stager.h2d(P.row_block.p, row_block.data(), row_block.size() * sizeof(int32_t), st));
+        if (!P.has_structure(pat_id, 2, cfg.max_block_size)) {
+            P.struct_pat_id = 0;
+            std::vector<int32_t> ptrs, row_block;
+            find_jacobi_blocks(pat, cfg.max_block_size, ptrs, row_block);
+            P.n_blocks = (int32_t)ptrs.size() - 1;
+            OGL_TRY(P.block_ptrs.alloc(ptrs.size(), st));
+            OGL_TRY(P.row_block.alloc(std::max<size_t>(1, row_block.size()), st));
+            OGL_TRY(P.values.alloc(std::max<size_t>(1, (size_t)P.n_blocks * k * k), st));
+            OGL_TRY(reg->stager.h2d(P.block_ptrs.p, ptrs.data(), ptrs.size() * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(P.row_block.p, row_block.data(),
+                                    row_block.size() * sizeof(int32_t), st));
+            P.struct_pat_id = pat_id;
+            P.struct_kind = 2;
+            P.struct_stride = cfg.max_block_size;
+        }
         DevBlockJacobi J;
         J.n_rows = pat.n_rows;
         J.n_blocks = P.n_blocks;

@@ -87,7 +87,15 @@ struct PrecondData {
     // entry of W^T
     DevBuf<int32_t> w_row_ptrs, w_cols, wt_row_ptrs, wt_cols, wt_map;
     DevBuf<double> w_vals, wt_vals;
-    int32_t w_nnz = 0;
+    int32_t w_nnz = 0, w_max_row = 0;
+    // the pattern-only part (block pointers / W and W^T patterns) is kept for as long as it was
+    // derived from the same sparsity pattern: only the values are regenerated per solve
+    uint64_t struct_pat_id = 0;
+    int struct_kind = 0, struct_stride = 0;
+    bool has_structure(uint64_t id, int k, int st) const
+    {
+        return id != 0 && struct_pat_id == id && struct_kind == k && struct_stride == st;
+    }
     bool matches(int k, size_t n, int st) const { return kind == k && n_rows == n && stride == st; }
 };
 
@@ -120,6 +128,7 @@ struct ogl_solver {
     // ---- HostMatrixWrapper state ----
     ogl::HostPattern pat;
     bool have_pattern = false;
+    uint64_t pat_id = 0;  // unique per built sparsity pattern (keys the preconditioner structure)
     bool matrix_set = false;
     ogl::DevBuf<int32_t> d_row_ptrs, d_cols, d_ldu_mapping;  // "<field>_local_*"
     ogl::DevBuf<double> d_vals;                              // "<field>_matrix" values
