@@ -10,9 +10,13 @@ matrix, b and x already resident in HBM.
   value     = CG iterations per second; at N GPUs the global box is 216 x 216 x (216 N), cut into
               N z-slabs (weak scaling: 10M rows per GPU, halo exchange + scalar all-reduces over
               RCCL), and value counts 10M-row block iterations: N * iterations / time.
-  roofline  = the in-loop CSR SpMV: algorithmic bytes 12 nnz + 20 N + 4 over the
-              kernel's mean duration, measured with HIP events on the solver's stream inside the
-              timed steps (profile_kernels=1), against 8 TB/s.
+  roofline  = the in-loop SpMV of matrixFormat Csr: algorithmic bytes 12 nnz + 20 N + 4 (SURVEY.md
+              §8d) over the kernel's mean duration, measured with HIP events on the solver's stream
+              inside the timed steps (profile_kernels=1), against 8 TB/s.  By default the kernel
+              runs on the index-compressed copy of the matrix (compressIndices: 1-byte column codes,
+              9 instead of 12 bytes per entry), so it MOVES fewer bytes than the CSR figure:
+              `moved_model` / `moved_frac` give the bytes of that layout over the same time.
+              --no-compress measures the plain CSR-stream kernel.
   cpu_baseline = the oracle (sequential restatement, 1 core, "port") on the same matrix for a
               bounded number of iterations; plus its OpenMP variant as `cpu_baseline_omp`.
 
@@ -51,6 +55,8 @@ def parse():
     ap.add_argument("--asym", action="store_true", help="non-symmetric coefficients (momentum-like)")
     ap.add_argument("--format", default="Csr", choices=["Csr", "Ell"],
                     help="matrixFormat (Csr = the headline; Ell = configs[4]'s comparison)")
+    ap.add_argument("--no-compress", action="store_true",
+                    help="compressIndices false: SpMV on the plain CSR arrays (CSR-stream kernel)")
     ap.add_argument("--cpu-iters", type=int, default=-1,
                     help="oracle iterations for cpu_baseline (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-profile", action="store_true",
@@ -71,7 +77,7 @@ def pmc_traffic(kernel):
         return None, None
     with open(files[-1]) as fh:
         d = json.load(fh)
-    k = d.get(kernel)
+    k = d.get(kernel) or d.get(kernel.replace("<0, 1>", "<0, true>"))  # older template spelling
     if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         return None, None
     total = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
@@ -173,7 +179,8 @@ def main():
                               tolerance=0.0, rel_tol=0.0, max_iter=args.iters, min_iter=0,
                               eval_frequency=1, adapt_min_iter=0,
                               matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
-                              export_res=0, profile_kernels=0 if args.no_profile else 1)
+                              export_res=0, profile_kernels=0 if args.no_profile else 1,
+                              compress_indices=0 if args.no_compress else 1)
     s = reg.solver("p", cfg)
     t0 = time.perf_counter()
     s.set_matrix(case)                       # pattern + H2D + device permutation (not timed below)
@@ -219,7 +226,11 @@ def main():
         spmv_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in perfs) / max(1, launches)
         spmv_src = f"{launches} in-loop launches of the timed steps, HIP event pairs"
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
-    traffic, traffic_src = (pmc_traffic("k_spmv_stream<0, 1>") if (n == 216 and args.format == "Csr")
+    layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[s.get_property("spmvLayout")]
+    kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell"}[layout]
+    # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
+    b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout == "sell" else b_spmv
+    traffic, traffic_src = (pmc_traffic(kernel + "<0, 1>") if (n == 216 and args.format == "Csr")
                             else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
     if args.solver != "GKOCG" or precond not in (capi.PRECOND_BJ, capi.PRECOND_NONE) or args.block_size != 1:
@@ -247,12 +258,18 @@ def main():
                            if world > 1 else "single GPU",
         },
         "roofline": {
-            "kernel": ("k_spmv_ell" if args.format == "Ell" else "k_spmv_stream") + "<PLAIN, fused p.q>",
+            "kernel": kernel + "<PLAIN, fused p.q>", "layout": layout,
             "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_peak": achieved / HBM_COPY_GBPS,
+            "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": b_spmv,
+            # what the layout in use really has to move, over the same time: the honest distance
+            # to the memory system's ceiling (6.29 TB/s measured copy, 8 TB/s spec)
+            "moved_model_bytes_per_launch": b_moved,
+            "moved_model": b_moved / (spmv_ms * 1e-3) / 1e9,
+            "moved_frac": b_moved / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "moved_frac_of_measured_copy_peak": b_moved / (spmv_ms * 1e-3) / 1e9 / HBM_COPY_GBPS,
             "avg_kernel_ms": spmv_ms, "timing": spmv_src,
         },
         "cg_iteration": {

@@ -90,6 +90,10 @@ typedef struct ogl_config {
     int32_t krylov_dim;         /* 0 = Ginkgo default (100); GMRES only; NOT a reference keyword   */
     int32_t sparsity_power;     /* 1     Preconditioner.H:227 (only 1 is built)  "sparsityPower"     */
     int32_t profile_kernels;    /* 0; 1 = hipEvent-time the in-loop SpMV (bench.py roofline leg)    */
+    int32_t compress_indices;   /* 1; Coo/Csr formats: run the SpMV on the index-compressed chunked
+                                   ELL copy of the matrix when the pattern qualifies (same bits in
+                                   y; 9 instead of 12 bytes per entry). NOT a reference keyword:
+                                   "compressIndices"                                               */
 } ogl_config;
 
 /* Fill with the reference code's defaults. */
@@ -293,6 +297,13 @@ int ogl_host_pattern(const ogl_ldu_view *ldu, ogl_matrix_dims *dims, ogl_label *
 /* StoppingCriterion::build_dist_stopping_criterion's adaptive policy (StoppingCriterion.H:197-209). */
 void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,
                               ogl_scalar prev_rel_cost, ogl_label *min_iter, ogl_label *frequency);
+
+/* Index-compressed chunked ELL layout (compress_indices) of a row-major sorted CSR pattern: builds
+ * it, decodes it back and compares with the input.  stats[0] = 1 if the pattern qualifies (else 0
+ * and the rest is 0), stats[1] = padded value slots, stats[2] = dictionary entries, stats[3] = code
+ * bytes.  OGL_ERR_STATE if the decoded pattern differs from the input. */
+int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                        int64_t stats[4]);
 
 #ifdef __cplusplus
 }

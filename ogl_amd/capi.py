@@ -35,7 +35,7 @@ class Config(C.Structure):
         ("update_init_guess", C.c_int32), ("scaling", C.c_double), ("reorder_on_host", C.c_int32),
         ("export_res", C.c_int32), ("verbose", C.c_int32), ("force_host_buffer", C.c_int32),
         ("ranks_per_gpu", C.c_int32), ("krylov_dim", C.c_int32), ("sparsity_power", C.c_int32),
-        ("profile_kernels", C.c_int32),
+        ("profile_kernels", C.c_int32), ("compress_indices", C.c_int32),
     ]
 
 
@@ -81,6 +81,7 @@ EXPORTED_SYMBOLS = [
     "ogl_solver_get_comm_pattern", "ogl_host_init_local_sparsity", "ogl_host_symmetric_update",
     "ogl_host_symmetric_update_w_interface", "ogl_host_non_symmetric_update_w_interface",
     "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
+    "ogl_host_sell_check",
 ]
 
 
@@ -387,6 +388,16 @@ def host_pattern(case):
     _check(lib().ogl_host_pattern(C.byref(arr.view), C.byref(d), *[_pl(a) for a in loc],
                                   *[_pl(a) for a in nl], _pl(ids), _pl(sizes), _pl(send)))
     return d, tuple(loc), tuple(nl), (ids, sizes, send)
+
+
+def host_sell_check(row_ptrs, cols):
+    """Index-compressed chunked ELL layout of a CSR pattern: (qualifies, padded_slots, dict_entries,
+    code_bytes); raises if the layout does not decode back to the pattern."""
+    rp, cc = _l(row_ptrs), _l(cols)
+    stats = (C.c_int64 * 4)()
+    _check(lib().ogl_host_sell_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
+                                     cc.ctypes.data_as(C.c_void_p), stats))
+    return bool(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
 
 
 def host_adapt_criterion(cfg, prev_solve_iters, prev_rel_cost):

@@ -29,4 +29,21 @@ constexpr int NNZ_PAD = 8;
 
 inline int64_t n_chunks(int64_t n_rows) { return (n_rows + CHUNK_ROWS - 1) / CHUNK_ROWS; }
 
+// Index-compressed chunked ELL ("SELL-512 with diagonal codes"): the layout the Coo/Csr-format path
+// runs on when the sparsity pattern allows it.  Per chunk of CHUNK_ROWS rows: `width` = its longest
+// row, values slot-major [width][CHUNK_ROWS], and ONE BYTE per (row, slot) that names an entry of
+// the chunk's dictionary of (column - row) offsets (255 = padding slot).  Moves 9 bytes per stored
+// entry instead of CSR's 12; rows are still summed in stored column order, so y and the fused dot
+// partials are bit-identical to the CSR kernel's.
+struct SellChunk {
+    int64_t val_off;      // first value of the chunk (doubles)
+    int64_t code_off;     // first code byte of the chunk
+    int32_t dict_off;     // first dictionary entry of the chunk
+    int32_t dict_len;     // <= SELL_MAX_DICT
+    int32_t width;        // slots per row in this chunk
+    int32_t code_stride;  // code bytes per thread (ROWS_PER_THREAD rows x width, rounded up to 16)
+};
+constexpr int SELL_MAX_DICT = 255;        // code 255 marks a padding slot
+constexpr double SELL_MAX_PADDING = 1.25;  // padded slots / nnz above which CSR moves fewer bytes
+
 }  // namespace ogl

@@ -278,6 +278,80 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
     return OGL_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Index-compressed chunked ELL (SellChunk, common.hpp).  The pattern qualifies when every chunk of
+// CHUNK_ROWS rows uses at most SELL_MAX_DICT distinct (column - row) offsets -- true for structured
+// and banded finite-volume meshes, where a chunk sees a handful of diagonals -- and the padding to
+// the chunk's longest row stays below SELL_MAX_PADDING x nnz.
+// ---------------------------------------------------------------------------------------
+bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                       SellLayout &out)
+{
+    out = SellLayout{};
+    const int64_t nc = n_chunks(n_rows);
+    const int64_t nnz = n_rows > 0 ? row_ptrs[n_rows] : 0;
+    out.chunks.resize((size_t)nc);
+    std::vector<int32_t> ds;
+    int64_t val_len = 0, code_len = 0;
+    for (int64_t c = 0; c < nc; ++c) {
+        const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
+        const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+        int32_t width = 0;
+        ds.clear();
+        size_t last = 0;  // most entries repeat the offset found `dict_len` entries ago
+        for (ogl_label r = r0; r < r1; ++r) {
+            width = std::max(width, row_ptrs[r + 1] - row_ptrs[r]);
+            for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                const int32_t d = cols[k] - r;
+                if (!ds.empty()) {
+                    if (ds[last] == d) continue;
+                    size_t i = 0;
+                    while (i < ds.size() && ds[i] != d) ++i;
+                    if (i < ds.size()) {
+                        last = i;
+                        continue;
+                    }
+                }
+                if (ds.size() == (size_t)SELL_MAX_DICT) return false;
+                ds.push_back(d);
+                last = ds.size() - 1;
+            }
+        }
+        std::sort(ds.begin(), ds.end());
+        SellChunk &h = out.chunks[(size_t)c];
+        h.val_off = val_len;
+        h.code_off = code_len;
+        h.dict_off = (int32_t)out.dict.size();
+        h.dict_len = (int32_t)ds.size();
+        h.width = width;
+        h.code_stride = (2 * width + 15) / 16 * 16;
+        out.dict.insert(out.dict.end(), ds.begin(), ds.end());
+        val_len += (int64_t)width * CHUNK_ROWS;
+        code_len += (int64_t)h.code_stride * BLOCK;
+        if ((double)val_len > SELL_MAX_PADDING * (double)nnz + 8.0 * CHUNK_ROWS) return false;
+    }
+    out.n_slots = val_len;
+    out.codes.assign((size_t)code_len + 16, (uint8_t)255);
+    out.map.assign((size_t)val_len + 2, -1);
+    for (int64_t c = 0; c < nc; ++c) {
+        const SellChunk &h = out.chunks[(size_t)c];
+        const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
+        const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+        const int32_t *d0 = out.dict.data() + h.dict_off;
+        for (ogl_label r = r0; r < r1; ++r) {
+            const int32_t lr = r - r0, t = lr / ROWS_PER_THREAD, which = lr % ROWS_PER_THREAD;
+            uint8_t *code = out.codes.data() + h.code_off + (int64_t)t * h.code_stride;
+            for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s) {
+                out.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS + lr)] = k;
+                const int32_t d = cols[k] - r;
+                code[ROWS_PER_THREAD * s + which] =
+                    (uint8_t)(std::lower_bound(d0, d0 + h.dict_len, d) - d0);
+            }
+        }
+    }
+    return true;
+}
+
 }  // namespace ogl
 
 // ---------------------------------------------------------------------------------------
@@ -400,6 +474,48 @@ extern "C" void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_s
     *frequency = fr;
 }
 
+extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                                   int64_t stats[4])
+{
+    if (n_rows < 0 || !row_ptrs || !stats || (n_rows > 0 && !cols))
+        return fail(OGL_ERR_INVALID, "NULL argument");
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    SellLayout L;
+    if (n_rows == 0 || !build_sell_layout(n_rows, row_ptrs, cols, L)) return OGL_OK;
+    // decode exactly as k_spmv_sell does: thread t of chunk c owns rows c*CHUNK_ROWS + 2t, +1
+    for (size_t c = 0; c < L.chunks.size(); ++c) {
+        const SellChunk &h = L.chunks[c];
+        if (h.dict_len > SELL_MAX_DICT || h.code_stride % 16 != 0 || h.code_stride < 2 * h.width)
+            return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
+        for (int t = 0; t < BLOCK; ++t)
+            for (int which = 0; which < ROWS_PER_THREAD; ++which) {
+                const int64_t row = (int64_t)c * CHUNK_ROWS + t * ROWS_PER_THREAD + which;
+                const uint8_t *code = L.codes.data() + h.code_off + (int64_t)t * h.code_stride;
+                ogl_label k = row < n_rows ? row_ptrs[row] : 0;
+                const ogl_label k_end = row < n_rows ? row_ptrs[row + 1] : 0;
+                for (int s = 0; s < h.width; ++s) {
+                    const uint8_t cd = code[ROWS_PER_THREAD * s + which];
+                    const int32_t m = L.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS +
+                                                     t * ROWS_PER_THREAD + which)];
+                    if (cd == 255) {
+                        if (m != -1) return fail(OGL_ERR_STATE, "row %ld: padding slot is mapped", (long)row);
+                        continue;
+                    }
+                    if (k >= k_end || cd >= h.dict_len || m != k ||
+                        row + L.dict[(size_t)h.dict_off + cd] != cols[k])
+                        return fail(OGL_ERR_STATE, "row %ld slot %d decodes wrongly", (long)row, s);
+                    ++k;
+                }
+                if (k != k_end) return fail(OGL_ERR_STATE, "row %ld lost entries", (long)row);
+            }
+    }
+    stats[0] = 1;
+    stats[1] = L.n_slots;
+    stats[2] = (int64_t)L.dict.size();
+    stats[3] = (int64_t)L.codes.size() - 16;
+    return OGL_OK;
+}
+
 extern "C" void ogl_config_default(ogl_config *c)
 {
     *c = ogl_config{};
@@ -429,4 +545,5 @@ extern "C" void ogl_config_default(ogl_config *c)
     c->krylov_dim = 0;
     c->sparsity_power = 1;
     c->profile_kernels = 0;
+    c->compress_indices = 1;
 }

@@ -55,6 +55,18 @@ bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p);
 void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
                         std::vector<ogl_label> &block_ptrs, std::vector<ogl_label> &row_block);
 
+// Index-compressed chunked ELL of a row-major sorted pattern (SellChunk, common.hpp).  Returns false
+// (and leaves `out` unusable) when the pattern does not qualify; the CSR-stream kernel runs then.
+struct SellLayout {
+    std::vector<SellChunk> chunks;
+    std::vector<int32_t> dict;   // ascending (column - row) offsets, chunk after chunk
+    std::vector<uint8_t> codes;  // thread-major code bytes (+16 bytes of padding)
+    std::vector<int32_t> map;    // value slot -> position in the CSR value array, -1 = padding
+    int64_t n_slots = 0;         // padded value slots
+};
+bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                       SellLayout &out);
+
 // HostMatrix.C:180-207: concatenated bouCoeffs of the (non-)processor interfaces, times -1.
 void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *out);
 

@@ -718,6 +718,98 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, in
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Index-compressed chunked ELL SpMV (DevSell, kernels.hpp).  Per lane and group of 8 slots: one
+// 16-byte load brings the 16 column codes of its two rows, eight 16-byte loads the values; the
+// chunk's dictionary (<= 255 offsets) sits in LDS and turns a code into column = row + offset.
+// 9 bytes per stored entry instead of 12 -- measured 145 us against 187 us for the CSR-stream
+// kernel on the 216^3 matrix (profiles/spmv_tune_r01.txt).  Same per-row order as k_spmv_stream.
+// ------------------------------------------------------------------------------------------
+template <int MODE, int NDOT>
+__global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
+                                                     const SellChunk *__restrict__ chunks,
+                                                     const int *__restrict__ dict,
+                                                     const uint8_t *__restrict__ codes,
+                                                     const double *__restrict__ vals,
+                                                     const double *__restrict__ x,
+                                                     const double *__restrict__ b,
+                                                     double *__restrict__ y,
+                                                     const double *__restrict__ w,
+                                                     double *__restrict__ dot_partials,
+                                                     double *__restrict__ dot2_partials,
+                                                     const DevScalars *gate)
+{
+    __shared__ double slot[N_WAVES];
+    __shared__ int sdict[256];
+    if (gate && gate->stop) return;
+    const int chunk = xcd_chunk(blockIdx.x);
+    if (chunk >= n_chunks) return;
+    const SellChunk h = chunks[chunk];
+    const int t = threadIdx.x;
+    if (t < h.dict_len) sdict[t] = dict[h.dict_off + t];
+    __syncthreads();
+    const RowPair rp = my_rows(chunk, n_rows);
+    const int row = chunk * CHUNK_ROWS + t * ROWS_PER_THREAD;
+    double2 acc;
+    acc.x = acc.y = 0.0;
+    if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
+    const double *v = vals + h.val_off + t * ROWS_PER_THREAD;
+    const uint8_t *c = codes + h.code_off + (long)t * h.code_stride;
+    constexpr int BATCH = 8;
+    for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+        const uint4 cw = *reinterpret_cast<const uint4 *>(c + 2 * s0);
+        const unsigned w4[4] = {cw.x, cw.y, cw.z, cw.w};
+        double2 vv[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const int s = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+            vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
+        }
+        double x0[BATCH], x1[BATCH];
+        bool ok0[BATCH], ok1[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            const unsigned pair = (w4[k / 2] >> (16 * (k & 1))) & 0xffffu;
+            const unsigned c0 = pair & 0xffu, c1 = pair >> 8;
+            // padding slots carry code 255; rows past n_rows only have padding slots
+            ok0[k] = (s0 + k < h.width) && c0 != 255u;
+            ok1[k] = (s0 + k < h.width) && c1 != 255u;
+            x0[k] = ok0[k] ? x[row + sdict[c0]] : 0.0;
+            x1[k] = ok1[k] ? x[row + 1 + sdict[c1]] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            if (ok0[k]) {
+                const double p = vv[k].x * x0[k];
+                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+            }
+            if (ok1[k]) {
+                const double p = vv[k].y * x1[k];
+                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+            }
+        }
+    }
+    st2(y, rp, acc);
+    if (NDOT >= 1) {
+        const double2 vw = ld2(w, rp);
+        double d = 0.0, d2 = 0.0;
+        if (rp.n > 0) {
+            d += vw.x * acc.x;
+            d2 += acc.x * acc.x;
+        }
+        if (rp.n > 1) {
+            d += vw.y * acc.y;
+            d2 += acc.y * acc.y;
+        }
+        const double s = block_sum(d, slot);
+        if (threadIdx.x == 0) dot_partials[chunk] = s;
+        if (NDOT >= 2) {
+            const double s2 = block_sum(d2, slot);
+            if (threadIdx.x == 0) dot2_partials[chunk] = s2;
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_gather_coeffs_masked(long n, const int *__restrict__ map,
                                                                 const double *__restrict__ src,
                                                                 double *__restrict__ out)
@@ -1178,6 +1270,27 @@ void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x,
         OGL_ELL(SPMV_PLAIN, 0);
     }
 #undef OGL_ELL
+}
+
+void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
+                      double *y, const SpmvDots &dots, const DevScalars *gate)
+{
+    if (A.n_rows == 0) return;
+    const int nc = (int)n_chunks(A.n_rows);
+    const dim3 grid(xcd_grid(nc)), block(BLOCK);
+#define OGL_SELL(MODE, NDOT)                                                                     \
+    hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
+                       A.dict, A.codes, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+    if (mode == SPMV_RESIDUAL) {
+        OGL_SELL(SPMV_RESIDUAL, 0);
+    } else if (dots.part && dots.part_yy) {
+        OGL_SELL(SPMV_PLAIN, 2);
+    } else if (dots.part) {
+        OGL_SELL(SPMV_PLAIN, 1);
+    } else {
+        OGL_SELL(SPMV_PLAIN, 0);
+    }
+#undef OGL_SELL
 }
 
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,

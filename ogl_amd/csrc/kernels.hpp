@@ -78,6 +78,16 @@ struct DevEll {
 };
 void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,
                      double *y, const SpmvDots &dots, const DevScalars *gate);
+// Index-compressed chunked ELL (SellChunk, common.hpp), device view.
+struct DevSell {
+    int32_t n_rows = 0;
+    const SellChunk *chunks = nullptr;  // [n_chunks]
+    const int32_t *dict = nullptr;      // column - row offsets, ascending per chunk
+    const uint8_t *codes = nullptr;     // thread-major: [thread][slot][row of the pair]
+    const double *vals = nullptr;
+};
+void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
+                      double *y, const SpmvDots &dots, const DevScalars *gate);
 // out[i] = map[i] >= 0 ? source[map[i]] : 0   (coefficient permutation into the padded ELL slots)
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,
                                  double *out);

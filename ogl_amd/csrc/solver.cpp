@@ -180,6 +180,44 @@ int ogl_solver::build_ell()
     return OGL_OK;
 }
 
+DevSell ogl_solver::sell() const
+{
+    DevSell S;
+    S.n_rows = pat.n_rows;
+    S.chunks = d_sell_chunks.p;
+    S.dict = d_sell_dict.p;
+    S.codes = d_sell_codes.p;
+    S.vals = d_sell_vals.p;
+    return S;
+}
+
+// Once per sparsity pattern: derive the compressed layout on the host; sell_map (like ell_map)
+// refreshes the values from the permuted CSR values on the device.
+int ogl_solver::build_sell()
+{
+    hipStream_t st = reg->stream;
+    SellLayout L;
+    if (pat.n_rows == 0 || !build_sell_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), L)) {
+        sell_state = -1;
+        return OGL_OK;
+    }
+    OGL_TRY(d_sell_chunks.alloc(L.chunks.size(), st));
+    OGL_TRY(d_sell_dict.alloc(L.dict.size(), st));
+    OGL_TRY(d_sell_codes.alloc(L.codes.size(), st));
+    OGL_TRY(d_sell_map.alloc(L.map.size(), st));
+    OGL_TRY(d_sell_vals.alloc(L.map.size(), st));
+    OGL_TRY(reg->stager.h2d(d_sell_chunks.p, L.chunks.data(), L.chunks.size() * sizeof(SellChunk), st));
+    OGL_TRY(reg->stager.h2d(d_sell_dict.p, L.dict.data(), L.dict.size() * sizeof(int32_t), st));
+    OGL_TRY(reg->stager.h2d(d_sell_codes.p, L.codes.data(), L.codes.size(), st));
+    OGL_TRY(reg->stager.h2d(d_sell_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
+    sell_slots = L.n_slots;
+    sell_state = 1;
+    // bytes one SpMV reads of this layout (bench.py's moved-bytes model)
+    props["sellMatrixBytes"] = 8.0 * (double)L.n_slots + (double)(L.codes.size() - 16) +
+                               (double)(L.chunks.size() * sizeof(SellChunk)) + 4.0 * (double)L.dict.size();
+    return OGL_OK;
+}
+
 DevHalo ogl_solver::halo() const
 {
     DevHalo H;
@@ -244,6 +282,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         pat_id = ++pattern_counter;
         matrix_set = false;
         ell_ready = false;
+        sell_state = 0;
         x_resident = b_resident = false;
         const size_t nnz = (size_t)pat.local_nnz;
         OGL_TRY(d_row_ptrs.alloc((size_t)pat.n_rows + 1, st));
@@ -357,6 +396,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         }
         matrix_set = true;
         ell_values_stale = true;
+        sell_values_stale = true;
     }
     if (cfg.matrix_format == OGL_FORMAT_ELL) {
         if (!ell_ready) OGL_TRY(build_ell());
@@ -365,7 +405,15 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
                                         d_ell_vals.p);
             ell_values_stale = false;
         }
+    } else if (cfg.compress_indices) {
+        if (sell_state == 0) OGL_TRY(build_sell());
+        if (sell_state == 1 && sell_values_stale) {
+            launch_gather_coeffs_masked(st, sell_slots, d_sell_map.p, d_vals.p, d_sell_vals.p);
+            sell_values_stale = false;
+        }
     }
+    // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
+    props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : (use_sell() ? 2.0 : 0.0);
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
     t_update_matrix_ms = now_ms() - t0;
@@ -572,6 +620,8 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     // per-chunk tree, so the sums are bit-identical to a dot over the finished y).
     if (cfg.matrix_format == OGL_FORMAT_ELL && ell_ready && !ell_values_stale)
         launch_spmv_ell(st, ell(), mode, x, b, y, dots, gate);
+    else if (use_sell())
+        launch_spmv_sell(st, sell(), mode, x, b, y, dots, gate);
     else
         launch_spmv(st, csr(), mode, x, b, y, dots, gate);
     if (has_halo) {

@@ -140,6 +140,23 @@ struct ogl_solver {
     int64_t ell_stride = 0;
     bool ell_ready = false, ell_values_stale = true;
     int build_ell();
+    // index-compressed chunked ELL copy (SellChunk, common.hpp): what the Coo/Csr formats run on when
+    // cfg.compress_indices is set and the pattern qualifies.  sell_state: 0 = not tried for this
+    // pattern, 1 = built, -1 = pattern does not qualify (CSR-stream kernel runs)
+    ogl::DevBuf<ogl::SellChunk> d_sell_chunks;
+    ogl::DevBuf<int32_t> d_sell_dict, d_sell_map;
+    ogl::DevBuf<uint8_t> d_sell_codes;
+    ogl::DevBuf<double> d_sell_vals;
+    int64_t sell_slots = 0;
+    int sell_state = 0;
+    bool sell_values_stale = true;
+    int build_sell();
+    ogl::DevSell sell() const;
+    bool use_sell() const
+    {
+        return cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices && sell_state == 1 &&
+               !sell_values_stale;
+    }
     ogl::DevEll ell() const;
     // halo part
     std::vector<int32_t> boundary_rows, boundary_ptrs;

@@ -1,0 +1,151 @@
+"""compress_indices: the Coo/Csr formats run the SpMV on the index-compressed chunked ELL copy when the
+pattern qualifies.  Same bits as the CSR-stream kernel and as the oracle, everywhere it is used; the
+CSR-stream kernel takes over when the pattern does not qualify."""
+import numpy as np
+import pytest
+
+from ogl_amd import capi, synthetic
+from helpers import blocked, oracle_csr, oracle_matrix
+
+pytestmark = pytest.mark.gpu
+
+LAYOUT_CSR, LAYOUT_ELL, LAYOUT_SELL = 0.0, 1.0, 2.0
+
+
+@pytest.fixture(scope="module")
+def reg():
+    r = capi.Registry()
+    yield r
+    r.close()
+
+
+def cfg(compress, **kw):
+    base = dict(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, tolerance=1e-11, rel_tol=0.0,
+                max_iter=300, export_res=1, matrix_format=capi.FORMAT_CSR, adapt_min_iter=0,
+                compress_indices=compress)
+    base.update(kw)
+    return capi.default_config(**base)
+
+
+CASES = [dict(gx=5, gy=4, gz=3), dict(gx=6, gy=5, gz=4, periodic_x=True), dict(gx=33, gy=31, gz=29),
+         dict(gx=1, gy=1, gz=1), dict(gx=1031, gy=1, gz=1), dict(gx=64, gy=64, gz=3)]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[str(i) for i in range(len(CASES))])
+@pytest.mark.parametrize("sym", [True, False])
+def test_spmv_same_bits_compressed_or_not(reg, oracle, kw, sym):
+    case = synthetic.poisson_block(symmetric=sym, off_upper=-0.9, off_lower=-0.9 if sym else -1.1, **kw)
+    rng = np.random.default_rng(20241016)
+    x = rng.uniform(-1, 1, case.n_cells)
+    rp, cols, vals = oracle_csr(oracle, case)
+    ref = oracle.spmv(rp, cols, vals, x)
+    on = reg.solver("sell_on", cfg(1)).set_matrix(case)
+    off = reg.solver("sell_off", cfg(0)).set_matrix(case)
+    assert on.get_property("spmvLayout") == LAYOUT_SELL
+    assert off.get_property("spmvLayout") == LAYOUT_CSR
+    np.testing.assert_array_equal(on.spmv(x), ref)
+    np.testing.assert_array_equal(off.spmv(x), ref)
+
+
+def test_default_config_compresses_and_ell_format_does_not(reg):
+    case = synthetic.poisson_case(9)
+    assert capi.default_config().compress_indices == 1
+    s = reg.solver("sell_default", capi.default_config()).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL
+    e = reg.solver("sell_ellfmt", cfg(1, matrix_format=capi.FORMAT_ELL)).set_matrix(case)
+    assert e.get_property("spmvLayout") == LAYOUT_ELL
+
+
+def random_ldu(n, per_row, seed):
+    """symmetric-pattern lduMatrix with `per_row` random upper neighbours per cell, faces in OpenFOAM's
+    upper-triangular order"""
+    rng = np.random.default_rng(seed)
+    pairs = set()
+    for i in range(n - 1):
+        for j in rng.integers(i + 1, n, per_row):
+            pairs.add((i, int(j)))
+    pairs = np.array(sorted(pairs), dtype=np.int32)
+    f = len(pairs)
+    return synthetic.LduCase(n, pairs[:, 0].copy(), pairs[:, 1].copy(), rng.uniform(1, 2, n) + 4 * per_row,
+                             rng.uniform(-1, 1, f), rng.uniform(-1, 1, f))
+
+
+def test_unstructured_pattern_falls_back_to_csr_stream(reg, oracle):
+    case = random_ldu(3000, 3, 11)
+    s = reg.solver("sell_random", cfg(1)).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_CSR
+    rp, cols, vals = oracle_csr(oracle, case)
+    x = np.random.default_rng(2).uniform(-1, 1, case.n_cells)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+def test_wide_banded_rows(reg, oracle):
+    # 41 diagonals -> three 16-byte code words per thread and 6 value batches
+    n = 1500
+    lower = np.repeat(np.arange(n, dtype=np.int32), 20)
+    upper = lower + np.tile(np.arange(1, 21, dtype=np.int32), n)
+    keep = upper < n
+    lower, upper = lower[keep], upper[keep]
+    rng = np.random.default_rng(8)
+    case = synthetic.LduCase(n, lower, upper, rng.uniform(40, 50, n), rng.uniform(-1, 1, len(lower)),
+                             rng.uniform(-1, 1, len(lower)))
+    s = reg.solver("sell_wide", cfg(1)).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL
+    rp, cols, vals = oracle_csr(oracle, case)
+    x = rng.uniform(-1, 1, n)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+@pytest.mark.parametrize("solver", [capi.SOLVER_CG, capi.SOLVER_BICGSTAB, capi.SOLVER_GMRES])
+def test_solvers_same_history_compressed_or_not(reg, oracle, solver):
+    sym = solver == capi.SOLVER_CG
+    case = synthetic.poisson_case(20, symmetric=sym)      # 8000 rows: 16 chunks, the last one partial
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    out = {}
+    for tag, c in (("on", 1), ("off", 0)):
+        s = reg.solver(f"sell_solver{solver}_{tag}", cfg(c, solver=solver, krylov_dim=20)).set_matrix(case)
+        assert s.get_property("spmvLayout") == (LAYOUT_SELL if c else LAYOUT_CSR)
+        x, perf = s.solve(b, np.zeros_like(b))
+        out[tag] = (x, s.history().copy(), perf.n_iterations)
+    np.testing.assert_array_equal(out["on"][1], out["off"][1])
+    np.testing.assert_array_equal(out["on"][0], out["off"][0])
+    assert out["on"][2] == out["off"][2]
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    kw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
+    with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+        if solver == capi.SOLVER_CG:
+            ref = oracle.cg(A, b, np.zeros_like(b), oracle.jacobi_generate_scalar(rp, cols, vals), **kw)
+        elif solver == capi.SOLVER_BICGSTAB:
+            ref = oracle.bicgstab(A, b, np.zeros_like(b), oracle.jacobi_generate_scalar(rp, cols, vals), **kw)
+        else:
+            ref = oracle.gmres(A, b, np.zeros_like(b), oracle.Precond(rp, cols, vals, 1), krylov_dim=20, **kw)
+    np.testing.assert_array_equal(out["on"][1], ref.history)
+    np.testing.assert_array_equal(out["on"][0], ref.x)
+
+
+def test_compressed_values_follow_coefficient_updates(reg, oracle):
+    case = synthetic.poisson_case(9)
+    s = reg.solver("sell_upd", cfg(1)).set_matrix(case)
+    x = np.random.default_rng(4).uniform(-1, 1, case.n_cells)
+    y0 = s.spmv(x)
+    case2 = synthetic.poisson_case(9)
+    case2.diag[:] = case2.diag * 1.5
+    case2.upper[:] = case2.upper * 0.5
+    s.set_matrix(case2)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL
+    rp, cols, vals = oracle_csr(oracle, case2)
+    y1 = s.spmv(x)
+    np.testing.assert_array_equal(y1, oracle.spmv(rp, cols, vals, x))
+    assert not np.array_equal(y0, y1)
+
+
+def test_pattern_change_rebuilds_the_layout(reg, oracle):
+    s = reg.solver("sell_repattern", cfg(1))
+    for n in (6, 11):
+        case = synthetic.poisson_case(n)
+        s.set_matrix(case)
+        assert s.get_property("spmvLayout") == LAYOUT_SELL
+        rp, cols, vals = oracle_csr(oracle, case)
+        x = np.random.default_rng(n).uniform(-1, 1, case.n_cells)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))

@@ -1,0 +1,84 @@
+"""Host side of the index-compressed chunked ELL layout (compress_indices; SellChunk in
+ogl_amd/csrc/common.hpp): ogl_host_sell_check builds the layout from a CSR pattern, decodes it the way
+k_spmv_sell does and compares with the input.  No GPU needed."""
+import numpy as np
+import pytest
+
+from ogl_amd import capi, synthetic
+from helpers import oracle_csr
+
+CHUNK = 512
+
+
+def poisson_pattern(oracle, **kw):
+    case = synthetic.poisson_block(**kw)
+    rp, cols, _ = oracle_csr(oracle, case)
+    return rp, cols
+
+
+@pytest.mark.parametrize("kw", [dict(gx=5, gy=4, gz=3), dict(gx=33, gy=31, gz=29), dict(gx=1, gy=1, gz=1),
+                                dict(gx=1031, gy=1, gz=1), dict(gx=64, gy=8, gz=1),
+                                dict(gx=6, gy=5, gz=4, periodic_x=True)])
+@pytest.mark.parametrize("sym", [True, False])
+def test_structured_patterns_qualify_and_decode(oracle, kw, sym):
+    rp, cols = poisson_pattern(oracle, symmetric=sym, **kw)
+    ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
+    n, nnz = len(rp) - 1, int(rp[-1])
+    n_chunks = (n + CHUNK - 1) // CHUNK
+    assert ok
+    assert slots % CHUNK == 0 and slots >= nnz
+    # every chunk is padded to its own longest row only
+    widths = [int(np.diff(rp[c * CHUNK:min(n, (c + 1) * CHUNK) + 1]).max()) for c in range(n_chunks)]
+    assert slots == CHUNK * sum(widths)
+    assert code_bytes == 256 * sum((2 * w + 15) // 16 * 16 for w in widths)
+    assert dict_entries <= 255 * n_chunks
+
+
+def test_seven_point_box_uses_seven_offsets_per_chunk(oracle):
+    rp, cols = poisson_pattern(oracle, gx=16, gy=16, gz=16, symmetric=True)
+    ok, slots, dict_entries, _ = capi.host_sell_check(rp, cols)
+    assert ok and dict_entries == 7 * (16 ** 3 // CHUNK)
+    assert slots == 7 * 16 ** 3
+
+
+def test_unstructured_pattern_does_not_qualify():
+    # 6 random neighbours per row: far more than 255 distinct offsets in a chunk
+    rng = np.random.default_rng(5)
+    n = 4096
+    rows = []
+    for r in range(n):
+        c = np.unique(np.concatenate([[r], rng.integers(0, n, 6)]))
+        rows.append(c)
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    cols = np.concatenate(rows).astype(np.int32)
+    assert capi.host_sell_check(rp, cols) == (False, 0, 0, 0)
+
+
+def test_one_long_row_per_chunk_is_too_much_padding():
+    # tridiagonal matrix + a 200-wide row in every chunk: padded slots ~ 200/3 x nnz
+    n = 2048
+    rows = []
+    for r in range(n):
+        c = {max(r - 1, 0), r, min(r + 1, n - 1)}
+        if r % CHUNK == 7:
+            c |= set(range(r, min(n, r + 200)))
+        rows.append(np.array(sorted(c)))
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    cols = np.concatenate(rows).astype(np.int32)
+    assert capi.host_sell_check(rp, cols)[0] is False
+
+
+def test_wide_banded_rows_qualify():
+    # 41 diagonals: width 41 -> three 16-byte code words per thread
+    n = 1500
+    offs = np.arange(-20, 21)
+    rows = [np.array([r + o for o in offs if 0 <= r + o < n]) for r in range(n)]
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    cols = np.concatenate(rows).astype(np.int32)
+    ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
+    assert ok and slots == 3 * CHUNK * 41 and dict_entries == 3 * 41
+    assert code_bytes == 3 * 256 * 96
+
+
+def test_empty_pattern():
+    assert capi.host_sell_check(np.zeros(1, np.int32), np.zeros(0, np.int32)) == (False, 0, 0, 0)
