@@ -640,6 +640,93 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2(int n, double *__restrict__ 
     }
 }
 
+// The same two steps with the x update DEFERRED by one turn, so that p is read once per turn instead
+// of twice (80 N instead of 88 N bytes per turn with scalar Jacobi):
+//   step_2r (turn j)  : r -= t_j q ; partials of the next rho and sum|r|        (x, p untouched)
+//   step_1x (turn j+1): x += t_j p  with the OLD p, then p = z + (rho/prev_rho) p
+// t_j = rho_j / beta_j is formed from the same two scalars as in step_2 (after the check that closed
+// turn j they sit in prev_rho and beta), so x receives the same bits, one kernel later.  When that
+// check stops the solve, the step_1x of turn j+1 still applies the pending update (it recognises
+// its turn by iter == turn + 1: no check runs after the stop) and leaves p alone; the host flushes
+// with an extra step_1x when the stop came after the last enqueued turn.
+__global__ __launch_bounds__(BLOCK) void k_cg_step1x(int n, double *__restrict__ p,
+                                                     double *__restrict__ x,
+                                                     const double *__restrict__ r,
+                                                     const double *__restrict__ inv_diag,
+                                                     const DevScalars *s, int turn)
+{
+    const int stop = s->stop;
+    const bool pending = turn > 0 && (!stop || s->iter == turn + 1);
+    if (stop && !pending) return;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 vp = ld2(p, rp);
+    if (pending) {
+        const double beta = s->beta;
+        if (beta != 0.0) {
+            const double t = s->prev_rho / beta;
+            double2 vx = ld2(x, rp);
+            vx.x += t * vp.x;
+            vx.y += t * vp.y;
+            st2(x, rp, vx);
+        }
+    }
+    if (stop) return;
+    const double rho = s->rho, prev = s->prev_rho;
+    const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
+    double2 vz = ld2(r, rp);
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        vz.x = vz.x * vi.x;
+        vz.y = vz.y * vi.y;
+    }
+    vp.x = vz.x + tmp * vp.x;
+    vp.y = vz.y + tmp * vp.y;
+    st2(p, rp, vp);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__ r,
+                                                     const double *__restrict__ q,
+                                                     const double *__restrict__ inv_diag,
+                                                     double *__restrict__ part_rho,
+                                                     double *__restrict__ part_norm,
+                                                     const DevScalars *s)
+{
+    __shared__ double slot[N_WAVES];
+    if (s->stop) return;
+    const double rho = s->rho, beta = s->beta;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vr = ld2(r, rp);
+    if (beta != 0.0) {
+        const double t = rho / beta;
+        const double2 vq = ld2(q, rp);
+        vr.x -= t * vq.x;
+        vr.y -= t * vq.y;
+        st2(r, rp, vr);
+    }
+    double2 vz = vr;
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        vz.x = vr.x * vi.x;
+        vz.y = vr.y * vi.y;
+    }
+    double d = 0.0, a = 0.0;
+    if (rp.n > 0) {
+        d += vr.x * vz.x;
+        a += fabs(vr.x);
+    }
+    if (rp.n > 1) {
+        d += vr.y * vz.y;
+        a += fabs(vr.y);
+    }
+    const double s0 = block_sum(d, slot);
+    const double s1 = block_sum(a, slot);
+    if (threadIdx.x == 0) {
+        part_rho[chunk] = s0;
+        part_norm[chunk] = s1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ELL SpMV (matrixFormat Ell).  Slot-major planes: every load is a 16-byte (values) / 8-byte
 // (columns) coalesced access over the chunk's rows, no LDS, no row pointers; a thread owns rows
@@ -1452,6 +1539,23 @@ void launch_cg_step1(hipStream_t st, int32_t n, double *p, const double *r, cons
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
     hipLaunchKernelGGL(k_cg_step1, dim3(nc), dim3(BLOCK), 0, st, n, p, r, inv_diag, s);
+}
+
+void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
+                      const double *inv_diag, const DevScalars *s, int turn)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_cg_step1x, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, s, turn);
+}
+
+void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
+                      double *part_rho, double *part_norm, const DevScalars *s)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_cg_step2r, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho,
+                       part_norm, s);
 }
 
 void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const double *p,

@@ -160,6 +160,14 @@ void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const doub
                      const double *q, const double *inv_diag, double *part_rho, double *part_norm,
                      const DevScalars *s);
 
+// The same steps with the x update deferred by one turn (p is then read once per turn):
+//   step_2r: r -= (rho/beta) q + partials;  step_1x(turn): x += (prev_rho/beta) p_old, then step_1.
+// step_1x applies the pending update of turn-1 also when the solve has just stopped.
+void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
+                      const double *inv_diag, const DevScalars *s, int turn);
+void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
+                      double *part_rho, double *part_norm, const DevScalars *s);
+
 // --- BiCGStab steps ([UPSTREAM] bicgstab::step_1/2/3, finalize) ---
 void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,
                        const double *inv_diag, double *y, const DevScalars *s);

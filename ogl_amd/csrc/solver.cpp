@@ -915,13 +915,14 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 launch_partials_dot(st, n, d_r.p, d_z.p, d_part0.p, s);
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else if (!bicg) {
-                launch_cg_step1(st, n, d_p.p, d_r.p, precond, s);
+                // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once
+                launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s, enq);
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
                                   SpmvDots{d_p.p, d_part0.p, nullptr}, s));
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
                 OGL_TRY(finalize(FIN_BETA, f1));
-                launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, precond, d_part0.p, d_part1.p, s);
+                launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s);
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else {
                 launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
@@ -972,6 +973,13 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     OGL_HIP_CHECK(hipGetLastError());
     DevScalars fin;
     OGL_HIP_CHECK(hipMemcpy(&fin, s, sizeof(fin), hipMemcpyDeviceToHost));
+    if (!gmres && !bicg && !generic && fin.iter - 1 >= enq) {
+        // the stop came with the check of the last enqueued turn: no step_1x followed to apply
+        // that turn's x update
+        launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s, fin.iter - 1);
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        OGL_HIP_CHECK(hipGetLastError());
+    }
     if (gmres) {
         // final solve_krylov on the (partial) cycle: Arnoldi steps done since the last restart
         const int steps = fin.iter - 1;
