@@ -170,6 +170,31 @@ def main():
             reg.close()
             reg = capi.Registry(device_id=local_rank)
             reg.set_host_comm(rank, world, _allreduce, _exchange)
+        # scalar all-reduces: peer-write mailboxes over xGMI inside the finaliser kernels (hipIpc;
+        # collective self-test in peer_connect).  If any rank cannot join, all ranks keep the
+        # transport's own all-reduce.
+        ok, mine = 1, None
+        try:
+            if os.environ.get("OGL_BENCH_PEER", "1") == "1":
+                mine = reg.peer_handle()
+        except capi.OglError as e:
+            print(f"bench.py: rank {rank}: no peer mailbox ({e})", file=sys.stderr)
+        handles = [None] * world
+        dist.all_gather_object(handles, mine)          # every rank takes part, handle or not
+        if any(h is None for h in handles):
+            ok = 0
+        else:
+            try:
+                reg.peer_connect(rank, world, handles)
+            except capi.OglError as e:
+                ok = 0
+                print(f"bench.py: rank {rank}: peer all-reduce unavailable ({e})", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            transport = transport.replace("halo + all-reduce", "halo, peer-write all-reduce (hipIpc)")
+        else:
+            reg.peer_disable()
     precond = {"BJ": capi.PRECOND_BJ, "none": capi.PRECOND_NONE, "ISAI": capi.PRECOND_ISAI,
                "GISAI": capi.PRECOND_GISAI}[args.precond]
     solver_kind = {"GKOCG": capi.SOLVER_CG, "GKOBiCGStab": capi.SOLVER_BICGSTAB,
@@ -330,8 +355,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (json.dumps(out) + "\n").encode())
 
+
+# The contract is ONE JSON line on stdout: gloo and RCCL print banners to file descriptor 1 from
+# native code, so everything but the final line is sent to stderr.
+_REAL_STDOUT = 1
 
 if __name__ == "__main__":
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     main()

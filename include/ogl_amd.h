@@ -176,6 +176,18 @@ int ogl_registry_set_host_comm(ogl_registry *reg, int32_t rank, int32_t n_ranks,
 int ogl_rccl_unique_id(void *id_out);
 int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n_ranks, const void *id);
 
+/* Peer-write all-reduce over xGMI for the scalar reductions of the Krylov loop (the MPI_Allreduce
+ * behind gko's distributed dot / norm1, StoppingCriterion.C:19,54-63,94).  Optional, on top of
+ * either transport above (which keeps the halo exchange): every rank exports a 64-byte IPC handle
+ * of its mailbox, the host all-gathers them (MPI_Allgather in OpenFOAM), every rank connects.
+ * peer_connect is COLLECTIVE: it runs a self-test all-reduce and fails on every rank alike if the
+ * mesh does not work; call ogl_registry_peer_disable then and the transport's own all-reduce is
+ * used.  At most 16 ranks, one node. */
+#define OGL_PEER_HANDLE_BYTES 64
+int ogl_registry_peer_handle(ogl_registry *reg, void *handle_out);
+int ogl_registry_peer_connect(ogl_registry *reg, int32_t rank, int32_t n_ranks, const void *handles);
+int ogl_registry_peer_disable(ogl_registry *reg);
+
 /* ------------------------------------------------------------------------------------ */
 /* The plug-in path                                                                      */
 /* ------------------------------------------------------------------------------------ */

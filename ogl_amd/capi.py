@@ -19,6 +19,7 @@ PRECOND_NONE, PRECOND_BJ, PRECOND_ISAI, PRECOND_GISAI = 0, 1, 2, 3
 FORMAT_COO, FORMAT_CSR, FORMAT_ELL = 0, 1, 2
 IFACE_PROCESSOR, IFACE_CYCLIC = 0, 1
 RCCL_ID_BYTES = 128
+PEER_HANDLE_BYTES = 64
 
 _LP = C.POINTER(C.c_int32)
 _SP = C.POINTER(C.c_double)
@@ -71,7 +72,8 @@ EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, _LP, _LP, _SP, _SP)
 EXPORTED_SYMBOLS = [
     "ogl_last_error", "ogl_abi_version", "ogl_config_default", "ogl_registry_create",
     "ogl_registry_destroy", "ogl_registry_set_host_comm", "ogl_rccl_unique_id",
-    "ogl_registry_init_rccl", "ogl_solver_get_or_create", "ogl_solver_set_matrix",
+    "ogl_registry_init_rccl", "ogl_registry_peer_handle", "ogl_registry_peer_connect",
+    "ogl_registry_peer_disable", "ogl_solver_get_or_create", "ogl_solver_set_matrix",
     "ogl_solver_solve", "ogl_solver_history", "ogl_solver_export_system",
     "ogl_solver_get_property",
     "ogl_solver_set_property", "ogl_solver_apply_resident", "ogl_solver_upload_solution",
@@ -204,6 +206,22 @@ class Registry:
     def init_rccl(self, rank, n_ranks, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, RCCL_ID_BYTES)
         _check(lib().ogl_registry_init_rccl(self._h, rank, n_ranks, buf))
+
+    def peer_handle(self) -> bytes:
+        """64-byte IPC handle of this rank's all-reduce mailbox (to be all-gathered by the host)."""
+        buf = C.create_string_buffer(PEER_HANDLE_BYTES)
+        _check(lib().ogl_registry_peer_handle(self._h, buf))
+        return buf.raw
+
+    def peer_connect(self, rank, n_ranks, handles):
+        """Collective: map the other ranks' mailboxes and self-test the peer-write all-reduce."""
+        blob = b"".join(handles)
+        assert len(blob) == PEER_HANDLE_BYTES * n_ranks
+        buf = C.create_string_buffer(blob, len(blob))
+        _check(lib().ogl_registry_peer_connect(self._h, rank, n_ranks, buf))
+
+    def peer_disable(self):
+        _check(lib().ogl_registry_peer_disable(self._h))
 
     def solver(self, field_name, cfg):
         return Solver(self, field_name, cfg)

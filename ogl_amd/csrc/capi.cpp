@@ -89,6 +89,35 @@ extern "C" int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n
     OGL_GUARD_END
 }
 
+extern "C" int ogl_registry_peer_handle(ogl_registry *reg, void *handle_out)
+{
+    OGL_GUARD_BEGIN
+    if (!reg || !handle_out) return fail(OGL_ERR_INVALID, "registry/handle_out is NULL");
+    return reg->peer_export(handle_out);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_registry_peer_connect(ogl_registry *reg, int32_t rank, int32_t n_ranks,
+                                         const void *handles)
+{
+    OGL_GUARD_BEGIN
+    if (!reg || !handles) return fail(OGL_ERR_INVALID, "registry/handles is NULL");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(OGL_ERR_INVALID, "bad rank/n_ranks");
+    if (!reg->comm || reg->comm->n_ranks != n_ranks || reg->comm->rank != rank)
+        return fail(OGL_ERR_STATE, "peer_connect: set the transport (host or RCCL) with the same rank/n_ranks first");
+    return reg->peer_connect(rank, n_ranks, handles);
+    OGL_GUARD_END
+}
+
+extern "C" int ogl_registry_peer_disable(ogl_registry *reg)
+{
+    OGL_GUARD_BEGIN
+    if (!reg) return fail(OGL_ERR_INVALID, "registry is NULL");
+    reg->peer_ready = false;
+    return OGL_OK;
+    OGL_GUARD_END
+}
+
 template <class T>
 static int fetch(ogl_solver *s, T *dst, const T *dev, size_t count)
 {

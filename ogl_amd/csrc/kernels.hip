@@ -1189,6 +1189,77 @@ __device__ void criterion_check(DevScalars *s, const DevCriterion &c, double nor
     if (stop) s->stop = 1;
 }
 
+// Peer-write all-reduce (PeerArgs, kernels.hpp).  Called by every thread of a workgroup of >= 64
+// threads; v0, v1 are thread 0's local sums on entry and the rank-ordered global sums on return
+// (thread 0 only).  Lane (q, e) sends half-word e to rank q and waits for rank q's half-word e.
+constexpr long long PEER_TIMEOUT_TICKS = 60LL * 100000000LL;  // 60 s of the 100 MHz wall clock
+__device__ __forceinline__ size_t peer_word(int slot, int src, int e)
+{
+    return ((size_t)slot * PEER_MAX_RANKS + src) * PEER_ELEMS + e;
+}
+__device__ bool peer_allreduce2(const PeerArgs &pa, double &v0, double &v1)
+{
+    __shared__ unsigned halves[PEER_MAX_RANKS * PEER_ELEMS];
+    __shared__ double mine[2];
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) {
+        mine[0] = v0;
+        mine[1] = v1;
+        timed_out = 0;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < pa.world * PEER_ELEMS) {
+        const int q = t / PEER_ELEMS, e = t % PEER_ELEMS;
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(mine[e >> 1]);
+        const unsigned half = (e & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        const unsigned long long word = ((unsigned long long)pa.seq << 32) | half;
+        const int slot = (int)(pa.seq % PEER_SLOTS);
+        __hip_atomic_store(pa.box[q] + peer_word(slot, pa.rank, e), word, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long *src = pa.box[pa.rank] + peer_word(slot, q, e);
+        const long long t0 = wall_clock64();
+        unsigned long long w;
+        for (;;) {
+            w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(w >> 32) == pa.seq) break;
+            if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+                timed_out = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        halves[q * PEER_ELEMS + e] = (unsigned)w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int q = 0; q < pa.world; ++q) {
+            const unsigned *h = halves + q * PEER_ELEMS;
+            s0 += __longlong_as_double((long long)(((unsigned long long)h[1] << 32) | h[0]));
+            s1 += __longlong_as_double((long long)(((unsigned long long)h[3] << 32) | h[2]));
+        }
+        v0 = s0;
+        v1 = s1;
+    }
+    return timed_out == 0;
+}
+
+__global__ __launch_bounds__(64) void k_peer_allreduce(PeerArgs pa, double *vals, int n, int32_t *error)
+{
+    double v0 = 0.0, v1 = 0.0;
+    if (threadIdx.x == 0) {
+        v0 = vals[0];
+        if (n > 1) v1 = vals[1];
+    }
+    const bool ok = peer_allreduce2(pa, v0, v1);
+    if (threadIdx.x == 0) {
+        vals[0] = v0;
+        if (n > 1) vals[1] = v1;
+        if (!ok && error) *error = 1;
+    }
+}
+
 template <int PHASE>
 __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a)
 {
@@ -1221,7 +1292,13 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
             s->sums[1] = v1;
         }
     }
+    bool comm_ok = true;
+    if (a.peer.world > 1 && a.do_reduce && a.do_logic) comm_ok = peer_allreduce2(a.peer, v0, v1);
     if (!a.do_logic || threadIdx.x != 0) return;
+    if (!comm_ok) {  // a rank is gone: end the solve, the host reports OGL_ERR_COMM
+        L.comm_error = 1;
+        L.stop = 1;
+    }
     if (!a.do_reduce) {
         v0 = L.sums[0];
         v1 = L.sums[1];
@@ -1689,6 +1766,11 @@ void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
         hipLaunchKernelGGL((k_finalize<FIN_RAW>), grid, block, 0, st, s, a);
         break;
     }
+}
+
+void launch_peer_allreduce(hipStream_t st, const PeerArgs &pa, double *vals, int n, int32_t *error)
+{
+    hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, st, pa, vals, n, error);
 }
 
 void launch_reset_scalars(hipStream_t st, DevScalars *s)

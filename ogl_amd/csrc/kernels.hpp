@@ -22,7 +22,7 @@ struct DevScalars {
     int32_t n_evals;                    // checks that evaluated the norm
     int32_t stop_phase;                 // BiCGStab: 1 = stopped at the mid-step check (finalize x)
     int32_t stop_turn;                  // BiCGStab: turn index of that stop
-    int32_t pad_;
+    int32_t comm_error;                 // peer all-reduce timed out (a rank is gone): solve fails
     double stale_norm;                  // GMRES: sum|r| of the last restart (what the criterion sees)
 };
 
@@ -217,7 +217,28 @@ enum FinPhase {
 // GMRES small dense state in one device array of doubles:
 //   H[(m+1) x m] column-major | givens_sin[m] | givens_cos[m] | rnc[m+1] | y[m]
 inline size_t gmres_state_len(int m) { return (size_t)(m + 1) * m + 2 * (size_t)m + (m + 1) + m; }
+// Peer-write all-reduce over xGMI (SURVEY.md §8e "peer-write mesh all-reduce"): every rank owns a
+// small mailbox in fine-grained device memory that all ranks have mapped (hipIpc).  All-reduce
+// number `seq`: a rank stores its values into column `rank` of slot seq % PEER_SLOTS of EVERY
+// mailbox, as 64-bit words (32 data bits | seq << 32) so that data and flag arrive in one atomic
+// store, then reads its own mailbox until every column carries `seq`, and adds the columns in rank
+// order -- every rank gets the same bits.  It runs INSIDE the finaliser kernel: no extra launch,
+// no host, no collective library on the latency path of the two reductions per CG turn.
+constexpr int PEER_MAX_RANKS = 16;
+constexpr int PEER_SLOTS = 4;
+constexpr int PEER_ELEMS = 4;  // two doubles as four half-words
+constexpr size_t PEER_BOX_WORDS = (size_t)PEER_SLOTS * PEER_MAX_RANKS * PEER_ELEMS;
+struct PeerArgs {
+    int32_t world = 0;  // 0 / 1: no exchange
+    int32_t rank = 0;
+    uint32_t seq = 0;   // never 0 (the mailboxes start zeroed)
+    unsigned long long *box[PEER_MAX_RANKS] = {};  // mailbox of rank q as mapped in this process
+};
+// vals[0..n) (n <= 2, device memory) summed over the ranks in place; *error set on timeout
+void launch_peer_allreduce(hipStream_t st, const PeerArgs &pa, double *vals, int n, int32_t *error);
+
 struct FinArgs {
+    PeerArgs peer{};  // world > 1: all-reduce the sums inside the kernel (do_reduce && do_logic)
     const double *part[2] = {nullptr, nullptr};
     int32_t n_part = 0;     // entries per partial array
     int32_t n_sums = 1;     // 1 or 2

@@ -103,6 +103,7 @@ ogl_registry::~ogl_registry()
     if (stream) (void)hipStreamSynchronize(stream);
     solvers.clear();
     comm.reset();
+    peer_close();
     cached_precond.values.release();
     cached_precond.block_ptrs.release();
     cached_precond.row_block.release();
@@ -113,6 +114,97 @@ ogl_registry::~ogl_registry()
         (void)hipEventDestroy(ev_received);
     }
     if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// peer-write all-reduce mesh (PeerArgs, kernels.hpp)
+// ------------------------------------------------------------------------------------------
+int ogl_registry::peer_export(void *handle_out)
+{
+    OGL_HIP_CHECK(hipSetDevice(device));
+    if (!peer_local) {
+        void *p = nullptr;
+        const size_t bytes = PEER_BOX_WORDS * sizeof(unsigned long long);
+        // fine-grained: stores from other GPUs become visible to a kernel that is already running
+        OGL_HIP_CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+        OGL_HIP_CHECK(hipMemset(p, 0, bytes));
+        peer_local = static_cast<unsigned long long *>(p);
+        OGL_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&peer_error), sizeof(int32_t)));
+        OGL_HIP_CHECK(hipMemset(peer_error, 0, sizeof(int32_t)));
+        OGL_HIP_CHECK(hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(h) == OGL_PEER_HANDLE_BYTES, "ipc handle size");
+    OGL_HIP_CHECK(hipIpcGetMemHandle(&h, peer_local));
+    std::memcpy(handle_out, &h, sizeof(h));
+    return OGL_OK;
+}
+
+int ogl_registry::peer_connect(int rank, int n_ranks, const void *handles)
+{
+    OGL_HIP_CHECK(hipSetDevice(device));
+    if (!peer_local) return fail(OGL_ERR_STATE, "peer_connect before peer_handle");
+    if (n_ranks > PEER_MAX_RANKS)
+        return fail(OGL_ERR_UNSUPPORTED, "peer all-reduce: at most %d ranks", PEER_MAX_RANKS);
+    peer_ready = false;
+    peer = PeerArgs{};
+    for (int q = 0; q < n_ranks; ++q) {
+        if (q == rank) {
+            peer.box[q] = peer_local;
+            continue;
+        }
+        if (!peer_mapped[q]) {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, static_cast<const char *>(handles) + (size_t)q * sizeof(h), sizeof(h));
+            OGL_HIP_CHECK(hipIpcOpenMemHandle(&peer_mapped[q], h, hipIpcMemLazyEnablePeerAccess));
+        }
+        peer.box[q] = static_cast<unsigned long long *>(peer_mapped[q]);
+    }
+    peer.world = n_ranks;
+    peer.rank = rank;
+    // collective self-test (every rank is inside peer_connect now): two all-reduces of known values
+    DevBuf<double> d;
+    OGL_TRY(d.alloc(2, stream));
+    for (int round = 0; round < 2; ++round) {
+        const double mine[2] = {rank + 1.0 + round, 0.5 * (rank + 1.0)};
+        OGL_HIP_CHECK(hipMemcpyAsync(d.p, mine, sizeof(mine), hipMemcpyHostToDevice, stream));
+        launch_peer_allreduce(stream, peer_next(), d.p, 2, peer_error);
+        double got[2] = {0, 0};
+        int32_t err = 0;
+        OGL_HIP_CHECK(hipMemcpyAsync(got, d.p, sizeof(got), hipMemcpyDeviceToHost, stream));
+        OGL_HIP_CHECK(hipMemcpyAsync(&err, peer_error, sizeof(err), hipMemcpyDeviceToHost, stream));
+        OGL_HIP_CHECK(hipStreamSynchronize(stream));
+        const double tri = 0.5 * n_ranks * (n_ranks + 1.0);
+        if (err || got[0] != tri + (double)round * n_ranks || got[1] != 0.5 * tri)
+            return fail(OGL_ERR_COMM, "peer all-reduce self-test failed (round %d: %g %g, timeout %d)",
+                        round, got[0], got[1], (int)err);
+    }
+    peer_ready = true;
+    return OGL_OK;
+}
+
+void ogl_registry::peer_close()
+{
+    peer_ready = false;
+    for (auto &m : peer_mapped)
+        if (m) {
+            (void)hipIpcCloseMemHandle(m);
+            m = nullptr;
+        }
+    if (peer_local) (void)hipFree(peer_local);
+    if (peer_error) (void)hipFree(peer_error);
+    peer_local = nullptr;
+    peer_error = nullptr;
+    peer = PeerArgs{};
+}
+
+int ogl_registry::allreduce(double *dev, int n)
+{
+    if (!comm->multi()) return OGL_OK;
+    if (!peer_ready) return comm->allreduce(dev, n, stream);
+    for (int i = 0; i < n; i += 2)
+        launch_peer_allreduce(stream, peer_next(), dev + i, std::min(2, n - i), peer_error);
+    return OGL_OK;
 }
 
 ogl_solver::~ogl_solver()
@@ -652,6 +744,14 @@ int ogl_solver::finalize(int phase, FinArgs &a)
         launch_finalize(st, phase, d_scal.p, a);
         return OGL_OK;
     }
+    if (reg->peer_ready) {  // the all-reduce runs inside the finaliser (peer mailboxes over xGMI)
+        a.peer = reg->peer_next();
+        a.do_reduce = 1;
+        a.do_logic = 1;
+        launch_finalize(st, phase, d_scal.p, a);
+        a.peer = PeerArgs{};
+        return OGL_OK;
+    }
     a.do_reduce = 1;
     a.do_logic = 0;
     launch_finalize(st, phase, d_scal.p, a);
@@ -762,7 +862,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         double nn = (double)n;
         OGL_HIP_CHECK(hipMemcpyAsync(sums_ptr(s), &nn, sizeof(double), hipMemcpyHostToDevice, st));
         OGL_HIP_CHECK(hipStreamSynchronize(st));
-        OGL_TRY(reg->comm->allreduce(sums_ptr(s), 1, st));
+        OGL_TRY(reg->allreduce(sums_ptr(s), 1));
         OGL_HIP_CHECK(hipMemcpyAsync(&nn, sums_ptr(s), sizeof(double), hipMemcpyDeviceToHost, st));
         OGL_HIP_CHECK(hipStreamSynchronize(st));
         fa.n_global = nn;
@@ -973,6 +1073,9 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     OGL_HIP_CHECK(hipGetLastError());
     DevScalars fin;
     OGL_HIP_CHECK(hipMemcpy(&fin, s, sizeof(fin), hipMemcpyDeviceToHost));
+    if (fin.comm_error)
+        return fail(OGL_ERR_COMM, "peer all-reduce timed out: a rank did not take part (check %d)",
+                    fin.iter);
     if (!gmres && !bicg && !generic && fin.iter - 1 >= enq) {
         // the stop came with the check of the last enqueued turn: no step_1x followed to apply
         // that turn's x update
@@ -1031,7 +1134,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     if (reg->comm->multi()) {  // broadcast from rank 0 (:291-292) so every rank adapts alike
         double v = reg->comm->rank == 0 ? rel_cost : 0.0;
         OGL_HIP_CHECK(hipMemcpy(sums_ptr(s), &v, sizeof(double), hipMemcpyHostToDevice));
-        OGL_TRY(reg->comm->allreduce(sums_ptr(s), 1, st));
+        OGL_TRY(reg->allreduce(sums_ptr(s), 1));
         OGL_HIP_CHECK(hipStreamSynchronize(st));
         OGL_HIP_CHECK(hipMemcpy(&rel_cost, sums_ptr(s), sizeof(double), hipMemcpyDeviceToHost));
     }

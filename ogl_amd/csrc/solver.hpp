@@ -117,6 +117,28 @@ struct ogl_registry {
     // "Cached_preconditinoner" (sic) -- one registry-wide slot (Preconditioner.H:357)
     ogl::PrecondData cached_precond;
     bool has_cached_precond = false;
+    // Peer-write all-reduce mesh (PeerArgs, kernels.hpp): own mailbox + the other ranks' mailboxes
+    // mapped through hipIpc.  When `peer_ready`, the scalar all-reduces run inside the finaliser
+    // kernels instead of through comm->allreduce (the halo exchange stays with `comm`).
+    unsigned long long *peer_local = nullptr;
+    void *peer_mapped[ogl::PEER_MAX_RANKS] = {};  // hipIpcOpenMemHandle results (closed on destroy)
+    int32_t *peer_error = nullptr;                // device flag for the stand-alone all-reduce kernel
+    ogl::PeerArgs peer{};                         // world/rank/box[]; seq is stamped per call
+    uint32_t peer_seq = 0;
+    bool peer_ready = false;
+    int peer_export(void *handle_out);
+    int peer_connect(int rank, int n_ranks, const void *handles);
+    void peer_close();
+    // next all-reduce's arguments (every rank calls this the same number of times, in the same order)
+    ogl::PeerArgs peer_next()
+    {
+        ogl::PeerArgs p = peer;
+        if (++peer_seq == 0) ++peer_seq;
+        p.seq = peer_seq;
+        return p;
+    }
+    // in-place SUM of n <= 2 doubles over the ranks, on `stream`
+    int allreduce(double *dev, int n);
     ~ogl_registry();
 };
 

@@ -75,6 +75,28 @@ struct InstallCommHook {
                 rc = ogl_registry_init_rccl(reg, Pstream::myProcNo(), Pstream::nProcs(), id.begin());
             }
             if (rc != OGL_OK) FatalErrorInFunction << ogl_last_error() << abort(FatalError);
+            // scalar all-reduces through peer-written mailboxes over xGMI (single node, <= 16
+            // ranks): all-gather the 64-byte IPC handles, connect (collective self-test), and keep
+            // the transport's own all-reduce if any rank cannot join
+            if (controls.lookupOrDefault<Switch>("peerAllReduce", true) &&
+                Pstream::nProcs() <= 16) {
+                List<List<char>> handles(Pstream::nProcs());
+                handles[Pstream::myProcNo()].setSize(OGL_PEER_HANDLE_BYTES, '\0');
+                label ok = ogl_registry_peer_handle(reg, handles[Pstream::myProcNo()].begin()) == OGL_OK;
+                Pstream::gatherList(handles);
+                Pstream::scatterList(handles);
+                reduce(ok, minOp<label>());
+                if (ok) {
+                    List<char> flat(OGL_PEER_HANDLE_BYTES * Pstream::nProcs());
+                    forAll(handles, p)
+                        std::copy(handles[p].begin(), handles[p].end(),
+                                  flat.begin() + OGL_PEER_HANDLE_BYTES * p);
+                    ok = ogl_registry_peer_connect(reg, Pstream::myProcNo(), Pstream::nProcs(),
+                                                   flat.begin()) == OGL_OK;
+                    reduce(ok, minOp<label>());
+                }
+                if (!ok) ogl_registry_peer_disable(reg);
+            }
         };
     }
 } installCommHook_;

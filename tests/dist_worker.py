@@ -54,7 +54,18 @@ def allreduce(a):
     return t.numpy()
 
 
-def oracle_dist_matrix(case):
+def allreduce_rank_order(a):
+    """((0 + v_0) + v_1) + ... : the order of the peer-write all-reduce (kernels.hip)."""
+    mine = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    out = np.zeros_like(mine.numpy())
+    for p in parts:
+        out = out + p.numpy()
+    return out
+
+
+def oracle_dist_matrix(case, allreduce=allreduce):
     ifs = orc_ifaces(orc, case)
     rp, cols, vals = oracle_csr(orc, case)
     nl_rows, nl_cols, nl_perm = orc.init_non_local_sparsity(ifs)
@@ -99,7 +110,8 @@ def main():
     b = b_g[case.global_index]
     skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
 
-    A, (rp, cols, vals), nl, comm = oracle_dist_matrix(case)
+    A, (rp, cols, vals), nl, comm = oracle_dist_matrix(
+        case, allreduce_rank_order if args.mode == "gpu-peer" else allreduce)
     inv = orc.jacobi_generate_scalar(rp, cols, vals) if args.precond else None
 
     # ---- product host logic per rank vs the oracle (pure host, no GPU) ----
@@ -145,9 +157,15 @@ def main():
         n_dev = torch.cuda.device_count()
         dev = rank % max(1, n_dev)
         reg = capi.Registry(device_id=dev)
-        if args.mode == "gpu-host":
+        if args.mode in ("gpu-host", "gpu-peer"):
             ex = make_exchange(None)
             reg.set_host_comm(rank, world, allreduce, lambda nb, ct, s: ex(nb, ct, s))
+            if args.mode == "gpu-peer":
+                # scalar all-reduces through the peer mailboxes (hipIpc), inside the finaliser
+                # kernels; the halo exchange stays on the host-buffer transport
+                handles = [None] * world
+                dist.all_gather_object(handles, reg.peer_handle())
+                reg.peer_connect(rank, world, handles)
         else:
             uid = [capi.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
@@ -157,7 +175,7 @@ def main():
             (capi.SOLVER_BICGSTAB if args.asym else capi.SOLVER_CG), krylov_dim=args.gmres,
             preconditioner=capi.PRECOND_BJ if args.precond else capi.PRECOND_NONE,
             tolerance=1e-11, rel_tol=0.0, max_iter=300, export_res=1, adapt_min_iter=0,
-            matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode == "gpu-host"))
+            matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode != "gpu-rccl"))
         s = reg.solver("p", cfg).set_matrix(case)
         # device halo matrix == oracle's
         r_, c_, m_, v_ = s.non_local_matrix()
@@ -169,8 +187,8 @@ def main():
         hist = s.history()
         with blocked(orc, capi.lib().ogl_reduction_chunk_rows()):
             ref = solve(A, b, np.zeros_like(b), inv, **skw)
-        if args.mode == "gpu-host":
-            # same local trees, same 2-operand gloo sum: bit-identical
+        if args.mode in ("gpu-host", "gpu-peer"):
+            # same local trees, same order of the sum over ranks: bit-identical
             assert perf.n_iterations == (ref.n_iterations // 2 if (args.asym and not args.gmres)
                                          else ref.n_iterations)
             np.testing.assert_array_equal(hist, ref.history)

@@ -74,3 +74,23 @@ def test_oracle_two_ranks_gmres():
 @pytest.mark.gpu
 def test_gpu_rccl_single_rank():
     run_ranks(1, "--mode", "gpu-rccl", "--shape", "12,12,12", "--procs", "1,1,1")
+
+
+# Peer-write all-reduce (PeerArgs, kernels.hpp): the scalar reductions go through hipIpc-mapped
+# mailboxes inside the finaliser kernels.  The ranks share the one GPU of the box here (IPC between
+# processes on one device); bit-identical to the distributed oracle with rank-ordered sums.
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,procs,n", [("16,16,16", "1,1,2", 2), ("12,12,12", "2,2,1", 4),
+                                          ("12,12,12", "2,2,2", 8)])
+def test_gpu_peer_allreduce_cg(shape, procs, n):
+    run_ranks(n, "--mode", "gpu-peer", "--shape", shape, "--procs", procs)
+
+
+@pytest.mark.gpu
+def test_gpu_peer_allreduce_bicgstab():
+    run_ranks(3, "--mode", "gpu-peer", "--shape", "12,12,12", "--procs", "1,1,3", "--asym", "1")
+
+
+@pytest.mark.gpu
+def test_gpu_peer_allreduce_gmres():
+    run_ranks(2, "--mode", "gpu-peer", "--shape", "10,10,10", "--procs", "1,1,2", "--gmres", "20")
