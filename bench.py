@@ -252,6 +252,11 @@ def main():
         spmv_src = f"{launches} in-loop launches of the timed steps, HIP event pairs"
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
     layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[s.get_property("spmvLayout")]
+    if world > 1 and s.get_property("peerHalo") == 1.0:
+        # the transport above was only the bootstrap: halo values are put straight into the
+        # neighbours' receive blocks (hipIpc-mapped) by the pack kernel
+        transport = "peer-put halo + peer-write all-reduce over xGMI (hipIpc), bootstrap: " + \
+                    ("RCCL" if transport.startswith("RCCL") else "gloo")
     kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell"}[layout]
     # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
     b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout == "sell" else b_spmv

@@ -176,10 +176,14 @@ int ogl_registry_set_host_comm(ogl_registry *reg, int32_t rank, int32_t n_ranks,
 int ogl_rccl_unique_id(void *id_out);
 int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n_ranks, const void *id);
 
-/* Peer-write all-reduce over xGMI for the scalar reductions of the Krylov loop (the MPI_Allreduce
- * behind gko's distributed dot / norm1, StoppingCriterion.C:19,54-63,94).  Optional, on top of
- * either transport above (which keeps the halo exchange): every rank exports a 64-byte IPC handle
- * of its mailbox, the host all-gathers them (MPI_Allgather in OpenFOAM), every rank connects.
+/* Peer mesh over xGMI (hipIpc): the scalar reductions of the Krylov loop (the MPI_Allreduce behind
+ * gko's distributed dot / norm1, StoppingCriterion.C:19,54-63,94) run inside the finaliser kernels
+ * through peer-written mailboxes, and the halo values of every SpMV (sparse_communicator,
+ * CsrMatrixWrapper.H:195-204) are put straight into the neighbours' receive blocks by the pack
+ * kernel.  Optional, on top of either transport above (which remains the fallback and the
+ * bootstrap): every rank exports a 64-byte IPC handle of its mailbox + arena, the host all-gathers
+ * them (MPI_Allgather in OpenFOAM), every rank connects BEFORE the first set_matrix of any field.
+ * With the mesh up, building a field's sparsity pattern is collective over the ranks.
  * peer_connect is COLLECTIVE: it runs a self-test all-reduce and fails on every rank alike if the
  * mesh does not work; call ogl_registry_peer_disable then and the transport's own all-reduce is
  * used.  At most 16 ranks, one node. */

@@ -1260,6 +1260,67 @@ __global__ __launch_bounds__(64) void k_peer_allreduce(PeerArgs pa, double *vals
     }
 }
 
+// ---- peer-put halo exchange (PeerHalo, kernels.hpp) ----
+__global__ __launch_bounds__(BLOCK) void k_pack_put(int n_send, const int *__restrict__ send_idxs,
+                                                    PeerHalo P, const double *__restrict__ x,
+                                                    const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= n_send) return;
+    int i = 0;
+    while (i + 1 < P.n_neigh && j >= P.send_off[i + 1]) ++i;
+    P.remote_recv[i][j - P.send_off[i]] = x[send_idxs[j]];
+    __threadfence_system();  // the put has left this GPU before the kernel (and its signal) completes
+}
+
+__global__ __launch_bounds__(64) void k_halo_signal(PeerHalo P, const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const int i = threadIdx.x;
+    if (i < P.n_neigh)
+        __hip_atomic_store(P.remote_flag[i], (unsigned long long)P.seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(64) void k_halo_wait(PeerHalo P, const DevScalars *gate, DevScalars *s)
+{
+    __shared__ int timed_out;
+    if (gate && gate->stop) return;
+    if (threadIdx.x == 0) timed_out = 0;
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < P.n_neigh) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned long long w =
+                __hip_atomic_load(P.local_flag + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((uint32_t)w == P.seq) break;
+            if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+                timed_out = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && timed_out) {  // a neighbour is gone: end the solve
+        s->comm_error = 1;
+        s->stop = 1;
+    }
+}
+
+__global__ void k_peer_post(unsigned long long *dst, unsigned long long w0, unsigned long long w1,
+                            unsigned long long w2, unsigned long long w3)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __hip_atomic_store(dst + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 3, w3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(dst, w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int PHASE>
 __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a)
 {
@@ -1771,6 +1832,32 @@ void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
 void launch_peer_allreduce(hipStream_t st, const PeerArgs &pa, double *vals, int n, int32_t *error)
 {
     hipLaunchKernelGGL(k_peer_allreduce, dim3(1), dim3(64), 0, st, pa, vals, n, error);
+}
+
+void launch_pack_put(hipStream_t st, const DevHalo &H, const PeerHalo &P, const double *x,
+                     const DevScalars *gate)
+{
+    if (H.n_send == 0) return;
+    hipLaunchKernelGGL(k_pack_put, dim3(blocks_for(H.n_send)), dim3(BLOCK), 0, st, H.n_send,
+                       H.send_idxs, P, x, gate);
+}
+
+void launch_halo_signal(hipStream_t st, const PeerHalo &P, const DevScalars *gate)
+{
+    if (P.n_neigh == 0) return;
+    hipLaunchKernelGGL(k_halo_signal, dim3(1), dim3(64), 0, st, P, gate);
+}
+
+void launch_halo_wait(hipStream_t st, const PeerHalo &P, const DevScalars *gate, DevScalars *s)
+{
+    if (P.n_neigh == 0) return;
+    hipLaunchKernelGGL(k_halo_wait, dim3(1), dim3(64), 0, st, P, gate, s);
+}
+
+void launch_peer_post(hipStream_t st, unsigned long long *dst, unsigned long long w0,
+                      unsigned long long w1, unsigned long long w2, unsigned long long w3)
+{
+    hipLaunchKernelGGL(k_peer_post, dim3(1), dim3(64), 0, st, dst, w0, w1, w2, w3);
 }
 
 void launch_reset_scalars(hipStream_t st, DevScalars *s)

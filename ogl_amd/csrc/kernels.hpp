@@ -237,6 +237,33 @@ struct PeerArgs {
 // vals[0..n) (n <= 2, device memory) summed over the ranks in place; *error set on timeout
 void launch_peer_allreduce(hipStream_t st, const PeerArgs &pa, double *vals, int n, int32_t *error);
 
+// Peer-put halo exchange (SURVEY.md §8e "pack x[send_idxs] then peer-to-peer put to each neighbour
+// over xGMI").  A rank's IPC allocation is [mailbox | control slots | arena]; every solver with
+// processor interfaces owns an arena block [flags 2 x n_neigh | recv parity 0 | recv parity 1].
+// SpMV number `seq` of a solver: k_pack_put stores x[send_idxs] straight into the neighbours' recv
+// segments of parity seq & 1, k_halo_signal then stores `seq` into their flag for this rank; the
+// local SpMV runs; k_halo_wait spins until every neighbour's flag carries `seq`; the non-local
+// kernel reads the recv block.  Two parities: a neighbour can be at most one SpMV ahead.
+constexpr size_t PEER_CTRL_WORDS = (size_t)PEER_MAX_RANKS * 4;  // per source rank: epoch + 3 words
+constexpr size_t PEER_ARENA_OFF = PEER_BOX_WORDS + PEER_CTRL_WORDS;  // 8-byte words from the base
+constexpr int PEER_MAX_NEIGH = 16;
+struct PeerHalo {
+    int32_t n_neigh = 0;
+    uint32_t seq = 0;
+    int32_t send_off[PEER_MAX_NEIGH + 1] = {};             // send buffer blocks, by neighbour
+    double *remote_recv[PEER_MAX_NEIGH] = {};              // neighbour i's segment for this rank
+    unsigned long long *remote_flag[PEER_MAX_NEIGH] = {};  // neighbour i's flag for this rank
+    const unsigned long long *local_flag = nullptr;        // this rank's flags, one per neighbour
+};
+void launch_pack_put(hipStream_t st, const DevHalo &H, const PeerHalo &P, const double *x,
+                     const DevScalars *gate);
+void launch_halo_signal(hipStream_t st, const PeerHalo &P, const DevScalars *gate);
+// `s` receives comm_error / stop when a neighbour does not show up within the timeout
+void launch_halo_wait(hipStream_t st, const PeerHalo &P, const DevScalars *gate, DevScalars *s);
+// control message to another rank: dst[1..3] = w1..w3, then dst[0] = w0 (the epoch)
+void launch_peer_post(hipStream_t st, unsigned long long *dst, unsigned long long w0,
+                      unsigned long long w1, unsigned long long w2, unsigned long long w3);
+
 struct FinArgs {
     PeerArgs peer{};  // world > 1: all-reduce the sums inside the kernel (do_reduce && do_logic)
     const double *part[2] = {nullptr, nullptr};

@@ -124,10 +124,16 @@ int ogl_registry::peer_export(void *handle_out)
     OGL_HIP_CHECK(hipSetDevice(device));
     if (!peer_local) {
         void *p = nullptr;
-        const size_t bytes = PEER_BOX_WORDS * sizeof(unsigned long long);
+        // [mailbox | control slots | halo arena]; OGL_PEER_ARENA_MB (default 64) bounds the halo
+        // blocks of all fields of this rank (2 x 8 bytes per halo entry and field)
+        size_t arena_mb = 64;
+        if (const char *e = std::getenv("OGL_PEER_ARENA_MB")) arena_mb = (size_t)std::max(1, atoi(e));
+        arena_words = arena_mb * (1u << 20) / sizeof(unsigned long long);
+        arena_used = 0;
+        const size_t bytes = (PEER_ARENA_OFF + arena_words) * sizeof(unsigned long long);
         // fine-grained: stores from other GPUs become visible to a kernel that is already running
         OGL_HIP_CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
-        OGL_HIP_CHECK(hipMemset(p, 0, bytes));
+        OGL_HIP_CHECK(hipMemset(p, 0, PEER_ARENA_OFF * sizeof(unsigned long long)));
         peer_local = static_cast<unsigned long long *>(p);
         OGL_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&peer_error), sizeof(int32_t)));
         OGL_HIP_CHECK(hipMemset(peer_error, 0, sizeof(int32_t)));
@@ -196,6 +202,106 @@ void ogl_registry::peer_close()
     peer_local = nullptr;
     peer_error = nullptr;
     peer = PeerArgs{};
+}
+
+// ------------------------------------------------------------------------------------------
+// Peer-put halo: per sparsity pattern, every rank takes a block of its arena, tells each neighbour
+// where that neighbour's values go (control slot [this rank] of the neighbour's allocation, written
+// by a one-thread kernel), reads what the neighbours said, and all ranks agree (all-reduce, which is
+// also the barrier that frees the control slots) whether this field uses the peer-put exchange.
+// ------------------------------------------------------------------------------------------
+int ogl_solver::setup_peer_halo()
+{
+    peer_halo = false;
+    peer_nb.clear();
+    halo_seq = 0;
+    props["peerHalo"] = 0.0;
+    ogl_registry &R = *reg;
+    if (!R.peer_ready) return OGL_OK;
+    hipStream_t st = R.stream;
+    const int nn = (int)neighbours.size();
+    const size_t nh = (size_t)pat.non_local_nnz;
+    const uint32_t epoch = ++R.halo_epoch;
+    double cannot = 0.0;
+    const size_t words = (2 * (size_t)nn + 2 * nh + 15) / 16 * 16;
+    if (nn > PEER_MAX_NEIGH || R.arena_used + words > R.arena_words) cannot = 1.0;
+    if (cannot == 0.0) {
+        peer_block = R.arena_used;
+        R.arena_used += words;
+        if (nn)
+            OGL_HIP_CHECK(hipMemsetAsync(R.peer_local + PEER_ARENA_OFF + peer_block, 0,
+                                         2 * (size_t)nn * sizeof(unsigned long long), st));
+    }
+    int32_t seg = 0;
+    for (int i = 0; i < nn; ++i) {
+        unsigned long long *dst = R.peer.box[neighbours[i]] + PEER_BOX_WORDS + (size_t)R.peer.rank * 4;
+        launch_peer_post(st, dst, epoch, cannot == 0.0 ? (unsigned long long)peer_block : ~0ull,
+                         ((unsigned long long)nn << 32) | (unsigned)i,
+                         ((unsigned long long)nh << 32) | (unsigned)seg);
+        seg += counts[i];
+    }
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    peer_nb.resize(nn);
+    for (int i = 0; i < nn; ++i) {
+        const unsigned long long *src = R.peer_local + PEER_BOX_WORDS + (size_t)neighbours[i] * 4;
+        unsigned long long w[4] = {0, 0, 0, 0};
+        const double t0 = now_ms();
+        for (;;) {
+            OGL_HIP_CHECK(hipMemcpy(w, src, sizeof(w), hipMemcpyDeviceToHost));
+            if ((uint32_t)w[0] == epoch) {
+                // the epoch word is stored last: re-read once so that the payload is the final one
+                OGL_HIP_CHECK(hipMemcpy(w, src, sizeof(w), hipMemcpyDeviceToHost));
+                break;
+            }
+            if (now_ms() - t0 > 60e3)
+                return fail(OGL_ERR_COMM, "peer halo handshake: rank %d did not answer", neighbours[i]);
+        }
+        if (w[1] == ~0ull) cannot = 1.0;
+        peer_nb[i].block = (size_t)w[1];
+        peer_nb[i].n_neigh = (int32_t)(w[2] >> 32);
+        peer_nb[i].my_index = (int32_t)(w[2] & 0xffffffffu);
+        peer_nb[i].n_halo = (int32_t)(w[3] >> 32);
+        peer_nb[i].my_seg = (int32_t)(w[3] & 0xffffffffu);
+    }
+    DevBuf<double> agree;
+    OGL_TRY(agree.alloc(2, st));
+    OGL_HIP_CHECK(hipMemcpyAsync(agree.p, &cannot, sizeof(double), hipMemcpyHostToDevice, st));
+    OGL_TRY(R.allreduce(agree.p, 1));
+    OGL_HIP_CHECK(hipMemcpyAsync(&cannot, agree.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    peer_halo = cannot == 0.0;
+    props["peerHalo"] = peer_halo ? 1.0 : 0.0;
+    return OGL_OK;
+}
+
+PeerHalo ogl_solver::peer_halo_args(uint32_t seq) const
+{
+    const ogl_registry &R = *reg;
+    const int nn = (int)neighbours.size();
+    const unsigned par = seq & 1u;
+    PeerHalo P;
+    P.n_neigh = nn;
+    P.seq = seq;
+    int32_t off = 0;
+    for (int i = 0; i < nn; ++i) {
+        P.send_off[i] = off;
+        off += counts[i];
+        const PeerNeighbour &nb = peer_nb[i];
+        unsigned long long *base = R.peer.box[neighbours[i]] + PEER_ARENA_OFF + nb.block;
+        P.remote_flag[i] = base + (size_t)par * nb.n_neigh + nb.my_index;
+        P.remote_recv[i] = reinterpret_cast<double *>(base + 2 * (size_t)nb.n_neigh +
+                                                      (size_t)par * nb.n_halo + nb.my_seg);
+    }
+    P.send_off[nn] = off;
+    P.local_flag = R.peer_local + PEER_ARENA_OFF + peer_block + (size_t)par * nn;
+    return P;
+}
+
+double *ogl_solver::peer_recv(uint32_t seq) const
+{
+    const size_t nn = neighbours.size();
+    return reinterpret_cast<double *>(reg->peer_local + PEER_ARENA_OFF + peer_block + 2 * nn +
+                                      (size_t)(seq & 1u) * (size_t)pat.non_local_nnz);
 }
 
 int ogl_registry::allreduce(double *dev, int n)
@@ -432,6 +538,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         if ((size_t)pat.non_local_nnz != pat.send_idxs.size())
             return fail(OGL_ERR_INVALID, "send/receive sizes differ");
         OGL_TRY(ensure_vectors());
+        OGL_TRY(setup_peer_halo());  // collective when the peer mesh is up (every rank, every pattern)
     }
 
     // ---- coefficients (update_local_matrix_data :592-705) ----
@@ -693,7 +800,17 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
 {
     hipStream_t st = reg->stream;
     const bool has_halo = pat.non_local_nnz > 0;
-    if (has_halo) {
+    const double *recv = d_recv.p;
+    PeerHalo ph;
+    if (has_halo && peer_halo) {
+        // peer-put: the values go straight into the neighbours' receive blocks over xGMI, then the
+        // flags; they fly while the local SpMV below runs
+        if (++halo_seq == 0) ++halo_seq;
+        ph = peer_halo_args(halo_seq);
+        recv = peer_recv(halo_seq);
+        launch_pack_put(st, halo(), ph, x, gate);
+        launch_halo_signal(st, ph, gate);
+    } else if (has_halo) {
         // pack on the compute stream, exchange on the communication stream: the neighbour copies
         // fly while the local SpMV below runs; the non-local kernel waits for their arrival
         if (!reg->comm_stream) {
@@ -717,8 +834,11 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     else
         launch_spmv(st, csr(), mode, x, b, y, dots, gate);
     if (has_halo) {
-        OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
-        launch_spmv_non_local(st, halo(), mode, d_recv.p, y, gate);
+        if (peer_halo)
+            launch_halo_wait(st, ph, gate, d_scal.p);
+        else
+            OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
+        launch_spmv_non_local(st, halo(), mode, recv, y, gate);
         if (dots.part)
             launch_partials_dot_chunks(st, pat.n_rows, dots.with, y, dots.part, gate,
                                        d_boundary_chunks.p, n_boundary_chunks);

@@ -126,6 +126,11 @@ struct ogl_registry {
     ogl::PeerArgs peer{};                         // world/rank/box[]; seq is stamped per call
     uint32_t peer_seq = 0;
     bool peer_ready = false;
+    // peer-put halo arena behind the mailbox in the same IPC allocation (PeerHalo, kernels.hpp):
+    // solvers take blocks at pattern-build time; every rank builds patterns in the same order, so
+    // `halo_epoch` names the same handshake on all ranks
+    size_t arena_words = 0, arena_used = 0;
+    uint32_t halo_epoch = 0;
     int peer_export(void *handle_out);
     int peer_connect(int rank, int n_ranks, const void *handles);
     void peer_close();
@@ -174,6 +179,18 @@ struct ogl_solver {
     bool sell_values_stale = true;
     int build_sell();
     ogl::DevSell sell() const;
+    // peer-put halo exchange (PeerHalo, kernels.hpp): agreed per sparsity pattern by all ranks
+    struct PeerNeighbour {
+        size_t block = 0;   // the neighbour's arena block (words from its arena start)
+        int32_t n_neigh = 0, my_index = 0, n_halo = 0, my_seg = 0;  // its layout, this rank's place
+    };
+    bool peer_halo = false;
+    size_t peer_block = 0;  // this solver's arena block
+    std::vector<PeerNeighbour> peer_nb;
+    uint32_t halo_seq = 0;
+    int setup_peer_halo();
+    ogl::PeerHalo peer_halo_args(uint32_t seq) const;
+    double *peer_recv(uint32_t seq) const;
     bool use_sell() const
     {
         return cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices && sell_state == 1 &&
