@@ -258,6 +258,15 @@ struct PeerHalo {
 void launch_pack_put(hipStream_t st, const DevHalo &H, const PeerHalo &P, const double *x,
                      const DevScalars *gate);
 void launch_halo_signal(hipStream_t st, const PeerHalo &P, const DevScalars *gate);
+// the same three steps in two launches: [pack + put + signal by the last workgroup] and, after the
+// local SpMV, [wait + y += A_non_local recv + dot partials of the chunks that hold boundary rows]
+// (one workgroup per such chunk; chunk_row_ptr = ranges of H.boundary_rows per listed chunk)
+void launch_pack_put_signal(hipStream_t st, const DevHalo &H, const PeerHalo &P, const double *x,
+                            const DevScalars *gate, unsigned *ticket);
+void launch_halo_finish(hipStream_t st, const DevHalo &H, int mode, int32_t n_rows,
+                        const int32_t *chunk_list, const int32_t *chunk_row_ptr, int32_t n_chunks_b,
+                        const double *recv, double *y, const SpmvDots &dots, const PeerHalo &P,
+                        const DevScalars *gate, DevScalars *s);
 // `s` receives comm_error / stop when a neighbour does not show up within the timeout
 void launch_halo_wait(hipStream_t st, const PeerHalo &P, const DevScalars *gate, DevScalars *s);
 // control message to another rank: dst[1..3] = w1..w3, then dst[0] = w0 (the epoch)

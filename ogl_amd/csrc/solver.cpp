@@ -505,10 +505,19 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         boundary_ptrs.push_back(pat.non_local_nnz);
         const size_t hn = (size_t)pat.non_local_nnz;
         {  // chunks whose fused dot partials must be redone after the non-local part was added
-            std::vector<int32_t> bc;
-            for (int32_t r : boundary_rows)
-                if (bc.empty() || bc.back() != r / CHUNK_ROWS) bc.push_back(r / CHUNK_ROWS);
+            std::vector<int32_t> bc, bc_ptr;
+            for (size_t i = 0; i < boundary_rows.size(); ++i) {
+                const int32_t r = boundary_rows[i];
+                if (bc.empty() || bc.back() != r / CHUNK_ROWS) {
+                    bc.push_back(r / CHUNK_ROWS);
+                    bc_ptr.push_back((int32_t)i);
+                }
+            }
+            bc_ptr.push_back((int32_t)boundary_rows.size());
             n_boundary_chunks = (int32_t)bc.size();
+            OGL_TRY(d_boundary_chunk_ptr.alloc(bc_ptr.size(), st));
+            OGL_TRY(reg->stager.h2d(d_boundary_chunk_ptr.p, bc_ptr.data(), bc_ptr.size() * sizeof(int32_t), st));
+            OGL_TRY(d_ticket.alloc(1, st));
             OGL_TRY(d_boundary_chunks.alloc(bc.size(), st));
             if (!bc.empty())
                 OGL_TRY(reg->stager.h2d(d_boundary_chunks.p, bc.data(), bc.size() * sizeof(int32_t), st));
@@ -808,8 +817,7 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
         if (++halo_seq == 0) ++halo_seq;
         ph = peer_halo_args(halo_seq);
         recv = peer_recv(halo_seq);
-        launch_pack_put(st, halo(), ph, x, gate);
-        launch_halo_signal(st, ph, gate);
+        launch_pack_put_signal(st, halo(), ph, x, gate, d_ticket.p);
     } else if (has_halo) {
         // pack on the compute stream, exchange on the communication stream: the neighbour copies
         // fly while the local SpMV below runs; the non-local kernel waits for their arrival
@@ -833,11 +841,12 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
         launch_spmv_sell(st, sell(), mode, x, b, y, dots, gate);
     else
         launch_spmv(st, csr(), mode, x, b, y, dots, gate);
-    if (has_halo) {
-        if (peer_halo)
-            launch_halo_wait(st, ph, gate, d_scal.p);
-        else
-            OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
+    if (has_halo && peer_halo) {
+        // wait for the neighbours' flags, add the non-local part, redo the touched chunks' partials
+        launch_halo_finish(st, halo(), mode, pat.n_rows, d_boundary_chunks.p, d_boundary_chunk_ptr.p,
+                           n_boundary_chunks, recv, y, dots, ph, gate, d_scal.p);
+    } else if (has_halo) {
+        OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
         launch_spmv_non_local(st, halo(), mode, recv, y, gate);
         if (dots.part)
             launch_partials_dot_chunks(st, pat.n_rows, dots.with, y, dots.part, gate,

@@ -188,6 +188,8 @@ struct ogl_solver {
     size_t peer_block = 0;  // this solver's arena block
     std::vector<PeerNeighbour> peer_nb;
     uint32_t halo_seq = 0;
+    ogl::DevBuf<int32_t> d_boundary_chunk_ptr;  // ranges of boundary_rows per boundary chunk
+    ogl::DevBuf<unsigned> d_ticket;             // last-workgroup ticket of k_pack_put_signal
     int setup_peer_halo();
     ogl::PeerHalo peer_halo_args(uint32_t seq) const;
     double *peer_recv(uint32_t seq) const;
