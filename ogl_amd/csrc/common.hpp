@@ -31,19 +31,26 @@ inline int64_t n_chunks(int64_t n_rows) { return (n_rows + CHUNK_ROWS - 1) / CHU
 
 // Index-compressed chunked ELL ("SELL-512 with diagonal codes"): the layout the Coo/Csr-format path
 // runs on when the sparsity pattern allows it.  Per chunk of CHUNK_ROWS rows: `width` = its longest
-// row, values slot-major [width][CHUNK_ROWS], and ONE BYTE per (row, slot) that names an entry of
-// the chunk's dictionary of (column - row) offsets (255 = padding slot).  Moves 9 bytes per stored
-// entry instead of CSR's 12; rows are still summed in stored column order, so y and the fused dot
-// partials are bit-identical to the CSR kernel's.
+// row, values slot-major [width][CHUNK_ROWS], and the columns coded in one of two ways:
+//   pattern mode (code_stride == ROWS_PER_THREAD): ONE BYTE PER ROW naming one of <= 256 row
+//     patterns of the chunk; the table holds `width` (column - row) offsets per pattern,
+//     SELL_PAD_OFFSET in the unused tail slots.  8.1 bytes per stored entry on a 7-point stencil;
+//   offset mode (code_stride a multiple of 16): one byte per (row, slot) naming an entry of the
+//     chunk's ascending dictionary of <= 255 offsets (255 = padding slot).  9 bytes per entry.
+// CSR moves 12.  Rows are still summed in stored column order, so y and the fused dot partials are
+// bit-identical to the CSR kernel's.
 struct SellChunk {
     int64_t val_off;      // first value of the chunk (doubles)
     int64_t code_off;     // first code byte of the chunk
     int32_t dict_off;     // first dictionary entry of the chunk
-    int32_t dict_len;     // <= SELL_MAX_DICT
+    int32_t dict_len;     // table ints (pattern mode: patterns x width; offset mode: <= SELL_MAX_DICT)
     int32_t width;        // slots per row in this chunk
-    int32_t code_stride;  // code bytes per thread (ROWS_PER_THREAD rows x width, rounded up to 16)
+    int32_t code_stride;  // code bytes per thread: ROWS_PER_THREAD (pattern mode) or
+                          // ROWS_PER_THREAD x width rounded up to 16 (offset mode)
 };
-constexpr int SELL_MAX_DICT = 255;        // code 255 marks a padding slot
+constexpr int SELL_MAX_DICT = 255;        // offset mode: code 255 marks a padding slot
+constexpr int SELL_TABLE_INTS = 2048;     // LDS table of the SpMV kernel (8 KB)
+constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of a pattern
 constexpr double SELL_MAX_PADDING = 1.25;  // padded slots / nnz above which CSR moves fewer bytes
 
 }  // namespace ogl

@@ -291,58 +291,116 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     const int64_t nc = n_chunks(n_rows);
     const int64_t nnz = n_rows > 0 ? row_ptrs[n_rows] : 0;
     out.chunks.resize((size_t)nc);
-    std::vector<int32_t> ds;
+    std::vector<int32_t> ds;    // distinct offsets of the chunk
+    std::vector<int32_t> pats;  // distinct row patterns of the chunk, `width` offsets each
+    std::vector<int32_t> pat;
+    std::vector<uint8_t> pid(CHUNK_ROWS);
     int64_t val_len = 0, code_len = 0;
+    // pass 1: per chunk the width, the coding mode, the dictionary / pattern table and the offsets
+    std::vector<uint8_t> pid_all;  // pattern ids of the chunks in pattern mode, chunk after chunk
     for (int64_t c = 0; c < nc; ++c) {
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
         int32_t width = 0;
-        ds.clear();
-        size_t last = 0;  // most entries repeat the offset found `dict_len` entries ago
-        for (ogl_label r = r0; r < r1; ++r) {
-            width = std::max(width, row_ptrs[r + 1] - row_ptrs[r]);
-            for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
-                const int32_t d = cols[k] - r;
-                if (!ds.empty()) {
-                    if (ds[last] == d) continue;
-                    size_t i = 0;
-                    while (i < ds.size() && ds[i] != d) ++i;
-                    if (i < ds.size()) {
-                        last = i;
-                        continue;
+        for (ogl_label r = r0; r < r1; ++r) width = std::max(width, row_ptrs[r + 1] - row_ptrs[r]);
+        // (a) row patterns: one byte per row
+        bool pat_mode = width > 0;
+        pats.clear();
+        size_t last_pat = 0;
+        for (ogl_label lr = 0; lr < CHUNK_ROWS && pat_mode; ++lr) {
+            const ogl_label r = r0 + lr;
+            pat.assign((size_t)width, SELL_PAD_OFFSET);
+            if (r < r1)
+                for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s)
+                    pat[(size_t)s] = cols[k] - r;
+            const size_t n_pat = pats.size() / (size_t)width;
+            auto same = [&](size_t i) {
+                return std::equal(pat.begin(), pat.end(), pats.begin() + (ptrdiff_t)(i * width));
+            };
+            size_t id = n_pat;
+            if (n_pat && same(last_pat)) {
+                id = last_pat;
+            } else {
+                for (size_t i = 0; i < n_pat; ++i)
+                    if (same(i)) {
+                        id = i;
+                        break;
                     }
-                }
-                if (ds.size() == (size_t)SELL_MAX_DICT) return false;
-                ds.push_back(d);
-                last = ds.size() - 1;
             }
+            if (id == n_pat) {
+                if (n_pat == 256 || (n_pat + 1) * (size_t)width > (size_t)SELL_TABLE_INTS) {
+                    pat_mode = false;
+                    break;
+                }
+                pats.insert(pats.end(), pat.begin(), pat.end());
+            }
+            last_pat = id;
+            pid[(size_t)lr] = (uint8_t)id;
         }
-        std::sort(ds.begin(), ds.end());
+        // (b) otherwise offsets: one byte per (row, slot)
+        ds.clear();
+        if (!pat_mode) {
+            size_t last = 0;
+            for (ogl_label r = r0; r < r1; ++r)
+                for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                    const int32_t d = cols[k] - r;
+                    if (!ds.empty()) {
+                        if (ds[last] == d) continue;
+                        size_t i = 0;
+                        while (i < ds.size() && ds[i] != d) ++i;
+                        if (i < ds.size()) {
+                            last = i;
+                            continue;
+                        }
+                    }
+                    if (ds.size() == (size_t)SELL_MAX_DICT) return false;
+                    ds.push_back(d);
+                    last = ds.size() - 1;
+                }
+            std::sort(ds.begin(), ds.end());
+        }
         SellChunk &h = out.chunks[(size_t)c];
         h.val_off = val_len;
         h.code_off = code_len;
         h.dict_off = (int32_t)out.dict.size();
-        h.dict_len = (int32_t)ds.size();
         h.width = width;
-        h.code_stride = (2 * width + 15) / 16 * 16;
-        out.dict.insert(out.dict.end(), ds.begin(), ds.end());
+        if (pat_mode) {
+            h.dict_len = (int32_t)pats.size();
+            h.code_stride = ROWS_PER_THREAD;
+            out.dict.insert(out.dict.end(), pats.begin(), pats.end());
+            pid_all.insert(pid_all.end(), pid.begin(), pid.end());
+        } else {
+            h.dict_len = (int32_t)ds.size();
+            h.code_stride = (ROWS_PER_THREAD * width + 15) / 16 * 16;
+            out.dict.insert(out.dict.end(), ds.begin(), ds.end());
+        }
         val_len += (int64_t)width * CHUNK_ROWS;
         code_len += (int64_t)h.code_stride * BLOCK;
+        code_len = (code_len + 15) / 16 * 16;
         if ((double)val_len > SELL_MAX_PADDING * (double)nnz + 8.0 * CHUNK_ROWS) return false;
     }
     out.n_slots = val_len;
     out.codes.assign((size_t)code_len + 16, (uint8_t)255);
     out.map.assign((size_t)val_len + 2, -1);
+    // pass 2: codes and the value map
+    size_t pid_pos = 0;
     for (int64_t c = 0; c < nc; ++c) {
         const SellChunk &h = out.chunks[(size_t)c];
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+        const bool pat_mode = h.code_stride == ROWS_PER_THREAD;
+        if (pat_mode) {  // rows 2t, 2t+1 of thread t are adjacent bytes
+            std::copy(pid_all.begin() + (ptrdiff_t)pid_pos, pid_all.begin() + (ptrdiff_t)(pid_pos + CHUNK_ROWS),
+                      out.codes.begin() + h.code_off);
+            pid_pos += CHUNK_ROWS;
+        }
         const int32_t *d0 = out.dict.data() + h.dict_off;
         for (ogl_label r = r0; r < r1; ++r) {
             const int32_t lr = r - r0, t = lr / ROWS_PER_THREAD, which = lr % ROWS_PER_THREAD;
             uint8_t *code = out.codes.data() + h.code_off + (int64_t)t * h.code_stride;
             for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s) {
                 out.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS + lr)] = k;
+                if (pat_mode) continue;
                 const int32_t d = cols[k] - r;
                 code[ROWS_PER_THREAD * s + which] =
                     (uint8_t)(std::lower_bound(d0, d0 + h.dict_len, d) - d0);
@@ -485,7 +543,12 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
     // decode exactly as k_spmv_sell does: thread t of chunk c owns rows c*CHUNK_ROWS + 2t, +1
     for (size_t c = 0; c < L.chunks.size(); ++c) {
         const SellChunk &h = L.chunks[c];
-        if (h.dict_len > SELL_MAX_DICT || h.code_stride % 16 != 0 || h.code_stride < 2 * h.width)
+        const bool pat_mode = h.code_stride == ROWS_PER_THREAD;
+        if (h.code_off % 16 != 0 ||
+            (pat_mode ? (h.width <= 0 || h.dict_len % h.width != 0 || h.dict_len > SELL_TABLE_INTS ||
+                         h.dict_len / h.width > 256)
+                      : (h.dict_len > SELL_MAX_DICT || h.code_stride % 16 != 0 ||
+                         h.code_stride < ROWS_PER_THREAD * h.width)))
             return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
         for (int t = 0; t < BLOCK; ++t)
             for (int which = 0; which < ROWS_PER_THREAD; ++which) {
@@ -494,15 +557,25 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                 ogl_label k = row < n_rows ? row_ptrs[row] : 0;
                 const ogl_label k_end = row < n_rows ? row_ptrs[row + 1] : 0;
                 for (int s = 0; s < h.width; ++s) {
-                    const uint8_t cd = code[ROWS_PER_THREAD * s + which];
                     const int32_t m = L.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS +
                                                      t * ROWS_PER_THREAD + which)];
-                    if (cd == 255) {
+                    int32_t off;
+                    if (pat_mode) {
+                        const int32_t id = code[which];
+                        if ((id + 1) * h.width > h.dict_len)
+                            return fail(OGL_ERR_STATE, "row %ld: pattern id out of range", (long)row);
+                        off = L.dict[(size_t)h.dict_off + (size_t)id * h.width + s];
+                    } else {
+                        const uint8_t cd = code[ROWS_PER_THREAD * s + which];
+                        if (cd != 255 && cd >= h.dict_len)
+                            return fail(OGL_ERR_STATE, "row %ld: code out of range", (long)row);
+                        off = cd == 255 ? SELL_PAD_OFFSET : L.dict[(size_t)h.dict_off + cd];
+                    }
+                    if (off == SELL_PAD_OFFSET) {
                         if (m != -1) return fail(OGL_ERR_STATE, "row %ld: padding slot is mapped", (long)row);
                         continue;
                     }
-                    if (k >= k_end || cd >= h.dict_len || m != k ||
-                        row + L.dict[(size_t)h.dict_off + cd] != cols[k])
+                    if (k >= k_end || m != k || row + off != cols[k])
                         return fail(OGL_ERR_STATE, "row %ld slot %d decodes wrongly", (long)row, s);
                     ++k;
                 }

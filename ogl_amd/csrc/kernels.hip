@@ -806,11 +806,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, in
 }
 
 // ------------------------------------------------------------------------------------------
-// Index-compressed chunked ELL SpMV (DevSell, kernels.hpp).  Per lane and group of 8 slots: one
-// 16-byte load brings the 16 column codes of its two rows, eight 16-byte loads the values; the
-// chunk's dictionary (<= 255 offsets) sits in LDS and turns a code into column = row + offset.
-// 9 bytes per stored entry instead of 12 -- measured 145 us against 187 us for the CSR-stream
-// kernel on the 216^3 matrix (profiles/spmv_tune_r01.txt).  Same per-row order as k_spmv_stream.
+// Index-compressed chunked ELL SpMV (SellChunk, common.hpp).  Values: eight 16-byte loads per lane
+// and group of 8 slots.  Columns, per chunk: pattern mode -- one 2-byte load brings the pattern ids
+// of the lane's two rows, the pattern table in LDS gives the offsets; offset mode -- one 16-byte
+// load brings 16 column codes, the offset dictionary in LDS turns a code into column = row +
+// offset.  8.1 / 9 bytes per stored entry instead of 12 -- measured 137 / 146 us against 187 us
+// for the CSR-stream kernel on the 216^3 matrix (profiles/spmv_tune_r01.txt).  Same per-row order
+// as k_spmv_stream.
 // ------------------------------------------------------------------------------------------
 template <int MODE, int NDOT>
 __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
@@ -827,13 +829,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const DevScalars *gate)
 {
     __shared__ double slot[N_WAVES];
-    __shared__ int sdict[256];
+    __shared__ int stab[SELL_TABLE_INTS];
     if (gate && gate->stop) return;
     const int chunk = xcd_chunk(blockIdx.x);
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
-    if (t < h.dict_len) sdict[t] = dict[h.dict_off + t];
+    for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];
     __syncthreads();
     const RowPair rp = my_rows(chunk, n_rows);
     const int row = chunk * CHUNK_ROWS + t * ROWS_PER_THREAD;
@@ -841,38 +843,74 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     acc.x = acc.y = 0.0;
     if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
     const double *v = vals + h.val_off + t * ROWS_PER_THREAD;
-    const uint8_t *c = codes + h.code_off + (long)t * h.code_stride;
     constexpr int BATCH = 8;
-    for (int s0 = 0; s0 < h.width; s0 += BATCH) {
-        const uint4 cw = *reinterpret_cast<const uint4 *>(c + 2 * s0);
-        const unsigned w4[4] = {cw.x, cw.y, cw.z, cw.w};
-        double2 vv[BATCH];
+    if (h.code_stride == ROWS_PER_THREAD) {
+        // pattern mode: one byte per row -> `width` offsets of the row in the LDS table
+        const unsigned short pp =
+            *reinterpret_cast<const unsigned short *>(codes + h.code_off + t * ROWS_PER_THREAD);
+        const int p0 = (int)(pp & 0xffu) * h.width, p1 = (int)(pp >> 8) * h.width;
+        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+            double2 vv[BATCH];
+            int d0[BATCH], d1[BATCH];
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int s = min(s0 + k, h.width - 1);  // clamp: always a valid plane
-            vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
-        }
-        double x0[BATCH], x1[BATCH];
-        bool ok0[BATCH], ok1[BATCH];
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const unsigned pair = (w4[k / 2] >> (16 * (k & 1))) & 0xffffu;
-            const unsigned c0 = pair & 0xffu, c1 = pair >> 8;
-            // padding slots carry code 255; rows past n_rows only have padding slots
-            ok0[k] = (s0 + k < h.width) && c0 != 255u;
-            ok1[k] = (s0 + k < h.width) && c1 != 255u;
-            x0[k] = ok0[k] ? x[row + sdict[c0]] : 0.0;
-            x1[k] = ok1[k] ? x[row + 1 + sdict[c1]] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            if (ok0[k]) {
-                const double p = vv[k].x * x0[k];
-                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+            for (int k = 0; k < BATCH; ++k) {
+                const int s = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
+                d0[k] = (s0 + k < h.width) ? stab[p0 + s] : SELL_PAD_OFFSET;
+                d1[k] = (s0 + k < h.width) ? stab[p1 + s] : SELL_PAD_OFFSET;
             }
-            if (ok1[k]) {
-                const double p = vv[k].y * x1[k];
-                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+            double x0[BATCH], x1[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                x0[k] = d0[k] != SELL_PAD_OFFSET ? x[row + d0[k]] : 0.0;
+                x1[k] = d1[k] != SELL_PAD_OFFSET ? x[row + 1 + d1[k]] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                if (d0[k] != SELL_PAD_OFFSET) {
+                    const double p = vv[k].x * x0[k];
+                    acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+                }
+                if (d1[k] != SELL_PAD_OFFSET) {
+                    const double p = vv[k].y * x1[k];
+                    acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+                }
+            }
+        }
+    } else {
+        // offset mode: one byte per (row, slot) -> entry of the chunk's offset dictionary
+        const uint8_t *c = codes + h.code_off + (long)t * h.code_stride;
+        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+            const uint4 cw = *reinterpret_cast<const uint4 *>(c + 2 * s0);
+            const unsigned w4[4] = {cw.x, cw.y, cw.z, cw.w};
+            double2 vv[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int s = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
+            }
+            double x0[BATCH], x1[BATCH];
+            bool ok0[BATCH], ok1[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const unsigned pair = (w4[k / 2] >> (16 * (k & 1))) & 0xffffu;
+                const unsigned c0 = pair & 0xffu, c1 = pair >> 8;
+                // padding slots carry code 255; rows past n_rows only have padding slots
+                ok0[k] = (s0 + k < h.width) && c0 != 255u;
+                ok1[k] = (s0 + k < h.width) && c1 != 255u;
+                x0[k] = ok0[k] ? x[row + stab[c0]] : 0.0;
+                x1[k] = ok1[k] ? x[row + 1 + stab[c1]] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                if (ok0[k]) {
+                    const double p = vv[k].x * x0[k];
+                    acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+                }
+                if (ok1[k]) {
+                    const double p = vv[k].y * x1[k];
+                    acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+                }
             }
         }
     }

@@ -149,3 +149,23 @@ def test_pattern_change_rebuilds_the_layout(reg, oracle):
         rp, cols, vals = oracle_csr(oracle, case)
         x = np.random.default_rng(n).uniform(-1, 1, case.n_cells)
         np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+def test_offset_mode_when_a_chunk_has_too_many_row_patterns(reg, oracle):
+    # every row couples to a pseudo-random 90 % of the 20 following rows: hundreds of distinct row
+    # patterns per chunk but only 41 distinct offsets -> the chunks use one byte per (row, slot)
+    n = 1300
+    rng = np.random.default_rng(12)
+    pairs = [(i, i + d) for i in range(n) for d in range(1, 21) if i + d < n and rng.random() < 0.9]
+    pairs = np.array(pairs, dtype=np.int32)
+    f = len(pairs)
+    case = synthetic.LduCase(n, pairs[:, 0].copy(), pairs[:, 1].copy(), rng.uniform(40, 50, n),
+                             rng.uniform(-1, 1, f), rng.uniform(-1, 1, f))
+    rp, cols, vals = oracle_csr(oracle, case)
+    ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
+    n_chunks = (n + 511) // 512
+    assert ok and code_bytes > 512 * n_chunks          # not the 2-bytes-per-thread pattern mode
+    s = reg.solver("sell_offsets", cfg(1)).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL
+    x = rng.uniform(-1, 1, n)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))

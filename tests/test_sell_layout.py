@@ -30,15 +30,38 @@ def test_structured_patterns_qualify_and_decode(oracle, kw, sym):
     # every chunk is padded to its own longest row only
     widths = [int(np.diff(rp[c * CHUNK:min(n, (c + 1) * CHUNK) + 1]).max()) for c in range(n_chunks)]
     assert slots == CHUNK * sum(widths)
-    assert code_bytes == 256 * sum((2 * w + 15) // 16 * 16 for w in widths)
-    assert dict_entries <= 255 * n_chunks
+    # structured patterns take the pattern mode: one byte per row (2 per thread)
+    assert code_bytes == 512 * n_chunks
+    assert dict_entries <= 2048 * n_chunks
 
 
-def test_seven_point_box_uses_seven_offsets_per_chunk(oracle):
+def test_seven_point_box_row_patterns(oracle):
+    # 16^3 box: a chunk = two xy-planes; a row's pattern is fixed by which of its 6 neighbours exist
     rp, cols = poisson_pattern(oracle, gx=16, gy=16, gz=16, symmetric=True)
-    ok, slots, dict_entries, _ = capi.host_sell_check(rp, cols)
-    assert ok and dict_entries == 7 * (16 ** 3 // CHUNK)
-    assert slots == 7 * 16 ** 3
+    ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
+    assert ok and slots == 7 * 16 ** 3 and code_bytes == 512 * (16 ** 3 // CHUNK)
+    # interior chunks: 3 x 3 (x, y position classes) patterns of 7 offsets; first and last chunk also
+    assert dict_entries % 7 == 0 and 9 * 7 * 8 <= dict_entries <= 27 * 7 * 8
+
+
+def test_many_row_patterns_fall_back_to_offset_codes():
+    # 40 diagonals of which every row uses a pseudo-random subset: > 256 row patterns per chunk, but
+    # only 40 distinct offsets -> one byte per (row, slot)
+    rng = np.random.default_rng(9)
+    n = 1024
+    offs = np.arange(-20, 20)
+    rows = []
+    for r in range(n):
+        pick = offs[rng.random(40) < 0.92]
+        c = np.unique(np.concatenate([[r], [r + o for o in pick if 0 <= r + o < n]]))
+        rows.append(c)
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    cols = np.concatenate(rows).astype(np.int32)
+    ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
+    widths = [max(len(c) for c in rows[i * CHUNK:(i + 1) * CHUNK]) for i in range(2)]
+    assert ok and slots == CHUNK * sum(widths)
+    assert code_bytes == 256 * sum((2 * w + 15) // 16 * 16 for w in widths)
+    assert dict_entries <= 2 * 41
 
 
 def test_unstructured_pattern_does_not_qualify():
@@ -76,8 +99,9 @@ def test_wide_banded_rows_qualify():
     rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
     cols = np.concatenate(rows).astype(np.int32)
     ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
-    assert ok and slots == 3 * CHUNK * 41 and dict_entries == 3 * 41
-    assert code_bytes == 3 * 256 * 96
+    assert ok and slots == 3 * CHUNK * 41
+    # 41 row patterns per chunk (20 truncated at each end + the full one) x 41 offsets fit the table
+    assert code_bytes == 3 * 512 and dict_entries % 41 == 0
 
 
 def test_empty_pattern():

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <vector>
 
@@ -174,6 +175,64 @@ __global__ __launch_bounds__(BLOCK) void k_ell(int n_rows, int n_chunks, int wid
     if (t == 0) part[chunk] = sm;
 }
 
+// VARIANT pid: one byte per ROW naming a row pattern (list of `width` offsets, INT_MIN = padding) in the
+// chunk's pattern table (LDS).
+constexpr int PID_TABLE = 2048;
+template <int XCD>
+__global__ __launch_bounds__(BLOCK) void k_sell_pid(int n_rows, int n_chunks, const ChunkHdr *__restrict__ hdr,
+                                                    const int *__restrict__ dict,
+                                                    const uint8_t *__restrict__ codes,
+                                                    const double *__restrict__ vals,
+                                                    const double *__restrict__ x, double *__restrict__ y,
+                                                    double *__restrict__ part)
+{
+    __shared__ double slot[N_WAVES];
+    __shared__ int stab[PID_TABLE];
+    const int chunk = XCD ? xcd_chunk(blockIdx.x) : (int)blockIdx.x;
+    if (chunk >= n_chunks) return;
+    const ChunkHdr h = hdr[chunk];
+    const int t = threadIdx.x;
+    for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];
+    __syncthreads();
+    const int row = chunk * CHUNK + 2 * t;
+    const int nv = min(2, max(0, n_rows - row));
+    const unsigned short pp = *reinterpret_cast<const unsigned short *>(codes + h.code_off + 2 * t);
+    const int p0 = (pp & 0xff) * h.width, p1 = (pp >> 8) * h.width;
+    double a0 = 0.0, a1 = 0.0;
+    const double *v = vals + h.val_off + 2 * t;
+    for (int s0 = 0; s0 < h.width; s0 += 8) {
+        double2 vv[8];
+        int d0[8], d1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int s = min(s0 + k, h.width - 1);
+            vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK);
+            d0[k] = (s0 + k < h.width) ? stab[p0 + s] : INT_MIN;
+            d1[k] = (s0 + k < h.width) ? stab[p1 + s] : INT_MIN;
+        }
+        double x0[8], x1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            x0[k] = d0[k] != INT_MIN ? x[row + d0[k]] : 0.0;
+            x1[k] = d1[k] != INT_MIN ? x[row + 1 + d1[k]] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (d0[k] != INT_MIN) a0 = a0 + vv[k].x * x0[k];
+            if (d1[k] != INT_MIN) a1 = a1 + vv[k].y * x1[k];
+        }
+    }
+    if (nv == 2)
+        *reinterpret_cast<double2 *>(y + row) = make_double2(a0, a1);
+    else if (nv == 1)
+        y[row] = a0;
+    double d = 0.0;
+    if (nv > 0) d += x[row] * a0;
+    if (nv > 1) d += x[row + 1] * a1;
+    const double sm = block_sum(d, slot);
+    if (t == 0) part[chunk] = sm;
+}
+
 struct Csr {
     int n = 0, nnz = 0;
     std::vector<int> rp, cols;
@@ -318,6 +377,46 @@ int main(int argc, char **argv)
         }
     }
 
+    // ---- pattern-id layout: per chunk a table of distinct row patterns ----
+    std::vector<ChunkHdr> phdr(nc);
+    std::vector<int> ptab;
+    std::vector<uint8_t> pcodes((size_t)nc * 2 * BLOCK + 16, 0);
+    for (int c = 0; c < nc; ++c) {
+        ChunkHdr &h = phdr[c];
+        h = hdr[c];
+        h.code_off = (long)c * 2 * BLOCK;
+        h.code_stride = 2;
+        h.dict_off = (int)ptab.size();
+        std::vector<std::vector<int>> pats;
+        const int w = h.width;
+        for (int lr = 0; lr < CHUNK; ++lr) {
+            const int r = c * CHUNK + lr;
+            std::vector<int> pat(w, INT_MIN);
+            if (r < A.n)
+                for (int k = A.rp[r], s = 0; k < A.rp[r + 1]; ++k, ++s) pat[s] = A.cols[k] - r;
+            size_t id = 0;
+            while (id < pats.size() && pats[id] != pat) ++id;
+            if (id == pats.size()) pats.push_back(pat);
+            if (id > 255 || pats.size() * w > PID_TABLE) {
+                printf("chunk %d: too many row patterns\n", c);
+                return 1;
+            }
+            pcodes[h.code_off + lr] = (uint8_t)id;   // rows 2t, 2t+1 are adjacent bytes
+        }
+        for (auto &p : pats) ptab.insert(ptab.end(), p.begin(), p.end());
+        h.dict_len = (int)(pats.size() * w);
+    }
+    printf("pattern-id layout: table ints %zu (%.1f per chunk)\n", ptab.size(), (double)ptab.size() / nc);
+    ChunkHdr *d_phdr;
+    int *d_ptab;
+    uint8_t *d_pcodes;
+    CK(hipMalloc(&d_phdr, sizeof(ChunkHdr) * nc));
+    CK(hipMalloc(&d_ptab, sizeof(int) * (ptab.size() + 1)));
+    CK(hipMalloc(&d_pcodes, pcodes.size()));
+    CK(hipMemcpy(d_phdr, phdr.data(), sizeof(ChunkHdr) * nc, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_ptab, ptab.data(), sizeof(int) * ptab.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_pcodes, pcodes.data(), pcodes.size(), hipMemcpyHostToDevice));
+
     ChunkHdr *d_hdr;
     int *d_dict, *d_ecols;
     uint8_t *d_codes;
@@ -356,6 +455,12 @@ int main(int argc, char **argv)
                                        d_dict, d_codes, d_svals, x, d_y, d_part);
                 },
                 d_x0, d_x1, d_y, yref, reps, moved_sell);
+        time_it("sell 1-byte ROW pattern ids, xcd-grouped", A,
+                [&](const double *x) {
+                    hipLaunchKernelGGL((k_sell_pid<1>), dim3(xcd_grid(nc)), dim3(BLOCK), 0, 0, A.n, nc, d_phdr,
+                                       d_ptab, d_pcodes, d_svals, x, d_y, d_part);
+                },
+                d_x0, d_x1, d_y, yref, reps, 8.0 * val_len + 2.0 * BLOCK * nc + 16.0 * A.n + 32.0 * nc);
         time_it("sell 1-byte codes, LDS dict, plain", A,
                 [&](const double *x) {
                     hipLaunchKernelGGL((k_sell<0, 0>), dim3(nc), dim3(BLOCK), 0, 0, A.n, nc, d_hdr, d_dict,
