@@ -123,78 +123,6 @@ def main():
     # any smooth right-hand side will do for a fixed-iteration run; x0 = 0
     b = synthetic.x_star(case.global_index, case.global_n) + 0.5
 
-    reg = capi.Registry(device_id=local_rank, hip_stream=torch.cuda.current_stream().cuda_stream)
-    transport = "single GPU"
-    if world > 1:
-        # device transport: RCCL over xGMI.  If the communicator cannot be built on this node the
-        # ranks agree (over gloo) to fall back to the host-buffer transport -- slower, but the
-        # sharded path still runs and the JSON line says which transport was measured.
-        ok = 1
-        try:
-            if os.environ.get("OGL_BENCH_TRANSPORT", "rccl") != "rccl":
-                raise capi.OglError(capi.ERR_COMM, "host transport requested")
-            uid = [capi.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            reg.init_rccl(rank, world, uid[0])
-        except capi.OglError as e:
-            ok = 0
-            if rank == 0:
-                print(f"bench.py: RCCL unavailable ({e}); using the host-buffer transport",
-                      file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        transport = "RCCL halo + all-reduce"
-        if int(flag.item()) == 0:
-            transport = "host-buffer (gloo) halo + all-reduce"
-
-            def _allreduce(a):
-                t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                return t.numpy()
-
-            def _exchange(neighbours, counts, send):
-                recv = np.zeros_like(send)
-                offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
-                reqs, bufs = [], []
-                for i, nb in enumerate(neighbours):
-                    s_t = torch.from_numpy(np.ascontiguousarray(send[offs[i]:offs[i + 1]]))
-                    r_t = torch.zeros(int(counts[i]), dtype=torch.float64)
-                    reqs += [dist.isend(s_t, int(nb)), dist.irecv(r_t, int(nb))]
-                    bufs.append((i, r_t, s_t))
-                for q in reqs:
-                    q.wait()
-                for i, r_t, _ in bufs:
-                    recv[offs[i]:offs[i + 1]] = r_t.numpy()
-                return recv
-
-            reg.close()
-            reg = capi.Registry(device_id=local_rank)
-            reg.set_host_comm(rank, world, _allreduce, _exchange)
-        # scalar all-reduces: peer-write mailboxes over xGMI inside the finaliser kernels (hipIpc;
-        # collective self-test in peer_connect).  If any rank cannot join, all ranks keep the
-        # transport's own all-reduce.
-        ok, mine = 1, None
-        try:
-            if os.environ.get("OGL_BENCH_PEER", "1") == "1":
-                mine = reg.peer_handle()
-        except capi.OglError as e:
-            print(f"bench.py: rank {rank}: no peer mailbox ({e})", file=sys.stderr)
-        handles = [None] * world
-        dist.all_gather_object(handles, mine)          # every rank takes part, handle or not
-        if any(h is None for h in handles):
-            ok = 0
-        else:
-            try:
-                reg.peer_connect(rank, world, handles)
-            except capi.OglError as e:
-                ok = 0
-                print(f"bench.py: rank {rank}: peer all-reduce unavailable ({e})", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            transport = transport.replace("halo + all-reduce", "halo, peer-write all-reduce (hipIpc)")
-        else:
-            reg.peer_disable()
     precond = {"BJ": capi.PRECOND_BJ, "none": capi.PRECOND_NONE, "ISAI": capi.PRECOND_ISAI,
                "GISAI": capi.PRECOND_GISAI}[args.precond]
     solver_kind = {"GKOCG": capi.SOLVER_CG, "GKOBiCGStab": capi.SOLVER_BICGSTAB,
@@ -206,22 +134,114 @@ def main():
                               matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
                               export_res=0, profile_kernels=0 if args.no_profile else 1,
                               compress_indices=0 if args.no_compress else 1)
-    s = reg.solver("p", cfg)
-    t0 = time.perf_counter()
-    s.set_matrix(case)                       # pattern + H2D + device permutation (not timed below)
-    t_first_matrix = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    s.set_matrix(case)                       # values-only refresh, as every later time step
-    t_refresh_matrix = time.perf_counter() - t0
-    s.upload_rhs(b)
-    s.upload_solution(None)
+
+    def all_ok(ok):
+        """True iff every rank says ok (gloo)."""
+        if world == 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def _allreduce(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def _exchange(neighbours, counts, send):
+        recv = np.zeros_like(send)
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+        reqs, bufs = [], []
+        for i, nb in enumerate(neighbours):
+            s_t = torch.from_numpy(np.ascontiguousarray(send[offs[i]:offs[i + 1]]))
+            r_t = torch.zeros(int(counts[i]), dtype=torch.float64)
+            reqs += [dist.isend(s_t, int(nb)), dist.irecv(r_t, int(nb))]
+            bufs.append((i, r_t, s_t))
+        for q in reqs:
+            q.wait()
+        for i, r_t, _ in bufs:
+            recv[offs[i]:offs[i + 1]] = r_t.numpy()
+        return recv
+
+    def bring_up(use_peer):
+        """Registry + transport + solver with the matrix and b resident, warm-up steps done.
+        Transport at N > 1, each step agreed by all ranks over gloo: RCCL over xGMI, else the
+        host-buffer callbacks; on top (use_peer) the peer mesh: halo values put straight into the
+        neighbours' receive blocks and all-reduces inside the finaliser kernels (hipIpc)."""
+        reg = capi.Registry(device_id=local_rank, hip_stream=torch.cuda.current_stream().cuda_stream)
+        transport = "single GPU"
+        if world > 1:
+            ok = True
+            try:
+                if os.environ.get("OGL_BENCH_TRANSPORT", "rccl") != "rccl":
+                    raise capi.OglError(capi.ERR_COMM, "host transport requested")
+                uid = [capi.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                reg.init_rccl(rank, world, uid[0])
+            except capi.OglError as e:
+                ok = False
+                if rank == 0:
+                    print(f"bench.py: RCCL unavailable ({e}); using the host-buffer transport",
+                          file=sys.stderr)
+            transport = "RCCL halo + all-reduce"
+            if not all_ok(ok):
+                transport = "host-buffer (gloo) halo + all-reduce"
+                reg.close()
+                reg = capi.Registry(device_id=local_rank)
+                reg.set_host_comm(rank, world, _allreduce, _exchange)
+            mine = None
+            try:
+                if use_peer and os.environ.get("OGL_BENCH_PEER", "1") == "1":
+                    mine = reg.peer_handle()
+            except capi.OglError as e:
+                print(f"bench.py: rank {rank}: no peer mailbox ({e})", file=sys.stderr)
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)          # every rank takes part, handle or not
+            ok = all(h is not None for h in handles)
+            if ok:
+                try:
+                    reg.peer_connect(rank, world, handles)   # collective self-test inside
+                except capi.OglError as e:
+                    ok = False
+                    print(f"bench.py: rank {rank}: peer mesh unavailable ({e})", file=sys.stderr)
+            if all_ok(ok):
+                transport = transport.replace("halo + all-reduce", "halo, peer-write all-reduce (hipIpc)")
+            else:
+                reg.peer_disable()
+        s = reg.solver("p", cfg)
+        t0 = time.perf_counter()
+        s.set_matrix(case)                       # pattern + H2D + device permutation (not timed below)
+        t_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        s.set_matrix(case)                       # values-only refresh, as every later time step
+        t_refresh = time.perf_counter() - t0
+        s.upload_rhs(b)
+        for _ in range(args.warmup):
+            s.upload_solution(None)
+            s.apply_resident()
+        return reg, s, transport, t_first, t_refresh
+
+    # If the peer mesh passes its self-test but a solve over it fails (every rank then times out
+    # with OGL_ERR_COMM), all ranks start over on the plain transport.
+    state, err = None, None
+    try:
+        state = bring_up(True)
+    except capi.OglError as e:
+        err = e
+    if not all_ok(state is not None):
+        if world == 1:
+            raise err
+        print(f"bench.py: rank {rank}: bring-up with the peer mesh failed ({err}); retrying without",
+              file=sys.stderr)
+        if state is not None:
+            state[0].close()
+        state = bring_up(False)
+    reg, s, transport, t_first_matrix, t_refresh_matrix = state
 
     def step():
         s.upload_solution(None)              # x0 = 0, device memset
         return s.apply_resident()
 
-    for _ in range(args.warmup):
-        step()
     barrier()
     t0 = time.perf_counter()
     perfs = [step() for _ in range(args.steps)]
