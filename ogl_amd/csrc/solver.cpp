@@ -2,6 +2,7 @@
 #include "solver.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -389,6 +390,26 @@ DevSell ogl_solver::sell() const
     return S;
 }
 
+int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, Stager &stager,
+                   hipStream_t st)
+{
+    ready = false;
+    SellLayout L;
+    if (n_rows == 0 || !build_sell_layout(n_rows, row_ptrs, cols, L)) return OGL_OK;
+    OGL_TRY(chunks.alloc(L.chunks.size(), st));
+    OGL_TRY(dict.alloc(L.dict.size(), st));
+    OGL_TRY(codes.alloc(L.codes.size(), st));
+    OGL_TRY(map.alloc(L.map.size(), st));
+    OGL_TRY(vals.alloc(L.map.size(), st));
+    OGL_TRY(stager.h2d(chunks.p, L.chunks.data(), L.chunks.size() * sizeof(SellChunk), st));
+    OGL_TRY(stager.h2d(dict.p, L.dict.data(), L.dict.size() * sizeof(int32_t), st));
+    OGL_TRY(stager.h2d(codes.p, L.codes.data(), L.codes.size(), st));
+    OGL_TRY(stager.h2d(map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
+    slots = L.n_slots;
+    ready = true;
+    return OGL_OK;
+}
+
 // Once per sparsity pattern: derive the compressed layout on the host; sell_map (like ell_map)
 // refreshes the values from the permuted CSR values on the device.
 int ogl_solver::build_sell()
@@ -476,7 +497,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         OGL_TRY(build_host_pattern(ldu, np));
         pat = std::move(np);
         have_pattern = true;
-        static uint64_t pattern_counter = 0;
+        static std::atomic<uint64_t> pattern_counter{0};  // registries may live on different threads
         pat_id = ++pattern_counter;
         matrix_set = false;
         ell_ready = false;
@@ -685,7 +706,12 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
                 OGL_TRY(reg->stager.h2d(P.wt_row_ptrs.p, trp.data(), trp.size() * sizeof(int32_t), st));
                 OGL_TRY(reg->stager.h2d(P.wt_cols.p, tc.data(), wn * sizeof(int32_t), st));
                 OGL_TRY(reg->stager.h2d(P.wt_map.p, tmap.data(), wn * sizeof(int32_t), st));
+                if (cfg.compress_indices)
+                    OGL_TRY(P.wt_sell.build(N, trp.data(), tc.data(), reg->stager, st));
             }
+            if (!spd || !cfg.compress_indices) P.wt_sell.ready = false;
+            P.w_sell.ready = false;
+            if (cfg.compress_indices) OGL_TRY(P.w_sell.build(N, wrp.data(), wc.data(), reg->stager, st));
             P.w_nnz = (int32_t)wn;
             P.w_max_row = max_row;
             P.struct_pat_id = pat_id;
@@ -695,6 +721,8 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p,
                              P.w_max_row);
         if (spd) launch_gather_coeffs(st, P.w_nnz, P.wt_map.p, P.w_vals.p, P.wt_vals.p);
+        P.w_sell.refresh(P.w_vals.p, st);
+        if (spd) P.wt_sell.refresh(P.wt_vals.p, st);
         P.kind = spd ? 3 : 4;
         P.stride = 0;
     } else if (cfg.max_block_size == 1) {  // scalar Jacobi: 1 / diag
@@ -744,16 +772,29 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
         W.row_ptrs = precond_data->w_row_ptrs.p;
         W.cols = precond_data->w_cols.p;
         W.vals = precond_data->w_vals.p;
+        const bool w_sell = cfg.compress_indices && precond_data->w_sell.ready;
         if (precond_data->kind == 4) {
-            launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, out, SpmvDots{}, gate);
+            if (w_sell)
+                launch_spmv_sell(reg->stream, precond_data->w_sell.view(pat.n_rows), SPMV_PLAIN, in,
+                                 nullptr, out, SpmvDots{}, gate);
+            else
+                launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, out, SpmvDots{}, gate);
             return;
         }
         DevCsr WT = W;
         WT.row_ptrs = precond_data->wt_row_ptrs.p;
         WT.cols = precond_data->wt_cols.p;
         WT.vals = precond_data->wt_vals.p;
-        launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, d_isai_tmp.p, SpmvDots{}, gate);
-        launch_spmv(reg->stream, WT, SPMV_PLAIN, d_isai_tmp.p, nullptr, out, SpmvDots{}, gate);
+        if (w_sell)
+            launch_spmv_sell(reg->stream, precond_data->w_sell.view(pat.n_rows), SPMV_PLAIN, in, nullptr,
+                             d_isai_tmp.p, SpmvDots{}, gate);
+        else
+            launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, d_isai_tmp.p, SpmvDots{}, gate);
+        if (cfg.compress_indices && precond_data->wt_sell.ready)
+            launch_spmv_sell(reg->stream, precond_data->wt_sell.view(pat.n_rows), SPMV_PLAIN,
+                             d_isai_tmp.p, nullptr, out, SpmvDots{}, gate);
+        else
+            launch_spmv(reg->stream, WT, SPMV_PLAIN, d_isai_tmp.p, nullptr, out, SpmvDots{}, gate);
         return;
     }
     DevBlockJacobi J;

@@ -74,6 +74,35 @@ private:
     int next_ = 0;
 };
 
+class Stager;
+
+// Device copy of an index-compressed chunked ELL (SellChunk, common.hpp) of some CSR matrix whose
+// values live elsewhere: pattern once (`build`), values by `refresh` from the CSR value array.
+struct SellDev {
+    DevBuf<SellChunk> chunks;
+    DevBuf<int32_t> dict, map;
+    DevBuf<uint8_t> codes;
+    DevBuf<double> vals;
+    int64_t slots = 0;
+    bool ready = false;  // false: the pattern does not qualify (or build was never called)
+    int build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, Stager &stager,
+              hipStream_t st);
+    void refresh(const double *csr_vals, hipStream_t st)
+    {
+        if (ready) launch_gather_coeffs_masked(st, slots, map.p, csr_vals, vals.p);
+    }
+    DevSell view(int32_t n_rows) const
+    {
+        DevSell S;
+        S.n_rows = n_rows;
+        S.chunks = chunks.p;
+        S.dict = dict.p;
+        S.codes = codes.p;
+        S.vals = vals.p;
+        return S;
+    }
+};
+
 // A generated preconditioner ("Cached_preconditinoner" holds one of these, Preconditioner.H:357)
 struct PrecondData {
     int kind = 0;  // 0 none, 1 scalar Jacobi (inverse diagonal), 2 block Jacobi
@@ -88,6 +117,7 @@ struct PrecondData {
     DevBuf<int32_t> w_row_ptrs, w_cols, wt_row_ptrs, wt_cols, wt_map;
     DevBuf<double> w_vals, wt_vals;
     int32_t w_nnz = 0, w_max_row = 0;
+    SellDev w_sell, wt_sell;  // compressed copies the apply runs on when compress_indices is set
     // the pattern-only part (block pointers / W and W^T patterns) is kept for as long as it was
     // derived from the same sparsity pattern: only the values are regenerated per solve
     uint64_t struct_pat_id = 0;
