@@ -343,24 +343,6 @@ __global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__r
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_bj_apply(int n_rows, const int *__restrict__ block_ptrs,
-                                                    const int *__restrict__ row_block,
-                                                    const double *__restrict__ blocks, int ld,
-                                                    const double *__restrict__ in,
-                                                    double *__restrict__ out,
-                                                    const DevScalars *gate)
-{
-    if (gate && gate->stop) return;
-    const int row = blockIdx.x * BLOCK + threadIdx.x;
-    if (row >= n_rows) return;
-    const int b = row_block[row];
-    const int r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
-    const double *a = blocks + (size_t)b * ld * ld + (size_t)(row - r0) * ld;
-    double sum = 0.0;
-    for (int j = 0; j < bs; ++j) sum += a[j] * in[r0 + j];
-    out[row] = sum;
-}
-
 // ISAI generate: same operation order as oracle/ogl_oracle.c (csr_entry, solve_dense)
 __device__ double csr_entry(const int *__restrict__ row_ptrs, const int *__restrict__ cols,
                             const double *__restrict__ vals, int r, int c)
@@ -473,6 +455,54 @@ __device__ __forceinline__ void st2(double *__restrict__ p, const RowPair &r, do
         p[r.row] = v.x;
 }
 static_assert(ROWS_PER_THREAD == 2, "vector kernels are written for two rows per thread");
+
+// block-Jacobi apply (DevBlockJacobi): one row per thread, CHUNK_ROWS threads per workgroup (the
+// dependent index loads want many rows in flight).  NDOT = 1: also the chunk's partial of
+// sum_i in_i*out_i (CG's rho = r . M^-1 r): the products go through LDS to the first BLOCK
+// threads, which add their two rows and run the usual per-chunk tree -- same bits as k_partials.
+template <int NDOT>
+__global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply(int n_rows,
+                                                         const int *__restrict__ block_ptrs,
+                                                         const int *__restrict__ row_block,
+                                                         const double *__restrict__ blocks, int ld,
+                                                         const double *__restrict__ in,
+                                                         double *__restrict__ out,
+                                                         double *__restrict__ dot_part,
+                                                         const DevScalars *gate)
+{
+    __shared__ double prod[CHUNK_ROWS];
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = blockIdx.x;
+    const int row = chunk * CHUNK_ROWS + threadIdx.x;
+    double sum = 0.0, mine = 0.0;
+    if (row < n_rows) {
+        const int b = row_block[row];
+        const int r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
+        const double *a = blocks + (size_t)b * ld * ld + (size_t)(row - r0) * ld;
+        for (int j = 0; j < bs; ++j) sum += a[j] * in[r0 + j];
+        out[row] = sum;
+        mine = in[row];
+    }
+    if (NDOT >= 1) {
+        prod[threadIdx.x] = mine * sum;
+        __syncthreads();
+        double d = 0.0;
+        if (threadIdx.x < BLOCK) {
+            const RowPair rp = my_rows(chunk, n_rows);
+            if (rp.n > 0) d += prod[ROWS_PER_THREAD * threadIdx.x];
+            if (rp.n > 1) d += prod[ROWS_PER_THREAD * threadIdx.x + 1];
+            d = wave_sum(d);
+            if ((threadIdx.x & (WAVE - 1)) == 0) slot[threadIdx.x / WAVE] = d;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = slot[0];
+            for (int w = 1; w < N_WAVES; ++w) s += slot[w];
+            dot_part[chunk] = s;
+        }
+    }
+}
 
 enum PartialOp { P_SUM = 0, P_DOT = 1, P_NORM1 = 2 };
 template <int OP>
@@ -1726,11 +1756,16 @@ void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J
 }
 
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
-                     const DevScalars *gate)
+                     double *dot_part, const DevScalars *gate)
 {
     if (J.n_rows == 0) return;
-    hipLaunchKernelGGL(k_bj_apply, dim3(blocks_for(J.n_rows)), dim3(BLOCK), 0, st, J.n_rows,
-                       J.block_ptrs, J.row_block, J.blocks, J.stride, in, out, gate);
+    const dim3 grid((unsigned)n_chunks(J.n_rows)), block(CHUNK_ROWS);
+    if (dot_part)
+        hipLaunchKernelGGL((k_bj_apply<1>), grid, block, 0, st, J.n_rows, J.block_ptrs, J.row_block,
+                           J.blocks, J.stride, in, out, dot_part, gate);
+    else
+        hipLaunchKernelGGL((k_bj_apply<0>), grid, block, 0, st, J.n_rows, J.block_ptrs, J.row_block,
+                           J.blocks, J.stride, in, out, dot_part, gate);
 }
 
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,

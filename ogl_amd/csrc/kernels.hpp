@@ -117,9 +117,10 @@ struct DevBlockJacobi {
 constexpr int MAX_JACOBI_BLOCK = 32;
 // blocks[b] = inverse of A(block b, block b) by Gauss-Jordan with partial pivoting
 void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J);
-// out = M^-1 in : per row, the block row times the block's slice of `in`, summed left to right
+// out = M^-1 in : per row, the block row times the block's slice of `in`, summed left to right;
+// dot_part != nullptr: also the per-chunk partials of sum_i in_i * out_i
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
-                     const DevScalars *gate);
+                     double *dot_part, const DevScalars *gate);
 
 // ISAI / GISAI with sparsityPower 1 (Preconditioner.H:225-258): row i of the approximate inverse W
 // solves a dense system over its own pattern (<= 32 entries), one thread per row, Gaussian

@@ -763,8 +763,16 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
     return OGL_OK;
 }
 
-void ogl_solver::apply_preconditioner(const double *in, double *out, const DevScalars *gate)
+void ogl_solver::apply_preconditioner(const double *in, double *out, const DevScalars *gate,
+                                      double *dot_part)
 {
+    hipStream_t st = reg->stream;
+    // the last kernel of the apply also leaves the partials of in . out
+    SpmvDots last{};
+    if (dot_part) {
+        last.with = in;
+        last.part = dot_part;
+    }
     if (precond_data->kind == 3 || precond_data->kind == 4) {  // ISAI: one or two SpMVs
         DevCsr W;
         W.n_rows = pat.n_rows;
@@ -773,28 +781,23 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
         W.cols = precond_data->w_cols.p;
         W.vals = precond_data->w_vals.p;
         const bool w_sell = cfg.compress_indices && precond_data->w_sell.ready;
-        if (precond_data->kind == 4) {
-            if (w_sell)
-                launch_spmv_sell(reg->stream, precond_data->w_sell.view(pat.n_rows), SPMV_PLAIN, in,
-                                 nullptr, out, SpmvDots{}, gate);
-            else
-                launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, out, SpmvDots{}, gate);
-            return;
-        }
+        const bool general = precond_data->kind == 4;
+        double *w_out = general ? out : d_isai_tmp.p;
+        if (w_sell)
+            launch_spmv_sell(st, precond_data->w_sell.view(pat.n_rows), SPMV_PLAIN, in, nullptr, w_out,
+                             general ? last : SpmvDots{}, gate);
+        else
+            launch_spmv(st, W, SPMV_PLAIN, in, nullptr, w_out, general ? last : SpmvDots{}, gate);
+        if (general) return;
         DevCsr WT = W;
         WT.row_ptrs = precond_data->wt_row_ptrs.p;
         WT.cols = precond_data->wt_cols.p;
         WT.vals = precond_data->wt_vals.p;
-        if (w_sell)
-            launch_spmv_sell(reg->stream, precond_data->w_sell.view(pat.n_rows), SPMV_PLAIN, in, nullptr,
-                             d_isai_tmp.p, SpmvDots{}, gate);
-        else
-            launch_spmv(reg->stream, W, SPMV_PLAIN, in, nullptr, d_isai_tmp.p, SpmvDots{}, gate);
         if (cfg.compress_indices && precond_data->wt_sell.ready)
-            launch_spmv_sell(reg->stream, precond_data->wt_sell.view(pat.n_rows), SPMV_PLAIN,
-                             d_isai_tmp.p, nullptr, out, SpmvDots{}, gate);
+            launch_spmv_sell(st, precond_data->wt_sell.view(pat.n_rows), SPMV_PLAIN, d_isai_tmp.p,
+                             nullptr, out, last, gate);
         else
-            launch_spmv(reg->stream, WT, SPMV_PLAIN, d_isai_tmp.p, nullptr, out, SpmvDots{}, gate);
+            launch_spmv(st, WT, SPMV_PLAIN, d_isai_tmp.p, nullptr, out, last, gate);
         return;
     }
     DevBlockJacobi J;
@@ -804,7 +807,7 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
     J.block_ptrs = precond_data->block_ptrs.p;
     J.row_block = precond_data->row_block.p;
     J.blocks = precond_data->values.p;
-    launch_bj_apply(reg->stream, J, in, out, gate);
+    launch_bj_apply(st, J, in, out, dot_part, gate);
 }
 
 int ogl_solver::init_preconditioner()
@@ -1103,8 +1106,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         // p = q = 0 ([UPSTREAM] cg::initialize); z is never materialised (z = r * inv_diag on the fly)
         launch_cg_rho_norm(st, n, d_r.p, precond, d_part0.p, d_part1.p, s);
         if (generic) {  // rho = r . (M^-1 r) with the block preconditioner
-            apply_preconditioner(d_r.p, d_z.p, s);
-            launch_partials_dot(st, n, d_r.p, d_z.p, d_part0.p, s);
+            apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);
         }
     }
     FinArgs chk{};
@@ -1181,8 +1183,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
                 OGL_TRY(finalize(FIN_BETA, f1));
                 launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, nullptr, d_part0.p, d_part1.p, s);
-                apply_preconditioner(d_r.p, d_z.p, s);
-                launch_partials_dot(st, n, d_r.p, d_z.p, d_part0.p, s);
+                apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);  // z = M^-1 r and the partials of r.z
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else if (!bicg) {
                 // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once

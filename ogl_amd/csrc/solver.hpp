@@ -271,7 +271,10 @@ struct ogl_solver {
     int ensure_vectors();
     int init_preconditioner();
     int generate_preconditioner(ogl::PrecondData &P);
-    void apply_preconditioner(const double *in, double *out, const ogl::DevScalars *gate);
+    // out = M^-1 in for the block-Jacobi / ISAI / GISAI kinds; dot_part != nullptr: also the per-chunk
+    // partials of sum_i in_i * out_i (CG's rho), out of the same kernel
+    void apply_preconditioner(const double *in, double *out, const ogl::DevScalars *gate,
+                              double *dot_part = nullptr);
     int dist_spmv(int mode, const double *x, const double *b, double *y, const ogl::SpmvDots &dots,
                   const ogl::DevScalars *gate);
     int finalize(int phase, ogl::FinArgs &a);
