@@ -1260,7 +1260,6 @@ __device__ void criterion_check(DevScalars *s, const DevCriterion &c, double nor
 // Peer-write all-reduce (PeerArgs, kernels.hpp).  Called by every thread of a workgroup of >= 64
 // threads; v0, v1 are thread 0's local sums on entry and the rank-ordered global sums on return
 // (thread 0 only).  Lane (q, e) sends half-word e to rank q and waits for rank q's half-word e.
-constexpr long long PEER_TIMEOUT_TICKS = 60LL * 100000000LL;  // 60 s of the 100 MHz wall clock
 __device__ __forceinline__ size_t peer_word(int slot, int src, int e)
 {
     return ((size_t)slot * PEER_MAX_RANKS + src) * PEER_ELEMS + e;
@@ -1291,7 +1290,7 @@ __device__ bool peer_allreduce2(const PeerArgs &pa, double &v0, double &v1)
         for (;;) {
             w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((unsigned)(w >> 32) == pa.seq) break;
-            if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > pa.timeout_ticks) {
                 timed_out = 1;
                 break;
             }
@@ -1398,7 +1397,7 @@ __global__ __launch_bounds__(BLOCK) void k_halo_finish(int n_rows,
             const unsigned long long f = __hip_atomic_load(P.local_flag + threadIdx.x, __ATOMIC_ACQUIRE,
                                                            __HIP_MEMORY_SCOPE_SYSTEM);
             if ((uint32_t)f == P.seq) break;
-            if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > P.timeout_ticks) {
                 timed_out = 1;
                 break;
             }
@@ -1468,7 +1467,7 @@ __global__ __launch_bounds__(64) void k_halo_wait(PeerHalo P, const DevScalars *
             const unsigned long long w =
                 __hip_atomic_load(P.local_flag + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((uint32_t)w == P.seq) break;
-            if (wall_clock64() - t0 > PEER_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > P.timeout_ticks) {
                 timed_out = 1;
                 break;
             }

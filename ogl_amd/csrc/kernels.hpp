@@ -226,6 +226,9 @@ inline size_t gmres_state_len(int m) { return (size_t)(m + 1) * m + 2 * (size_t)
 // order -- every rank gets the same bits.  It runs INSIDE the finaliser kernel: no extra launch,
 // no host, no collective library on the latency path of the two reductions per CG turn.
 constexpr int PEER_MAX_RANKS = 16;
+// a rank that does not show up within this time fails the solve with OGL_ERR_COMM instead of
+// hanging the GPU (OGL_PEER_TIMEOUT_S overrides the 60 s)
+constexpr long long PEER_DEFAULT_TIMEOUT_TICKS = 60LL * 100000000LL;
 constexpr int PEER_SLOTS = 4;
 constexpr int PEER_ELEMS = 4;  // two doubles as four half-words
 constexpr size_t PEER_BOX_WORDS = (size_t)PEER_SLOTS * PEER_MAX_RANKS * PEER_ELEMS;
@@ -233,6 +236,7 @@ struct PeerArgs {
     int32_t world = 0;  // 0 / 1: no exchange
     int32_t rank = 0;
     uint32_t seq = 0;   // never 0 (the mailboxes start zeroed)
+    long long timeout_ticks = PEER_DEFAULT_TIMEOUT_TICKS;  // of the 100 MHz wall clock
     unsigned long long *box[PEER_MAX_RANKS] = {};  // mailbox of rank q as mapped in this process
 };
 // vals[0..n) (n <= 2, device memory) summed over the ranks in place; *error set on timeout
@@ -251,6 +255,7 @@ constexpr int PEER_MAX_NEIGH = 16;
 struct PeerHalo {
     int32_t n_neigh = 0;
     uint32_t seq = 0;
+    long long timeout_ticks = PEER_DEFAULT_TIMEOUT_TICKS;
     int32_t send_off[PEER_MAX_NEIGH + 1] = {};             // send buffer blocks, by neighbour
     double *remote_recv[PEER_MAX_NEIGH] = {};              // neighbour i's segment for this rank
     unsigned long long *remote_flag[PEER_MAX_NEIGH] = {};  // neighbour i's flag for this rank

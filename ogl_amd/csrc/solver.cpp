@@ -169,6 +169,8 @@ int ogl_registry::peer_connect(int rank, int n_ranks, const void *handles)
     }
     peer.world = n_ranks;
     peer.rank = rank;
+    if (const char *e = std::getenv("OGL_PEER_TIMEOUT_S"))
+        peer.timeout_ticks = (long long)(std::max(0.001, atof(e)) * 1e8);
     // collective self-test (every rank is inside peer_connect now): two all-reduces of known values
     DevBuf<double> d;
     OGL_TRY(d.alloc(2, stream));
@@ -254,7 +256,7 @@ int ogl_solver::setup_peer_halo()
                 OGL_HIP_CHECK(hipMemcpy(w, src, sizeof(w), hipMemcpyDeviceToHost));
                 break;
             }
-            if (now_ms() - t0 > 60e3)
+            if (now_ms() - t0 > (double)R.peer.timeout_ticks / 1e5)
                 return fail(OGL_ERR_COMM, "peer halo handshake: rank %d did not answer", neighbours[i]);
         }
         if (w[1] == ~0ull) cannot = 1.0;
@@ -283,6 +285,7 @@ PeerHalo ogl_solver::peer_halo_args(uint32_t seq) const
     PeerHalo P;
     P.n_neigh = nn;
     P.seq = seq;
+    P.timeout_ticks = R.peer.timeout_ticks;
     int32_t off = 0;
     for (int i = 0; i < nn; ++i) {
         P.send_off[i] = off;

@@ -94,3 +94,15 @@ def test_gpu_peer_allreduce_bicgstab():
 @pytest.mark.gpu
 def test_gpu_peer_allreduce_gmres():
     run_ranks(2, "--mode", "gpu-peer", "--shape", "10,10,10", "--procs", "1,1,2", "--gmres", "20")
+
+
+@pytest.mark.gpu
+def test_gpu_peer_rank_dropout_fails_loudly():
+    # OGL_PEER_TIMEOUT_S shortens the 60 s after which a missing rank ends the solve with ERR_COMM
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OGL_PEER_TIMEOUT_S="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "peer_dropout_worker.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
+    assert p.stdout.count("dropout ok") == 2 and "failed loudly" in p.stdout, p.stdout
