@@ -91,6 +91,9 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
 // out[i] = map[i] >= 0 ? source[map[i]] : 0   (coefficient permutation into the padded ELL slots)
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,
                                  double *out);
+// the same into the value planes of a chunked layout (SellChunk), one workgroup per chunk
+void launch_gather_sell(hipStream_t st, int32_t n_chunks, const SellChunk *chunks, const int32_t *map,
+                        const double *source, double *out);
 
 // y[row] (+/-)= sum_k vals[k] * recv[cols[k]] over the boundary rows, continuing y's accumulator.
 void launch_spmv_non_local(hipStream_t st, const DevHalo &H, int mode, const double *recv,

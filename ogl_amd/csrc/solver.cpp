@@ -640,7 +640,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     } else if (cfg.compress_indices) {
         if (sell_state == 0) OGL_TRY(build_sell());
         if (sell_state == 1 && sell_values_stale) {
-            launch_gather_coeffs_masked(st, sell_slots, d_sell_map.p, d_vals.p, d_sell_vals.p);
+            launch_gather_sell(st, (int32_t)d_sell_chunks.n, d_sell_chunks.p, d_sell_map.p, d_vals.p,
+                               d_sell_vals.p);
             sell_values_stale = false;
         }
     }

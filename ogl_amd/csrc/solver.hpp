@@ -89,7 +89,7 @@ struct SellDev {
               hipStream_t st);
     void refresh(const double *csr_vals, hipStream_t st)
     {
-        if (ready) launch_gather_coeffs_masked(st, slots, map.p, csr_vals, vals.p);
+        if (ready) launch_gather_sell(st, (int32_t)chunks.n, chunks.p, map.p, csr_vals, vals.p);
     }
     DevSell view(int32_t n_rows) const
     {
