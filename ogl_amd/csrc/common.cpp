@@ -1,6 +1,50 @@
 #include "common.hpp"
 
+#include <dlfcn.h>
+
+#include <mutex>
+
 namespace ogl {
+
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+};
+const Roctx &roctx()
+{
+    static Roctx api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // rocprofv3 listens to the rocprofiler-sdk flavour of ROCTx; libroctx64 is the older one
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so",
+                                 "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1", "libroctx64.so.4",
+                                 "libroctx64.so"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+                api.push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                api.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (api.push && api.pop) return;
+                api = Roctx{};
+            }
+        }
+    });
+    return api;
+}
+}  // namespace
+
+TraceRange::TraceRange(const char *phase, const std::string &field)
+{
+    const Roctx &r = roctx();
+    if (!r.push) return;
+    const std::string name = std::string("ogl:") + phase + ":" + field;
+    r.push(name.c_str());
+    pushed_ = true;
+}
+
+TraceRange::~TraceRange()
+{
+    if (pushed_) roctx().pop();
+}
 
 std::string &last_error()
 {

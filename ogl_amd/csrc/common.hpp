@@ -27,6 +27,21 @@ constexpr int SPMV_TILE = 4096;
 // Vector loads read up to 3 entries past a tile end: value/column arrays carry this much padding.
 constexpr int NNZ_PAD = 8;
 
+// ROCTx range around a phase of the plug-in call -- the analogue of the nvtxRangePushA/Pop inside
+// the reference's TIME_WITH_FIELDNAME (common/common.H:54-87).  libroctx64 is bound at run time;
+// without it (or without a profiler attached) the ranges cost a function-pointer test.
+// `rocprofv3 --marker-trace` shows them as "ogl:<phase>:<field>".
+class TraceRange {
+public:
+    TraceRange(const char *phase, const std::string &field);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+
+private:
+    bool pushed_ = false;
+};
+
 inline int64_t n_chunks(int64_t n_rows) { return (n_rows + CHUNK_ROWS - 1) / CHUNK_ROWS; }
 
 // Index-compressed chunked ELL ("SELL-512 with diagonal codes"): the layout the Coo/Csr-format path

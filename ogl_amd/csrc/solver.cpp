@@ -493,6 +493,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
 {
     OGL_HIP_CHECK(hipSetDevice(reg->device));
     hipStream_t st = reg->stream;
+    TraceRange trace("update_matrix", field);
     const double t0 = now_ms();
     const bool first = !have_pattern || !same_shape(ldu, pat);
     if (first) {  // :79-87
@@ -1325,7 +1326,11 @@ int ogl_solver::apply_resident(ogl_perf *perf)
     OGL_HIP_CHECK(hipSetDevice(reg->device));
     ogl_perf local{};
     if (!perf) perf = &local;
-    OGL_TRY(init_preconditioner());
+    TraceRange trace("solve", field);
+    {
+        TraceRange trace_pc("init_preconditioner", field);
+        OGL_TRY(init_preconditioner());
+    }
     switch (cfg.solver) {
     case OGL_SOLVER_CG:
         return run_cg(perf);
@@ -1349,21 +1354,27 @@ int ogl_solver::solve(const double *source, double *psi, ogl_perf *perf)
     if (!perf) perf = &local;
     *perf = ogl_perf{};
     const double t0 = now_ms();
-    if (!b_resident || cfg.update_rhs) {  // :217-226
-        OGL_TRY(upload_vec(d_b, source));
-        b_resident = true;
+    {
+        TraceRange trace("upload_rhs_and_guess", field);
+        if (!b_resident || cfg.update_rhs) {  // :217-226
+            OGL_TRY(upload_vec(d_b, source));
+            b_resident = true;
+        }
+        if (!x_resident || cfg.update_init_guess) {  // :228-237
+            OGL_TRY(upload_vec(d_x, psi));
+            x_resident = true;
+        }
+        if (cfg.scaling != 1.0) launch_scale(st, pat.n_rows, d_b.p, cfg.scaling);  // :242-252
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
     }
-    if (!x_resident || cfg.update_init_guess) {  // :228-237
-        OGL_TRY(upload_vec(d_x, psi));
-        x_resident = true;
-    }
-    if (cfg.scaling != 1.0) launch_scale(st, pat.n_rows, d_b.p, cfg.scaling);  // :242-252
-    OGL_HIP_CHECK(hipStreamSynchronize(st));
     perf->t_upload_ms = now_ms() - t0;
     perf->t_update_matrix_ms = t_update_matrix_ms;
     OGL_TRY(apply_resident(perf));
     const double t1 = now_ms();
-    OGL_TRY(reg->stager.d2h(psi, d_x.p, (size_t)pat.n_rows * sizeof(double), st));  // :278-279
+    {
+        TraceRange trace("copy_back", field);
+        OGL_TRY(reg->stager.d2h(psi, d_x.p, (size_t)pat.n_rows * sizeof(double), st));  // :278-279
+    }
     perf->t_copy_back_ms = now_ms() - t1;
     return OGL_OK;
 }
