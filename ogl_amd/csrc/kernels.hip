@@ -683,10 +683,10 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x(int n, double *__restrict__
                                                      double *__restrict__ x,
                                                      const double *__restrict__ r,
                                                      const double *__restrict__ inv_diag,
-                                                     const DevScalars *s, int turn)
+                                                     const DevScalars *s)
 {
     const int stop = s->stop;
-    const bool pending = turn > 0 && (!stop || s->iter == turn + 1);
+    const bool pending = s->x_pending != 0;
     if (stop && !pending) return;
     const RowPair rp = my_rows(blockIdx.x, n);
     double2 vp = ld2(p, rp);
@@ -1518,8 +1518,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
 {
     __shared__ double slot[FIN_WAVES];
     if (PHASE != FIN_MEAN && PHASE != FIN_NORMFACTOR && PHASE != FIN_RAW &&
-        PHASE != FIN_GMRES_SOLVE && s->stop)
+        PHASE != FIN_GMRES_SOLVE && s->stop) {
+        // after a stop the one step_1x that followed has applied the pending x update
+        if (PHASE == FIN_BETA && threadIdx.x == 0 && s->x_pending) s->x_pending = 0;
         return;
+    }
     // thread 0 fetches the scalar block up front (its latency hides behind the partial loads),
     // does the logic in registers and stores the block once: the criterion's dependent global
     // round trips would otherwise cost more than the reduction itself
@@ -1566,14 +1569,16 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
     } else if (PHASE == FIN_CG_CHECK) {
         L.prev_rho = L.rho;  // swap(prev_rho, rho) of the previous turn
         L.rho = v0;
-        criterion_check(&L, a.crit, v1, a.history);
+        criterion_check(&L, L.crit, v1, a.history);
+        L.x_pending = a.turn ? 1 : 0;  // deferred-x path: step_2r's update waits for the next step_1x
     } else if (PHASE == FIN_BETA) {
         L.beta = v0;
+        L.x_pending = 0;  // the step_1x before this SpMV has applied it
     } else if (PHASE == FIN_BICG_ALPHA) {  // beta = rr.v ; alpha = rho / beta (0 when beta == 0)
         L.beta = v0;
         L.alpha = (v0 != 0.0) ? L.rho / v0 : 0.0;
     } else if (PHASE == FIN_BICG_CHECK2) {  // mid-turn check on s
-        criterion_check(&L, a.crit, v0, a.history);
+        criterion_check(&L, L.crit, v0, a.history);
         if (L.stop) {
             L.stop_phase = 1;
             L.stop_turn = a.turn;
@@ -1617,7 +1622,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
         g.rnc[it + 1] = -g.gs[it] * g.rnc[it];
         g.rnc[it] = g.gc[it] * g.rnc[it];
     } else if (PHASE == FIN_GMRES_CHECK) {
-        criterion_check(&L, a.crit, L.stale_norm, a.history);
+        criterion_check(&L, L.crit, L.stale_norm, a.history);
     } else if (PHASE == FIN_GMRES_SOLVE) {  // solve_upper_triangular over `turn` columns
         GmresState g(a.gm, a.m);
         for (int i = a.turn - 1; i >= 0; --i) {
@@ -1629,10 +1634,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
     *s = L;
 }
 
-__global__ void k_reset_scalars(DevScalars *s)
+__global__ void k_reset_scalars(DevScalars *s, DevCriterion crit)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     DevScalars z{};
+    z.crit = crit;
     z.rho = 1.0;  // becomes prev_rho = 1 at the first check ([UPSTREAM] cg::initialize)
     z.prev_rho = 1.0;
     z.alpha = z.omega = z.gamma = z.beta = 1.0;
@@ -1885,11 +1891,11 @@ void launch_cg_step1(hipStream_t st, int32_t n, double *p, const double *r, cons
 }
 
 void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
-                      const double *inv_diag, const DevScalars *s, int turn)
+                      const double *inv_diag, const DevScalars *s)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_cg_step1x, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, s, turn);
+    hipLaunchKernelGGL(k_cg_step1x, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, s);
 }
 
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
@@ -2096,9 +2102,9 @@ void launch_peer_post(hipStream_t st, unsigned long long *dst, unsigned long lon
     hipLaunchKernelGGL(k_peer_post, dim3(1), dim3(64), 0, st, dst, w0, w1, w2, w3);
 }
 
-void launch_reset_scalars(hipStream_t st, DevScalars *s)
+void launch_reset_scalars(hipStream_t st, DevScalars *s, const DevCriterion &crit)
 {
-    hipLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(64), 0, st, s);
+    hipLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(64), 0, st, s, crit);
 }
 
 }  // namespace ogl

@@ -7,6 +7,12 @@
 
 namespace ogl {
 
+// OpenFOAMDistStoppingCriterion parameters (StoppingCriterion.H:32-72)
+struct DevCriterion {
+    double tolerance, rel_tol;
+    int32_t min_iter, max_iter, frequency, export_res;
+};
+
 // Solver scalars and criterion state, resident in device memory for the whole solve so that the
 // loop never synchronises with the host (the reference syncs D2H on every evaluated check,
 // StoppingCriterion.C:95-97).
@@ -24,12 +30,9 @@ struct DevScalars {
     int32_t stop_turn;                  // BiCGStab: turn index of that stop
     int32_t comm_error;                 // peer all-reduce timed out (a rank is gone): solve fails
     double stale_norm;                  // GMRES: sum|r| of the last restart (what the criterion sees)
-};
-
-// OpenFOAMDistStoppingCriterion parameters (StoppingCriterion.H:32-72)
-struct DevCriterion {
-    double tolerance, rel_tol;
-    int32_t min_iter, max_iter, frequency, export_res;
+    DevCriterion crit;                  // this solve's criterion (kernel arguments stay solve-independent)
+    int32_t x_pending;                  // GKOCG: step_2r's x update is still to be applied by a step_1x
+    int32_t pad_;
 };
 
 // Persistent device CSR ("<field>_matrix", CsrMatrixWrapper.H:163-210) + halo part.
@@ -168,7 +171,7 @@ void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const doub
 //   step_2r: r -= (rho/beta) q + partials;  step_1x(turn): x += (prev_rho/beta) p_old, then step_1.
 // step_1x applies the pending update of turn-1 also when the solve has just stopped.
 void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
-                      const double *inv_diag, const DevScalars *s, int turn);
+                      const double *inv_diag, const DevScalars *s);
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                       double *part_rho, double *part_norm, const DevScalars *s);
 
@@ -290,7 +293,6 @@ struct FinArgs {
     int32_t do_reduce = 1;  // reduce partials -> s->sums
     int32_t do_logic = 1;   // scalar logic from s->sums (after the all-reduce when multi-rank)
     double n_local = 0, n_global = 0;  // FIN_MEAN
-    DevCriterion crit{};
     double *history = nullptr;
     int32_t turn = 0;  // BiCGStab turn index (FIN_BICG_CHECK2); GMRES: column `it`
     double *gm = nullptr;  // GMRES dense state
@@ -300,6 +302,6 @@ struct FinArgs {
 void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a);
 
 // cg::initialize scalars: rho = 0? (unused), prev_rho = 1, iter = 0, stop = 0, norm_factor = 1
-void launch_reset_scalars(hipStream_t st, DevScalars *s);
+void launch_reset_scalars(hipStream_t st, DevScalars *s, const DevCriterion &crit);
 
 }  // namespace ogl

@@ -1024,7 +1024,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     OGL_HIP_CHECK(hipEventCreate(&ev_chk[1]));
 
     const double t_start = now_ms();
-    launch_reset_scalars(st, s);
+    launch_reset_scalars(st, s, crit);
 
     FinArgs fa;
     // norm factor, part 1: xbar = mean(x) (StoppingCriterion.C:17-19)
@@ -1066,7 +1066,6 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     fg.part[0] = d_part0.p;
     fg.part[1] = d_part1.p;
     fg.n_part = nc;
-    fg.crit = crit;
     fg.history = d_history.p;
     fg.gm = d_gm.p;
     fg.m = m;
@@ -1119,7 +1118,6 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     chk.part[1] = d_part1.p;
     chk.n_part = nc;
     chk.n_sums = 2;
-    chk.crit = crit;
     chk.history = d_history.p;
     if (!gmres) {
         OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
@@ -1131,7 +1129,6 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     f1.part[0] = d_part0.p;
     f1.n_part = nc;
     f1.n_sums = 1;
-    f1.crit = crit;
     f1.history = d_history.p;
     FinArgs f2 = f1;  // two partial arrays
     f2.part[1] = d_part1.p;
@@ -1192,13 +1189,14 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else if (!bicg) {
                 // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once
-                launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s, enq);
+                launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s);
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
                                   SpmvDots{d_p.p, d_part0.p, nullptr}, s));
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
                 OGL_TRY(finalize(FIN_BETA, f1));
                 launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s);
+                chk.turn = 1;  // this check leaves an x update pending for the next step_1x
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else {
                 launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
@@ -1252,10 +1250,10 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     if (fin.comm_error)
         return fail(OGL_ERR_COMM, "peer all-reduce timed out: a rank did not take part (check %d)",
                     fin.iter);
-    if (!gmres && !bicg && !generic && fin.iter - 1 >= enq) {
+    if (fin.x_pending) {
         // the stop came with the check of the last enqueued turn: no step_1x followed to apply
         // that turn's x update
-        launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s, fin.iter - 1);
+        launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s);
         OGL_HIP_CHECK(hipStreamSynchronize(st));
         OGL_HIP_CHECK(hipGetLastError());
     }
