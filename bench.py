@@ -57,6 +57,9 @@ def parse():
                     help="matrixFormat (Csr = the headline; Ell = configs[4]'s comparison)")
     ap.add_argument("--no-compress", action="store_true",
                     help="compressIndices false: SpMV on the plain CSR arrays (CSR-stream kernel)")
+    ap.add_argument("--graph", default="off", choices=["on", "off"],
+                    help="replay batches of GKOCG turns as a hipGraph (needs --no-profile: event-timed "
+                         "SpMVs cannot be captured); measured no faster than stream launches")
     ap.add_argument("--cpu-iters", type=int, default=-1,
                     help="oracle iterations for cpu_baseline (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--no-profile", action="store_true",
@@ -209,6 +212,7 @@ def main():
             else:
                 reg.peer_disable()
         s = reg.solver("p", cfg)
+        s.set_property("hipGraph", 1.0 if args.graph == "on" else 0.0)
         t0 = time.perf_counter()
         s.set_matrix(case)                       # pattern + H2D + device permutation (not timed below)
         t_first = time.perf_counter() - t0

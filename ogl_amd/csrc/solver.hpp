@@ -220,6 +220,9 @@ struct ogl_solver {
     uint32_t halo_seq = 0;
     ogl::DevBuf<int32_t> d_boundary_chunk_ptr;  // ranges of boundary_rows per boundary chunk
     ogl::DevBuf<unsigned> d_ticket;             // last-workgroup ticket of k_pack_put_signal
+    // a full batch of single-rank GKOCG turns captured as a hipGraph (run_krylov)
+    hipGraphExec_t cg_graph = nullptr;
+    std::vector<uintptr_t> cg_graph_key;
     int setup_peer_halo();
     ogl::PeerHalo peer_halo_args(uint32_t seq) const;
     double *peer_recv(uint32_t seq) const;

@@ -68,3 +68,21 @@ def test_converged_initial_guess_leaves_x_alone(reg, oracle, system):
     x2, perf2 = s2.solve(b, x1.copy())
     assert perf2.n_iterations == 1          # the initial check already stops
     np.testing.assert_array_equal(x2, x1)
+
+
+def test_hipgraph_replay_gives_the_same_bits(reg, oracle, system):
+    """property hipGraph: full batches of 16 turns are captured once and replayed; the stop may fall
+    anywhere inside a replayed batch."""
+    case, b, A, inv = system
+    for max_iter in (16, 17, 40, 64, 65):
+        kw = dict(tolerance=0.0, rel_tol=0.0, max_iter=max_iter)
+        s = reg.solver("dx_graph", capi.default_config(
+            solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, export_res=1, adapt_min_iter=0,
+            update_init_guess=1, **kw)).set_matrix(case)
+        s.set_property("hipGraph", 1.0)
+        x, perf = s.solve(b, np.zeros_like(b))
+        with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+            ref = oracle.cg(A, b, np.zeros_like(b), inv, **kw)
+        assert perf.n_iterations == ref.n_iterations
+        np.testing.assert_array_equal(s.history(), ref.history)
+        np.testing.assert_array_equal(x, ref.x)

@@ -15,6 +15,10 @@ run cg_bj_32   --iters 200 --edge 32
 run cg_bj_64   --iters 200 --edge 64
 run cg_bj_64np --iters 200 --edge 64 --no-profile
 run cg_bj_100  --iters 200 --edge 100
+run cg_bj_32np  --iters 200 --edge 32 --no-profile
+run cg_bj_100np --iters 200 --edge 100 --no-profile
+run cg_bj_128np --iters 200 --edge 128 --no-profile
+run cg_bj_160np --iters 200 --edge 160 --no-profile
 run cg_bj_128  --iters 200 --edge 128
 run bicg_bj_64 --iters 200 --edge 64 --solver GKOBiCGStab --asym
 run gmres_bj_64 --iters 200 --edge 64 --solver GKOGMRES --krylov-dim 30
