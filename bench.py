@@ -62,6 +62,9 @@ def parse():
                          "SpMVs cannot be captured); measured no faster than stream launches")
     ap.add_argument("--cpu-iters", type=int, default=-1,
                     help="oracle iterations for cpu_baseline (-1: sized for ~15 s, 0: skip)")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="event-time the in-loop SpMV of every k-th turn (an event pair costs ~2 us of "
+                         "the stream's time)")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not event-time the in-loop SpMV (roofline then comes from a "
                          "separate back-to-back SpMV loop)")
@@ -135,7 +138,7 @@ def main():
                               tolerance=0.0, rel_tol=0.0, max_iter=args.iters, min_iter=0,
                               eval_frequency=1, adapt_min_iter=0,
                               matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
-                              export_res=0, profile_kernels=0 if args.no_profile else 1,
+                              export_res=0, profile_kernels=0 if args.no_profile else args.profile_stride,
                               compress_indices=0 if args.no_compress else 1)
 
     def all_ok(ok):
@@ -273,7 +276,8 @@ def main():
     else:
         launches = sum(p.spmv_launches for p in perfs)
         spmv_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in perfs) / max(1, launches)
-        spmv_src = f"{launches} in-loop launches of the timed steps, HIP event pairs"
+        spmv_src = (f"{launches} in-loop launches of the timed steps (every "
+                    f"{args.profile_stride}th turn), HIP event pairs")
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
     layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[s.get_property("spmvLayout")]
     if world > 1 and s.get_property("peerHalo") == 1.0:

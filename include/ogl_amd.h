@@ -89,7 +89,8 @@ typedef struct ogl_config {
     int32_t ranks_per_gpu;      /* 1     ExecutorHandler.H:135 (only 1 works)    "ranksPerGPU"       */
     int32_t krylov_dim;         /* 0 = Ginkgo default (100); GMRES only; NOT a reference keyword   */
     int32_t sparsity_power;     /* 1     Preconditioner.H:227 (only 1 is built)  "sparsityPower"     */
-    int32_t profile_kernels;    /* 0; 1 = hipEvent-time the in-loop SpMV (bench.py roofline leg)    */
+    int32_t profile_kernels;    /* 0; k > 0 = hipEvent-time the in-loop SpMV of every k-th turn
+                                   (bench.py roofline leg)                                         */
     int32_t compress_indices;   /* 1; Coo/Csr formats: run the SpMV on the index-compressed chunked
                                    ELL copy of the matrix when the pattern qualifies (same bits in
                                    y; 9 instead of 12 bytes per entry). NOT a reference keyword:

@@ -1014,7 +1014,9 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     }
 
     // profile_kernels: one event pair per in-loop SpMV (the first of a BiCGStab turn)
-    const int prof_cap = cfg.profile_kernels ? std::min(max_turns, 4096) : 0;
+    // profile_kernels = k > 0: every k-th turn's SpMV is bracketed by an event pair (k = 1: all)
+    const int prof_stride = std::max(0, cfg.profile_kernels);
+    const int prof_cap = prof_stride ? std::min((max_turns + prof_stride - 1) / prof_stride, 4096) : 0;
     while ((int)prof_ev.size() < 2 * prof_cap) {
         hipEvent_t e;
         OGL_HIP_CHECK(hipEventCreate(&e));
@@ -1141,7 +1143,8 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     int enq = 0;
     auto enqueue_direct = [&](int count) -> int {
         for (int i = 0; i < count; ++i, ++enq) {
-            const bool prof = enq < prof_cap;
+            const bool prof = prof_stride && enq % prof_stride == 0 && enq / prof_stride < prof_cap;
+            const int pe = prof ? enq / prof_stride : 0;  // event pair of this turn
             if (gmres) {
                 // [UPSTREAM] Gmres loop: check (on the residual of the last restart), restart
                 // when the cycle is full, then one Arnoldi step
@@ -1162,9 +1165,9 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                     launch_mul(st, n, d_w.p, v_it, precond, s);
                     w = d_w.p;
                 }
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, w, nullptr, nx, SpmvDots{}, s));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 // finish_arnoldi (modified Gram-Schmidt): H(k,it) = nx.V_k ; nx -= H(k,it) V_k
                 fg.turn = it;
                 fg.n_sums = 1;
@@ -1180,10 +1183,10 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 launch_gmres_scale(st, n, nx, nx, beta_ptr, s);
             } else if (!bicg && generic) {
                 launch_cg_step1(st, n, d_p.p, d_z.p, nullptr, s);  // p = z + (rho/prev_rho) p
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
                                   SpmvDots{d_p.p, d_part0.p, nullptr}, s));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 OGL_TRY(finalize(FIN_BETA, f1));
                 launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, nullptr, d_part0.p, d_part1.p, s);
                 apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);  // z = M^-1 r and the partials of r.z
@@ -1191,10 +1194,10 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             } else if (!bicg) {
                 // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once
                 launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s);
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
                                   SpmvDots{d_p.p, d_part0.p, nullptr}, s));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 OGL_TRY(finalize(FIN_BETA, f1));
                 launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s);
                 chk.turn = 1;  // this check leaves an x update pending for the next step_1x
@@ -1202,10 +1205,10 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             } else {
                 launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
                 if (generic) apply_preconditioner(d_p.p, y, s);
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p,
                                   SpmvDots{d_rr.p, d_part0.p, nullptr}, s));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * enq + 1], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 OGL_TRY(finalize(FIN_BICG_ALPHA, f1));
                 launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part0.p, s);
                 if (generic) apply_preconditioner(d_s.p, z, s);
@@ -1333,7 +1336,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     perf->spmv_launches = 0;
     if (prof_cap) {
         double acc = 0;
-        const int m = std::min(turns_done, prof_cap);
+        const int m = std::min((turns_done + prof_stride - 1) / prof_stride, prof_cap);
         for (int i = 0; i < m; ++i) {
             float ms = 0.f;
             OGL_HIP_CHECK(hipEventElapsedTime(&ms, prof_ev[2 * i], prof_ev[2 * i + 1]));
