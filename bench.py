@@ -57,6 +57,10 @@ def parse():
                     help="matrixFormat (Csr = the headline; Ell = configs[4]'s comparison)")
     ap.add_argument("--no-compress", action="store_true",
                     help="compressIndices false: SpMV on the plain CSR arrays (CSR-stream kernel)")
+    ap.add_argument("--shuffle", type=int, default=0,
+                    help="renumber the cells at random inside windows of this many cells (a stand-in for "
+                         "an unstructured mesh: the compressed layouts do not qualify, the CSR-stream "
+                         "kernel runs); single rank only")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="replay batches of GKOCG turns as a hipGraph (needs --no-profile: event-timed "
                          "SpMVs cannot be captured); measured no faster than stream launches")
@@ -125,6 +129,9 @@ def main():
                                        off_upper=-0.9, off_lower=-1.1)
     else:
         case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
+    if args.shuffle:
+        assert world == 1, "--shuffle is a single-rank option"
+        case = synthetic.renumber_case(case, args.shuffle)
     N, nnz = case.n_cells, case.nnz
     # any smooth right-hand side will do for a fixed-iteration run; x0 = 0
     b = synthetic.x_star(case.global_index, case.global_n) + 0.5
@@ -307,7 +314,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix"
-                        f"{' (non-symmetric)' if args.asym else ''}, {args.solver}"
+                        f"{' (non-symmetric)' if args.asym else ''}"
+                        f"{f' (cells shuffled within windows of {args.shuffle})' if args.shuffle else ''}, {args.solver}"
                         f"{'(' + str(args.krylov_dim) + ')' if args.solver == 'GKOGMRES' else ''} + "
                         f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
                         "fp64/int32 persistent device CSR (BASELINE.json configs[1])",

@@ -176,3 +176,32 @@ def rhs_for_x_star(case: LduCase, halo_from_global=True):
         return apply_case(case, xs), xs
     # neighbour cell of a processor face = same cell shifted by one in the cut direction
     raise NotImplementedError("use rhs_global_slice for decomposed cases")
+
+
+def renumber_case(case: LduCase, window: int, seed: int = 20241016) -> LduCase:
+    """The same system with the cells renumbered at random inside consecutive windows of `window`
+    cells -- a stand-in for an unstructured mesh after bandwidth-reducing renumbering: the diagonals
+    of the box dissolve into a band of irregular offsets.  Faces are put back into OpenFOAM's
+    upper-triangular order (owner < neighbour, sorted by owner then neighbour)."""
+    rng = np.random.default_rng(seed)
+    n = case.n_cells
+    new_id = np.empty(n, dtype=np.int64)
+    for start in range(0, n, window):
+        stop = min(n, start + window)
+        new_id[start:stop] = start + rng.permutation(stop - start)
+    a, b = new_id[case.lower_addr], new_id[case.upper_addr]
+    swapped = a > b
+    lo, up = np.where(swapped, b, a), np.where(swapped, a, b)
+    order = np.lexsort((up, lo))
+    upper = case.upper if case.lower is None else np.where(swapped, case.lower, case.upper)
+    lower = None if case.lower is None else np.where(swapped, case.upper, case.lower)[order]
+    diag = np.empty_like(case.diag)
+    diag[new_id] = case.diag
+    gi = None
+    if case.global_index is not None:
+        gi = np.empty_like(case.global_index)
+        gi[new_id] = case.global_index
+    ifaces = [Interface(f.kind, new_id[f.face_cells].astype(np.int32), f.bou_coeffs, f.neighb_proc,
+                        f.neighb_patch) for f in case.interfaces]
+    return LduCase(n, lo[order].astype(np.int32), up[order].astype(np.int32), diag, upper[order], lower,
+                   ifaces, gi, case.global_n)
