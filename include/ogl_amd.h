@@ -93,7 +93,7 @@ typedef struct ogl_config {
                                    (bench.py roofline leg)                                         */
     int32_t compress_indices;   /* 1; Coo/Csr formats: run the SpMV on the index-compressed chunked
                                    ELL copy of the matrix when the pattern qualifies (same bits in
-                                   y; 9 instead of 12 bytes per entry). NOT a reference keyword:
+                                   y; 8.1-9 instead of 12 bytes per entry). NOT a reference keyword:
                                    "compressIndices"                                               */
 } ogl_config;
 
