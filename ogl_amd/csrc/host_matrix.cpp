@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <map>
 #include <tuple>
 
@@ -315,7 +316,7 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
                     pat[(size_t)s] = cols[k] - r;
             const size_t n_pat = pats.size() / (size_t)width;
             auto same = [&](size_t i) {
-                return std::equal(pat.begin(), pat.end(), pats.begin() + (ptrdiff_t)(i * width));
+                return std::equal(pat.begin(), pat.end(), pats.begin() + (std::ptrdiff_t)(i * width));
             };
             size_t id = n_pat;
             if (n_pat && same(last_pat)) {
@@ -390,7 +391,7 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
         const bool pat_mode = h.code_stride == ROWS_PER_THREAD;
         if (pat_mode) {  // rows 2t, 2t+1 of thread t are adjacent bytes
-            std::copy(pid_all.begin() + (ptrdiff_t)pid_pos, pid_all.begin() + (ptrdiff_t)(pid_pos + CHUNK_ROWS),
+            std::copy(pid_all.begin() + (std::ptrdiff_t)pid_pos, pid_all.begin() + (std::ptrdiff_t)(pid_pos + CHUNK_ROWS),
                       out.codes.begin() + h.code_off);
             pid_pos += CHUNK_ROWS;
         }

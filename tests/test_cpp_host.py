@@ -27,3 +27,13 @@ def test_cpp_plugin_surface_cpu():
 def test_cpp_plugin_surface_gpu():
     out = _run("gpu")
     assert out.count("[  OK  ]") >= 3
+
+
+def test_host_logic_under_asan_ubsan():
+    """host_matrix.cpp + common.cpp (pure host, no HIP) built with g++ -fsanitize=address,undefined and
+    driven through the ogl_host_* ABI (tests/cpp/asan_host_logic.cpp)."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp, "asan_host_logic"], stdout=subprocess.DEVNULL)
+    p = subprocess.run([os.path.join(cpp, "asan_host_logic")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "0 failure(s)" in p.stdout and "ERROR" not in p.stderr
