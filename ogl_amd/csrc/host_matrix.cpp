@@ -122,6 +122,35 @@ void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
         for (ogl_label r = block_ptrs[b]; r < block_ptrs[b + 1]; ++r) row_block[r] = (ogl_label)b;
 }
 
+// Sampled fingerprint of the addressing (FNV-1a over up to ~2048 evenly spaced faces and interface
+// cells): the reference keeps the pattern of a field for ever once built (HostMatrix.C:79-87); this
+// build also rebuilds it when the addressing changed under the same counts.
+uint64_t addressing_fingerprint(const ogl_ldu_view &ldu)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](int64_t v) {
+        for (int b = 0; b < 8; ++b) {
+            h ^= (uint64_t)(v >> (8 * b)) & 0xffu;
+            h *= 1099511628211ull;
+        }
+    };
+    auto sample = [&](const ogl_label *a, int64_t n) {
+        if (!a || n <= 0) return;
+        const int64_t step = std::max<int64_t>(1, n / 1024);
+        for (int64_t i = 0; i < n; i += step) mix(a[i]);
+        mix(a[n - 1]);
+    };
+    sample(ldu.lower_addr, ldu.n_faces);
+    sample(ldu.upper_addr, ldu.n_faces);
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+        const ogl_interface &itf = ldu.interfaces[i];
+        mix(itf.kind);
+        mix(itf.kind == OGL_IFACE_PROCESSOR ? itf.neighb_proc : itf.neighb_patch);
+        sample(itf.face_cells, itf.size);
+    }
+    return h;
+}
+
 bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p)
 {
     if (ldu.n_cells != p.n_rows || ldu.n_faces != p.upper_nnz) return false;
@@ -129,7 +158,8 @@ bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p)
     int64_t loc = 0, nl = 0;
     for (ogl_label i = 0; i < ldu.n_interfaces; ++i)
         (ldu.interfaces[i].kind == OGL_IFACE_PROCESSOR ? nl : loc) += ldu.interfaces[i].size;
-    return loc == p.local_iface_nnz && nl == p.non_local_nnz;
+    if (loc != p.local_iface_nnz || nl != p.non_local_nnz) return false;
+    return addressing_fingerprint(ldu) == p.fingerprint;
 }
 
 int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
@@ -276,6 +306,7 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
             p.send_idxs.insert(p.send_idxs.end(), cells.begin(), cells.end());
         }
     }
+    p.fingerprint = addressing_fingerprint(ldu);
     return OGL_OK;
 }
 

@@ -11,6 +11,7 @@ namespace ogl {
 
 // PersistentSparsityPattern (HostMatrix.H:21-64) x2 + CommunicationPattern (HostMatrix.H:67-79)
 struct HostPattern {
+    uint64_t fingerprint = 0;  // addressing_fingerprint() of the view the pattern was built from
     ogl_label n_rows = 0;
     ogl_label upper_nnz = 0;
     bool symmetric = true;
@@ -47,6 +48,8 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p);
 
 // Cheap identity check used to decide whether a cached pattern still matches a new view
 // ("For now we assume columns and rows to be constant", HostMatrix.H:33).
+uint64_t addressing_fingerprint(const ogl_ldu_view &ldu);
+// same counts and same (sampled) addressing as the view the pattern was built from
 bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p);
 
 // Jacobi block pointers for maxBlockSize > 1 ([UPSTREAM] gko::preconditioner::Jacobi
