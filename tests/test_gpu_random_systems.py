@@ -51,23 +51,53 @@ def systems(draw):
     return case, rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture,
+COMBOS = st.sampled_from([
+    # (solver, preconditioner, maxBlockSize)   -- CG / ISAI only on the symmetric systems
+    ("cg", "bj", 1), ("cg", "none", 1), ("cg", "bj", 3), ("cg", "bj", 6), ("cg", "isai", 1),
+    ("bicgstab", "bj", 1), ("bicgstab", "none", 1), ("bicgstab", "bj", 4), ("bicgstab", "gisai", 1),
+    ("gmres", "bj", 1), ("gmres", "none", 1), ("gmres", "bj", 5), ("gmres", "gisai", 1),
+])
+
+
+@settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture,
                                                                  HealthCheck.too_slow])
-@given(systems())
-def test_random_systems_bit_identical(reg, oracle, sysdata):
+@given(systems(), COMBOS, st.integers(3, 12))
+def test_random_systems_bit_identical(reg, oracle, sysdata, combo, krylov_dim):
     case, x, b = sysdata
     sym = case.lower is None
-    solver = capi.SOLVER_CG if sym else capi.SOLVER_BICGSTAB
+    solver, precond, k = combo
+    if not sym and solver == "cg":
+        solver = "bicgstab"
+    if not sym and precond == "isai":
+        precond = "gisai"
     kw = dict(tolerance=1e-12, rel_tol=0.0, max_iter=60)
-    cfg = capi.default_config(solver=solver, preconditioner=capi.PRECOND_BJ, export_res=1, adapt_min_iter=0,
-                              update_init_guess=1, **kw)
-    s = reg.solver("rand_sym" if sym else "rand_asym", cfg).set_matrix(case)
+    cfg = capi.default_config(
+        solver={"cg": capi.SOLVER_CG, "bicgstab": capi.SOLVER_BICGSTAB, "gmres": capi.SOLVER_GMRES}[solver],
+        preconditioner={"bj": capi.PRECOND_BJ, "none": capi.PRECOND_NONE, "isai": capi.PRECOND_ISAI,
+                        "gisai": capi.PRECOND_GISAI}[precond],
+        max_block_size=k, krylov_dim=krylov_dim, export_res=1, adapt_min_iter=0, update_init_guess=1, **kw)
+    s = reg.solver(f"rand_{solver}_{precond}_{k}_{int(sym)}", cfg).set_matrix(case)
     A, (rp, cols, vals) = oracle_matrix(oracle, case)
-    rp_d, cols_d, vals_d = s.local_matrix_csr() if hasattr(s, "local_matrix_csr") else (None, None, None)
     np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
-    xs, perf = s.solve(b, np.zeros_like(b))
-    inv = oracle.jacobi_generate_scalar(rp, cols, vals)
+    # ISAI needs rows of at most 32 pattern entries: the product refuses wider ones
+    width = int(np.diff(rp).max())
+    try:
+        xs, perf = s.solve(b, np.zeros_like(b))
+    except capi.OglError as e:
+        assert precond in ("isai", "gisai") and width > 32 and e.status == capi.ERR_UNSUPPORTED, e
+        return
+    if precond == "none":
+        P = None
+    elif precond == "bj":
+        P = oracle.Precond(rp, cols, vals, k)
+    else:
+        P = oracle.Precond(rp, cols, vals, isai="spd" if precond == "isai" else "general")
     with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
-        ref = (oracle.cg if sym else oracle.bicgstab)(A, b, np.zeros_like(b), inv, **kw)
+        if solver == "cg":
+            ref = oracle.cg(A, b, np.zeros_like(b), P, **kw)
+        elif solver == "bicgstab":
+            ref = oracle.bicgstab(A, b, np.zeros_like(b), P, **kw)
+        else:
+            ref = oracle.gmres(A, b, np.zeros_like(b), P, krylov_dim=krylov_dim, **kw)
     np.testing.assert_array_equal(s.history(), ref.history)
     np.testing.assert_array_equal(xs, ref.x)
