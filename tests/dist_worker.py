@@ -94,17 +94,29 @@ def main():
     ap.add_argument("--precond", type=int, default=1)
     ap.add_argument("--asym", type=int, default=0)
     ap.add_argument("--gmres", type=int, default=0)
+    ap.add_argument("--random", type=int, default=-1,
+                    help="seed: random irregular global system cut into contiguous row blocks of random "
+                         "sizes (instead of the structured box of --shape/--procs)")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    gx, gy, gz = map(int, args.shape.split(","))
-    px, py, pz = map(int, args.procs.split(","))
-    assert px * py * pz == world
-    kw = dict(symmetric=not args.asym)
-    if args.asym:
-        kw.update(off_upper=-0.9, off_lower=-1.1)
-    case = synthetic.poisson_block(gx, gy, gz, px, py, pz, rank, **kw)
-    glob = synthetic.poisson_block(gx, gy, gz, **kw)
+    if args.random >= 0:
+        rng = np.random.default_rng(args.random)
+        n_glob = int(rng.integers(600, 2500))
+        glob = synthetic.random_global_case(n_glob, int(rng.integers(1, 5)), int(rng.choice([4, 60, 900])),
+                                            symmetric=not args.asym, seed=args.random)
+        cuts = np.sort(rng.choice(np.arange(1, n_glob), world - 1, replace=False)) if world > 1 else []
+        bounds = [0, *[int(c) for c in cuts], n_glob]
+        case = synthetic.partition_rows(glob, bounds, rank)
+    else:
+        gx, gy, gz = map(int, args.shape.split(","))
+        px, py, pz = map(int, args.procs.split(","))
+        assert px * py * pz == world
+        kw = dict(symmetric=not args.asym)
+        if args.asym:
+            kw.update(off_upper=-0.9, off_lower=-1.1)
+        case = synthetic.poisson_block(gx, gy, gz, px, py, pz, rank, **kw)
+        glob = synthetic.poisson_block(gx, gy, gz, **kw)
     xs_g = synthetic.x_star(glob.global_index, glob.global_n)
     b_g = synthetic.apply_case(glob, xs_g)
     b = b_g[case.global_index]

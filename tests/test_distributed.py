@@ -106,3 +106,31 @@ def test_gpu_peer_rank_dropout_fails_loudly():
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
     assert p.stdout.count("dropout ok") == 2 and "failed loudly" in p.stdout, p.stdout
+
+
+# Irregular decompositions: a random global system cut into contiguous row blocks of random sizes
+# (rows with several non-local entries, ranks with 1..n-1 neighbours, interfaces of any length).
+@pytest.mark.parametrize("seed,n", [(1, 2), (2, 3), (3, 4), (4, 5)])
+def test_oracle_random_partition(seed, n):
+    run_ranks(n, "--mode", "oracle", "--random", str(seed))
+
+
+def test_oracle_random_partition_bicgstab():
+    run_ranks(3, "--mode", "oracle", "--random", "11", "--asym", "1")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", [(5, 2), (6, 3), (7, 4), (8, 6)])
+def test_gpu_peer_random_partition(seed, n):
+    run_ranks(n, "--mode", "gpu-peer", "--random", str(seed))
+
+
+@pytest.mark.gpu
+def test_gpu_peer_random_partition_bicgstab_and_gmres():
+    run_ranks(3, "--mode", "gpu-peer", "--random", "9", "--asym", "1")
+    run_ranks(3, "--mode", "gpu-peer", "--random", "10", "--gmres", "15")
+
+
+@pytest.mark.gpu
+def test_gpu_host_buffer_random_partition():
+    run_ranks(3, "--mode", "gpu-host", "--random", "12")
