@@ -134,3 +134,15 @@ def test_gpu_peer_random_partition_bicgstab_and_gmres():
 @pytest.mark.gpu
 def test_gpu_host_buffer_random_partition():
     run_ranks(3, "--mode", "gpu-host", "--random", "12")
+
+
+@pytest.mark.gpu
+def test_gpu_peer_mesh_soak():
+    # 40 solves with changing solver / stop position / right-hand side on one persistent set of fields
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "peer_stress_worker.py"), "--solves", "40", "--seed", "21"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
+    assert p.stdout.count("solves ok") == 3, p.stdout
