@@ -184,12 +184,12 @@ __global__ __launch_bounds__(BLOCK) void k_sell_pid(int n_rows, int n_chunks, co
                                                     const uint8_t *__restrict__ codes,
                                                     const double *__restrict__ vals,
                                                     const double *__restrict__ x, double *__restrict__ y,
-                                                    double *__restrict__ part)
+                                                    double *__restrict__ part, const int *__restrict__ order = nullptr)
 {
     __shared__ double slot[N_WAVES];
     __shared__ int stab[PID_TABLE];
-    const int chunk = XCD ? xcd_chunk(blockIdx.x) : (int)blockIdx.x;
-    if (chunk >= n_chunks) return;
+    const int chunk = XCD == 2 ? order[blockIdx.x] : (XCD ? xcd_chunk(blockIdx.x) : (int)blockIdx.x);
+    if (chunk < 0 || chunk >= n_chunks) return;
     const ChunkHdr h = hdr[chunk];
     const int t = threadIdx.x;
     for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];
@@ -458,9 +458,38 @@ int main(int argc, char **argv)
         time_it("sell 1-byte ROW pattern ids, xcd-grouped", A,
                 [&](const double *x) {
                     hipLaunchKernelGGL((k_sell_pid<1>), dim3(xcd_grid(nc)), dim3(BLOCK), 0, 0, A.n, nc, d_phdr,
-                                       d_ptab, d_pcodes, d_svals, x, d_y, d_part);
+                                       d_ptab, d_pcodes, d_svals, x, d_y, d_part, (const int *)nullptr);
                 },
                 d_x0, d_x1, d_y, yref, reps, 8.0 * val_len + 2.0 * BLOCK * nc + 16.0 * A.n + 32.0 * nc);
+        for (double frac : {1.0, 0.5, 2.0}) {
+            // band-aware order: XCD of chunk c = floor(frac(c * CHUNK / band) * 8); block b (XCD b % 8) takes
+            // entry b / 8 of its XCD's ascending list
+            const double band = frac * (double)n * n;
+            std::vector<std::vector<int>> lists(8);
+            for (int c = 0; c < nc; ++c) {
+                const double ph = (double)c * CHUNK / band;
+                int xq = (int)((ph - floor(ph)) * 8.0);
+                lists[xq > 7 ? 7 : xq].push_back(c);
+            }
+            size_t mx = 0;
+            for (auto &l : lists) mx = std::max(mx, l.size());
+            std::vector<int> order(mx * 8, -1);
+            for (int xq = 0; xq < 8; ++xq)
+                for (size_t i = 0; i < lists[xq].size(); ++i) order[i * 8 + xq] = lists[xq][i];
+            int *d_order;
+            CK(hipMalloc(&d_order, sizeof(int) * order.size()));
+            CK(hipMemcpy(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
+            char name[96];
+            snprintf(name, sizeof(name), "sell ROW pattern ids, band-aware x%.1f", frac);
+            const int grid = (int)order.size();
+            time_it(name, A,
+                    [&](const double *x) {
+                        hipLaunchKernelGGL((k_sell_pid<2>), dim3(grid), dim3(BLOCK), 0, 0, A.n, nc, d_phdr,
+                                           d_ptab, d_pcodes, d_svals, x, d_y, d_part, d_order);
+                    },
+                    d_x0, d_x1, d_y, yref, reps, 8.0 * val_len + 2.0 * BLOCK * nc + 16.0 * A.n + 32.0 * nc);
+            CK(hipFree(d_order));
+        }
         time_it("sell 1-byte codes, LDS dict, plain", A,
                 [&](const double *x) {
                     hipLaunchKernelGGL((k_sell<0, 0>), dim3(nc), dim3(BLOCK), 0, 0, A.n, nc, d_hdr, d_dict,
