@@ -461,7 +461,29 @@ int main(int argc, char **argv)
                                        d_ptab, d_pcodes, d_svals, x, d_y, d_part, (const int *)nullptr);
                 },
                 d_x0, d_x1, d_y, yref, reps, 8.0 * val_len + 2.0 * BLOCK * nc + 16.0 * A.n + 32.0 * nc);
-        for (double frac : {1.0, 0.5, 2.0}) {
+        for (int G : {1, 2, 8, 16, 32}) {
+            // groups of G consecutive chunks per XCD on one common front, as an order table
+            const int Q = 8 * G, grid = ((nc + Q - 1) / Q) * Q;
+            std::vector<int> order(grid, -1);
+            for (int b = 0; b < grid; ++b) {
+                const int sl = b / 8, xq = b % 8;
+                const int c = (sl / G) * Q + xq * G + sl % G;
+                order[b] = c < nc ? c : -1;
+            }
+            int *d_order;
+            CK(hipMalloc(&d_order, sizeof(int) * order.size()));
+            CK(hipMemcpy(d_order, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice));
+            char name[96];
+            snprintf(name, sizeof(name), "sell ROW pattern ids, xcd groups of %d", G);
+            time_it(name, A,
+                    [&](const double *x) {
+                        hipLaunchKernelGGL((k_sell_pid<2>), dim3(grid), dim3(BLOCK), 0, 0, A.n, nc, d_phdr,
+                                           d_ptab, d_pcodes, d_svals, x, d_y, d_part, d_order);
+                    },
+                    d_x0, d_x1, d_y, yref, reps, 8.0 * val_len + 2.0 * BLOCK * nc + 16.0 * A.n + 32.0 * nc);
+            CK(hipFree(d_order));
+        }
+        for (double frac : {1.0}) {
             // band-aware order: XCD of chunk c = floor(frac(c * CHUNK / band) * 8); block b (XCD b % 8) takes
             // entry b / 8 of its XCD's ascending list
             const double band = frac * (double)n * n;
