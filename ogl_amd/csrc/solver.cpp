@@ -254,10 +254,15 @@ int ogl_solver::setup_peer_halo()
     const uint32_t epoch = ++R.halo_epoch;
     double cannot = 0.0;
     const size_t words = (2 * (size_t)nn + 2 * nh + 15) / 16 * 16;
-    if (nn > PEER_MAX_NEIGH || R.arena_used + words > R.arena_words) cannot = 1.0;
+    // a pattern rebuild reuses the field's block when it is large enough (the arena only grows)
+    const bool reuse = peer_block_words >= words && words > 0;
+    if (nn > PEER_MAX_NEIGH || (!reuse && R.arena_used + words > R.arena_words)) cannot = 1.0;
     if (cannot == 0.0) {
-        peer_block = R.arena_used;
-        R.arena_used += words;
+        if (!reuse) {
+            peer_block = R.arena_used;
+            peer_block_words = words;
+            R.arena_used += words;
+        }
         if (nn)
             OGL_HIP_CHECK(hipMemsetAsync(R.peer_local + PEER_ARENA_OFF + peer_block, 0,
                                          2 * (size_t)nn * sizeof(unsigned long long), st));

@@ -216,6 +216,7 @@ struct ogl_solver {
     };
     bool peer_halo = false;
     size_t peer_block = 0;  // this solver's arena block
+    size_t peer_block_words = 0;
     std::vector<PeerNeighbour> peer_nb;
     uint32_t halo_seq = 0;
     ogl::DevBuf<int32_t> d_boundary_chunk_ptr;  // ranges of boundary_rows per boundary chunk

@@ -29,14 +29,18 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(args.seed)                   # same stream on every rank
-    n_glob = int(rng.integers(1500, 4000))
-    glob = synthetic.random_global_case(n_glob, 3, 80, symmetric=True, seed=args.seed)
-    cuts = np.sort(rng.choice(np.arange(1, n_glob), world - 1, replace=False))
-    bounds = [0, *[int(c) for c in cuts], n_glob]
-    case = synthetic.partition_rows(glob, bounds, rank)
-    A, (rp, cols, vals), nl, comm = oracle_dist_matrix(case, allreduce_rank_order)
-    inv = orc.jacobi_generate_scalar(rp, cols, vals)
-    P = orc.Precond(rp, cols, vals, 1)
+
+    def build(seed):
+        """a new global system and partition: every field's pattern changes on every rank"""
+        n_glob = int(rng.integers(1500, 4000))
+        glob = synthetic.random_global_case(n_glob, 3, 80, symmetric=True, seed=seed)
+        cuts = np.sort(rng.choice(np.arange(1, n_glob), world - 1, replace=False))
+        bounds = [0, *[int(c) for c in cuts], n_glob]
+        case = synthetic.partition_rows(glob, bounds, rank)
+        A, (rp, cols, vals), nl, comm = oracle_dist_matrix(case, allreduce_rank_order)
+        return n_glob, case, A, orc.jacobi_generate_scalar(rp, cols, vals), orc.Precond(rp, cols, vals, 1)
+
+    n_glob, case, A, inv, P = build(args.seed)
 
     reg = capi.Registry(device_id=rank % max(1, torch.cuda.device_count()))
     ex = make_exchange(None)
@@ -46,6 +50,11 @@ def main():
     reg.peer_connect(rank, world, handles)
     solvers = {}
     for it in range(args.solves):
+        if it and it % 12 == 0:                              # topology change: collective pattern rebuild
+            n_glob, case, A, inv, P = build(args.seed + it)
+            for sv in solvers.values():
+                sv.set_matrix(case)
+                assert sv.get_property("peerHalo") == 1.0
         kind = ["cg", "bicgstab", "gmres"][int(rng.integers(0, 3))]
         max_iter = int(rng.integers(1, 45))
         tol = float(10.0 ** rng.uniform(-12, -2))
