@@ -280,6 +280,19 @@ __global__ __launch_bounds__(BLOCK) void k_jacobi_generate(int n_rows,
     inv_diag[row] = 1.0 / d;
 }
 
+// The same from the precomputed position of each row's first diagonal entry (-1: none -> 1/0 as
+// above): 12 bytes per row instead of a walk through the row.
+__global__ __launch_bounds__(BLOCK) void k_jacobi_generate_pos(int n_rows, const int *__restrict__ diag_pos,
+                                                               const double *__restrict__ vals,
+                                                               double *__restrict__ inv_diag)
+{
+    const int row = blockIdx.x * BLOCK + threadIdx.x;
+    if (row >= n_rows) return;
+    const int k = diag_pos[row];
+    const double d = k >= 0 ? vals[k] : 0.0;
+    inv_diag[row] = 1.0 / d;
+}
+
 // Block Jacobi generate: one thread inverts one diagonal block in place (global memory; runs
 // once per preconditioner generation).  Same operation order as oracle/ogl_oracle.c invert_block:
 // Gauss-Jordan, partial (row) pivoting, pivot row scaled first, then the other rows eliminated,
@@ -1760,6 +1773,13 @@ void launch_gather_coeffs(hipStream_t st, int32_t nnz, const int32_t *ldu_mappin
     if (nnz == 0) return;
     hipLaunchKernelGGL(k_gather_coeffs, dim3(blocks_for(((int64_t)nnz + 3) / 4)), dim3(BLOCK), 0,
                        st, nnz, ldu_mapping, source, coeffs);
+}
+
+void launch_jacobi_generate_pos(hipStream_t st, const DevCsr &A, const int32_t *diag_pos, double *inv_diag)
+{
+    if (A.n_rows == 0) return;
+    hipLaunchKernelGGL(k_jacobi_generate_pos, dim3(blocks_for(A.n_rows)), dim3(BLOCK), 0, st, A.n_rows,
+                       diag_pos, A.vals, inv_diag);
 }
 
 void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag)

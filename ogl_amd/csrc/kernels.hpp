@@ -109,6 +109,8 @@ void launch_gather_coeffs(hipStream_t st, int32_t nnz, const int32_t *ldu_mappin
                           const double *source, double *coeffs);
 // inv_diag[i] = 1 / A(i,i)   (Jacobi generate with max_block_size 1)
 void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag);
+// the same with diag_pos[i] = position of row i's first diagonal entry (-1: none), found once per pattern
+void launch_jacobi_generate_pos(hipStream_t st, const DevCsr &A, const int32_t *diag_pos, double *inv_diag);
 
 // Block Jacobi with maxBlockSize k > 1 (Preconditioner.H:91-105): inverted diagonal blocks,
 // row-major, `stride` x `stride` doubles per block.

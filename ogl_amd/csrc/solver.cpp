@@ -550,6 +550,17 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
                                 pat.row_ptrs.size() * sizeof(int32_t), st));
         OGL_TRY(reg->stager.h2d(d_cols.p, pat.cols.data(), nnz * sizeof(int32_t), st));
         OGL_TRY(reg->stager.h2d(d_ldu_mapping.p, pat.ldu_mapping.data(), nnz * sizeof(int32_t), st));
+        {  // Csr::extract_diagonal takes the first (i, i) entry of a row
+            std::vector<int32_t> dpos((size_t)pat.n_rows, -1);
+            for (int32_t r = 0; r < pat.n_rows; ++r)
+                for (int32_t k = pat.row_ptrs[r]; k < pat.row_ptrs[r + 1]; ++k)
+                    if (pat.cols[k] == r) {
+                        dpos[(size_t)r] = k;
+                        break;
+                    }
+            OGL_TRY(d_diag_pos.alloc(std::max<size_t>(1, dpos.size()), st));
+            OGL_TRY(reg->stager.h2d(d_diag_pos.p, dpos.data(), dpos.size() * sizeof(int32_t), st));
+        }
 
         // halo: rows owning non-local entries (row-sorted triplets -> one run per row)
         boundary_rows.clear();
@@ -765,7 +776,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         P.stride = 0;
     } else if (cfg.max_block_size == 1) {  // scalar Jacobi: 1 / diag
         OGL_TRY(P.values.alloc(n + 2, st));
-        launch_jacobi_generate(st, csr(), P.values.p);
+        launch_jacobi_generate_pos(st, csr(), d_diag_pos.p, P.values.p);
         P.kind = 1;
         P.stride = 0;
     } else {

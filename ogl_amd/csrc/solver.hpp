@@ -190,6 +190,7 @@ struct ogl_solver {
     ogl::DevBuf<int32_t> d_row_ptrs, d_cols, d_ldu_mapping;  // "<field>_local_*"
     ogl::DevBuf<double> d_vals;                              // "<field>_matrix" values
     ogl::DevBuf<double> d_source;                            // unsorted [upper|lower|diag|iface]
+    ogl::DevBuf<int32_t> d_diag_pos;  // position of each row's first diagonal entry (scalar Jacobi)
     // matrixFormat Ell: slot-major copy of the local matrix (built on demand, refreshed from vals)
     ogl::DevBuf<int32_t> d_ell_cols, d_ell_map;
     ogl::DevBuf<double> d_ell_vals;
