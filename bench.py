@@ -61,6 +61,8 @@ def parse():
                     help="renumber the cells at random inside windows of this many cells (a stand-in for "
                          "an unstructured mesh: the compressed layouts do not qualify, the CSR-stream "
                          "kernel runs); single rank only")
+    ap.add_argument("--rcm", action="store_true",
+                    help="after --shuffle: renumber with reverse Cuthill-McKee, as renumberMesh would")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="replay batches of GKOCG turns as a hipGraph (needs --no-profile: event-timed "
                          "SpMVs cannot be captured); measured no faster than stream launches")
@@ -132,6 +134,8 @@ def main():
     if args.shuffle:
         assert world == 1, "--shuffle is a single-rank option"
         case = synthetic.renumber_case(case, args.shuffle)
+        if args.rcm:
+            case = synthetic.rcm_case(case)
     N, nnz = case.n_cells, case.nnz
     # any smooth right-hand side will do for a fixed-iteration run; x0 = 0
     b = synthetic.x_star(case.global_index, case.global_n) + 0.5
@@ -315,7 +319,7 @@ def main():
         "config": {
             "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix"
                         f"{' (non-symmetric)' if args.asym else ''}"
-                        f"{f' (cells shuffled within windows of {args.shuffle})' if args.shuffle else ''}, {args.solver}"
+                        f"{f' (cells shuffled within windows of {args.shuffle}' + (', then RCM' if args.rcm else '') + ')' if args.shuffle else ''}, {args.solver}"
                         f"{'(' + str(args.krylov_dim) + ')' if args.solver == 'GKOGMRES' else ''} + "
                         f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
                         "fp64/int32 persistent device CSR (BASELINE.json configs[1])",

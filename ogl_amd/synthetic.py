@@ -178,17 +178,11 @@ def rhs_for_x_star(case: LduCase, halo_from_global=True):
     raise NotImplementedError("use rhs_global_slice for decomposed cases")
 
 
-def renumber_case(case: LduCase, window: int, seed: int = 20241016) -> LduCase:
-    """The same system with the cells renumbered at random inside consecutive windows of `window`
-    cells -- a stand-in for an unstructured mesh after bandwidth-reducing renumbering: the diagonals
-    of the box dissolve into a band of irregular offsets.  Faces are put back into OpenFOAM's
+def permute_case(case: LduCase, new_id) -> LduCase:
+    """The same system with cell c renamed new_id[c].  Faces are put back into OpenFOAM's
     upper-triangular order (owner < neighbour, sorted by owner then neighbour)."""
-    rng = np.random.default_rng(seed)
+    new_id = np.asarray(new_id, dtype=np.int64)
     n = case.n_cells
-    new_id = np.empty(n, dtype=np.int64)
-    for start in range(0, n, window):
-        stop = min(n, start + window)
-        new_id[start:stop] = start + rng.permutation(stop - start)
     a, b = new_id[case.lower_addr], new_id[case.upper_addr]
     swapped = a > b
     lo, up = np.where(swapped, b, a), np.where(swapped, a, b)
@@ -207,44 +201,26 @@ def renumber_case(case: LduCase, window: int, seed: int = 20241016) -> LduCase:
                    ifaces, gi, case.global_n)
 
 
-def random_global_case(n, per_row, reach, symmetric=True, seed=0):
-    """Diagonally dominant random lduMatrix: every cell couples to `per_row` random cells among the
-    next `reach` ones (faces in upper-triangular order)."""
+def renumber_case(case: LduCase, window: int, seed: int = 20241016) -> LduCase:
+    """Cells renumbered at random inside consecutive windows of `window` cells -- a stand-in for an
+    unstructured mesh: the diagonals of the box dissolve into a band of irregular offsets."""
     rng = np.random.default_rng(seed)
-    pairs = set()
-    for i in range(n - 1):
-        for j in rng.integers(i + 1, min(n, i + 1 + reach), per_row):
-            pairs.add((i, int(j)))
-    pairs = np.array(sorted(pairs), dtype=np.int32).reshape(-1, 2)
-    f = len(pairs)
-    upper = rng.uniform(-1, -0.1, f)
-    lower = None if symmetric else rng.uniform(-1, -0.1, f)
-    diag = np.full(n, 1.0)
-    np.add.at(diag, pairs[:, 0], np.abs(upper))
-    np.add.at(diag, pairs[:, 1], np.abs(upper if symmetric else lower))
-    return LduCase(n, pairs[:, 0].copy(), pairs[:, 1].copy(), diag, upper, lower, [],
-                   np.arange(n, dtype=np.int64), n)
+    n = case.n_cells
+    new_id = np.empty(n, dtype=np.int64)
+    for start in range(0, n, window):
+        stop = min(n, start + window)
+        new_id[start:stop] = start + rng.permutation(stop - start)
+    return permute_case(case, new_id)
 
 
-def partition_rows(glob: LduCase, bounds, rank) -> LduCase:
-    """Rank `rank`'s rows [bounds[rank], bounds[rank+1]) of a global case: faces inside the block stay
-    faces, faces that cross into rank q become one processor interface per neighbour (ascending q),
-    ordered by (global owner, global neighbour) on both sides, bouCoeffs = -(off-diagonal entry)."""
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    a, b = glob.lower_addr.astype(np.int64), glob.upper_addr.astype(np.int64)
-    owner = np.searchsorted(np.asarray(bounds[1:]), np.arange(glob.n_cells), side="right")
-    ra, rb = owner[a], owner[b]
-    inside = (ra == rank) & (rb == rank)
-    low_coeff = glob.upper if glob.lower is None else glob.lower
-    ifaces = []
-    for q in sorted(set(rb[(ra == rank) & (rb != rank)]) | set(ra[(rb == rank) & (ra != rank)])):
-        mine_low = (ra == rank) & (rb == q)      # my cell is the face owner: entry (a, b) = upper
-        mine_up = (rb == rank) & (ra == q)       # my cell is the neighbour: entry (b, a) = lower
-        sel = np.flatnonzero(mine_low | mine_up)  # already sorted by (owner, neighbour)
-        cells = np.where(mine_low[sel], a[sel], b[sel]) - lo
-        coeff = np.where(mine_low[sel], glob.upper[sel], low_coeff[sel])
-        ifaces.append(Interface(IFACE_PROCESSOR, cells.astype(np.int32), -coeff, int(q), -1))
-    return LduCase(hi - lo, (a[inside] - lo).astype(np.int32), (b[inside] - lo).astype(np.int32),
-                   glob.diag[lo:hi].copy(), glob.upper[inside].copy(),
-                   None if glob.lower is None else glob.lower[inside].copy(), ifaces,
-                   np.arange(lo, hi, dtype=np.int64), glob.n_cells)
+def rcm_case(case: LduCase) -> LduCase:
+    """What OpenFOAM's renumberMesh does: reverse Cuthill-McKee ordering of the cell graph (scipy)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n = case.n_cells
+    ones = np.ones(case.lower_addr.size, dtype=np.int8)
+    g = sp.coo_matrix((ones, (case.lower_addr, case.upper_addr)), shape=(n, n)).tocsr()
+    order = reverse_cuthill_mckee(g + g.T, symmetric_mode=True)   # order[k] = old id of new cell k
+    new_id = np.empty(n, dtype=np.int64)
+    new_id[order] = np.arange(n)
+    return permute_case(case, new_id)
