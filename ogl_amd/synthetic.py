@@ -224,3 +224,46 @@ def rcm_case(case: LduCase) -> LduCase:
     new_id = np.empty(n, dtype=np.int64)
     new_id[order] = np.arange(n)
     return permute_case(case, new_id)
+
+
+def random_global_case(n, per_row, reach, symmetric=True, seed=0):
+    """Diagonally dominant random lduMatrix: every cell couples to `per_row` random cells among the
+    next `reach` ones (faces in upper-triangular order)."""
+    rng = np.random.default_rng(seed)
+    pairs = set()
+    for i in range(n - 1):
+        for j in rng.integers(i + 1, min(n, i + 1 + reach), per_row):
+            pairs.add((i, int(j)))
+    pairs = np.array(sorted(pairs), dtype=np.int32).reshape(-1, 2)
+    f = len(pairs)
+    upper = rng.uniform(-1, -0.1, f)
+    lower = None if symmetric else rng.uniform(-1, -0.1, f)
+    diag = np.full(n, 1.0)
+    np.add.at(diag, pairs[:, 0], np.abs(upper))
+    np.add.at(diag, pairs[:, 1], np.abs(upper if symmetric else lower))
+    return LduCase(n, pairs[:, 0].copy(), pairs[:, 1].copy(), diag, upper, lower, [],
+                   np.arange(n, dtype=np.int64), n)
+
+
+def partition_rows(glob: LduCase, bounds, rank) -> LduCase:
+    """Rank `rank`'s rows [bounds[rank], bounds[rank+1]) of a global case: faces inside the block stay
+    faces, faces that cross into rank q become one processor interface per neighbour (ascending q),
+    ordered by (global owner, global neighbour) on both sides, bouCoeffs = -(off-diagonal entry)."""
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    a, b = glob.lower_addr.astype(np.int64), glob.upper_addr.astype(np.int64)
+    owner = np.searchsorted(np.asarray(bounds[1:]), np.arange(glob.n_cells), side="right")
+    ra, rb = owner[a], owner[b]
+    inside = (ra == rank) & (rb == rank)
+    low_coeff = glob.upper if glob.lower is None else glob.lower
+    ifaces = []
+    for q in sorted(set(rb[(ra == rank) & (rb != rank)]) | set(ra[(rb == rank) & (ra != rank)])):
+        mine_low = (ra == rank) & (rb == q)      # my cell is the face owner: entry (a, b) = upper
+        mine_up = (rb == rank) & (ra == q)       # my cell is the neighbour: entry (b, a) = lower
+        sel = np.flatnonzero(mine_low | mine_up)  # already sorted by (owner, neighbour)
+        cells = np.where(mine_low[sel], a[sel], b[sel]) - lo
+        coeff = np.where(mine_low[sel], glob.upper[sel], low_coeff[sel])
+        ifaces.append(Interface(IFACE_PROCESSOR, cells.astype(np.int32), -coeff, int(q), -1))
+    return LduCase(hi - lo, (a[inside] - lo).astype(np.int32), (b[inside] - lo).astype(np.int32),
+                   glob.diag[lo:hi].copy(), glob.upper[inside].copy(),
+                   None if glob.lower is None else glob.lower[inside].copy(), ifaces,
+                   np.arange(lo, hi, dtype=np.int64), glob.n_cells)
