@@ -1094,10 +1094,22 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_step3(int n, double *__restrict_
                                                       const double *__restrict__ rr,
                                                       double *__restrict__ part_rho,
                                                       double *__restrict__ part_norm,
-                                                      const DevScalars *s)
+                                                      const DevScalars *s, int turn)
 {
     __shared__ double slot[N_WAVES];
-    if (s->stop) return;
+    if (s->stop) {
+        // bicgstab::finalize: x += alpha y, only on the turn whose mid-step check stopped the solver
+        if (s->stop_phase == 1 && s->stop_turn == turn) {
+            const double alpha = s->alpha;
+            const RowPair rp = my_rows(blockIdx.x, n);
+            double2 vx = ld2(x, rp);
+            const double2 vy = ld2(y, rp);
+            vx.x += alpha * vy.x;
+            vx.y += alpha * vy.y;
+            st2(x, rp, vx);
+        }
+        return;
+    }
     const double alpha = s->alpha, omega = s->omega;
     const int chunk = blockIdx.x;
     const RowPair rp = my_rows(chunk, n);
@@ -1126,21 +1138,6 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_step3(int n, double *__restrict_
         part_rho[chunk] = s0;
         part_norm[chunk] = s1;
     }
-}
-
-// bicgstab::finalize: x += alpha y, only on the turn whose mid-step check stopped the solver
-__global__ __launch_bounds__(BLOCK) void k_bicg_finalize_x(int n, double *__restrict__ x,
-                                                           const double *__restrict__ y,
-                                                           const DevScalars *s, int turn)
-{
-    if (!(s->stop && s->stop_phase == 1 && s->stop_turn == turn)) return;
-    const double alpha = s->alpha;
-    const RowPair rp = my_rows(blockIdx.x, n);
-    double2 vx = ld2(x, rp);
-    const double2 vy = ld2(y, rp);
-    vx.x += alpha * vy.x;
-    vx.y += alpha * vy.y;
-    st2(x, rp, vx);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1956,20 +1953,12 @@ void launch_bicg_step2(hipStream_t st, int32_t n, const double *r, const double 
 
 void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const double *sv,
                        const double *t, const double *y, const double *z, const double *rr,
-                       double *part_rho, double *part_norm, const DevScalars *s)
+                       double *part_rho, double *part_norm, const DevScalars *s, int turn)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
     hipLaunchKernelGGL(k_bicg_step3, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr,
-                       part_rho, part_norm, s);
-}
-
-void launch_bicg_finalize_x(hipStream_t st, int32_t n, double *x, const double *y,
-                            const DevScalars *s, int turn)
-{
-    const int nc = (int)n_chunks(n);
-    if (nc == 0) return;
-    hipLaunchKernelGGL(k_bicg_finalize_x, dim3(nc), dim3(BLOCK), 0, st, n, x, y, s, turn);
+                       part_rho, part_norm, s, turn);
 }
 
 void launch_gmres_scale(hipStream_t st, int32_t n, double *out, const double *in,

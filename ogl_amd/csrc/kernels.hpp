@@ -184,9 +184,9 @@ void launch_bicg_step2(hipStream_t st, int32_t n, const double *r, const double 
                        const double *inv_diag, double *z, double *part_norm, const DevScalars *s);
 void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const double *sv,
                        const double *t, const double *y, const double *z, const double *rr,
-                       double *part_rho, double *part_norm, const DevScalars *s);
-void launch_bicg_finalize_x(hipStream_t st, int32_t n, double *x, const double *y,
-                            const DevScalars *s, int turn);
+                       double *part_rho, double *part_norm, const DevScalars *s, int turn);
+// (step_3 of the turn whose mid-step check stopped the solve applies bicgstab::finalize,
+//  x += alpha y, instead of its own work)
 
 // --- GMRES vector kernels ([UPSTREAM] gmres::restart / finish_arnoldi / solve_krylov) ---
 // out = in / *denom

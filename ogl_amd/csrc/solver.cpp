@@ -1257,12 +1257,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 if (generic) apply_preconditioner(d_s.p, z, s);
                 f1.turn = enq;
                 OGL_TRY(finalize(FIN_BICG_CHECK2, f1));
-                launch_bicg_finalize_x(st, n, d_x.p, y, s, enq);
                 OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
                                   SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
                 OGL_TRY(finalize(FIN_BICG_OMEGA, f2));
                 launch_bicg_step3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p,
-                                  d_part1.p, s);
+                                  d_part1.p, s, enq);
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             }
         }
