@@ -62,7 +62,11 @@ def parse():
                          "an unstructured mesh: the compressed layouts do not qualify, the CSR-stream "
                          "kernel runs); single rank only")
     ap.add_argument("--rcm", action="store_true",
-                    help="after --shuffle: renumber with reverse Cuthill-McKee, as renumberMesh would")
+                    help="after --shuffle: renumber the CASE with reverse Cuthill-McKee (scipy), as "
+                         "renumberMesh would, before the library sees it")
+    ap.add_argument("--renumber", default="auto", choices=["auto", "on", "off"],
+                    help="keyword `renumber`: the library's own RCM numbering of its device copy "
+                         "(auto = only when the numbering it is handed gathers x badly)")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="replay batches of GKOCG turns as a hipGraph (needs --no-profile: event-timed "
                          "SpMVs cannot be captured); measured no faster than stream launches")
@@ -137,8 +141,8 @@ def main():
         if args.rcm:
             case = synthetic.rcm_case(case)
     N, nnz = case.n_cells, case.nnz
-    # any smooth right-hand side will do for a fixed-iteration run; x0 = 0
-    b = synthetic.x_star(case.global_index, case.global_n) + 0.5
+    # b = A x* with x*_i = sin(2 pi i / N) on the global numbering, x0 = 0
+    b, _ = synthetic.rhs_for_x_star(case)
 
     precond = {"BJ": capi.PRECOND_BJ, "none": capi.PRECOND_NONE, "ISAI": capi.PRECOND_ISAI,
                "GISAI": capi.PRECOND_GISAI}[args.precond]
@@ -150,7 +154,8 @@ def main():
                               eval_frequency=1, adapt_min_iter=0,
                               matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
                               export_res=0, profile_kernels=0 if args.no_profile else args.profile_stride,
-                              compress_indices=0 if args.no_compress else 1)
+                              compress_indices=0 if args.no_compress else 1,
+                              renumber={"off": 0, "on": 1, "auto": 2}[args.renumber])
 
     def all_ok(ok):
         """True iff every rank says ok (gloo)."""
@@ -291,6 +296,7 @@ def main():
                     f"{args.profile_stride}th turn), HIP event pairs")
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
     layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[s.get_property("spmvLayout")]
+    renumbered = s.get_property("renumbered") == 1.0
     if world > 1 and s.get_property("peerHalo") == 1.0:
         # the transport above was only the bootstrap: halo values are put straight into the
         # neighbours' receive blocks (hipIpc-mapped) by the pack kernel
@@ -299,8 +305,8 @@ def main():
     kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell"}[layout]
     # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
     b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout == "sell" else b_spmv
-    traffic, traffic_src = (pmc_traffic(kernel + "<0, 1>") if (n == 216 and args.format == "Csr")
-                            else (None, None))
+    traffic, traffic_src = (pmc_traffic(kernel + "<0, 1>")
+                            if (n == 216 and args.format == "Csr" and not args.shuffle) else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
     if args.solver != "GKOCG" or precond not in (capi.PRECOND_BJ, capi.PRECOND_NONE) or args.block_size != 1:
         b_cg = None              # the per-iteration byte model of SURVEY.md §8d is for CG only
@@ -322,8 +328,16 @@ def main():
                         f"{f' (cells shuffled within windows of {args.shuffle}' + (', then RCM' if args.rcm else '') + ')' if args.shuffle else ''}, {args.solver}"
                         f"{'(' + str(args.krylov_dim) + ')' if args.solver == 'GKOGMRES' else ''} + "
                         f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
-                        "fp64/int32 persistent device CSR (BASELINE.json configs[1])",
+                        + {"sell": "fp64 SpMV on the index-compressed SELL copy (1-byte column codes) of the "
+                                   "persistent fp64/int32 device CSR",
+                           "csr": "fp64/int32 persistent device CSR (CSR-stream SpMV)",
+                           "ell": "fp64/int32 ELL copy of the persistent device CSR"}[layout]
+                        + (", device copy renumbered by the library (RCM)" if renumbered else "")
+                        + " (BASELINE.json configs[1])",
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
+            "renumber": args.renumber, "renumbered": renumbered,
+            "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
+                                         "in_use": s.get_property("gatherSectorRatio")},
             "parallelism": f"rows sharded into {world} z-slab(s), {transport}"
                            if world > 1 else "single GPU",
         },
@@ -333,6 +347,9 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_src,
+            # the PMC passes are separate rocprofv3 runs of this same command (tools/gpu_pmc.sh);
+            # the number is read from the committed summary, not collected by this process
+            "traffic_measured_in_this_run": False,
             "algorithmic_bytes_per_launch": b_spmv,
             # what the layout in use really has to move, over the same time: the honest distance
             # to the memory system's ceiling (6.29 TB/s measured copy, 8 TB/s spec)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OGL_AMD_ABI_VERSION 1
+#define OGL_AMD_ABI_VERSION 2
 
 typedef int32_t ogl_label;
 typedef double ogl_scalar;
@@ -95,6 +95,17 @@ typedef struct ogl_config {
                                    ELL copy of the matrix when the pattern qualifies (same bits in
                                    y; 8.1-9 instead of 12 bytes per entry). NOT a reference keyword:
                                    "compressIndices"                                               */
+    int32_t renumber;           /* 2; 0 off, 1 on, 2 auto.  The device matrix, b and x live in a
+                                   bandwidth-reducing (reverse Cuthill-McKee) numbering of the cells,
+                                   computed once per sparsity pattern -- what `renumberMesh` does for
+                                   a case, done by the backend for itself.  auto: only for >= 16384
+                                   rows and when the numbering it is handed makes the SpMV gather x badly (the
+                                   compressed layout does not qualify and > 0.25 sectors of x per
+                                   entry) and RCM improves that.  psi / source keep the caller's
+                                   order at the boundary.  Rows are still summed in stored (new)
+                                   column order, so results differ from the un-renumbered run at
+                                   rounding level, exactly as after renumberMesh.  NOT a reference
+                                   keyword: "renumber"                                              */
 } ogl_config;
 
 /* Fill with the reference code's defaults. */
@@ -152,8 +163,8 @@ typedef struct ogl_registry ogl_registry;
 typedef struct ogl_solver ogl_solver;
 
 /* Replaces ExecutorHandler (ExecutorHandler.H:83-93: device id) + DeviceIdGuard
- * (DeviceIdGuard.H:15-43).  device_id < 0 => rank / ranksPerGPU % n_devices once a communicator
- * is attached, 0 otherwise.  `hip_stream` may carry an existing hipStream_t (e.g. torch's current
+ * (DeviceIdGuard.H:15-43).  The device used is device_id % n_devices, as in the reference
+ * (ExecutorHandler.H:90-91: the adapter passes rank / ranksPerGPU); device_id < 0 => device 0.  `hip_stream` may carry an existing hipStream_t (e.g. torch's current
  * stream) so the caller's events see the work; NULL => the registry creates its own stream. */
 int ogl_registry_create(ogl_registry **out, int device_id, void *hip_stream);
 void ogl_registry_destroy(ogl_registry *reg);
@@ -277,6 +288,10 @@ int ogl_solver_get_non_local_matrix(ogl_solver *s, ogl_label *rows, ogl_label *c
                                     ogl_label *ldu_mapping, ogl_scalar *coeffs);
 int ogl_solver_get_comm_pattern(ogl_solver *s, ogl_label *target_ids, ogl_label *target_sizes,
                                 ogl_label *send_idxs);
+/* Renumbering in use for this field's pattern (config `renumber`): returns 1 and fills
+ * new_id[n_rows] (cell c of the lduMatrix is row new_id[c] of the arrays the three read-backs above
+ * return; new_id may be NULL), 0 if the caller's numbering is used, or a negative status. */
+int ogl_solver_get_renumbering(ogl_solver *s, ogl_label *new_id);
 
 /* ------------------------------------------------------------------------------------ */
 /* Pure host logic (runs without a GPU): HostMatrix/HostMatrixFreeFunctions.C:21-201     */
@@ -310,6 +325,26 @@ int ogl_host_pattern(const ogl_ldu_view *ldu, ogl_matrix_dims *dims, ogl_label *
                      ogl_label *local_cols, ogl_label *local_ldu_mapping, ogl_label *nl_rows,
                      ogl_label *nl_cols, ogl_label *nl_ldu_mapping, ogl_label *target_ids,
                      ogl_label *target_sizes, ogl_label *send_idxs);
+
+/* The renumbering pieces on their own (pure host).  ogl_host_rcm: reverse Cuthill-McKee order of a
+ * row-major pattern, new_id[old] = new.  ogl_host_gather_sector_ratio: distinct 64-byte sectors of x
+ * per stored entry over groups of 256 consecutive entries (the locality measure the auto policy
+ * uses); new_id NULL = the pattern's own numbering.  ogl_host_pattern_renumbered: ogl_host_pattern
+ * followed by the policy of config `renumber` (mode) -- same outputs in the chosen numbering plus
+ * new_id[n_cells] (identity when the caller's numbering was kept); returns 1 if renumbered. */
+int ogl_host_rcm(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, ogl_label *new_id);
+double ogl_host_gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                                    const ogl_label *new_id);
+int ogl_host_pattern_renumbered(const ogl_ldu_view *ldu, int32_t mode, int32_t compress_indices,
+                                ogl_matrix_dims *dims, ogl_label *local_rows, ogl_label *local_cols,
+                                ogl_label *local_ldu_mapping, ogl_label *nl_rows, ogl_label *nl_cols,
+                                ogl_label *nl_ldu_mapping, ogl_label *target_ids,
+                                ogl_label *target_sizes, ogl_label *send_idxs, ogl_label *new_id);
+
+/* Hash of the WHOLE addressing of a view (every face, every interface cell): what decides, next to
+ * the counts, whether a field's persistent pattern is rebuilt (the reference never rebuilds,
+ * HostMatrix.C:79-87). */
+uint64_t ogl_host_addressing_fingerprint(const ogl_ldu_view *ldu);
 
 /* StoppingCriterion::build_dist_stopping_criterion's adaptive policy (StoppingCriterion.H:197-209). */
 void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,

@@ -17,6 +17,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_COMM, ERR_STATE, ERR_UNSUPPORTED = -1, 
 SOLVER_CG, SOLVER_BICGSTAB, SOLVER_GMRES = 0, 1, 2
 PRECOND_NONE, PRECOND_BJ, PRECOND_ISAI, PRECOND_GISAI = 0, 1, 2, 3
 FORMAT_COO, FORMAT_CSR, FORMAT_ELL = 0, 1, 2
+RENUMBER_OFF, RENUMBER_ON, RENUMBER_AUTO = 0, 1, 2
 IFACE_PROCESSOR, IFACE_CYCLIC = 0, 1
 RCCL_ID_BYTES = 128
 PEER_HANDLE_BYTES = 64
@@ -37,6 +38,7 @@ class Config(C.Structure):
         ("export_res", C.c_int32), ("verbose", C.c_int32), ("force_host_buffer", C.c_int32),
         ("ranks_per_gpu", C.c_int32), ("krylov_dim", C.c_int32), ("sparsity_power", C.c_int32),
         ("profile_kernels", C.c_int32), ("compress_indices", C.c_int32),
+        ("renumber", C.c_int32),
     ]
 
 
@@ -83,7 +85,9 @@ EXPORTED_SYMBOLS = [
     "ogl_solver_get_comm_pattern", "ogl_host_init_local_sparsity", "ogl_host_symmetric_update",
     "ogl_host_symmetric_update_w_interface", "ogl_host_non_symmetric_update_w_interface",
     "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
-    "ogl_host_sell_check",
+    "ogl_host_sell_check", "ogl_solver_get_renumbering", "ogl_host_rcm",
+    "ogl_host_gather_sector_ratio", "ogl_host_pattern_renumbered",
+    "ogl_host_addressing_fingerprint",
 ]
 
 
@@ -112,6 +116,8 @@ def lib():
                      "ogl_host_non_symmetric_update_w_interface", "ogl_host_non_symmetric_update",
                      "ogl_host_adapt_criterion"):
             getattr(_lib, name).restype = None
+        _lib.ogl_host_gather_sector_ratio.restype = C.c_double
+        _lib.ogl_host_addressing_fingerprint.restype = C.c_uint64
     return _lib
 
 
@@ -336,6 +342,12 @@ class Solver:
                                                      _ps(vals)))
         return rows, cols, mp, vals
 
+    def renumbering(self):
+        """new_id (cell c of the lduMatrix is row new_id[c] on the device) or None if the caller's
+        numbering is in use."""
+        new_id = np.zeros(self.dims().n_rows, np.int32)
+        return new_id if _check(lib().ogl_solver_get_renumbering(self._h, _pl(new_id))) == 1 else None
+
     def comm_pattern(self):
         d = self.dims()
         ids, sizes = np.zeros(d.n_neighbours, np.int32), np.zeros(d.n_neighbours, np.int32)
@@ -406,6 +418,45 @@ def host_pattern(case):
     _check(lib().ogl_host_pattern(C.byref(arr.view), C.byref(d), *[_pl(a) for a in loc],
                                   *[_pl(a) for a in nl], _pl(ids), _pl(sizes), _pl(send)))
     return d, tuple(loc), tuple(nl), (ids, sizes, send)
+
+
+def host_pattern_renumbered(case, mode=RENUMBER_ON, compress_indices=1):
+    """host_pattern in the numbering config `renumber` = mode chooses, plus (renumbered, new_id)."""
+    arr = case if isinstance(case, LduArrays) else LduArrays(case)
+    d = MatrixDims()
+    none = None
+    _check(lib().ogl_host_pattern_renumbered(C.byref(arr.view), C.c_int32(mode),
+                                             C.c_int32(compress_indices), C.byref(d), none, none,
+                                             none, none, none, none, none, none, none, none))
+    loc = [np.zeros(d.local_nnz, np.int32) for _ in range(3)]
+    nl = [np.zeros(d.non_local_nnz, np.int32) for _ in range(3)]
+    ids, sizes = np.zeros(d.n_neighbours, np.int32), np.zeros(d.n_neighbours, np.int32)
+    send = np.zeros(d.n_send, np.int32)
+    new_id = np.zeros(d.n_rows, np.int32)
+    rc = _check(lib().ogl_host_pattern_renumbered(
+        C.byref(arr.view), C.c_int32(mode), C.c_int32(compress_indices), C.byref(d),
+        *[_pl(a) for a in loc], *[_pl(a) for a in nl], _pl(ids), _pl(sizes), _pl(send), _pl(new_id)))
+    return d, tuple(loc), tuple(nl), (ids, sizes, send), (rc == 1, new_id)
+
+
+def host_addressing_fingerprint(case):
+    arr = case if isinstance(case, LduArrays) else LduArrays(case)
+    return int(lib().ogl_host_addressing_fingerprint(C.byref(arr.view)))
+
+
+def host_rcm(row_ptrs, cols):
+    """Reverse Cuthill-McKee order of a row-major pattern: new_id[old] = new."""
+    rp, cc = _l(row_ptrs), _l(cols)
+    new_id = np.zeros(len(rp) - 1, np.int32)
+    _check(lib().ogl_host_rcm(C.c_int32(len(rp) - 1), _pl(rp), _pl(cc), _pl(new_id)))
+    return new_id
+
+
+def host_gather_sector_ratio(row_ptrs, cols, new_id=None):
+    rp, cc = _l(row_ptrs), _l(cols)
+    ni = None if new_id is None else _l(new_id)
+    return float(lib().ogl_host_gather_sector_ratio(C.c_int32(len(rp) - 1), _pl(rp), _pl(cc),
+                                                    None if ni is None else _pl(ni)))
 
 
 def host_sell_check(row_ptrs, cols):

@@ -26,9 +26,9 @@ extern "C" int ogl_registry_create(ogl_registry **out, int device_id, void *hip_
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
         return fail(OGL_ERR_NO_DEVICE,
                     "no HIP device visible: libogl_amd has no CPU path (gfx950 required)");
-    if (device_id < 0) device_id = 0;
-    if (device_id >= n_dev)
-        return fail(OGL_ERR_NO_DEVICE, "device %d requested, %d visible", device_id, n_dev);
+    // ExecutorHandler.H:90-91: device_id_ % get_num_devices() -- rank 8 of a 2 x 8 run (or any
+    // rank / ranksPerGPU beyond the node's device count) lands on a local device
+    device_id = device_id < 0 ? 0 : device_id % n_dev;
     hipDeviceProp_t prop;
     OGL_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -193,25 +193,48 @@ extern "C" int ogl_solver_export_system(ogl_solver *s, const char *directory)
     std::vector<double> vals((size_t)p.local_nnz), nl((size_t)p.non_local_nnz), b((size_t)p.n_rows);
     OGL_TRY(fetch(s, vals.data(), s->d_vals.p, vals.size()));
     OGL_TRY(fetch(s, nl.data(), s->d_nl_vals.p, nl.size()));
-    if (s->b_resident) OGL_TRY(fetch(s, b.data(), s->d_b.p, b.size()));
+    if (s->b_resident && p.n_rows > 0) OGL_TRY(s->download_rows(b.data(), s->d_b.p));
     auto open = [&](const std::string &fn) -> FILE * {
         FILE *f = std::fopen(fn.c_str(), "w");
         if (!f) fail(OGL_ERR_INVALID, "cannot write %s", fn.c_str());
         return f;
     };
+    // The files are written in the CALLER's cell numbering, row-major sorted (what
+    // test/data_validation.py expects), whatever numbering the device copy uses.
+    struct Entry {
+        int32_t col;
+        double val;
+    };
+    std::vector<Entry> row;
     FILE *f = open(base + "_A_local.mtx");
     if (!f) return OGL_ERR_INVALID;
     std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n", p.n_rows, p.n_rows,
                  p.local_nnz);
-    for (int32_t e = 0; e < p.local_nnz; ++e)
-        std::fprintf(f, "%d %d %.15g\n", p.rows[e] + 1, p.cols[e] + 1, vals[e]);
+    for (int32_t r = 0; r < p.n_rows; ++r) {
+        const int32_t k = p.renumbered() ? p.new_id[(size_t)r] : r;
+        row.clear();
+        for (int32_t e = p.row_ptrs[(size_t)k]; e < p.row_ptrs[(size_t)k + 1]; ++e)
+            row.push_back({p.renumbered() ? p.old_of[(size_t)p.cols[(size_t)e]] : p.cols[(size_t)e], vals[(size_t)e]});
+        if (p.renumbered())
+            std::stable_sort(row.begin(), row.end(), [](const Entry &a, const Entry &b) { return a.col < b.col; });
+        for (const Entry &e : row) std::fprintf(f, "%d %d %.15g\n", r + 1, e.col + 1, e.val);
+    }
     std::fclose(f);
     f = open(base + "_A_non_local.mtx");
     if (!f) return OGL_ERR_INVALID;
     std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n", p.n_rows,
                  p.non_local_nnz, p.non_local_nnz);  // N x H, CsrMatrixWrapper.H:185-188
-    for (int32_t e = 0; e < p.non_local_nnz; ++e)
-        std::fprintf(f, "%d %d %.15g\n", p.nl_rows[e] + 1, p.nl_cols[e] + 1, nl[e]);
+    {
+        std::vector<int32_t> ord((size_t)p.non_local_nnz);
+        for (size_t e = 0; e < ord.size(); ++e) ord[e] = (int32_t)e;
+        auto old_row = [&](int32_t e) { return p.renumbered() ? p.old_of[(size_t)p.nl_rows[(size_t)e]] : p.nl_rows[(size_t)e]; };
+        if (p.renumbered())
+            std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+                return old_row(a) != old_row(b) ? old_row(a) < old_row(b) : p.nl_cols[(size_t)a] < p.nl_cols[(size_t)b];
+            });
+        for (int32_t e : ord)
+            std::fprintf(f, "%d %d %.15g\n", old_row(e) + 1, p.nl_cols[(size_t)e] + 1, nl[(size_t)e]);
+    }
     std::fclose(f);
     if (s->b_resident) {
         f = open(base + "_rhs_b_.mtx");
@@ -290,7 +313,7 @@ extern "C" int ogl_solver_download_solution(ogl_solver *s, ogl_scalar *psi)
     if (!s || !psi) return fail(OGL_ERR_INVALID, "NULL argument");
     if (!s->x_resident) return fail(OGL_ERR_STATE, "no resident solution");
     OGL_HIP_CHECK(hipSetDevice(s->reg->device));
-    return s->reg->stager.d2h(psi, s->d_x.p, (size_t)s->pat.n_rows * sizeof(double), s->reg->stream);
+    return s->download_rows(psi, s->d_x.p);
     OGL_GUARD_END
 }
 
@@ -301,10 +324,10 @@ extern "C" int ogl_solver_spmv(ogl_solver *s, const ogl_scalar *x, ogl_scalar *y
     if (!s->matrix_set) return fail(OGL_ERR_STATE, "spmv before set_matrix");
     OGL_HIP_CHECK(hipSetDevice(s->reg->device));
     hipStream_t st = s->reg->stream;
-    const size_t bytes = (size_t)s->pat.n_rows * sizeof(double);
-    OGL_TRY(s->reg->stager.h2d(s->d_w.p, x, bytes, st));
+    (void)st;
+    OGL_TRY(s->upload_rows(s->d_w.p, x));
     OGL_TRY(s->dist_spmv(SPMV_PLAIN, s->d_w.p, nullptr, s->d_q.p, SpmvDots{}, nullptr));
-    OGL_TRY(s->reg->stager.d2h(y, s->d_q.p, bytes, st));
+    OGL_TRY(s->download_rows(y, s->d_q.p));
     OGL_HIP_CHECK(hipGetLastError());
     return OGL_OK;
     OGL_GUARD_END
@@ -398,6 +421,15 @@ extern "C" int ogl_solver_get_non_local_matrix(ogl_solver *s, ogl_label *rows, o
     OGL_TRY(fetch(s, coeffs, s->d_nl_vals.p, nnz));
     return OGL_OK;
     OGL_GUARD_END
+}
+
+extern "C" int ogl_solver_get_renumbering(ogl_solver *s, ogl_label *new_id)
+{
+    if (!s) return fail(OGL_ERR_INVALID, "NULL solver");
+    if (!s->have_pattern) return fail(OGL_ERR_STATE, "no matrix yet");
+    if (!s->pat.renumbered()) return 0;
+    if (new_id) std::copy(s->pat.new_id.begin(), s->pat.new_id.end(), new_id);
+    return 1;
 }
 
 extern "C" int ogl_solver_get_comm_pattern(ogl_solver *s, ogl_label *target_ids,

@@ -66,6 +66,7 @@ struct SellChunk {
 constexpr int SELL_MAX_DICT = 255;        // offset mode: code 255 marks a padding slot
 constexpr int SELL_TABLE_INTS = 2048;     // LDS table of the SpMV kernel (8 KB)
 constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of a pattern
+constexpr int RENUMBER_AUTO_MIN_ROWS = 16384;  // config renumber = auto: smaller systems keep their numbering
 constexpr double SELL_MAX_PADDING = 1.25;  // padded slots / nnz above which CSR moves fewer bytes
 
 }  // namespace ogl

@@ -4,7 +4,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
+#include <cstring>
 #include <map>
+#include <thread>
 #include <tuple>
 
 namespace ogl {
@@ -122,31 +125,72 @@ void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
         for (ogl_label r = block_ptrs[b]; r < block_ptrs[b + 1]; ++r) row_block[r] = (ogl_label)b;
 }
 
-// Sampled fingerprint of the addressing (FNV-1a over up to ~2048 evenly spaced faces and interface
-// cells): the reference keeps the pattern of a field for ever once built (HostMatrix.C:79-87); this
-// build also rebuilds it when the addressing changed under the same counts.
+// Fingerprint of the WHOLE addressing (every face, every interface cell): the reference keeps the
+// pattern of a field for ever once built (HostMatrix.C:79-87); this build also rebuilds it when the
+// addressing changed under the same counts.  240 MB at 30 M faces: four independent multiply-mix
+// lanes per thread and a few threads bring that to a few milliseconds (a byte-wise FNV would take
+// longer than the coefficient upload it guards).
+namespace {
+
+inline uint64_t mix64(uint64_t h, uint64_t v)
+{
+    h = (h ^ v) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+
+uint64_t hash_labels_serial(const ogl_label *a, int64_t n)
+{
+    uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull, h2 = 0xA4093822299F31D0ull,
+             h3 = 0x082EFA98EC4E6C89ull;
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w[4];
+        std::memcpy(w, a + i, sizeof(w));
+        h0 = mix64(h0, w[0]);
+        h1 = mix64(h1, w[1]);
+        h2 = mix64(h2, w[2]);
+        h3 = mix64(h3, w[3]);
+    }
+    for (; i < n; ++i) h0 = mix64(h0, (uint64_t)(uint32_t)a[i]);
+    return mix64(mix64(mix64(mix64(h0, h1), h2), h3), (uint64_t)n);
+}
+
+uint64_t hash_labels(const ogl_label *a, int64_t n)
+{
+    if (!a || n <= 0) return 0x452821E638D01377ull;
+    static const int n_threads = [] {
+        const char *e = std::getenv("OGL_STAGE_THREADS");
+        return std::max(1, std::min(16, e ? atoi(e) : 4));
+    }();
+    if (n_threads == 1 || n < (int64_t(1) << 20)) return hash_labels_serial(a, n);
+    // fixed split (multiples of 8 labels) so the value does not depend on scheduling
+    const int64_t part = ((n + n_threads - 1) / n_threads + 7) / 8 * 8;
+    std::vector<uint64_t> hs((size_t)n_threads, 0);
+    std::vector<std::thread> helpers;
+    for (int t = 1; t < n_threads; ++t) {
+        const int64_t off = (int64_t)t * part;
+        if (off >= n) break;
+        helpers.emplace_back([&, t, off] { hs[(size_t)t] = hash_labels_serial(a + off, std::min(part, n - off)); });
+    }
+    hs[0] = hash_labels_serial(a, std::min(part, n));
+    for (auto &h : helpers) h.join();
+    uint64_t h = 0xBE5466CF34E90C6Cull;
+    for (uint64_t v : hs) h = mix64(h, v);
+    return mix64(h, (uint64_t)n_threads);
+}
+
+}  // namespace
+
 uint64_t addressing_fingerprint(const ogl_ldu_view &ldu)
 {
     uint64_t h = 1469598103934665603ull;
-    auto mix = [&h](int64_t v) {
-        for (int b = 0; b < 8; ++b) {
-            h ^= (uint64_t)(v >> (8 * b)) & 0xffu;
-            h *= 1099511628211ull;
-        }
-    };
-    auto sample = [&](const ogl_label *a, int64_t n) {
-        if (!a || n <= 0) return;
-        const int64_t step = std::max<int64_t>(1, n / 1024);
-        for (int64_t i = 0; i < n; i += step) mix(a[i]);
-        mix(a[n - 1]);
-    };
-    sample(ldu.lower_addr, ldu.n_faces);
-    sample(ldu.upper_addr, ldu.n_faces);
+    h = mix64(h, hash_labels(ldu.lower_addr, ldu.n_faces));
+    h = mix64(h, hash_labels(ldu.upper_addr, ldu.n_faces));
     for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
         const ogl_interface &itf = ldu.interfaces[i];
-        mix(itf.kind);
-        mix(itf.kind == OGL_IFACE_PROCESSOR ? itf.neighb_proc : itf.neighb_patch);
-        sample(itf.face_cells, itf.size);
+        h = mix64(h, (uint64_t)(uint32_t)itf.kind);
+        h = mix64(h, (uint64_t)(uint32_t)(itf.kind == OGL_IFACE_PROCESSOR ? itf.neighb_proc : itf.neighb_patch));
+        h = mix64(h, hash_labels(itf.face_cells, itf.size));
     }
     return h;
 }
@@ -307,6 +351,245 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
         }
     }
     p.fingerprint = addressing_fingerprint(ldu);
+    return OGL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Renumbering
+// ---------------------------------------------------------------------------------------
+void rcm_order(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+               std::vector<ogl_label> &new_id)
+{
+    const ogl_label n = n_rows;
+    new_id.assign((size_t)n, 0);
+    if (n == 0) return;
+    auto degree = [&](ogl_label v) { return row_ptrs[v + 1] - row_ptrs[v]; };
+    std::vector<ogl_label> order((size_t)n);   // Cuthill-McKee order, filled front to back
+    std::vector<uint8_t> placed((size_t)n, 0);
+    std::vector<ogl_label> stamp((size_t)n, 0), work;  // scratch BFS of the start-node search
+    ogl_label epoch = 0;
+    work.reserve(1024);
+    // BFS over the not yet placed part of the graph from `root`; returns the eccentricity and the
+    // first node of minimum degree in the last level
+    auto sweep = [&](ogl_label root, ogl_label &far_node) {
+        ++epoch;
+        work.clear();
+        work.push_back(root);
+        stamp[(size_t)root] = epoch;
+        size_t level_begin = 0, level_end = 1;
+        int depth = 0;
+        for (;;) {
+            for (size_t i = level_begin; i < level_end; ++i) {
+                const ogl_label v = work[i];
+                for (ogl_label k = row_ptrs[v]; k < row_ptrs[v + 1]; ++k) {
+                    const ogl_label c = cols[k];
+                    if (c < 0 || c >= n || placed[(size_t)c] || stamp[(size_t)c] == epoch) continue;
+                    stamp[(size_t)c] = epoch;
+                    work.push_back(c);
+                }
+            }
+            if (work.size() == level_end) break;
+            level_begin = level_end;
+            level_end = work.size();
+            ++depth;
+        }
+        far_node = work[level_begin];
+        for (size_t i = level_begin; i < level_end; ++i)
+            if (degree(work[i]) < degree(far_node)) far_node = work[i];
+        return depth;
+    };
+    size_t filled = 0;
+    for (ogl_label seed = 0; seed < n; ++seed) {
+        if (placed[(size_t)seed]) continue;
+        // pseudo-peripheral start of this component (at most three sweeps)
+        ogl_label start = seed, far_node = seed;
+        int ecc = sweep(start, far_node);
+        for (int tries = 0; tries < 2 && far_node != start; ++tries) {
+            ogl_label far2 = far_node;
+            const int e2 = sweep(far_node, far2);
+            if (e2 <= ecc) {
+                if (degree(far_node) < degree(start)) start = far_node;
+                break;
+            }
+            start = far_node;
+            ecc = e2;
+            far_node = far2;
+        }
+        // Cuthill-McKee from `start`
+        size_t head = filled;
+        order[filled++] = start;
+        placed[(size_t)start] = 1;
+        while (head < filled) {
+            const ogl_label v = order[head++];
+            const size_t tail0 = filled;
+            for (ogl_label k = row_ptrs[v]; k < row_ptrs[v + 1]; ++k) {
+                const ogl_label c = cols[k];
+                if (c < 0 || c >= n || placed[(size_t)c]) continue;
+                placed[(size_t)c] = 1;
+                order[filled++] = c;
+            }
+            for (size_t i = tail0 + 1; i < filled; ++i) {  // ascending (degree, index)
+                const ogl_label c = order[i];
+                const ogl_label d = degree(c);
+                size_t j = i;
+                while (j > tail0 && (degree(order[j - 1]) > d ||
+                                     (degree(order[j - 1]) == d && order[j - 1] > c))) {
+                    order[j] = order[j - 1];
+                    --j;
+                }
+                order[j] = c;
+            }
+        }
+    }
+    for (ogl_label k = 0; k < n; ++k) new_id[(size_t)order[(size_t)(n - 1 - k)]] = k;  // reverse
+}
+
+double gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                           const ogl_label *new_id, const ogl_label *old_of)
+{
+    if (n_rows <= 0 || row_ptrs[n_rows] == 0) return 0.0;
+    constexpr int GROUP = 256;    // entries one wavefront instruction of k_spmv_stream gathers
+    constexpr int ROWS = 64;      // rows examined per sample
+    const int64_t n_samples = std::min<int64_t>(4096, (n_rows + ROWS - 1) / ROWS);
+    const double step = (double)n_rows / (double)n_samples;
+    std::vector<ogl_label> sect;
+    sect.reserve(GROUP);
+    int64_t entries = 0, sectors = 0;
+    auto flush = [&] {
+        std::sort(sect.begin(), sect.end());
+        sectors += std::unique(sect.begin(), sect.end()) - sect.begin();
+        entries += (int64_t)sect.size();
+        sect.clear();
+    };
+    for (int64_t smp = 0; smp < n_samples; ++smp) {
+        const ogl_label k0 = (ogl_label)((double)smp * step);
+        for (ogl_label k = k0; k < std::min<int64_t>(n_rows, (int64_t)k0 + ROWS); ++k) {
+            const ogl_label r = old_of ? old_of[k] : k;
+            for (ogl_label e = row_ptrs[r]; e < row_ptrs[r + 1]; ++e) {
+                sect.push_back((new_id ? new_id[cols[e]] : cols[e]) >> 3);
+                if ((int)sect.size() == GROUP) flush();
+            }
+        }
+        if (!sect.empty()) flush();
+    }
+    return entries ? (double)sectors / (double)entries : 0.0;
+}
+
+void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
+{
+    const ogl_label N = p.n_rows;
+    const int64_t nnz = p.local_nnz;
+    std::vector<ogl_label> old_of((size_t)N);
+    for (ogl_label c = 0; c < N; ++c) old_of[(size_t)new_id[(size_t)c]] = c;
+    std::vector<ogl_label> rp((size_t)N + 1, 0);
+    for (ogl_label k = 0; k < N; ++k) {
+        const ogl_label r = old_of[(size_t)k];
+        rp[(size_t)k + 1] = rp[(size_t)k] + (p.row_ptrs[r + 1] - p.row_ptrs[r]);
+    }
+    std::vector<ogl_label> rows((size_t)nnz), cols((size_t)nnz), map((size_t)nnz);
+    for (ogl_label k = 0; k < N; ++k) {
+        const ogl_label r = old_of[(size_t)k];
+        const ogl_label len = p.row_ptrs[r + 1] - p.row_ptrs[r];
+        ogl_label *c = cols.data() + rp[(size_t)k], *m = map.data() + rp[(size_t)k];
+        for (ogl_label i = 0; i < len; ++i) {
+            rows[(size_t)rp[(size_t)k] + i] = k;
+            c[i] = new_id[(size_t)p.cols[(size_t)p.row_ptrs[r] + i]];
+            m[i] = p.ldu_mapping[(size_t)p.row_ptrs[r] + i];
+        }
+        sort_segment(c, m, len);  // stable: equal columns keep the reference's order
+    }
+    p.rows.swap(rows);
+    p.cols.swap(cols);
+    p.ldu_mapping.swap(map);
+    p.row_ptrs.swap(rp);
+    // non-local part: rows renamed, row-sorted again (stable, so entries of one row keep their order)
+    const size_t nl = (size_t)p.non_local_nnz;
+    if (nl) {
+        std::vector<ogl_label> ord(nl);
+        for (size_t e = 0; e < nl; ++e) ord[e] = (ogl_label)e;
+        std::stable_sort(ord.begin(), ord.end(), [&](ogl_label a, ogl_label b) {
+            return new_id[(size_t)p.nl_rows[(size_t)a]] < new_id[(size_t)p.nl_rows[(size_t)b]];
+        });
+        std::vector<ogl_label> r2(nl), c2(nl), m2(nl);
+        for (size_t e = 0; e < nl; ++e) {
+            r2[e] = new_id[(size_t)p.nl_rows[(size_t)ord[e]]];
+            c2[e] = p.nl_cols[(size_t)ord[e]];
+            m2[e] = p.nl_ldu_mapping[(size_t)ord[e]];
+        }
+        p.nl_rows.swap(r2);
+        p.nl_cols.swap(c2);
+        p.nl_ldu_mapping.swap(m2);
+    }
+    for (auto &c : p.send_idxs) c = new_id[(size_t)c];  // the neighbours expect the same order
+    p.new_id = std::move(new_id);
+    p.old_of = std::move(old_of);
+}
+
+int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
+                     RenumberReport &rep)
+{
+    rep = RenumberReport{};
+    if (sell_built) *sell_built = false;
+    if (mode < 0 || mode > 2) return fail(OGL_ERR_INVALID, "renumber %d outside {0 off, 1 on, 2 auto}", mode);
+    const ogl_label N = p.n_rows;
+    if (mode == 0 || N < 2) return OGL_OK;
+    // auto leaves small systems alone: below this a solve is bound by launch latency, not by the
+    // x gather, and renumbering would only cost set-up time
+    if (mode == 2 && N < RENUMBER_AUTO_MIN_ROWS) return OGL_OK;
+    SellLayout natural;
+    bool have_natural = false;
+    if (mode == 2) {
+        if (try_sell) {
+            rep.sell_natural = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), natural);
+            have_natural = true;
+        }
+        rep.ratio_natural = rep.ratio_used =
+            gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
+        if (rep.sell_natural || rep.ratio_natural <= 0.25) {
+            rep.sell_used = rep.sell_natural;
+            if (sell_out && have_natural && sell_built) {
+                *sell_out = std::move(natural);
+                *sell_built = true;
+            }
+            return OGL_OK;
+        }
+    }
+    std::vector<ogl_label> new_id;
+    rcm_order(N, p.row_ptrs.data(), p.cols.data(), new_id);
+    if (mode == 2) {
+        std::vector<ogl_label> old_of((size_t)N);
+        for (ogl_label c = 0; c < N; ++c) old_of[(size_t)new_id[(size_t)c]] = c;
+        const double r = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), new_id.data(),
+                                             old_of.data());
+        bool adopt = r <= 0.9 * rep.ratio_natural;
+        HostPattern q;
+        if (!adopt && !try_sell) return OGL_OK;
+        q = p;  // try it: the permuted pattern is needed for the layout check anyway
+        renumber_pattern(q, std::move(new_id));
+        SellLayout L;
+        bool sell_ok = false;
+        if (try_sell) sell_ok = build_sell_layout(N, q.row_ptrs.data(), q.cols.data(), L);
+        if (!adopt && !sell_ok) {
+            if (sell_out && have_natural && sell_built) {
+                *sell_out = std::move(natural);
+                *sell_built = true;
+            }
+            return OGL_OK;
+        }
+        p = std::move(q);
+        rep.applied = true;
+        rep.ratio_used = r;
+        rep.sell_used = sell_ok;
+        if (sell_out && try_sell && sell_built) {
+            *sell_out = std::move(L);
+            *sell_built = true;
+        }
+        return OGL_OK;
+    }
+    rep.ratio_natural = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
+    renumber_pattern(p, std::move(new_id));
+    rep.applied = true;
+    rep.ratio_used = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
     return OGL_OK;
 }
 
@@ -547,6 +830,72 @@ extern "C" int ogl_host_pattern(const ogl_ldu_view *ldu, ogl_matrix_dims *dims,
     return OGL_OK;
 }
 
+extern "C" uint64_t ogl_host_addressing_fingerprint(const ogl_ldu_view *ldu)
+{
+    return ldu ? addressing_fingerprint(*ldu) : 0;
+}
+
+extern "C" int ogl_host_rcm(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                            ogl_label *new_id)
+{
+    if (n_rows < 0 || !row_ptrs || !new_id || (n_rows > 0 && !cols))
+        return fail(OGL_ERR_INVALID, "NULL argument");
+    std::vector<ogl_label> v;
+    rcm_order(n_rows, row_ptrs, cols, v);
+    std::copy(v.begin(), v.end(), new_id);
+    return OGL_OK;
+}
+
+extern "C" double ogl_host_gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs,
+                                               const ogl_label *cols, const ogl_label *new_id)
+{
+    if (n_rows <= 0 || !row_ptrs || !cols) return 0.0;
+    if (!new_id) return gather_sector_ratio(n_rows, row_ptrs, cols, nullptr, nullptr);
+    std::vector<ogl_label> old_of((size_t)n_rows);
+    for (ogl_label c = 0; c < n_rows; ++c) old_of[(size_t)new_id[c]] = c;
+    return gather_sector_ratio(n_rows, row_ptrs, cols, new_id, old_of.data());
+}
+
+extern "C" int ogl_host_pattern_renumbered(const ogl_ldu_view *ldu, int32_t mode,
+                                           int32_t compress_indices, ogl_matrix_dims *dims,
+                                           ogl_label *local_rows, ogl_label *local_cols,
+                                           ogl_label *local_ldu_mapping, ogl_label *nl_rows,
+                                           ogl_label *nl_cols, ogl_label *nl_ldu_mapping,
+                                           ogl_label *target_ids, ogl_label *target_sizes,
+                                           ogl_label *send_idxs, ogl_label *new_id)
+{
+    if (!ldu || !dims) return fail(OGL_ERR_INVALID, "ldu/dims is NULL");
+    HostPattern p;
+    if (int rc = build_host_pattern(*ldu, p)) return rc;
+    RenumberReport rep;
+    if (int rc = choose_numbering(p, mode, compress_indices != 0, nullptr, nullptr, rep)) return rc;
+    dims->n_rows = p.n_rows;
+    dims->local_nnz = p.local_nnz;
+    dims->non_local_nnz = p.non_local_nnz;
+    dims->n_halo = p.non_local_nnz;
+    dims->n_neighbours = (ogl_label)p.target_ids.size();
+    dims->n_send = (ogl_label)p.send_idxs.size();
+    auto put = [](ogl_label *dst, const std::vector<ogl_label> &src) {
+        if (dst) std::copy(src.begin(), src.end(), dst);
+    };
+    put(local_rows, p.rows);
+    put(local_cols, p.cols);
+    put(local_ldu_mapping, p.ldu_mapping);
+    put(nl_rows, p.nl_rows);
+    put(nl_cols, p.nl_cols);
+    put(nl_ldu_mapping, p.nl_ldu_mapping);
+    put(target_ids, p.target_ids);
+    put(target_sizes, p.target_sizes);
+    put(send_idxs, p.send_idxs);
+    if (new_id) {
+        if (p.renumbered())
+            put(new_id, p.new_id);
+        else
+            for (ogl_label c = 0; c < p.n_rows; ++c) new_id[c] = c;
+    }
+    return p.renumbered() ? 1 : 0;
+}
+
 // StoppingCriterion.H:197-209
 extern "C" void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,
                                          ogl_scalar prev_rel_cost, ogl_label *min_iter,
@@ -651,4 +1000,5 @@ extern "C" void ogl_config_default(ogl_config *c)
     c->sparsity_power = 1;
     c->profile_kernels = 0;
     c->compress_indices = 1;
+    c->renumber = 2;
 }

@@ -29,6 +29,13 @@ struct HostPattern {
     // communication pattern, ascending neighbour rank (HostMatrix.C:251-306)
     std::vector<ogl_label> target_ids, target_sizes, send_idxs;
 
+    // Renumbering (this build's addition, keyword `renumber`): empty = the caller's numbering;
+    // otherwise cell c of the lduMatrix is row/column new_id[c] of everything above (rows, cols,
+    // nl_rows, send_idxs are in the NEW numbering; ldu_mapping / nl_ldu_mapping still address the
+    // caller's coefficient arrays) and old_of is the inverse map.
+    std::vector<ogl_label> new_id, old_of;
+    bool renumbered() const { return !new_id.empty(); }
+
     // length of the unsorted coefficient source [upper | lower(asym) | diag | local-iface]
     // that ldu_mapping indexes (HostMatrix.C:644-682)
     int64_t source_len() const
@@ -49,7 +56,7 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p);
 // Cheap identity check used to decide whether a cached pattern still matches a new view
 // ("For now we assume columns and rows to be constant", HostMatrix.H:33).
 uint64_t addressing_fingerprint(const ogl_ldu_view &ldu);
-// same counts and same (sampled) addressing as the view the pattern was built from
+// same counts and same addressing (full hash) as the view the pattern was built from
 bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p);
 
 // Jacobi block pointers for maxBlockSize > 1 ([UPSTREAM] gko::preconditioner::Jacobi
@@ -69,6 +76,36 @@ struct SellLayout {
 };
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                        SellLayout &out);
+
+// ---- renumbering (no reference counterpart: OpenFOAM users run `renumberMesh`; here the backend
+// does it for itself when the numbering it is handed gathers x badly) ----
+// Reverse Cuthill-McKee order of the graph of a row-major pattern (George-Liu pseudo-peripheral
+// start per connected component, neighbours by ascending degree, index as tie break):
+// new_id[old] = new, a permutation of [0, n_rows).
+void rcm_order(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+               std::vector<ogl_label> &new_id);
+// How well the x gather of an SpMV coalesces under a numbering: distinct 64-byte sectors of x per
+// stored entry, over groups of 256 consecutive stored entries (what one wavefront instruction of the
+// CSR-stream kernel gathers), sampled.  1/8 is the floor (a dense run), ~1 is a random gather.
+// new_id == nullptr: the pattern's own numbering.
+double gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                           const ogl_label *new_id, const ogl_label *old_of);
+// Rewrites `p` (built by build_host_pattern in the caller's numbering) into the numbering new_id.
+// Rows keep their entries; within a row the entries are ordered by NEW column (stable).
+void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id);
+struct SellLayout;
+struct RenumberReport {
+    bool applied = false;
+    bool sell_natural = false, sell_used = false;  // compressed layout qualifies (only when tried)
+    double ratio_natural = 0.0, ratio_used = 0.0;  // gather_sector_ratio before / after
+};
+// mode 0: keep the caller's numbering; 1: always RCM; 2 (default, "auto"): keep it when the
+// compressed layout qualifies or the gather already coalesces (ratio <= 0.25), else try RCM and
+// adopt it when it makes the compressed layout qualify or cuts the sector ratio by >= 10 %.
+// `sell_out` (may be null) receives the compressed layout of the numbering that was chosen when
+// one was built on the way (sell_built tells), so the caller does not derive it twice.
+int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
+                     RenumberReport &rep);
 
 // HostMatrix.C:180-207: concatenated bouCoeffs of the (non-)processor interfaces, times -1.
 void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *out);

@@ -421,6 +421,22 @@ __global__ __launch_bounds__(64) void k_isai_generate(int n_rows, const int *__r
     for (int r = 0; r < bs; ++r) w_vals[w0 + r] = spd ? rhs[r] / scale : rhs[r];
 }
 
+__global__ __launch_bounds__(BLOCK) void k_permute_scatter(int n, const int *__restrict__ new_id,
+                                                           const double *__restrict__ in,
+                                                           double *__restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[new_id[i]] = in[i];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_permute_gather(int n, const int *__restrict__ new_id,
+                                                          const double *__restrict__ in,
+                                                          double *__restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = in[new_id[i]];
+}
+
 __global__ __launch_bounds__(BLOCK) void k_scale(int n, double *__restrict__ v, double f)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -1834,6 +1850,18 @@ void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_
     else
         OGL_ISAI(32);
 #undef OGL_ISAI
+}
+
+void launch_permute_scatter(hipStream_t st, int32_t n, const int32_t *new_id, const double *in, double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_permute_scatter, dim3(blocks_for(n)), dim3(BLOCK), 0, st, n, new_id, in, out);
+}
+
+void launch_permute_gather(hipStream_t st, int32_t n, const int32_t *new_id, const double *in, double *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_permute_gather, dim3(blocks_for(n)), dim3(BLOCK), 0, st, n, new_id, in, out);
 }
 
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor)

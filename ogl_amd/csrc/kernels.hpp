@@ -139,6 +139,11 @@ constexpr int MAX_ISAI_ROW = 32;
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
                           const int32_t *w_cols, double *w_vals, int32_t max_row);
 
+// renumbering (keyword `renumber`): host vectors arrive in the caller's cell order
+//   scatter: out[new_id[i]] = in[i]   (b, x on upload)      gather: out[i] = in[new_id[i]]   (x on copy-back)
+void launch_permute_scatter(hipStream_t st, int32_t n, const int32_t *new_id, const double *in, double *out);
+void launch_permute_gather(hipStream_t st, int32_t n, const int32_t *new_id, const double *in, double *out);
+
 // b *= scaling (lduLduBase.H:244-252)
 void launch_scale(hipStream_t st, int32_t n, double *v, double factor);
 // v[i] = s->xbar

@@ -448,11 +448,15 @@ int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label 
 
 // Once per sparsity pattern: derive the compressed layout on the host; sell_map (like ell_map)
 // refreshes the values from the permuted CSR values on the device.
-int ogl_solver::build_sell()
+int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
 {
     hipStream_t st = reg->stream;
-    SellLayout L;
-    if (pat.n_rows == 0 || !build_sell_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), L)) {
+    SellLayout own;
+    SellLayout &L = pre ? *pre : own;
+    const bool ok = pre ? pre_qualifies
+                        : (pat.n_rows > 0 &&
+                           build_sell_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), own));
+    if (pat.n_rows == 0 || !ok) {
         sell_state = -1;
         return OGL_OK;
     }
@@ -494,7 +498,24 @@ int ogl_solver::upload_vec(DevBuf<double> &dst, const double *src)
         OGL_HIP_CHECK(hipMemsetAsync(dst.p, 0, n * sizeof(double), reg->stream));
         return OGL_OK;
     }
-    return reg->stager.h2d(dst.p, src, n * sizeof(double), reg->stream);
+    return upload_rows(dst.p, src);
+}
+
+int ogl_solver::upload_rows(double *dst, const double *src)
+{
+    const size_t bytes = (size_t)pat.n_rows * sizeof(double);
+    if (!pat.renumbered()) return reg->stager.h2d(dst, src, bytes, reg->stream);
+    OGL_TRY(reg->stager.h2d(d_perm_tmp.p, src, bytes, reg->stream));
+    launch_permute_scatter(reg->stream, pat.n_rows, d_new_id.p, d_perm_tmp.p, dst);
+    return OGL_OK;
+}
+
+int ogl_solver::download_rows(double *dst, const double *src)
+{
+    const size_t bytes = (size_t)pat.n_rows * sizeof(double);
+    if (!pat.renumbered()) return reg->stager.d2h(dst, src, bytes, reg->stream);
+    launch_permute_gather(reg->stream, pat.n_rows, d_new_id.p, src, d_perm_tmp.p);
+    return reg->stager.d2h(dst, d_perm_tmp.p, bytes, reg->stream);
 }
 
 int ogl_solver::ensure_vectors()
@@ -528,10 +549,35 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     hipStream_t st = reg->stream;
     TraceRange trace("update_matrix", field);
     const double t0 = now_ms();
-    const bool first = !have_pattern || !same_shape(ldu, pat);
+    const bool try_sell = cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices;
+    bool first = !have_pattern || !same_shape(ldu, pat) || pat_renumber_mode != cfg.renumber ||
+                 (cfg.renumber == 2 && pat_try_sell != try_sell);
+    if (reg->comm->multi()) {
+        // a rebuild is collective once the peer mesh is up (setup_peer_halo): every rank rebuilds
+        // when any rank's addressing changed
+        OGL_TRY(d_flag.alloc(2, st));
+        const double mine = first ? 1.0 : 0.0;
+        double any = 0.0;
+        OGL_HIP_CHECK(hipMemcpyAsync(d_flag.p, &mine, sizeof(double), hipMemcpyHostToDevice, st));
+        OGL_TRY(reg->allreduce(d_flag.p, 1));
+        OGL_HIP_CHECK(hipMemcpyAsync(&any, d_flag.p, sizeof(double), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        first = any != 0.0;
+    }
     if (first) {  // :79-87
         HostPattern np;
         OGL_TRY(build_host_pattern(ldu, np));
+        // numbering of the device copy (config `renumber`); the compressed layout the policy may
+        // have derived on the way is kept for build_sell below
+        SellLayout pre_sell;
+        bool pre_built = false;
+        RenumberReport rep;
+        OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep));
+        pat_renumber_mode = cfg.renumber;
+        pat_try_sell = try_sell;
+        props["renumbered"] = rep.applied ? 1.0 : 0.0;
+        props["gatherSectorRatioNatural"] = rep.ratio_natural;
+        props["gatherSectorRatio"] = rep.ratio_used;
         pat = std::move(np);
         have_pattern = true;
         static std::atomic<uint64_t> pattern_counter{0};  // registries may live on different threads
@@ -616,6 +662,12 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         if ((size_t)pat.non_local_nnz != pat.send_idxs.size())
             return fail(OGL_ERR_INVALID, "send/receive sizes differ");
         OGL_TRY(ensure_vectors());
+        if (pat.renumbered()) {
+            OGL_TRY(d_new_id.alloc((size_t)pat.n_rows, st));
+            OGL_TRY(d_perm_tmp.alloc((size_t)pat.n_rows + 2, st));
+            OGL_TRY(reg->stager.h2d(d_new_id.p, pat.new_id.data(), (size_t)pat.n_rows * sizeof(int32_t), st));
+        }
+        if (pre_built && try_sell) OGL_TRY(build_sell(&pre_sell, rep.sell_used));
         OGL_TRY(setup_peer_halo());  // collective when the peer mesh is up (every rank, every pattern)
     }
 
@@ -1032,7 +1084,10 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     crit.export_res = cfg.export_res;
     ogl_host_adapt_criterion(&cfg, prev_iters, prev_cost, &crit.min_iter, &crit.frequency);
     if (crit.frequency < 1) return fail(OGL_ERR_INVALID, "evalFrequency must be >= 1");
-    const int max_checks = crit.max_iter + crit.frequency + 1;  // the check count never exceeds this
+    // the criterion stops at the first evaluated check at or after max(maxIter, minIter): checks
+    // below minIter are skipped without a verdict (StoppingCriterion.C:77-81), so a minIter above
+    // maxIter keeps the loop going, as in the reference
+    const int max_checks = std::max(crit.max_iter, crit.min_iter) + crit.frequency + 1;
     const int max_turns = bicg ? max_checks / 2 + 1 : max_checks;  // CG and GMRES: one check per turn
     OGL_TRY(d_history.alloc((size_t)max_checks + 4, st));
     if (cfg.export_res)
@@ -1065,7 +1120,15 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         OGL_HIP_CHECK(hipEventCreate(&e));
         prof_ev.push_back(e);
     }
-    hipEvent_t ev_chk[2] = {nullptr, nullptr};
+    struct EventPair {  // destroyed on every return path
+        hipEvent_t e[2] = {nullptr, nullptr};
+        ~EventPair()
+        {
+            for (auto &x : e)
+                if (x) (void)hipEventDestroy(x);
+        }
+        hipEvent_t &operator[](int i) { return e[i]; }
+    } ev_chk;
     OGL_HIP_CHECK(hipEventCreate(&ev_chk[0]));
     OGL_HIP_CHECK(hipEventCreate(&ev_chk[1]));
 
@@ -1364,8 +1427,6 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     }
     float chk_ms = 0.f;
     OGL_HIP_CHECK(hipEventElapsedTime(&chk_ms, ev_chk[0], ev_chk[1]));
-    (void)hipEventDestroy(ev_chk[0]);
-    (void)hipEventDestroy(ev_chk[1]);
 
     perf->initial_residual = fin.init_res;                  // lduLduBase.H:283
     perf->final_residual = fin.res;                         // :284
@@ -1461,7 +1522,7 @@ int ogl_solver::solve(const double *source, double *psi, ogl_perf *perf)
     const double t1 = now_ms();
     {
         TraceRange trace("copy_back", field);
-        OGL_TRY(reg->stager.d2h(psi, d_x.p, (size_t)pat.n_rows * sizeof(double), st));  // :278-279
+        OGL_TRY(download_rows(psi, d_x.p));  // :278-279
     }
     perf->t_copy_back_ms = now_ms() - t1;
     return OGL_OK;

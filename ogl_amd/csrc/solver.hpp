@@ -208,8 +208,20 @@ struct ogl_solver {
     int64_t sell_slots = 0;
     int sell_state = 0;
     bool sell_values_stale = true;
-    int build_sell();
+    // `pre` != nullptr: the layout choose_numbering already derived for this pattern
+    // (`pre_qualifies` tells whether it is usable)
+    int build_sell(ogl::SellLayout *pre = nullptr, bool pre_qualifies = false);
     ogl::DevSell sell() const;
+    // renumbering (config `renumber`): pat.new_id on the device + a staging vector, so that host
+    // vectors cross the boundary in the caller's cell order
+    ogl::DevBuf<int32_t> d_new_id;
+    ogl::DevBuf<double> d_perm_tmp;
+    int pat_renumber_mode = -1;  // cfg.renumber / layout eligibility the pattern was built under
+    bool pat_try_sell = false;
+    ogl::DevBuf<double> d_flag;  // 2 doubles: cross-rank agreement on pattern rebuilds
+    // host -> device / device -> host of one row vector, through the renumbering when there is one
+    int upload_rows(double *dst, const double *src);
+    int download_rows(double *dst, const double *src);
     // peer-put halo exchange (PeerHalo, kernels.hpp): agreed per sparsity pattern by all ranks
     struct PeerNeighbour {
         size_t block = 0;   // the neighbour's arena block (words from its arena start)

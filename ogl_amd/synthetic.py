@@ -28,6 +28,7 @@ class Interface:
     bou_coeffs: np.ndarray           # float64
     neighb_proc: int = -1
     neighb_patch: int = -1
+    neighb_global: Optional[np.ndarray] = None   # processor patch: global id of the cell across each face
 
 
 @dataclass
@@ -107,24 +108,25 @@ def poisson_block(gx, gy, gz, px=1, py=1, pz=1, rank=0, symmetric=True, periodic
     cl = np.arange(n, dtype=np.int32)
     ifaces = []
 
-    def add_proc(cond, nrank, to_higher):
+    def add_proc(cond, nrank, to_higher, g_step):
         cells = np.ascontiguousarray(cl[cond])
         # true off-diagonal entry = -bouCoeffs; row owner < column owner => "upper" coefficient
         coeff = off_upper if (to_higher or symmetric) else off_lower
-        ifaces.append(Interface(IFACE_PROCESSOR, cells, np.full(cells.size, -coeff), nrank, -1))
+        ifaces.append(Interface(IFACE_PROCESSOR, cells, np.full(cells.size, -coeff), nrank, -1,
+                                gi[cond] + g_step))
 
     if bz > 0:
-        add_proc(k == 0, rank - px * py, False)
+        add_proc(k == 0, rank - px * py, False, -gx * gy)
     if by > 0:
-        add_proc(j == 0, rank - px, False)
+        add_proc(j == 0, rank - px, False, -gx)
     if bx > 0:
-        add_proc(i == 0, rank - 1, False)
+        add_proc(i == 0, rank - 1, False, -1)
     if bx < px - 1:
-        add_proc(i == lx - 1, rank + 1, True)
+        add_proc(i == lx - 1, rank + 1, True, 1)
     if by < py - 1:
-        add_proc(j == ly - 1, rank + px, True)
+        add_proc(j == ly - 1, rank + px, True, gx)
     if bz < pz - 1:
-        add_proc(k == lz - 1, rank + px * py, True)
+        add_proc(k == lz - 1, rank + px * py, True, gx * gy)
     if periodic_x:
         left = np.ascontiguousarray(cl[i == 0])
         right = np.ascontiguousarray(cl[i == lx - 1])
@@ -169,13 +171,14 @@ def apply_case(case: LduCase, x, halo_fn=None):
     return y
 
 
-def rhs_for_x_star(case: LduCase, halo_from_global=True):
-    """b = A x* where neighbour-rank values of x* come from the analytic global formula."""
+def rhs_for_x_star(case: LduCase):
+    """(b, x*) with b = A x* (BASELINE.md §3); on a decomposed case the values of x* across the
+    processor patches come from the analytic global formula, so no communication is needed."""
     xs = x_star(case.global_index, case.global_n)
-    if not any(f.kind == IFACE_PROCESSOR for f in case.interfaces):
-        return apply_case(case, xs), xs
-    # neighbour cell of a processor face = same cell shifted by one in the cut direction
-    raise NotImplementedError("use rhs_global_slice for decomposed cases")
+
+    def halo(idx, _send):
+        return x_star(case.interfaces[idx].neighb_global, case.global_n)
+    return apply_case(case, xs, halo), xs
 
 
 def permute_case(case: LduCase, new_id) -> LduCase:
@@ -196,7 +199,7 @@ def permute_case(case: LduCase, new_id) -> LduCase:
         gi = np.empty_like(case.global_index)
         gi[new_id] = case.global_index
     ifaces = [Interface(f.kind, new_id[f.face_cells].astype(np.int32), f.bou_coeffs, f.neighb_proc,
-                        f.neighb_patch) for f in case.interfaces]
+                        f.neighb_patch, f.neighb_global) for f in case.interfaces]
     return LduCase(n, lo[order].astype(np.int32), up[order].astype(np.int32), diag, upper[order], lower,
                    ifaces, gi, case.global_n)
 

@@ -260,6 +260,34 @@ def rowptr_from_rows(nrows, rows):
     return rp
 
 
+def permute_csr(rowptr, cols, vals, new_id):
+    """P A P^T of a row-major CSR matrix: cell c becomes row/column new_id[c]; a row keeps its
+    entries, ordered by NEW column (stable, so entries with equal columns keep their stored order).
+    Not a reference function: it is the INPUT of a renumbered run (ogl_config.renumber) -- the
+    product reports the permutation it chose, the oracle solves the system permuted by it, and the
+    comparison stays bit for bit (oracle/README: the permutation is an explicit input)."""
+    rowptr = np.asarray(rowptr, np.int64)
+    cols = np.asarray(cols, np.int64)
+    new_id = np.asarray(new_id, np.int64)
+    n = rowptr.size - 1
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    nr, nc = new_id[rows], new_id[cols]
+    order = np.lexsort((np.arange(cols.size), nc, nr))
+    rp = np.zeros(n + 1, np.int64)
+    np.add.at(rp, nr + 1, 1)
+    return (np.cumsum(rp).astype(label), nc[order].astype(label),
+            np.asarray(vals, scalar)[order].copy(), order)
+
+
+def permute_non_local(nl_rows, nl_cols, nl_vals, new_id):
+    """Rows of the non-local triplets renamed and row-sorted again (stable); columns address the
+    receive buffer and do not change."""
+    nr = np.asarray(new_id, np.int64)[np.asarray(nl_rows, np.int64)]
+    order = np.argsort(nr, kind="stable")
+    return (nr[order].astype(label), np.asarray(nl_cols)[order].astype(label),
+            np.asarray(nl_vals, scalar)[order].copy(), order)
+
+
 def set_reduction(mode, chunk_rows=512, omp=False):
     lib(omp).orc_set_reduction(C.c_int(mode), C.c_int32(chunk_rows))
 

@@ -38,3 +38,18 @@ class blocked:
 def rel_dev(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+
+
+def to_new(v, new_id):
+    """A caller-order vector in the renumbered order: out[new_id[c]] = v[c]."""
+    out = np.empty_like(np.asarray(v))
+    out[new_id] = v
+    return out
+
+
+def oracle_matrix_renumbered(oracle, case, new_id, **kw):
+    """The oracle's matrix of `case` permuted by the numbering the product reports
+    (Solver.renumbering()): DistMatrix + (rowptr, cols, vals) of P A P^T."""
+    rowptr, cols, vals = oracle_csr(oracle, case, **kw)
+    rp, cc, vv, _ = oracle.permute_csr(rowptr, cols, vals, new_id)
+    return oracle.DistMatrix(rp, cc, vv), (rp, cc, vv)

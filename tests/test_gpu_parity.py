@@ -150,6 +150,8 @@ def test_cg_history(reg, oracle, chunk_rows, precond, n):
     (dict(max_iter=100, tolerance=2.0), 1, 1),
     (dict(max_iter=100, tolerance=1.0, min_iter=5), 6, 2),
     (dict(max_iter=0), 1, 1),
+    (dict(max_iter=3, min_iter=9), 10, 2),          # minIter above maxIter: runs on to minIter
+    (dict(max_iter=3, min_iter=9, eval_frequency=4), 13, 2),
 ])
 def test_criterion_bookkeeping(reg, oracle, kw, expect_iters, expect_evals):
     case = synthetic.poisson_case(8)
@@ -277,6 +279,22 @@ def test_errors(reg):
     with pytest.raises(capi.OglError) as e:
         reg.solver("err4", cg_cfg()).set_matrix(case)
     assert e.value.status == capi.ERR_STATE
+
+
+def test_device_id_wraps_like_the_reference():
+    """ExecutorHandler.H:90-91: device_id_ % num_devices -- rank 8 on the second node of a 2 x 8 run
+    (or any rank / ranksPerGPU past the local device count) must land on a local device."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    r = capi.Registry(device_id=n_dev + 0)           # -> device 0
+    try:
+        case = synthetic.poisson_case(4)
+        x, perf = r.solver("wrap", cg_cfg(max_iter=3)).set_matrix(case).solve(np.ones(64), np.zeros(64))
+        assert perf.n_iterations == 4
+    finally:
+        r.close()
+    r = capi.Registry(device_id=5 * n_dev + (n_dev - 1))
+    r.close()
 
 
 def test_empty_system(reg):

@@ -6,7 +6,7 @@ import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 from ogl_amd import capi, synthetic
-from helpers import blocked, oracle_csr, oracle_matrix
+from helpers import blocked, oracle_csr, oracle_matrix, oracle_matrix_renumbered, to_new
 
 pytestmark = pytest.mark.gpu
 
@@ -61,8 +61,8 @@ COMBOS = st.sampled_from([
 
 @settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture,
                                                                  HealthCheck.too_slow])
-@given(systems(), COMBOS, st.integers(3, 12))
-def test_random_systems_bit_identical(reg, oracle, sysdata, combo, krylov_dim):
+@given(systems(), COMBOS, st.integers(3, 12), st.booleans())
+def test_random_systems_bit_identical(reg, oracle, sysdata, combo, krylov_dim, renumber):
     case, x, b = sysdata
     sym = case.lower is None
     solver, precond, k = combo
@@ -75,10 +75,25 @@ def test_random_systems_bit_identical(reg, oracle, sysdata, combo, krylov_dim):
         solver={"cg": capi.SOLVER_CG, "bicgstab": capi.SOLVER_BICGSTAB, "gmres": capi.SOLVER_GMRES}[solver],
         preconditioner={"bj": capi.PRECOND_BJ, "none": capi.PRECOND_NONE, "isai": capi.PRECOND_ISAI,
                         "gisai": capi.PRECOND_GISAI}[precond],
-        max_block_size=k, krylov_dim=krylov_dim, export_res=1, adapt_min_iter=0, update_init_guess=1, **kw)
+        max_block_size=k, krylov_dim=krylov_dim, export_res=1, adapt_min_iter=0, update_init_guess=1,
+        renumber=capi.RENUMBER_ON if renumber else capi.RENUMBER_OFF, **kw)
     s = reg.solver(f"rand_{solver}_{precond}_{k}_{int(sym)}", cfg).set_matrix(case)
-    A, (rp, cols, vals) = oracle_matrix(oracle, case)
-    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+    new_id = s.renumbering()
+    assert (new_id is not None) == renumber
+    if renumber:
+        # the oracle solves the system in the numbering the product chose (explicit input); vectors
+        # cross the C ABI in the caller's order
+        A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+        d_rp, d_cols, _, d_vals = s.local_matrix()
+        np.testing.assert_array_equal(d_rp, rp)
+        np.testing.assert_array_equal(d_cols, cols)
+        np.testing.assert_array_equal(d_vals, vals)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, to_new(x, new_id))[new_id])
+        b_o = to_new(b, new_id)
+    else:
+        A, (rp, cols, vals) = oracle_matrix(oracle, case)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+        b_o = b
     # ISAI needs rows of at most 32 pattern entries: the product refuses wider ones
     width = int(np.diff(rp).max())
     try:
@@ -94,10 +109,10 @@ def test_random_systems_bit_identical(reg, oracle, sysdata, combo, krylov_dim):
         P = oracle.Precond(rp, cols, vals, isai="spd" if precond == "isai" else "general")
     with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
         if solver == "cg":
-            ref = oracle.cg(A, b, np.zeros_like(b), P, **kw)
+            ref = oracle.cg(A, b_o, np.zeros_like(b), P, **kw)
         elif solver == "bicgstab":
-            ref = oracle.bicgstab(A, b, np.zeros_like(b), P, **kw)
+            ref = oracle.bicgstab(A, b_o, np.zeros_like(b), P, **kw)
         else:
-            ref = oracle.gmres(A, b, np.zeros_like(b), P, krylov_dim=krylov_dim, **kw)
+            ref = oracle.gmres(A, b_o, np.zeros_like(b), P, krylov_dim=krylov_dim, **kw)
     np.testing.assert_array_equal(s.history(), ref.history)
-    np.testing.assert_array_equal(xs, ref.x)
+    np.testing.assert_array_equal(xs, ref.x[new_id] if renumber else ref.x)

@@ -1,0 +1,190 @@
+"""GPU tests of the built-in renumbering (config `renumber`).
+
+The product reports the permutation it chose (ogl_solver_get_renumbering); the oracle is handed the
+reference-order matrix permuted by it (oracle.permute_csr -- an explicit input, not a second RCM), so
+every comparison against the oracle run in the device's reduction tree stays BIT-EXACT.  Against the
+un-renumbered run the results agree at rounding level only (the rows are summed in a different
+column order, the reductions in a different row order) -- exactly as after OpenFOAM's renumberMesh.
+"""
+import numpy as np
+import pytest
+
+from ogl_amd import capi, synthetic
+from helpers import blocked, oracle_csr, oracle_matrix, oracle_matrix_renumbered, to_new
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20241016
+
+
+@pytest.fixture(scope="module")
+def reg():
+    r = capi.Registry()
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="module")
+def chunk_rows():
+    return capi.lib().ogl_reduction_chunk_rows()
+
+
+def cfg(**kw):
+    base = dict(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_NONE, tolerance=0.0, rel_tol=0.0,
+                max_iter=50, export_res=1, matrix_format=capi.FORMAT_CSR, adapt_min_iter=0,
+                renumber=capi.RENUMBER_ON)
+    base.update(kw)
+    return capi.default_config(**base)
+
+
+CASES = [
+    ("box5x4x3", lambda: synthetic.poisson_block(5, 4, 3)),
+    ("box_asym", lambda: synthetic.poisson_block(5, 4, 3, symmetric=False, off_upper=-0.9, off_lower=-1.1)),
+    ("periodic_asym", lambda: synthetic.poisson_block(6, 5, 4, periodic_x=True, symmetric=False,
+                                                      off_upper=-0.9, off_lower=-1.1)),
+    ("cube33_ragged", lambda: synthetic.poisson_block(33, 31, 29)),
+    ("shuffled20", lambda: synthetic.renumber_case(synthetic.poisson_case(20), 1000)),
+    ("random", lambda: synthetic.random_global_case(1500, 3, 900, symmetric=False, seed=5)),
+    ("line", lambda: synthetic.poisson_block(700, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("fmt", [capi.FORMAT_CSR, capi.FORMAT_ELL], ids=["Csr", "Ell"])
+def test_matrix_and_spmv(reg, oracle, name, make, fmt):
+    case = make()
+    s = reg.solver(f"rn_{name}_{fmt}", cfg(matrix_format=fmt)).set_matrix(case)
+    new_id = s.renumbering()
+    assert new_id is not None and s.get_property("renumbered") == 1.0
+    assert sorted(new_id.tolist()) == list(range(case.n_cells))
+    _, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    d_rp, d_cols, _, d_vals = s.local_matrix()
+    np.testing.assert_array_equal(d_rp, rp)
+    np.testing.assert_array_equal(d_cols, cols)
+    np.testing.assert_array_equal(d_vals, vals)
+    x = np.random.default_rng(SEED).uniform(-1, 1, case.n_cells)
+    y = s.spmv(x)                                   # caller's order in, caller's order out
+    np.testing.assert_array_equal(y, oracle.spmv(rp, cols, vals, to_new(x, new_id))[new_id])
+    # and the same operator as the un-renumbered reference matrix, at rounding level
+    o_rp, o_cols, o_vals = oracle_csr(oracle, case)
+    np.testing.assert_allclose(y, oracle.spmv(o_rp, o_cols, o_vals, x), rtol=1e-13, atol=1e-13)
+
+
+SOLVES = [
+    ("cg_none", dict(solver=capi.SOLVER_CG), True),
+    ("cg_bj", dict(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ), True),
+    ("cg_bj4", dict(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, max_block_size=4), True),
+    ("cg_isai", dict(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_ISAI), True),
+    ("bicg_bj", dict(solver=capi.SOLVER_BICGSTAB, preconditioner=capi.PRECOND_BJ), False),
+    ("bicg_gisai", dict(solver=capi.SOLVER_BICGSTAB, preconditioner=capi.PRECOND_GISAI), False),
+    ("gmres_bj", dict(solver=capi.SOLVER_GMRES, preconditioner=capi.PRECOND_BJ, krylov_dim=10), False),
+]
+
+
+@pytest.mark.parametrize("name,kw,sym", SOLVES, ids=[c[0] for c in SOLVES])
+def test_solver_history_bit_identical_to_oracle_on_the_permuted_system(reg, oracle, chunk_rows, name, kw, sym):
+    case = synthetic.renumber_case(synthetic.poisson_case(14, symmetric=sym), 700)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
+    s = reg.solver("rns_" + name, cfg(**kw, **skw)).set_matrix(case)
+    new_id = s.renumbering()
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    pk = kw.get("preconditioner", capi.PRECOND_NONE)
+    if pk == capi.PRECOND_NONE:
+        P = None
+    elif pk == capi.PRECOND_BJ:
+        P = oracle.Precond(rp, cols, vals, kw.get("max_block_size", 1))
+    else:
+        P = oracle.Precond(rp, cols, vals, isai="spd" if pk == capi.PRECOND_ISAI else "general")
+    fn = {capi.SOLVER_CG: oracle.cg, capi.SOLVER_BICGSTAB: oracle.bicgstab}.get(kw["solver"])
+    with blocked(oracle, chunk_rows):
+        if fn:
+            ref = fn(A, to_new(b, new_id), np.zeros_like(b), P, **skw)
+        else:
+            ref = oracle.gmres(A, to_new(b, new_id), np.zeros_like(b), P, krylov_dim=10, **skw)
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x[new_id])
+    assert perf.norm_factor == ref.norm_factor
+    np.testing.assert_allclose(x, xs, atol=1e-8, rtol=0)
+    # against the un-renumbered run: same answer, history equal at rounding level at the start
+    s0 = reg.solver("rns0_" + name, cfg(**kw, **skw, renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    x0, perf0 = s0.solve(b, np.zeros_like(b))
+    if pk != capi.PRECOND_BJ or kw.get("max_block_size", 1) == 1:
+        # (block-Jacobi blocks are runs of consecutive rows: another numbering, another preconditioner)
+        np.testing.assert_allclose(s.history()[:5], s0.history()[:5], rtol=1e-10)
+    np.testing.assert_allclose(x, x0, atol=1e-8, rtol=0)
+
+
+def test_auto_renumbers_a_badly_numbered_mesh_only(reg, oracle, chunk_rows):
+    box = synthetic.poisson_case(28)                              # 21,952 rows
+    s = reg.solver("rn_auto_box", cfg(renumber=capi.RENUMBER_AUTO)).set_matrix(box)
+    assert s.renumbering() is None and s.get_property("spmvLayout") == 2.0
+    sh = synthetic.renumber_case(box, 4096)
+    s = reg.solver("rn_auto_sh", cfg(renumber=capi.RENUMBER_AUTO, preconditioner=capi.PRECOND_BJ,
+                                     max_iter=40)).set_matrix(sh)
+    new_id = s.renumbering()
+    assert new_id is not None
+    assert s.get_property("gatherSectorRatioNatural") > 0.5 > 0.25 > s.get_property("gatherSectorRatio")
+    b = synthetic.apply_case(sh, synthetic.x_star(sh.global_index, sh.global_n))
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, sh, new_id)
+    with blocked(oracle, chunk_rows):
+        ref = oracle.cg(A, to_new(b, new_id), np.zeros_like(b), oracle.jacobi_generate_scalar(rp, cols, vals),
+                        tolerance=0.0, rel_tol=0.0, max_iter=40)
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x[new_id])
+
+
+def test_changing_the_keyword_rebuilds_the_pattern(reg, oracle):
+    case = synthetic.renumber_case(synthetic.poisson_case(10), 200)
+    s = reg.solver("rn_toggle", cfg(renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    assert s.renumbering() is None
+    np.testing.assert_array_equal(s.local_matrix()[1], oracle_csr(oracle, case)[1])
+    s = reg.solver("rn_toggle", cfg(renumber=capi.RENUMBER_ON)).set_matrix(case)
+    assert s.renumbering() is not None
+    s = reg.solver("rn_toggle", cfg(renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    assert s.renumbering() is None
+    np.testing.assert_array_equal(s.local_matrix()[1], oracle_csr(oracle, case)[1])
+
+
+def test_vectors_cross_the_boundary_in_the_callers_order(reg, oracle, chunk_rows):
+    """updateInitGuess false: the previous DEVICE solution is the next initial guess
+    (lduLduBase.H:235); upload / download / resident entry points permute on the way."""
+    case = synthetic.renumber_case(synthetic.poisson_case(9), 100)
+    rng = np.random.default_rng(SEED)
+    b1, b2 = rng.uniform(-1, 1, case.n_cells), rng.uniform(-1, 1, case.n_cells)
+    c = cfg(max_iter=12)
+    s = reg.solver("rn_vec", c).set_matrix(case)
+    new_id = s.renumbering()
+    x1, _ = s.solve(b1, np.zeros_like(b1))
+    x2, _ = reg.solver("rn_vec", c).set_matrix(case).solve(b2, np.full_like(b2, 9.0))  # psi ignored
+    A, _ = oracle_matrix_renumbered(oracle, case, new_id)
+    with blocked(oracle, chunk_rows):
+        r1 = oracle.cg(A, to_new(b1, new_id), np.zeros_like(b1), None, tolerance=0.0, rel_tol=0.0, max_iter=12)
+        r2 = oracle.cg(A, to_new(b2, new_id), r1.x, None, tolerance=0.0, rel_tol=0.0, max_iter=12)
+    np.testing.assert_array_equal(x1, r1.x[new_id])
+    np.testing.assert_array_equal(x2, r2.x[new_id])
+    np.testing.assert_array_equal(s.download_solution(), x2)
+    s.upload_solution(x1)
+    np.testing.assert_array_equal(s.download_solution(), x1)
+    s.upload_rhs(b1)
+    s.upload_solution(None)
+    s.apply_resident()
+    np.testing.assert_array_equal(s.download_solution(), x1)
+
+
+def test_export_is_written_in_the_callers_numbering(reg, tmp_path):
+    case = synthetic.renumber_case(synthetic.poisson_block(7, 6, 5, periodic_x=True, symmetric=False,
+                                                           off_upper=-0.9, off_lower=-1.1), 50)
+    b = np.arange(case.n_cells, dtype=np.float64)
+    files = {}
+    for mode in (capi.RENUMBER_OFF, capi.RENUMBER_ON):
+        s = reg.solver(f"rn_exp{mode}", cfg(renumber=mode, max_iter=2)).set_matrix(case)
+        s.solve(b, np.zeros_like(b))
+        d = str(tmp_path / f"m{mode}")
+        s.export_system(d)
+        files[mode] = {n: open(f"{d}/rn_exp{mode}_{n}.mtx").read() for n in ("A_local", "rhs_b_")}
+    assert files[0]["A_local"] == files[1]["A_local"]
+    assert files[0]["rhs_b_"] == files[1]["rhs_b_"]

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/markers
 rm -rf $OUT; mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 rocprofv3 --marker-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --cpu-iters 0 > $OUT/bench.json 2> $OUT/bench.err
 echo "rc=$?"
 F=$(find $OUT -name '*marker*stats*.csv' | head -1)

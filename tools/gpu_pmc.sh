@@ -6,7 +6,7 @@ TAG=${1:-r01}
 shift
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 DIRS=""
 for CNT in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   NAME=$(echo $CNT | tr ' ' '+')

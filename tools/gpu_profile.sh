@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --cpu-iters 0 "$@" > $OUT/bench.json 2> $OUT/bench.err
 echo "rc=$?"
 cat $OUT/bench.json | cut -c1-1500

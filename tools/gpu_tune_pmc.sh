@@ -3,8 +3,9 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/tune_pmc
 rm -rf $OUT; mkdir -p $OUT
-cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -- ./tools/spmv_tune 216 6 > $OUT/log.txt 2>&1
+cd "${GRAFT_REPO_ROOT:?}"
+mkdir -p tools/bin && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/spmv_tune.hip -o tools/bin/spmv_tune || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -- ./tools/bin/spmv_tune 216 6 > $OUT/log.txt 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(list)
