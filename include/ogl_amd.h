@@ -204,6 +204,14 @@ int ogl_registry_peer_handle(ogl_registry *reg, void *handle_out);
 int ogl_registry_peer_connect(ogl_registry *reg, int32_t rank, int32_t n_ranks, const void *handles);
 int ogl_registry_peer_disable(ogl_registry *reg);
 
+/* What the registry's communicator really is (bench.py --selfcheck prints it): transport 0 = none
+ * (single rank), 1 = host-buffer callbacks, 2 = RCCL; ranks_seen = what the transport itself
+ * reports (RCCL: ncclCommCount); peer_mesh = 1 when the hipIpc peer mesh passed its self-test. */
+typedef struct ogl_comm_info {
+    int32_t transport, rank, n_ranks, ranks_seen, peer_mesh, device;
+} ogl_comm_info;
+int ogl_registry_comm_info(ogl_registry *reg, ogl_comm_info *info);
+
 /* ------------------------------------------------------------------------------------ */
 /* The plug-in path                                                                      */
 /* ------------------------------------------------------------------------------------ */

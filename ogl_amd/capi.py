@@ -67,6 +67,11 @@ class MatrixDims(C.Structure):
                 ("n_halo", C.c_int32), ("n_neighbours", C.c_int32), ("n_send", C.c_int32)]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("transport", C.c_int32), ("rank", C.c_int32), ("n_ranks", C.c_int32),
+                ("ranks_seen", C.c_int32), ("peer_mesh", C.c_int32), ("device", C.c_int32)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, _SP, C.c_int32)
 EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, _LP, _LP, _SP, _SP)
 
@@ -87,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
     "ogl_host_sell_check", "ogl_solver_get_renumbering", "ogl_host_rcm",
     "ogl_host_gather_sector_ratio", "ogl_host_pattern_renumbered",
-    "ogl_host_addressing_fingerprint",
+    "ogl_host_addressing_fingerprint", "ogl_registry_comm_info",
 ]
 
 
@@ -225,6 +230,11 @@ class Registry:
         assert len(blob) == PEER_HANDLE_BYTES * n_ranks
         buf = C.create_string_buffer(blob, len(blob))
         _check(lib().ogl_registry_peer_connect(self._h, rank, n_ranks, buf))
+
+    def comm_info(self):
+        info = CommInfo()
+        _check(lib().ogl_registry_comm_info(self._h, C.byref(info)))
+        return info
 
     def peer_disable(self):
         _check(lib().ogl_registry_peer_disable(self._h))

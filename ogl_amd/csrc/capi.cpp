@@ -118,6 +118,19 @@ extern "C" int ogl_registry_peer_disable(ogl_registry *reg)
     OGL_GUARD_END
 }
 
+extern "C" int ogl_registry_comm_info(ogl_registry *reg, ogl_comm_info *info)
+{
+    if (!reg || !info) return fail(OGL_ERR_INVALID, "NULL argument");
+    const std::string name = reg->comm ? reg->comm->name() : "self";
+    info->transport = name == "rccl" ? 2 : (name == "host-buffer" ? 1 : 0);
+    info->rank = reg->comm ? reg->comm->rank : 0;
+    info->n_ranks = reg->comm ? reg->comm->n_ranks : 1;
+    info->ranks_seen = reg->comm ? reg->comm->ranks_seen() : 1;
+    info->peer_mesh = reg->peer_ready ? 1 : 0;
+    info->device = reg->device;
+    return OGL_OK;
+}
+
 template <class T>
 static int fetch(ogl_solver *s, T *dst, const T *dev, size_t count)
 {

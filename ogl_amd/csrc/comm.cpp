@@ -92,6 +92,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     std::string error;
 };
 
@@ -121,6 +122,7 @@ RcclApi &rccl()
         OGL_SYM(GroupStart, "ncclGroupStart")
         OGL_SYM(GroupEnd, "ncclGroupEnd")
         OGL_SYM(GetErrorString, "ncclGetErrorString")
+        OGL_SYM(CommCount, "ncclCommCount")
 #undef OGL_SYM
     });
     return api;
@@ -163,6 +165,13 @@ int RcclComm::init(int r, int n, const void *id_bytes)
 RcclComm::~RcclComm()
 {
     if (comm_) (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm_));
+}
+
+int RcclComm::ranks_seen() const
+{
+    int count = 0;
+    if (!comm_ || rccl().CommCount(static_cast<ncclComm_t>(comm_), &count) != ncclSuccess) return -1;
+    return count;
 }
 
 int RcclComm::allreduce(double *dev, int n, hipStream_t st)

@@ -28,6 +28,8 @@ public:
     virtual int exchange(const double *send, double *recv, const std::vector<int> &neighbours,
                          const std::vector<int> &counts, hipStream_t st) = 0;
     virtual const char *name() const = 0;
+    // ranks the transport itself reports (RCCL: ncclCommCount), for the bench's self-check
+    virtual int ranks_seen() const { return n_ranks; }
 };
 
 // Single rank: nothing to do.  (The reference refuses to run serial, lduLduBase.H:321-329; this
@@ -72,6 +74,7 @@ public:
     int exchange(const double *send, double *recv, const std::vector<int> &neighbours,
                  const std::vector<int> &counts, hipStream_t st) override;
     const char *name() const override { return "rccl"; }
+    int ranks_seen() const override;
 
 private:
     void *comm_ = nullptr;  // ncclComm_t

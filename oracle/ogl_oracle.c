@@ -1138,13 +1138,51 @@ int orc_omp_max_threads(void) {
 #endif
 }
 
-orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
-                     const orc_scalar *inv_diag, const orc_criterion *crit,
-                     orc_criterion_state *st, int n_threads) {
+/* STREAM-like triad a = b + s*c over three arrays of n doubles placed by first touch with the same
+ * static schedule; returns GB/s (24 bytes per element) of the best of `reps` passes.  Run in the same
+ * process as orc_cg_omp so the baseline can be read against what the host memory system gives. */
+double orc_stream_triad_omp(long n, int reps, int n_threads) {
+#ifndef _OPENMP
+    (void)n; (void)reps; (void)n_threads;
+    return -1.0;
+#else
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    double *a = (double *)xmalloc(sizeof(double) * (size_t)n);
+    double *b = (double *)xmalloc(sizeof(double) * (size_t)n);
+    double *c = (double *)xmalloc(sizeof(double) * (size_t)n);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; ++i) {
+        a[i] = 0.0;
+        b[i] = 1.0 + (double)(i & 7);
+        c[i] = 0.5;
+    }
+    double best = 1e30;
+    for (int rep = 0; rep < reps; ++rep) {
+        const double t0 = omp_get_wtime();
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < n; ++i) a[i] = b[i] + 3.0 * c[i];
+        const double t = omp_get_wtime() - t0;
+        if (t < best) best = t;
+    }
+    const double chk = a[n / 2];
+    free(a); free(b); free(c);
+    return chk > 0.0 ? 24.0 * (double)n / best / 1e9 : 0.0;
+#endif
+}
+
+/* The OpenMP CG with its two phases timed apart: t_setup_s = allocation + first-touch copy of the
+ * matrix and vectors (once per matrix in a real run), t_loop_s = initial residual, norm factor and
+ * the iterations (what a solve costs).  The norm factor is computed with the same parallel loops. */
+orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                           const orc_scalar *inv_diag, const orc_criterion *crit,
+                           orc_criterion_state *st, int n_threads, double *t_setup_s,
+                           double *t_loop_s) {
 #ifndef _OPENMP
     (void)A; (void)b; (void)x; (void)inv_diag; (void)crit; (void)st; (void)n_threads;
+    (void)t_setup_s; (void)t_loop_s;
     return -1;
 #else
+    const double t_begin = omp_get_wtime();
     if (A->n_halo > 0 || A->allreduce) return -1;
     if (n_threads > 0) omp_set_num_threads(n_threads);
     const orc_label n = A->n;
@@ -1182,11 +1220,14 @@ orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *
     orc_scalar rho = 0.0, prev_rho = 1.0, beta = 0.0, norm = 0.0;
     criterion_reset(st);
 #pragma omp parallel for schedule(static)
+    for (orc_label row = 0; row < n; ++row) z[row] = p[row] = q[row] = r[row] = 0.0;  /* first touch */
+    const double t_loop_begin = omp_get_wtime();
+    if (t_setup_s) *t_setup_s = t_loop_begin - t_begin;
+#pragma omp parallel for schedule(static)
     for (orc_label row = 0; row < n; ++row) {
         orc_scalar sum = b[row];
         for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) sum += -1.0 * vals[k] * x[cols[k]];
         r[row] = sum;
-        z[row] = p[row] = q[row] = 0.0;
     }
     for (;;) {
         rho = 0.0;
@@ -1206,7 +1247,19 @@ orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *
         } else {
             st->n_evals += 1;
             if (st->iter == 0) {
-                st->norm_factor = orc_compute_normfactor(A, r, x, b);
+                /* StoppingCriterion.C:11-69 with parallel loops (q is free at this point) */
+                orc_scalar xsum = 0.0, nf = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : xsum)
+                for (orc_label i = 0; i < n; ++i) xsum += x[i];
+                const orc_scalar xbar = xsum / (orc_scalar)n;
+#pragma omp parallel for schedule(static) reduction(+ : nf)
+                for (orc_label row = 0; row < n; ++row) {
+                    orc_scalar ax = 0.0;
+                    for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) ax += vals[k] * xbar;
+                    const orc_scalar t = b[row] - ax;
+                    nf += fabs(t - r[row]) + fabs(t);
+                }
+                st->norm_factor = nf + ORC_SMALL;
                 st->init_residual = norm / st->norm_factor;
             }
             norm /= st->norm_factor;
@@ -1239,9 +1292,16 @@ orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *
         }
         prev_rho = rho;
     }
+    if (t_loop_s) *t_loop_s = omp_get_wtime() - t_loop_begin;
     memcpy(x_out, x, sizeof(orc_scalar) * (size_t)n);
     free(r); free(z); free(p); free(q);
     free(rowptr); free(cols); free(vals); free(bb); free(xx); free(inv_copy);
     return st->iter;
 #endif
+}
+
+orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                     const orc_scalar *inv_diag, const orc_criterion *crit,
+                     orc_criterion_state *st, int n_threads) {
+    return orc_cg_omp_timed(A, b, x, inv_diag, crit, st, n_threads, 0, 0);
 }

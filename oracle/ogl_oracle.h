@@ -296,6 +296,13 @@ orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *
                      const orc_scalar *inv_diag, const orc_criterion *crit,
                      orc_criterion_state *st, int n_threads);
 int orc_omp_max_threads(void);
+/* the same solve with set-up (allocation + first-touch copy) and loop timed apart, in seconds */
+orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
+                           const orc_scalar *inv_diag, const orc_criterion *crit,
+                           orc_criterion_state *st, int n_threads, double *t_setup_s,
+                           double *t_loop_s);
+/* STREAM-like triad over 3 x n doubles, first-touch placed; GB/s of the best of `reps` passes */
+double orc_stream_triad_omp(long n, int reps, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -72,6 +72,8 @@ def _load(name):
     for f in ("orc_cg", "orc_bicgstab", "orc_cg_omp", "orc_cg_p", "orc_bicgstab_p"):
         getattr(lib, f).restype = C.c_int32
     lib.orc_omp_max_threads.restype = C.c_int
+    lib.orc_cg_omp_timed.restype = C.c_int32
+    lib.orc_stream_triad_omp.restype = C.c_double
     return lib
 
 
@@ -528,6 +530,38 @@ def cg_omp(A, b, x0, inv_diag=None, tolerance=1e-6, rel_tol=1e-6, min_iter=0, ma
            frequency=1, export_res=True, threads=0):
     return _solve("orc_cg_omp", A, b, x0, inv_diag, tolerance, rel_tol, min_iter, max_iter,
                   frequency, export_res, omp_threads=threads)
+
+
+def bind_omp_threads():
+    """Thread placement for the OpenMP baseline: one thread per core, neighbours close.  libgomp reads
+    these when it is loaded, so call this BEFORE the first lib(True)."""
+    if "liboracle_omp.so" in _libs:
+        return False
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    return True
+
+
+def cg_omp_timed(A, b, x0, inv_diag=None, tolerance=0.0, rel_tol=0.0, max_iter=100, threads=0):
+    """(Result, t_setup_s, t_loop_s): set-up (allocation + first-touch copy, once per matrix) and the
+    solve loop timed apart inside the C code."""
+    b, pb = _s(b)
+    x = np.array(x0, dtype=scalar, copy=True)
+    pinv = None
+    if inv_diag is not None:
+        inv_diag, pinv = _s(inv_diag)
+    crit = _CCriterion(tolerance, rel_tol, 0, max_iter, 1, 0)
+    st = _CState()
+    t_setup, t_loop = C.c_double(), C.c_double()
+    rc = lib(True).orc_cg_omp_timed(C.byref(A.c), pb, x.ctypes.data_as(_SP), pinv, C.byref(crit),
+                                    C.byref(st), C.c_int(threads), C.byref(t_setup), C.byref(t_loop))
+    if rc < 0:
+        raise RuntimeError("orc_cg_omp_timed unavailable")
+    return Result(x, st, np.zeros(1), False), t_setup.value, t_loop.value
+
+
+def stream_triad_omp(n, reps=5, threads=0):
+    return float(lib(True).orc_stream_triad_omp(C.c_long(n), C.c_int(reps), C.c_int(threads)))
 
 
 def omp_max_threads():
