@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="event-time the in-loop SpMV of every k-th turn (an event pair costs ~2 us of "
                          "the stream's time)")
+    ap.add_argument("--no-selfcheck", dest="selfcheck", action="store_false",
+                    help="N > 1: skip the cross-rank self-check that runs before anything is timed")
+    ap.add_argument("--selfcheck-edge", type=int, default=64, help="box edge per rank of the self-check")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not event-time the in-loop SpMV (roofline then comes from a "
                          "separate back-to-back SpMV loop)")
@@ -185,36 +188,34 @@ def main():
             recv[offs[i]:offs[i + 1]] = r_t.numpy()
         return recv
 
-    def bring_up(use_peer):
-        """Registry + transport + solver with the matrix and b resident, warm-up steps done.
-        Transport at N > 1, each step agreed by all ranks over gloo: RCCL over xGMI, else the
-        host-buffer callbacks; on top (use_peer) the peer mesh: halo values put straight into the
-        neighbours' receive blocks and all-reduces inside the finaliser kernels (hipIpc)."""
+    def connect(kind, use_peer):
+        """Registry + transport (N > 1), every step agreed by all ranks over gloo.  kind "rccl": RCCL
+        over xGMI; "host": the host-buffer callbacks (gloo).  use_peer: on top, the peer mesh -- halo
+        values put straight into the neighbours' receive blocks and all-reduces inside the finaliser
+        kernels (hipIpc).  Returns (registry, description) or None when a rank could not follow."""
         reg = capi.Registry(device_id=local_rank, hip_stream=torch.cuda.current_stream().cuda_stream)
-        transport = "single GPU"
-        if world > 1:
-            ok = True
-            try:
-                if os.environ.get("OGL_BENCH_TRANSPORT", "rccl") != "rccl":
-                    raise capi.OglError(capi.ERR_COMM, "host transport requested")
+        if world == 1:
+            return reg, "single GPU"
+        ok, why = True, ""
+        try:
+            if kind == "rccl":
                 uid = [capi.rccl_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
                 reg.init_rccl(rank, world, uid[0])
-            except capi.OglError as e:
-                ok = False
-                if rank == 0:
-                    print(f"bench.py: RCCL unavailable ({e}); using the host-buffer transport",
-                          file=sys.stderr)
-            transport = "RCCL halo + all-reduce"
-            if not all_ok(ok):
-                transport = "host-buffer (gloo) halo + all-reduce"
-                reg.close()
-                reg = capi.Registry(device_id=local_rank)
+            else:
                 reg.set_host_comm(rank, world, _allreduce, _exchange)
+        except capi.OglError as e:
+            ok, why = False, str(e)
+        if not all_ok(ok):
+            if why:
+                print(f"bench.py: rank {rank}: transport {kind} unavailable ({why})", file=sys.stderr)
+            reg.close()
+            return None
+        desc = ("RCCL" if kind == "rccl" else "host-buffer (gloo)") + " halo + all-reduce"
+        if use_peer:
             mine = None
             try:
-                if use_peer and os.environ.get("OGL_BENCH_PEER", "1") == "1":
-                    mine = reg.peer_handle()
+                mine = reg.peer_handle()
             except capi.OglError as e:
                 print(f"bench.py: rank {rank}: no peer mailbox ({e})", file=sys.stderr)
             handles = [None] * world
@@ -226,10 +227,64 @@ def main():
                 except capi.OglError as e:
                     ok = False
                     print(f"bench.py: rank {rank}: peer mesh unavailable ({e})", file=sys.stderr)
-            if all_ok(ok):
-                transport = transport.replace("halo + all-reduce", "halo, peer-write all-reduce (hipIpc)")
-            else:
-                reg.peer_disable()
+            if not all_ok(ok):
+                reg.close()
+                return None
+            desc = desc.replace("halo + all-reduce", "halo, peer-write all-reduce (hipIpc)")
+        return reg, desc
+
+    def selfcheck(reg):
+        """N > 1, before anything is timed: 20 GKOCG + BJ turns on a 64^3-per-rank
+        slab case through the transport just brought up.  The residual history must be bit-identical on
+        every rank and agree with a single-GPU solve of the assembled system (rank 0) to 1e-11; the
+        solution slices to 1e-12."""
+        e = args.selfcheck_edge
+        sc = synthetic.poisson_block(e, e, e * world, pz=world, rank=rank)
+        sb, _ = synthetic.rhs_for_x_star(sc)
+        c = capi.default_config(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, tolerance=0.0,
+                                rel_tol=0.0, max_iter=20, export_res=1, adapt_min_iter=0,
+                                matrix_format=capi.FORMAT_CSR)
+        rep = {"edge": e, "ok": False}
+        hist, x = None, None
+        try:
+            sv = reg.solver("selfcheck", c).set_matrix(sc)
+            x, perf = sv.solve(sb, np.zeros_like(sb))
+            hist = sv.history()
+            rep["peer_halo"] = sv.get_property("peerHalo") == 1.0
+        except capi.OglError as ex:
+            rep["error"] = str(ex)
+        if not all_ok(hist is not None):
+            return rep
+        every = [None] * world
+        dist.all_gather_object(every, hist.tobytes())
+        rep["history_bit_identical_on_all_ranks"] = all(h == every[0] for h in every)
+        # single-GPU solve of the assembled system on rank 0's device, broadcast to all
+        glob_n = e * e * e * world
+        href = torch.zeros(hist.size, dtype=torch.float64)
+        xref = torch.zeros(glob_n, dtype=torch.float64)
+        if rank == 0:
+            r1 = capi.Registry(device_id=local_rank)
+            g = synthetic.poisson_block(e, e, e * world)
+            gb, _ = synthetic.rhs_for_x_star(g)
+            s1 = r1.solver("selfcheck_global", c).set_matrix(g)
+            gx, _ = s1.solve(gb, np.zeros_like(gb))
+            href = torch.from_numpy(s1.history().copy())
+            xref = torch.from_numpy(gx.copy())
+            r1.close()
+        dist.broadcast(href, src=0)
+        dist.broadcast(xref, src=0)
+        href, xref = href.numpy(), xref.numpy()
+        dev_h = float(np.max(np.abs(hist - href) / np.abs(href)))
+        dev_x = float(np.max(np.abs(x - xref[sc.global_index])))
+        worst = torch.tensor([dev_h, dev_x], dtype=torch.float64)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        rep["max_rel_dev_history_vs_single_gpu"] = float(worst[0])
+        rep["max_abs_dev_x_vs_single_gpu"] = float(worst[1])
+        rep["ok"] = bool(rep["history_bit_identical_on_all_ranks"] and worst[0] <= 1e-11 and worst[1] <= 1e-12)
+        return rep
+
+    def load(reg):
+        """The benchmark's own system on a connected registry: matrix and b resident, warm-up done."""
         s = reg.solver("p", cfg)
         s.set_property("hipGraph", 1.0 if args.graph == "on" else 0.0)
         t0 = time.perf_counter()
@@ -242,24 +297,60 @@ def main():
         for _ in range(args.warmup):
             s.upload_solution(None)
             s.apply_resident()
-        return reg, s, transport, t_first, t_refresh
+        return s, t_first, t_refresh
 
-    # If the peer mesh passes its self-test but a solve over it fails (every rank then times out
-    # with OGL_ERR_COMM), all ranks start over on the plain transport.
-    state, err = None, None
-    try:
-        state = bring_up(True)
-    except capi.OglError as e:
-        err = e
-    if not all_ok(state is not None):
-        if world == 1:
-            raise err
-        print(f"bench.py: rank {rank}: bring-up with the peer mesh failed ({err}); retrying without",
-              file=sys.stderr)
-        if state is not None:
-            state[0].close()
-        state = bring_up(False)
+    # Transport ladder at N > 1: peer mesh over RCCL bootstrap -> peer mesh over the host bootstrap ->
+    # RCCL alone -> host-buffer alone.  A rung is kept only if every rank connects, the self-check
+    # passes and the benchmark system loads and warms up on it; otherwise all ranks step down together.
+    # (All of it in this process: nothing is re-exec'ed after the GPU has been touched.)
+    ladder = [("rccl", True), ("host", True), ("rccl", False), ("host", False)]
+    want = os.environ.get("OGL_BENCH_TRANSPORT", "")
+    if want:
+        ladder = [r for r in ladder if r[0] == want]
+    if os.environ.get("OGL_BENCH_PEER", "1") != "1":
+        ladder = [r for r in ladder if not r[1]]
+    if world == 1:
+        ladder = [("none", False)]
+    state, selfcheck_report, tried = None, None, []
+    for kind, use_peer in ladder:
+        got = connect(kind, use_peer)
+        if got is None:
+            tried.append(f"{kind}{'+peer' if use_peer else ''}: no connection")
+            continue
+        reg, transport = got
+        try:
+            info = reg.comm_info()
+            if world > 1 and args.selfcheck:
+                selfcheck_report = selfcheck(reg)
+                selfcheck_report["transport"] = transport
+                selfcheck_report["rccl_ranks_seen"] = info.ranks_seen if info.transport == 2 else None
+                if not all_ok(selfcheck_report["ok"]):
+                    tried.append(f"{kind}{'+peer' if use_peer else ''}: self-check failed {selfcheck_report}")
+                    if rank == 0:
+                        print(f"bench.py: self-check FAILED on {transport}: {selfcheck_report}", file=sys.stderr)
+                    reg.close()
+                    continue
+            s, t_first_matrix, t_refresh_matrix = None, 0.0, 0.0
+            err = None
+            try:
+                s, t_first_matrix, t_refresh_matrix = load(reg)
+            except capi.OglError as e:
+                err = e
+            if not all_ok(s is not None):
+                if world == 1:
+                    raise err
+                tried.append(f"{kind}{'+peer' if use_peer else ''}: load/warm-up failed ({err})")
+                reg.close()
+                continue
+            state = (reg, s, transport, t_first_matrix, t_refresh_matrix)
+            break
+        except Exception:
+            reg.close()
+            raise
+    if state is None:
+        raise SystemExit(f"bench.py: rank {rank}: no transport survived: {tried}")
     reg, s, transport, t_first_matrix, t_refresh_matrix = state
+    comm_info = reg.comm_info()
 
     def step():
         s.upload_solution(None)              # x0 = 0, device memset
@@ -340,6 +431,10 @@ def main():
                                          "in_use": s.get_property("gatherSectorRatio")},
             "parallelism": f"rows sharded into {world} z-slab(s), {transport}"
                            if world > 1 else "single GPU",
+            "transport": {"kind": {0: "none", 1: "host-buffer", 2: "rccl"}[comm_info.transport],
+                          "rccl_ranks_seen": comm_info.ranks_seen if comm_info.transport == 2 else None,
+                          "peer_mesh": bool(comm_info.peer_mesh), "stepped_down_from": tried},
+            "selfcheck": selfcheck_report,
         },
         "roofline": {
             "kernel": kernel + "<PLAIN, fused p.q>", "layout": layout,

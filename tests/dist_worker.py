@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--precond", type=int, default=1)
     ap.add_argument("--asym", type=int, default=0)
     ap.add_argument("--gmres", type=int, default=0)
+    ap.add_argument("--renumber", type=int, default=0,
+                    help="1: the library renumbers every rank's device copy (config renumber = on); the "
+                         "oracle then solves each rank's system permuted by the numbering the library reports")
     ap.add_argument("--random", type=int, default=-1,
                     help="seed: random irregular global system cut into contiguous row blocks of random "
                          "sizes (instead of the structured box of --shape/--procs)")
@@ -187,18 +190,45 @@ def main():
             (capi.SOLVER_BICGSTAB if args.asym else capi.SOLVER_CG), krylov_dim=args.gmres,
             preconditioner=capi.PRECOND_BJ if args.precond else capi.PRECOND_NONE,
             tolerance=1e-11, rel_tol=0.0, max_iter=300, export_res=1, adapt_min_iter=0,
-            matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode != "gpu-rccl"))
+            matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode != "gpu-rccl"),
+            renumber=capi.RENUMBER_ON if args.renumber else capi.RENUMBER_OFF)
         s = reg.solver("p", cfg).set_matrix(case)
+        new_id = s.renumbering()
+        assert (new_id is not None) == bool(args.renumber and case.n_cells >= 2)
+        if new_id is None:
+            new_id = np.arange(case.n_cells)
+        else:
+            # the oracle gets this rank's system in the numbering the library chose (explicit input):
+            # local block P A P^T, halo rows renamed, the send list in the same order with new names
+            p_rp, p_cols, p_vals, _ = orc.permute_csr(rp, cols, vals, new_id)
+            n_rows_, n_cols_, n_vals_, n_ord = orc.permute_non_local(nl[0], nl[1], nl[3], new_id)
+            ex2 = make_exchange(None)
+            ar = allreduce_rank_order if args.mode == "gpu-peer" else allreduce
+            A = orc.DistMatrix(p_rp, p_cols, p_vals, orc.rowptr_from_rows(case.n_cells, n_rows_), n_cols_,
+                               n_vals_, new_id[comm[2]].astype(np.int32), n_halo=n_rows_.size,
+                               exchange=lambda s_: ex2(comm[0], comm[1], s_), allreduce=ar,
+                               global_n=case.global_n)
+            nl = (n_rows_, n_cols_, nl[2][n_ord], n_vals_)
+            if args.precond:
+                inv = orc.jacobi_generate_scalar(p_rp, p_cols, p_vals)
+                if args.gmres:
+                    inv = orc.Precond(p_rp, p_cols, p_vals, 1)
         # device halo matrix == oracle's
         r_, c_, m_, v_ = s.non_local_matrix()
         np.testing.assert_array_equal(r_, nl[0])
         np.testing.assert_array_equal(c_, nl[1])
         np.testing.assert_array_equal(v_, nl[3])
-        np.testing.assert_array_equal(s.spmv(xg[case.global_index]), y)
+        if args.renumber:
+            np.testing.assert_allclose(s.spmv(xg[case.global_index]), y, rtol=1e-13, atol=1e-13)
+        else:
+            np.testing.assert_array_equal(s.spmv(xg[case.global_index]), y)
         x, perf = s.solve(b, np.zeros_like(b))
         hist = s.history()
+        b_o = np.empty_like(b)
+        b_o[new_id] = b
         with blocked(orc, capi.lib().ogl_reduction_chunk_rows()):
-            ref = solve(A, b, np.zeros_like(b), inv, **skw)
+            ref = solve(A, b_o, np.zeros_like(b), inv, **skw)
+        ref.x = ref.x[new_id]                      # back to the caller's order
         if args.mode in ("gpu-host", "gpu-peer"):
             # same local trees, same order of the sum over ranks: bit-identical
             assert perf.n_iterations == (ref.n_iterations // 2 if (args.asym and not args.gmres)

@@ -137,6 +137,38 @@ def test_gpu_host_buffer_random_partition():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode,extra", [("gpu-peer", []), ("gpu-host", []), ("gpu-peer", ["--asym", "1"]),
+                                        ("gpu-peer", ["--gmres", "15"])])
+def test_gpu_renumbered_ranks(mode, extra):
+    # every rank keeps its device copy in its own RCM numbering; halo columns and the order of the
+    # send list are untouched, so the neighbours never notice
+    run_ranks(3, "--mode", mode, "--random", "13", "--renumber", "1", *extra)
+    run_ranks(2, "--mode", mode, "--shape", "12,12,12", "--procs", "1,1,2", "--renumber", "1", *extra)
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()          # counting does not initialise the GPU
+
+
+two_devices = pytest.mark.skipif(_n_devices() < 2, reason="needs two MI355X: one rank per device")
+
+
+# One rank per DEVICE (skipped on the 1-GPU boxes of this pool): the first place RCCL with two ranks,
+# cross-device IPC stores and the spin-wait kernels meet real xGMI links.
+@pytest.mark.gpu
+@two_devices
+@pytest.mark.parametrize("mode", ["gpu-rccl", "gpu-peer", "gpu-host"])
+def test_two_devices_one_rank_each(mode):
+    n = min(_n_devices(), 8)
+    run_ranks(2, "--mode", mode, "--shape", "16,16,16", "--procs", "1,1,2")
+    run_ranks(n, "--mode", mode, "--random", str(20 + n))
+    if mode == "gpu-peer":
+        run_ranks(2, "--mode", mode, "--shape", "12,12,12", "--procs", "1,1,2", "--asym", "1")
+        run_ranks(2, "--mode", mode, "--shape", "12,12,12", "--procs", "1,1,2", "--renumber", "1")
+
+
+@pytest.mark.gpu
 def test_gpu_peer_mesh_soak():
     # 40 solves with changing solver / stop position / right-hand side on one persistent set of fields
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
