@@ -469,52 +469,19 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the oracle on the same matrix ----------------------
     headline = (args.solver == "GKOCG" and args.precond in ("BJ", "none") and args.block_size == 1
                 and not args.asym)
-    if rank == 0 and world == 1 and args.cpu_iters != 0 and headline:
-        from oracle import oracle as orc
-        orc.build()
-        orc.bind_omp_threads()
-        t0 = time.perf_counter()
-        rows, cols, perm = orc.init_local_sparsity(N, case.upper_addr, case.lower_addr, True)
-        vals = orc.update_local_matrix_data(case.diag, case.upper, None, [], perm)
-        rowptr = orc.rowptr_from_rows(N, rows)
-        A = orc.DistMatrix(rowptr, cols, vals)
-        inv = orc.jacobi_generate_scalar(rowptr, cols, vals) if precond else None
-        t_build = time.perf_counter() - t0
-        cpu_iters = args.cpu_iters
-        if cpu_iters < 0:                      # ~15 s of sequential work: probe with 2 iterations
-            t0 = time.perf_counter()
-            orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=2,
-                   export_res=False)
-            per_it = (time.perf_counter() - t0) / 3.0
-            cpu_iters = int(max(3, min(args.iters, 15.0 / max(per_it, 1e-6))))
-        t0 = time.perf_counter()
-        r = orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=cpu_iters,
-                   export_res=False)
-        t_cpu = time.perf_counter() - t0
-        out["cpu_baseline"] = {
-            "value": (r.n_iterations - 1) / t_cpu, "unit": "iter/s", "cores": 1, "kind": "port",
-            "sample": f"{r.n_iterations - 1} CG iterations of the same {n}^3 system, oracle "
-                      f"(sequential reference-executor restatement), {t_cpu:.1f} s "
-                      f"(+{t_build:.1f} s LDU->CSR)",
-        }
-        # OpenMP variant ("omp executor" semantics): threads bound one per core (set before libgomp
-        # loads), the matrix/vector first-touch copy timed apart from the solve loop, and a STREAM-like
-        # triad in the same process to read the number against
-        threads = orc.omp_max_threads()
-        omp_iters = min(args.iters, max(3, cpu_iters * min(threads, 8)))
-        r, t_setup, t_loop = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=omp_iters,
-                                              threads=threads)
-        triad = orc.stream_triad_omp(max(1 << 22, 4 * N), 5, threads)
-        omp_done = r.n_iterations - 1
-        out["cpu_baseline_omp"] = {
-            "value": omp_done / t_loop, "unit": "iter/s", "cores": threads, "kind": "port",
-            "GBps": b_cg * omp_done / t_loop / 1e9 if b_cg else None,
-            "stream_triad_GBps": triad,
-            "thread_binding": f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} "
-                              f"OMP_PLACES={os.environ.get('OMP_PLACES')}",
-            "sample": f"{omp_done} iterations, OpenMP variant on {threads} threads, loop {t_loop:.2f} s "
-                      f"(first-touch copy of the matrix {t_setup:.2f} s, not counted)",
-        }
+    if rank == 0 and world == 1 and args.cpu_iters != 0 and headline and not args.shuffle:
+        # a child process: thread placement must be fixed before an OpenMP runtime loads (this process
+        # already carries torch's), and the oracle shares nothing with the GPU run
+        import subprocess
+        cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--edge", str(n), "--precond", args.precond,
+               "--iters", str(args.iters), "--seq-iters", str(args.cpu_iters)]
+        env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        if p.returncode != 0:
+            raise SystemExit("cpu_baseline leg failed:\n" + p.stderr[-2000:])
+        legs = json.loads(p.stdout.strip().splitlines()[-1])
+        out["cpu_baseline"] = legs["seq"]
+        out["cpu_baseline_omp"] = legs["omp"]
 
     reg.close()
     if world > 1:

@@ -361,9 +361,11 @@ void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,
 /* Index-compressed chunked ELL layout (compress_indices) of a row-major sorted CSR pattern: builds
  * it, decodes it back and compares with the input.  stats[0] = 1 if the pattern qualifies (else 0
  * and the rest is 0), stats[1] = padded value slots, stats[2] = dictionary entries, stats[3] = code
- * bytes.  OGL_ERR_STATE if the decoded pattern differs from the input. */
+ * bytes, stats[4] / stats[5] = chunks coded with 16-bit deltas / with plain 32-bit columns (the
+ * others use 1-byte pattern or offset codes).  OGL_ERR_STATE if the decoded pattern differs from
+ * the input. */
 int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
-                        int64_t stats[4]);
+                        int64_t stats[6]);
 
 #ifdef __cplusplus
 }

@@ -52,17 +52,31 @@ inline int64_t n_chunks(int64_t n_rows) { return (n_rows + CHUNK_ROWS - 1) / CHU
 //     SELL_PAD_OFFSET in the unused tail slots.  8.1 bytes per stored entry on a 7-point stencil;
 //   offset mode (code_stride a multiple of 16): one byte per (row, slot) naming an entry of the
 //     chunk's ascending dictionary of <= 255 offsets (255 = padding slot).  9 bytes per entry.
-// CSR moves 12.  Rows are still summed in stored column order, so y and the fused dot partials are
-// bit-identical to the CSR kernel's.
+//   delta mode (dict_len == SELL_MODE_DELTA16; irregular patterns, e.g. an unstructured mesh in
+//     RCM numbering): 16 bits per (row, slot): the first code of a row is (first column - row) -
+//     dict_off, every later one the distance to the previous column of the row (rows are stored in
+//     ascending column order); 0xFFFF = padding.  10 bytes per entry.  Needs every distance and the
+//     spread of the first offsets over the chunk below 65535;
+//   column mode (dict_len == SELL_MODE_COL32): plain 32-bit columns, -1 = padding.  12 bytes per
+//     entry; the fallback that every chunk can take.
+//   Delta / column codes are stored as 16-byte words, group-major: word (g, t) holds the codes of
+//   SELL_D16_GROUP (SELL_C32_GROUP) consecutive slots of thread t's two rows, [slot][row of the pair];
+//   code_stride = 16 x groups.
+// CSR moves 12 + 4 per row.  Rows are still summed in stored column order, so y and the fused dot
+// partials are bit-identical to the CSR kernel's.
 struct SellChunk {
     int64_t val_off;      // first value of the chunk (doubles)
     int64_t code_off;     // first code byte of the chunk
-    int32_t dict_off;     // first dictionary entry of the chunk
-    int32_t dict_len;     // table ints (pattern mode: patterns x width; offset mode: <= SELL_MAX_DICT)
+    int32_t dict_off;     // first dictionary entry of the chunk (delta mode: the base of the first codes)
+    int32_t dict_len;     // table ints (pattern mode: patterns x width; offset mode: <= SELL_MAX_DICT);
+                          // SELL_MODE_DELTA16 / SELL_MODE_COL32 select the table-free modes
     int32_t width;        // slots per row in this chunk
     int32_t code_stride;  // code bytes per thread: ROWS_PER_THREAD (pattern mode) or
                           // ROWS_PER_THREAD x width rounded up to 16 (offset mode)
 };
+constexpr int32_t SELL_MODE_DELTA16 = -1, SELL_MODE_COL32 = -2;
+constexpr int SELL_D16_GROUP = 4, SELL_C32_GROUP = 2;  // slots per 16-byte code word
+constexpr int SELL_MAX_DELTA16 = 65534;                // 0xFFFF marks a padding slot
 constexpr int SELL_MAX_DICT = 255;        // offset mode: code 255 marks a padding slot
 constexpr int SELL_TABLE_INTS = 2048;     // LDS table of the SpMV kernel (8 KB)
 constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of a pattern

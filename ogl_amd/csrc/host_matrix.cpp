@@ -652,11 +652,12 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             last_pat = id;
             pid[(size_t)lr] = (uint8_t)id;
         }
-        // (b) otherwise offsets: one byte per (row, slot)
+        // (b) otherwise offsets: one byte per (row, slot), when the chunk has <= 255 distinct ones
         ds.clear();
-        if (!pat_mode) {
+        bool off8_mode = !pat_mode && width > 0;
+        if (off8_mode) {
             size_t last = 0;
-            for (ogl_label r = r0; r < r1; ++r)
+            for (ogl_label r = r0; r < r1 && off8_mode; ++r)
                 for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
                     const int32_t d = cols[k] - r;
                     if (!ds.empty()) {
@@ -668,12 +669,36 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
                             continue;
                         }
                     }
-                    if (ds.size() == (size_t)SELL_MAX_DICT) return false;
+                    if (ds.size() == (size_t)SELL_MAX_DICT) {
+                        off8_mode = false;
+                        break;
+                    }
                     ds.push_back(d);
                     last = ds.size() - 1;
                 }
-            std::sort(ds.begin(), ds.end());
+            if (off8_mode) std::sort(ds.begin(), ds.end());
         }
+        // (c) otherwise 16-bit deltas along the row: first code = (first column - row) - base, then
+        // column[s] - column[s-1] (rows are stored in ascending column order); 0xFFFF = padding
+        bool d16_mode = !pat_mode && !off8_mode && width > 0;
+        int32_t base = 0;
+        if (d16_mode) {
+            int64_t lo = INT64_MAX, hi = INT64_MIN;
+            for (ogl_label r = r0; r < r1 && d16_mode; ++r) {
+                if (row_ptrs[r] == row_ptrs[r + 1]) continue;
+                const int64_t first = (int64_t)cols[row_ptrs[r]] - r;
+                lo = std::min(lo, first);
+                hi = std::max(hi, first);
+                for (ogl_label k = row_ptrs[r] + 1; k < row_ptrs[r + 1]; ++k) {
+                    const int64_t d = (int64_t)cols[k] - cols[k - 1];
+                    if (d < 0 || d > SELL_MAX_DELTA16) d16_mode = false;
+                }
+            }
+            if (lo == INT64_MAX) lo = hi = 0;
+            if (hi - lo > SELL_MAX_DELTA16) d16_mode = false;
+            base = (int32_t)lo;
+        }
+        // (d) otherwise plain 32-bit columns (-1 = padding): always possible
         SellChunk &h = out.chunks[(size_t)c];
         h.val_off = val_len;
         h.code_off = code_len;
@@ -684,13 +709,28 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             h.code_stride = ROWS_PER_THREAD;
             out.dict.insert(out.dict.end(), pats.begin(), pats.end());
             pid_all.insert(pid_all.end(), pid.begin(), pid.end());
-        } else {
+            code_len += (int64_t)h.code_stride * BLOCK;
+        } else if (off8_mode) {
             h.dict_len = (int32_t)ds.size();
             h.code_stride = (ROWS_PER_THREAD * width + 15) / 16 * 16;
             out.dict.insert(out.dict.end(), ds.begin(), ds.end());
+            code_len += (int64_t)h.code_stride * BLOCK;
+        } else if (width > 0) {
+            // group-major 16-byte words: word (g, t) holds SELL_D16_GROUP (or SELL_C32_GROUP) slots of
+            // thread t's two rows; lane t of a wavefront reads consecutive words
+            const int per = d16_mode ? SELL_D16_GROUP : SELL_C32_GROUP;
+            const int groups = (width + per - 1) / per;
+            h.dict_len = d16_mode ? SELL_MODE_DELTA16 : SELL_MODE_COL32;
+            h.dict_off = d16_mode ? base : 0;
+            h.code_stride = 16 * groups;
+            code_len += (int64_t)h.code_stride * BLOCK;
+            (d16_mode ? out.n_delta16 : out.n_col32) += 1;
+        } else {
+            h.dict_len = 0;
+            h.code_stride = 16;
+            code_len += (int64_t)h.code_stride * BLOCK;
         }
         val_len += (int64_t)width * CHUNK_ROWS;
-        code_len += (int64_t)h.code_stride * BLOCK;
         code_len = (code_len + 15) / 16 * 16;
         if ((double)val_len > SELL_MAX_PADDING * (double)nnz + 8.0 * CHUNK_ROWS) return false;
     }
@@ -703,22 +743,38 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         const SellChunk &h = out.chunks[(size_t)c];
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
-        const bool pat_mode = h.code_stride == ROWS_PER_THREAD;
+        const bool d16_mode = h.dict_len == SELL_MODE_DELTA16, c32_mode = h.dict_len == SELL_MODE_COL32;
+        const bool pat_mode = !d16_mode && !c32_mode && h.code_stride == ROWS_PER_THREAD;
         if (pat_mode) {  // rows 2t, 2t+1 of thread t are adjacent bytes
             std::copy(pid_all.begin() + (std::ptrdiff_t)pid_pos, pid_all.begin() + (std::ptrdiff_t)(pid_pos + CHUNK_ROWS),
                       out.codes.begin() + h.code_off);
             pid_pos += CHUNK_ROWS;
         }
-        const int32_t *d0 = out.dict.data() + h.dict_off;
+        const int32_t *d0 = (d16_mode || c32_mode) ? nullptr : out.dict.data() + h.dict_off;
         for (ogl_label r = r0; r < r1; ++r) {
             const int32_t lr = r - r0, t = lr / ROWS_PER_THREAD, which = lr % ROWS_PER_THREAD;
             uint8_t *code = out.codes.data() + h.code_off + (int64_t)t * h.code_stride;
             for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s) {
                 out.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS + lr)] = k;
                 if (pat_mode) continue;
-                const int32_t d = cols[k] - r;
-                code[ROWS_PER_THREAD * s + which] =
-                    (uint8_t)(std::lower_bound(d0, d0 + h.dict_len, d) - d0);
+                if (d16_mode) {
+                    const int64_t v = s == 0 ? (int64_t)cols[k] - r - h.dict_off : (int64_t)cols[k] - cols[k - 1];
+                    uint8_t *w = out.codes.data() + h.code_off +
+                                 ((int64_t)(s / SELL_D16_GROUP) * BLOCK + t) * 16 +
+                                 ((s % SELL_D16_GROUP) * ROWS_PER_THREAD + which) * 2;
+                    const uint16_t v16 = (uint16_t)v;
+                    std::memcpy(w, &v16, 2);
+                } else if (c32_mode) {
+                    uint8_t *w = out.codes.data() + h.code_off +
+                                 ((int64_t)(s / SELL_C32_GROUP) * BLOCK + t) * 16 +
+                                 ((s % SELL_C32_GROUP) * ROWS_PER_THREAD + which) * 4;
+                    const int32_t v32 = cols[k];
+                    std::memcpy(w, &v32, 4);
+                } else {
+                    const int32_t d = cols[k] - r;
+                    code[ROWS_PER_THREAD * s + which] =
+                        (uint8_t)(std::lower_bound(d0, d0 + h.dict_len, d) - d0);
+                }
             }
         }
     }
@@ -914,22 +970,27 @@ extern "C" void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_s
 }
 
 extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
-                                   int64_t stats[4])
+                                   int64_t stats[6])
 {
     if (n_rows < 0 || !row_ptrs || !stats || (n_rows > 0 && !cols))
         return fail(OGL_ERR_INVALID, "NULL argument");
-    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    for (int i = 0; i < 6; ++i) stats[i] = 0;
     SellLayout L;
     if (n_rows == 0 || !build_sell_layout(n_rows, row_ptrs, cols, L)) return OGL_OK;
     // decode exactly as k_spmv_sell does: thread t of chunk c owns rows c*CHUNK_ROWS + 2t, +1
     for (size_t c = 0; c < L.chunks.size(); ++c) {
         const SellChunk &h = L.chunks[c];
-        const bool pat_mode = h.code_stride == ROWS_PER_THREAD;
-        if (h.code_off % 16 != 0 ||
-            (pat_mode ? (h.width <= 0 || h.dict_len % h.width != 0 || h.dict_len > SELL_TABLE_INTS ||
-                         h.dict_len / h.width > 256)
-                      : (h.dict_len > SELL_MAX_DICT || h.code_stride % 16 != 0 ||
-                         h.code_stride < ROWS_PER_THREAD * h.width)))
+        const bool d16_mode = h.dict_len == SELL_MODE_DELTA16, c32_mode = h.dict_len == SELL_MODE_COL32;
+        const bool pat_mode = !d16_mode && !c32_mode && h.code_stride == ROWS_PER_THREAD;
+        if (h.code_off % 16 != 0) return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
+        if (d16_mode || c32_mode) {
+            const int per = d16_mode ? SELL_D16_GROUP : SELL_C32_GROUP;
+            if (h.width <= 0 || h.code_stride != 16 * ((h.width + per - 1) / per))
+                return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
+        } else if (pat_mode ? (h.width <= 0 || h.dict_len % h.width != 0 || h.dict_len > SELL_TABLE_INTS ||
+                               h.dict_len / h.width > 256)
+                            : (h.dict_len > SELL_MAX_DICT || h.code_stride % 16 != 0 ||
+                               h.code_stride < ROWS_PER_THREAD * h.width))
             return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
         for (int t = 0; t < BLOCK; ++t)
             for (int which = 0; which < ROWS_PER_THREAD; ++which) {
@@ -937,26 +998,41 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                 const uint8_t *code = L.codes.data() + h.code_off + (int64_t)t * h.code_stride;
                 ogl_label k = row < n_rows ? row_ptrs[row] : 0;
                 const ogl_label k_end = row < n_rows ? row_ptrs[row + 1] : 0;
+                int64_t run = row + h.dict_off;  // delta16: running column
                 for (int s = 0; s < h.width; ++s) {
                     const int32_t m = L.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS +
                                                      t * ROWS_PER_THREAD + which)];
-                    int32_t off;
-                    if (pat_mode) {
+                    int64_t col = -1;  // decoded column, -1 = padding
+                    if (d16_mode) {
+                        uint16_t v;
+                        std::memcpy(&v, L.codes.data() + h.code_off + ((int64_t)(s / SELL_D16_GROUP) * BLOCK + t) * 16 +
+                                            ((s % SELL_D16_GROUP) * ROWS_PER_THREAD + which) * 2, 2);
+                        if (v != 0xFFFFu) {
+                            run += v;
+                            col = run;
+                        }
+                    } else if (c32_mode) {
+                        int32_t v;
+                        std::memcpy(&v, L.codes.data() + h.code_off + ((int64_t)(s / SELL_C32_GROUP) * BLOCK + t) * 16 +
+                                            ((s % SELL_C32_GROUP) * ROWS_PER_THREAD + which) * 4, 4);
+                        col = v;
+                    } else if (pat_mode) {
                         const int32_t id = code[which];
                         if ((id + 1) * h.width > h.dict_len)
                             return fail(OGL_ERR_STATE, "row %ld: pattern id out of range", (long)row);
-                        off = L.dict[(size_t)h.dict_off + (size_t)id * h.width + s];
+                        const int32_t off = L.dict[(size_t)h.dict_off + (size_t)id * h.width + s];
+                        if (off != SELL_PAD_OFFSET) col = row + off;
                     } else {
                         const uint8_t cd = code[ROWS_PER_THREAD * s + which];
                         if (cd != 255 && cd >= h.dict_len)
                             return fail(OGL_ERR_STATE, "row %ld: code out of range", (long)row);
-                        off = cd == 255 ? SELL_PAD_OFFSET : L.dict[(size_t)h.dict_off + cd];
+                        if (cd != 255) col = row + L.dict[(size_t)h.dict_off + cd];
                     }
-                    if (off == SELL_PAD_OFFSET) {
+                    if (col < 0) {
                         if (m != -1) return fail(OGL_ERR_STATE, "row %ld: padding slot is mapped", (long)row);
                         continue;
                     }
-                    if (k >= k_end || m != k || row + off != cols[k])
+                    if (k >= k_end || m != k || col != cols[k])
                         return fail(OGL_ERR_STATE, "row %ld slot %d decodes wrongly", (long)row, s);
                     ++k;
                 }
@@ -967,6 +1043,8 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
     stats[1] = L.n_slots;
     stats[2] = (int64_t)L.dict.size();
     stats[3] = (int64_t)L.codes.size() - 16;
+    stats[4] = L.n_delta16;
+    stats[5] = L.n_col32;
     return OGL_OK;
 }
 

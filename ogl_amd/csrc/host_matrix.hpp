@@ -73,6 +73,7 @@ struct SellLayout {
     std::vector<uint8_t> codes;  // thread-major code bytes (+16 bytes of padding)
     std::vector<int32_t> map;    // value slot -> position in the CSR value array, -1 = padding
     int64_t n_slots = 0;         // padded value slots
+    int64_t n_delta16 = 0, n_col32 = 0;  // chunks coded with 16-bit deltas / plain 32-bit columns
 };
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                        SellLayout &out);

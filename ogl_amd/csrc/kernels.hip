@@ -894,7 +894,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
-    for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];
+    for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];  // (none in delta / column mode)
     __syncthreads();
     const RowPair rp = my_rows(chunk, n_rows);
     const int row = chunk * CHUNK_ROWS + t * ROWS_PER_THREAD;
@@ -903,7 +903,98 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
     const double *v = vals + h.val_off + t * ROWS_PER_THREAD;
     constexpr int BATCH = 8;
-    if (h.code_stride == ROWS_PER_THREAD) {
+    if (h.dict_len == SELL_MODE_DELTA16) {
+        // delta mode: 16 bits per (row, slot), group-major 16-byte words of 4 slots x 2 rows; the
+        // column of a slot is the running sum of the row's codes (first code relative to
+        // row + dict_off).  The eight columns of a batch are formed first, then the eight gathers.
+        static_assert(SELL_D16_GROUP * 2 == BATCH, "two code words per batch");
+        const uint4 *cw = reinterpret_cast<const uint4 *>(codes + h.code_off) + t;
+        int c0 = row + h.dict_off, c1 = row + 1 + h.dict_off;
+        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+            const int g = s0 / SELL_D16_GROUP;
+            const uint4 wa = cw[(long)g * BLOCK];
+            uint4 wb;
+            wb.x = wb.y = wb.z = wb.w = 0xffffffffu;
+            if (s0 + SELL_D16_GROUP < h.width) wb = cw[(long)(g + 1) * BLOCK];
+            const unsigned w8[BATCH] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            double2 vv[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int sl = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                vv[k] = *reinterpret_cast<const double2 *>(v + (long)sl * CHUNK_ROWS);
+            }
+            int a0[BATCH], a1[BATCH];
+            bool ok0[BATCH], ok1[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const unsigned d0 = w8[k] & 0xffffu, d1 = w8[k] >> 16;
+                ok0[k] = (s0 + k < h.width) && d0 != 0xffffu;
+                ok1[k] = (s0 + k < h.width) && d1 != 0xffffu;
+                if (ok0[k]) c0 += (int)d0;
+                if (ok1[k]) c1 += (int)d1;
+                a0[k] = c0;
+                a1[k] = c1;
+            }
+            double x0[BATCH], x1[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                x0[k] = ok0[k] ? x[a0[k]] : 0.0;
+                x1[k] = ok1[k] ? x[a1[k]] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                if (ok0[k]) {
+                    const double p = vv[k].x * x0[k];
+                    acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+                }
+                if (ok1[k]) {
+                    const double p = vv[k].y * x1[k];
+                    acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+                }
+            }
+        }
+    } else if (h.dict_len == SELL_MODE_COL32) {
+        // column mode: plain 32-bit columns (-1 = padding), 16-byte words of 2 slots x 2 rows
+        static_assert(SELL_C32_GROUP * 4 == BATCH, "four code words per batch");
+        const int4 *cw = reinterpret_cast<const int4 *>(codes + h.code_off) + t;
+        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+            const int g = s0 / SELL_C32_GROUP;
+            int a0[BATCH], a1[BATCH];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int4 w;
+                w.x = w.y = w.z = w.w = -1;
+                if (s0 + SELL_C32_GROUP * q < h.width) w = cw[(long)(g + q) * BLOCK];
+                a0[2 * q] = w.x;
+                a1[2 * q] = w.y;
+                a0[2 * q + 1] = (s0 + 2 * q + 1 < h.width) ? w.z : -1;
+                a1[2 * q + 1] = (s0 + 2 * q + 1 < h.width) ? w.w : -1;
+            }
+            double2 vv[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int sl = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                vv[k] = *reinterpret_cast<const double2 *>(v + (long)sl * CHUNK_ROWS);
+            }
+            double x0[BATCH], x1[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                x0[k] = a0[k] >= 0 ? x[a0[k]] : 0.0;
+                x1[k] = a1[k] >= 0 ? x[a1[k]] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                if (a0[k] >= 0) {
+                    const double p = vv[k].x * x0[k];
+                    acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+                }
+                if (a1[k] >= 0) {
+                    const double p = vv[k].y * x1[k];
+                    acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+                }
+            }
+        }
+    } else if (h.code_stride == ROWS_PER_THREAD) {
         // pattern mode: one byte per row -> `width` offsets of the row in the LDS table
         const unsigned short pp =
             *reinterpret_cast<const unsigned short *>(codes + h.code_off + t * ROWS_PER_THREAD);

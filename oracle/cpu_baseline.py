@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""bench.py's cpu_baseline leg, run as a CHILD process of rank 0 (N = 1 only):
+
+  python -m oracle.cpu_baseline --edge 216 --precond BJ --iters 100 --seconds 15
+
+The oracle ("port" of the reference's CPU path: Ginkgo's reference / omp executors cannot be built
+here) on the same synthetic system as the GPU run: the sequential restatement on one
+core and its OpenMP variant on all cores.  A child process because thread placement has to be decided
+before an OpenMP runtime is loaded (OMP_PROC_BIND / OMP_PLACES are read once; the parent has torch's
+libgomp in it already) and so that nothing here shares an address space with the GPU run.  Prints one
+JSON object.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--edge", type=int, default=216)
+    ap.add_argument("--precond", default="BJ", choices=["BJ", "none"])
+    ap.add_argument("--iters", type=int, default=100, help="upper bound of CG iterations per leg")
+    ap.add_argument("--seq-iters", type=int, default=-1, help="-1: sized for about --seconds of work")
+    ap.add_argument("--seconds", type=float, default=15.0)
+    args = ap.parse_args()
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import numpy as np
+    from ogl_amd import synthetic          # numpy-only input generator (no device code)
+    from oracle import oracle as orc
+    orc.build()
+
+    case = synthetic.poisson_case(args.edge)
+    b, _ = synthetic.rhs_for_x_star(case)
+    n, nnz = case.n_cells, case.nnz
+    t0 = time.perf_counter()
+    rows, cols, perm = orc.init_local_sparsity(n, case.upper_addr, case.lower_addr, True)
+    vals = orc.update_local_matrix_data(case.diag, case.upper, None, [], perm)
+    rowptr = orc.rowptr_from_rows(n, rows)
+    A = orc.DistMatrix(rowptr, cols, vals)
+    inv = orc.jacobi_generate_scalar(rowptr, cols, vals) if args.precond == "BJ" else None
+    t_build = time.perf_counter() - t0
+    b_cg = 12 * nnz + 20 * n + 4 + (88 if inv is not None else 72) * n
+
+    seq_iters = args.seq_iters
+    if seq_iters < 0:                      # probe with 2 iterations
+        t0 = time.perf_counter()
+        orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=2, export_res=False)
+        per_it = (time.perf_counter() - t0) / 3.0
+        seq_iters = int(max(3, min(args.iters, args.seconds / max(per_it, 1e-6))))
+    t0 = time.perf_counter()
+    r = orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=seq_iters, export_res=False)
+    t_seq = time.perf_counter() - t0
+    done = r.n_iterations - 1
+    out = {"seq": {"value": done / t_seq, "unit": "iter/s", "cores": 1, "kind": "port",
+                   "GBps": b_cg * done / t_seq / 1e9,
+                   "sample": f"{done} CG iterations of the same {args.edge}^3 system, oracle (sequential "
+                             f"reference-executor restatement), {t_seq:.1f} s (+{t_build:.1f} s LDU->CSR)"}}
+
+    threads = orc.omp_max_threads()
+    omp_iters = min(args.iters, max(3, seq_iters * min(threads, 8)))
+    res, t_setup, t_loop = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=omp_iters, threads=threads)
+    triad = orc.stream_triad_omp(max(1 << 27, 8 * n), 5, threads)          # 3 x 1 GiB: past any L3
+    done = res.n_iterations - 1
+    out["omp"] = {"value": done / t_loop, "unit": "iter/s", "cores": threads, "kind": "port",
+                  "GBps": b_cg * done / t_loop / 1e9, "stream_triad_GBps": triad,
+                  "host_cpus": cores,
+                  "thread_binding": f"OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} "
+                                    f"OMP_PLACES={os.environ['OMP_PLACES']} (set before libgomp loads)",
+                  "sample": f"{done} iterations, OpenMP variant on {threads} threads, loop {t_loop:.2f} s "
+                            f"(first-touch copy of the matrix {t_setup:.2f} s, not counted)"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

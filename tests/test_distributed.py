@@ -138,12 +138,12 @@ def test_gpu_host_buffer_random_partition():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,extra", [("gpu-peer", []), ("gpu-host", []), ("gpu-peer", ["--asym", "1"]),
-                                        ("gpu-peer", ["--gmres", "15"])])
+                                        ("gpu-peer", ["--gmres", "20"])])
 def test_gpu_renumbered_ranks(mode, extra):
     # every rank keeps its device copy in its own RCM numbering; halo columns and the order of the
     # send list are untouched, so the neighbours never notice
     run_ranks(3, "--mode", mode, "--random", "13", "--renumber", "1", *extra)
-    run_ranks(2, "--mode", mode, "--shape", "12,12,12", "--procs", "1,1,2", "--renumber", "1", *extra)
+    run_ranks(2, "--mode", mode, "--shape", "10,10,10", "--procs", "1,1,2", "--renumber", "1", *extra)
 
 
 def _n_devices():

@@ -106,7 +106,7 @@ def test_reductions(reg, oracle, chunk_rows, n):
 
 
 @pytest.mark.parametrize("precond", [capi.PRECOND_NONE, capi.PRECOND_BJ], ids=["none", "BJ"])
-@pytest.mark.parametrize("n", [8, 16, 32])
+@pytest.mark.parametrize("n", [8, 16, 32, 64])     # 64 = BASELINE.json configs[0]'s size
 def test_cg_history(reg, oracle, chunk_rows, precond, n):
     case = synthetic.poisson_case(n)
     xs = synthetic.x_star(case.global_index, case.global_n)

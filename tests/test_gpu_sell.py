@@ -70,12 +70,56 @@ def random_ldu(n, per_row, seed):
                              rng.uniform(-1, 1, f), rng.uniform(-1, 1, f))
 
 
-def test_unstructured_pattern_falls_back_to_csr_stream(reg, oracle):
+def test_unstructured_pattern_runs_on_16_bit_deltas(reg, oracle):
     case = random_ldu(3000, 3, 11)
     s = reg.solver("sell_random", cfg(1)).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL
+    rp, cols, vals = oracle_csr(oracle, case)
+    assert capi.host_sell_modes(rp, cols) == (True, 6, 0)
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, case.n_cells)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+    # same bits from the CSR-stream kernel
+    off = reg.solver("sell_random_off", cfg(0)).set_matrix(case)
+    assert off.get_property("spmvLayout") == LAYOUT_CSR
+    np.testing.assert_array_equal(off.spmv(x), s.spmv(x))
+
+
+def test_far_couplings_take_32_bit_columns_in_their_chunk(reg, oracle):
+    # 70,000 cells; cells 600..1100 also couple to a cell ~66,000 further on: those chunks store plain
+    # 32-bit columns, the rest 16-bit deltas; all of it in one launch
+    n = 70_000
+    rng = np.random.default_rng(4)
+    lo = np.arange(n - 1, dtype=np.int32)
+    pairs = {(int(a), int(a) + 1) for a in lo}
+    pairs |= {(int(a), min(n - 1, int(a) + int(d))) for a, d in zip(rng.integers(0, n - 400, 3 * n), rng.integers(2, 400, 3 * n))}
+    pairs |= {(a, a + 66_000) for a in range(600, 1100)}
+    pairs = np.array(sorted(p for p in pairs if p[0] < p[1]), dtype=np.int32)
+    f = len(pairs)
+    case = synthetic.LduCase(n, pairs[:, 0].copy(), pairs[:, 1].copy(), rng.uniform(20, 30, n),
+                             rng.uniform(-1, 1, f), rng.uniform(-1, 1, f))
+    s = reg.solver("sell_far", cfg(1, renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL
+    rp, cols, vals = oracle_csr(oracle, case)
+    ok, d16, c32 = capi.host_sell_modes(rp, cols)
+    assert ok and c32 >= 2 and d16 > 100
+    x = rng.uniform(-1, 1, n)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+def test_one_long_row_per_chunk_falls_back_to_csr_stream(reg, oracle):
+    # padding to the chunk's longest row would cost more than CSR's indices: the CSR-stream kernel runs
+    n = 2048
+    lower = [r for r in range(n - 1)] + [r for r in range(7, n, 512) for _ in range(2, 200) if r + 199 < n]
+    upper = [r + 1 for r in range(n - 1)] + [r + d for r in range(7, n, 512) for d in range(2, 200) if r + 199 < n]
+    order = np.lexsort((upper, lower))
+    lower, upper = np.array(lower, np.int32)[order], np.array(upper, np.int32)[order]
+    rng = np.random.default_rng(3)
+    case = synthetic.LduCase(n, lower, upper, rng.uniform(300, 400, n), rng.uniform(-1, 1, len(lower)), None)
+    s = reg.solver("sell_longrow", cfg(1)).set_matrix(case)
     assert s.get_property("spmvLayout") == LAYOUT_CSR
     rp, cols, vals = oracle_csr(oracle, case)
-    x = np.random.default_rng(2).uniform(-1, 1, case.n_cells)
+    x = rng.uniform(-1, 1, n)
     np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
 
 

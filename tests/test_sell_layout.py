@@ -64,17 +64,58 @@ def test_many_row_patterns_fall_back_to_offset_codes():
     assert dict_entries <= 2 * 41
 
 
-def test_unstructured_pattern_does_not_qualify():
-    # 6 random neighbours per row: far more than 255 distinct offsets in a chunk
-    rng = np.random.default_rng(5)
-    n = 4096
+def random_rows(n, per_row, reach, seed):
+    rng = np.random.default_rng(seed)
     rows = []
     for r in range(n):
-        c = np.unique(np.concatenate([[r], rng.integers(0, n, 6)]))
-        rows.append(c)
+        lo, hi = max(0, r - reach), min(n, r + reach + 1)
+        rows.append(np.unique(np.concatenate([[r], rng.integers(lo, hi, per_row)])))
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    return rp, np.concatenate(rows).astype(np.int32), rows
+
+
+def test_unstructured_pattern_takes_16_bit_deltas():
+    # 6 random neighbours per row: far more than 255 distinct offsets in a chunk, but every distance
+    # between consecutive columns of a row fits 16 bits -> 10 bytes per entry instead of CSR's 12
+    n = 4096
+    rp, cols, rows = random_rows(n, 6, n, 5)
+    ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
+    assert ok and dict_entries == 0
+    widths = [max(len(c) for c in rows[i * CHUNK:(i + 1) * CHUNK]) for i in range(n // CHUNK)]
+    assert slots == CHUNK * sum(widths)
+    assert code_bytes == sum(256 * 16 * ((w + 3) // 4) for w in widths)     # 4 slots x 2 rows per word
+    assert capi.host_sell_modes(rp, cols) == (True, n // CHUNK, 0)
+
+
+def test_far_apart_columns_take_32_bit_columns_per_chunk():
+    # a band of +-300 around the diagonal plus, in the second chunk only, couplings 70,000 rows away:
+    # that chunk cannot use 16-bit deltas and stores plain columns, the others are unaffected
+    n = 80_000
+    rp, cols, rows = random_rows(n, 4, 300, 6)
+    ok, d16_before, c32 = capi.host_sell_modes(rp, cols)
+    assert ok and c32 == 0 and d16_before >= n // CHUNK - 1      # (the short last chunk may take 1-byte codes)
+    for r in range(CHUNK, 2 * CHUNK, 3):
+        rows[r] = np.unique(np.concatenate([rows[r], [r + 70_000]]))
     rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
     cols = np.concatenate(rows).astype(np.int32)
-    assert capi.host_sell_check(rp, cols) == (False, 0, 0, 0)
+    ok, d16, c32 = capi.host_sell_modes(rp, cols)
+    assert ok and c32 == 1 and d16 == d16_before - 1
+    # the spread of the FIRST offsets of a chunk must fit too: rows starting 70,000 columns back
+    rows[5 * CHUNK + 1] = np.unique(np.concatenate([rows[5 * CHUNK + 1], [5 * CHUNK + 1 - 3000]]))
+    rows[5 * CHUNK + 2] = np.unique(np.concatenate([[2], [65_000], rows[5 * CHUNK + 2]]))
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    cols = np.concatenate(rows).astype(np.int32)
+    assert capi.host_sell_modes(rp, cols) == (True, d16 - 1, 2)
+
+
+def test_unsorted_rows_take_32_bit_columns():
+    # deltas must be >= 0: a row stored out of column order (never produced by the LDU conversion, but
+    # the layout is also used for other CSR matrices) falls back to plain columns and still decodes
+    n = 1024
+    rp, cols, rows = random_rows(n, 5, n, 7)
+    k = rp[100]
+    cols[k], cols[k + 1] = cols[k + 1], cols[k]
+    assert capi.host_sell_modes(rp, cols) == (True, 1, 1)
 
 
 def test_one_long_row_per_chunk_is_too_much_padding():
