@@ -539,13 +539,17 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
     SellLayout natural;
     bool have_natural = false;
     if (mode == 2) {
+        // "structured" = the compressed layout qualifies with 1-byte codes in every chunk; patterns
+        // that only fit the 16-bit delta / 32-bit column modes are judged by their gather locality
+        bool structured = false;
         if (try_sell) {
             rep.sell_natural = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), natural);
             have_natural = true;
+            structured = rep.sell_natural && natural.n_delta16 + natural.n_col32 == 0;
         }
         rep.ratio_natural = rep.ratio_used =
             gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
-        if (rep.sell_natural || rep.ratio_natural <= 0.25) {
+        if (structured || rep.ratio_natural <= 0.25) {
             rep.sell_used = rep.sell_natural;
             if (sell_out && have_natural && sell_built) {
                 *sell_out = std::move(natural);
@@ -569,7 +573,10 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
         SellLayout L;
         bool sell_ok = false;
         if (try_sell) sell_ok = build_sell_layout(N, q.row_ptrs.data(), q.cols.data(), L);
-        if (!adopt && !sell_ok) {
+        // a numbering that turns the pattern into a fully 1-byte-coded one is adopted whatever the
+        // sector ratio says
+        if (!adopt && sell_ok && L.n_delta16 + L.n_col32 == 0) adopt = true;
+        if (!adopt) {
             if (sell_out && have_natural && sell_built) {
                 *sell_out = std::move(natural);
                 *sell_built = true;

@@ -101,8 +101,8 @@ def test_far_apart_columns_take_32_bit_columns_per_chunk():
     ok, d16, c32 = capi.host_sell_modes(rp, cols)
     assert ok and c32 == 1 and d16 == d16_before - 1
     # the spread of the FIRST offsets of a chunk must fit too: rows starting 70,000 columns back
-    rows[5 * CHUNK + 1] = np.unique(np.concatenate([rows[5 * CHUNK + 1], [5 * CHUNK + 1 - 3000]]))
-    rows[5 * CHUNK + 2] = np.unique(np.concatenate([[2], [65_000], rows[5 * CHUNK + 2]]))
+    rows[140 * CHUNK + 1] = np.unique(np.concatenate([rows[140 * CHUNK + 1], [140 * CHUNK + 1 - 3000]]))
+    rows[140 * CHUNK + 2] = np.unique(np.concatenate([[2], [8_000], rows[140 * CHUNK + 2]]))
     rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
     cols = np.concatenate(rows).astype(np.int32)
     assert capi.host_sell_modes(rp, cols) == (True, d16 - 1, 2)
