@@ -473,13 +473,21 @@ def main():
         # a child process: thread placement must be fixed before an OpenMP runtime loads (this process
         # already carries torch's), and the oracle shares nothing with the GPU run
         import subprocess
-        cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--edge", str(n), "--precond", args.precond,
-               "--iters", str(args.iters), "--seq-iters", str(args.cpu_iters)]
         env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
-        p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-        if p.returncode != 0:
-            raise SystemExit("cpu_baseline leg failed:\n" + p.stderr[-2000:])
-        legs = json.loads(p.stdout.strip().splitlines()[-1])
+        base = [sys.executable, "-m", "oracle.cpu_baseline", "--edge", str(n), "--precond", args.precond,
+                "--iters", str(args.iters), "--seq-iters", str(args.cpu_iters)]
+
+        def child(extra, timeout):
+            p = subprocess.run(base + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+            if p.returncode != 0:
+                raise SystemExit("cpu_baseline leg failed:\n" + p.stderr[-2000:])
+            return json.loads(p.stdout.strip().splitlines()[-1])
+        # which placement and thread count move the most bytes on this host: bound one per core, or left
+        # to the scheduler (containers with a CPU quota below their CPU count do better unbound)
+        probes = [child(["--probe", "--bind", str(bnd)], 300) for bnd in (1, 0)]
+        best = max(probes, key=lambda q: q["GBps"])
+        legs = child(["--bind", str(best["bind"]), "--threads", str(best["threads"])], 900)
+        legs["omp"]["placement_probe"] = probes
         out["cpu_baseline"] = legs["seq"]
         out["cpu_baseline_omp"] = legs["omp"]
 

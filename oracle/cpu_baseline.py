@@ -24,11 +24,23 @@ def main():
     ap.add_argument("--iters", type=int, default=100, help="upper bound of CG iterations per leg")
     ap.add_argument("--seq-iters", type=int, default=-1, help="-1: sized for about --seconds of work")
     ap.add_argument("--seconds", type=float, default=15.0)
+    ap.add_argument("--bind", type=int, default=1,
+                    help="1: OMP_PROC_BIND=close OMP_PLACES=cores (set before libgomp loads); 0: leave the "
+                         "threads to the scheduler")
+    ap.add_argument("--probe", action="store_true",
+                    help="only the thread-count probe: STREAM-like triad over a ladder of thread counts "
+                         "under this binding; prints {threads, GBps} of the best")
+    ap.add_argument("--threads", type=int, default=0, help="OpenMP threads of the omp leg (0: probe)")
     args = ap.parse_args()
     cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    if args.bind:
+        os.environ["OMP_PROC_BIND"] = "close"
+        os.environ["OMP_PLACES"] = "cores"
+    else:
+        os.environ.pop("OMP_PROC_BIND", None)
+        os.environ.pop("OMP_PLACES", None)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # a CPU quota below the CPU count must not spin
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
@@ -37,6 +49,23 @@ def main():
     from ogl_amd import synthetic          # numpy-only input generator (no device code)
     from oracle import oracle as orc
     orc.build()
+
+    def probe():
+        """The thread count that moves the most bytes here: affinity masks say nothing about cgroup CPU
+        quotas, SMT siblings or how many cores it takes to saturate the memory controllers."""
+        ladder = sorted({t for t in (4, 8, 16, 32, 48, 64, 96, 128, 192, 256, cores) if t <= cores})
+        best = (0.0, 1)
+        for t in ladder:
+            gbps = orc.stream_triad_omp(1 << 26, 2, t)          # 3 x 512 MiB: past any L3
+            best = max(best, (gbps, t))
+            if gbps < 0.5 * best[0]:
+                break                                           # far past the knee: stop paying for it
+        return best
+
+    if args.probe:
+        gbps, t = probe()
+        print(json.dumps({"threads": t, "GBps": gbps, "bind": args.bind, "host_cpus": cores}))
+        return
 
     case = synthetic.poisson_case(args.edge)
     b, _ = synthetic.rhs_for_x_star(case)
@@ -65,17 +94,25 @@ def main():
                    "sample": f"{done} CG iterations of the same {args.edge}^3 system, oracle (sequential "
                              f"reference-executor restatement), {t_seq:.1f} s (+{t_build:.1f} s LDU->CSR)"}}
 
-    threads = orc.omp_max_threads()
-    omp_iters = min(args.iters, max(3, seq_iters * min(threads, 8)))
+    if args.threads > 0:
+        threads, triad = args.threads, None
+    else:
+        triad, threads = probe()
+    # sized by a 3-iteration probe to about --seconds of work
+    res, t_setup, t_loop = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=3, threads=threads)
+    omp_iters = int(max(3, min(args.iters, args.seconds / max(t_loop / 4.0, 1e-6))))
     res, t_setup, t_loop = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=omp_iters, threads=threads)
-    triad = orc.stream_triad_omp(max(1 << 27, 8 * n), 5, threads)          # 3 x 1 GiB: past any L3
+    if triad is None:
+        triad = orc.stream_triad_omp(1 << 26, 3, threads)
     done = res.n_iterations - 1
     out["omp"] = {"value": done / t_loop, "unit": "iter/s", "cores": threads, "kind": "port",
                   "GBps": b_cg * done / t_loop / 1e9, "stream_triad_GBps": triad,
                   "host_cpus": cores,
-                  "thread_binding": f"OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} "
-                                    f"OMP_PLACES={os.environ['OMP_PLACES']} (set before libgomp loads)",
-                  "sample": f"{done} iterations, OpenMP variant on {threads} threads, loop {t_loop:.2f} s "
+                  "thread_binding": (f"OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} OMP_PLACES="
+                                     f"{os.environ['OMP_PLACES']} (set before libgomp loads)") if args.bind
+                  else "none (scheduler)",
+                  "sample": f"{done} iterations, OpenMP variant on {threads} threads (the count that maximised a "
+                            f"STREAM triad on this host, out of {cores} CPUs), loop {t_loop:.2f} s "
                             f"(first-touch copy of the matrix {t_setup:.2f} s, not counted)"}
     print(json.dumps(out))
 
