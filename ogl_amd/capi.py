@@ -473,7 +473,7 @@ def host_sell_check(row_ptrs, cols):
     """Index-compressed chunked ELL layout of a CSR pattern: (qualifies, padded_slots, dict_entries,
     code_bytes); raises if the layout does not decode back to the pattern."""
     rp, cc = _l(row_ptrs), _l(cols)
-    stats = (C.c_int64 * 6)()
+    stats = (C.c_int64 * 8)()
     _check(lib().ogl_host_sell_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
                                      cc.ctypes.data_as(C.c_void_p), stats))
     return bool(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
@@ -482,10 +482,19 @@ def host_sell_check(row_ptrs, cols):
 def host_sell_modes(row_ptrs, cols):
     """(qualifies, chunks in 16-bit delta mode, chunks in 32-bit column mode)."""
     rp, cc = _l(row_ptrs), _l(cols)
-    stats = (C.c_int64 * 6)()
+    stats = (C.c_int64 * 8)()
     _check(lib().ogl_host_sell_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
                                      cc.ctypes.data_as(C.c_void_p), stats))
     return bool(stats[0]), int(stats[4]), int(stats[5])
+
+
+def host_sell_read_slots(row_ptrs, cols):
+    """(qualifies, allocated value slots, value slots the kernel reads)."""
+    rp, cc = _l(row_ptrs), _l(cols)
+    stats = (C.c_int64 * 8)()
+    _check(lib().ogl_host_sell_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
+                                     cc.ctypes.data_as(C.c_void_p), stats))
+    return bool(stats[0]), int(stats[1]), int(stats[6])
 
 
 def host_adapt_criterion(cfg, prev_solve_iters, prev_rel_cost):

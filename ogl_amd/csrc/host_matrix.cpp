@@ -525,6 +525,24 @@ void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
     p.old_of = std::move(old_of);
 }
 
+// Value slots the compressed SpMV READS per stored entry when the rows are taken in the order
+// order[0], order[1], ... (order == nullptr: the pattern's own): a wavefront of SELL_WAVE_ROWS rows
+// runs to the longest of its rows, shorter rows idle.  1 = no padding read.
+static double sell_read_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *order)
+{
+    if (n_rows <= 0 || row_ptrs[n_rows] == 0) return 1.0;
+    int64_t read = 0;
+    for (ogl_label k0 = 0; k0 < n_rows; k0 += SELL_WAVE_ROWS) {
+        ogl_label w = 0;
+        for (ogl_label k = k0; k < std::min<int64_t>(n_rows, (int64_t)k0 + SELL_WAVE_ROWS); ++k) {
+            const ogl_label r = order ? order[k] : k;
+            w = std::max(w, row_ptrs[r + 1] - row_ptrs[r]);
+        }
+        read += (int64_t)w * SELL_WAVE_ROWS;
+    }
+    return (double)read / (double)row_ptrs[n_rows];
+}
+
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
                      RenumberReport &rep)
 {
@@ -536,67 +554,74 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
     // auto leaves small systems alone: below this a solve is bound by launch latency, not by the
     // x gather, and renumbering would only cost set-up time
     if (mode == 2 && N < RENUMBER_AUTO_MIN_ROWS) return OGL_OK;
-    SellLayout natural;
-    bool have_natural = false;
-    if (mode == 2) {
-        // "structured" = the compressed layout qualifies with 1-byte codes in every chunk; patterns
-        // that only fit the 16-bit delta / 32-bit column modes are judged by their gather locality
-        bool structured = false;
-        if (try_sell) {
-            rep.sell_natural = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), natural);
-            have_natural = true;
-            structured = rep.sell_natural && natural.n_delta16 + natural.n_col32 == 0;
-        }
-        rep.ratio_natural = rep.ratio_used =
-            gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
-        if (structured || rep.ratio_natural <= 0.25) {
-            rep.sell_used = rep.sell_natural;
-            if (sell_out && have_natural && sell_built) {
-                *sell_out = std::move(natural);
-                *sell_built = true;
-            }
-            return OGL_OK;
-        }
-    }
-    std::vector<ogl_label> new_id;
-    rcm_order(N, p.row_ptrs.data(), p.cols.data(), new_id);
-    if (mode == 2) {
-        std::vector<ogl_label> old_of((size_t)N);
-        for (ogl_label c = 0; c < N; ++c) old_of[(size_t)new_id[(size_t)c]] = c;
-        const double r = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), new_id.data(),
-                                             old_of.data());
-        bool adopt = r <= 0.9 * rep.ratio_natural;
-        HostPattern q;
-        if (!adopt && !try_sell) return OGL_OK;
-        q = p;  // try it: the permuted pattern is needed for the layout check anyway
-        renumber_pattern(q, std::move(new_id));
-        SellLayout L;
-        bool sell_ok = false;
-        if (try_sell) sell_ok = build_sell_layout(N, q.row_ptrs.data(), q.cols.data(), L);
-        // a numbering that turns the pattern into a fully 1-byte-coded one is adopted whatever the
-        // sector ratio says
-        if (!adopt && sell_ok && L.n_delta16 + L.n_col32 == 0) adopt = true;
-        if (!adopt) {
-            if (sell_out && have_natural && sell_built) {
-                *sell_out = std::move(natural);
-                *sell_built = true;
-            }
-            return OGL_OK;
-        }
-        p = std::move(q);
-        rep.applied = true;
-        rep.ratio_used = r;
-        rep.sell_used = sell_ok;
-        if (sell_out && try_sell && sell_built) {
+    auto hand_over = [&](SellLayout &L, bool ok) {
+        rep.sell_used = ok;
+        if (sell_out && sell_built) {
             *sell_out = std::move(L);
             *sell_built = true;
         }
+    };
+    SellLayout natural;
+    bool have_natural = false;
+    rep.ratio_natural = rep.ratio_used =
+        gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
+    if (mode == 2 && try_sell) {
+        // "structured" = the compressed layout qualifies with 1-byte codes in every chunk: kept as it
+        // is.  Patterns that only fit the 16-bit delta / 32-bit column codes are judged by their
+        // gather locality and by the padding they make the kernel read.
+        rep.sell_natural = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), natural);
+        have_natural = true;
+        if (rep.sell_natural && natural.n_delta16 + natural.n_col32 == 0) {
+            hand_over(natural, true);
+            return OGL_OK;
+        }
+    }
+    // ---- step 1: the order of the rows at large: the caller's, or reverse Cuthill-McKee
+    std::vector<ogl_label> new_id, old_of;  // empty = the caller's numbering
+    if (mode == 1 || rep.ratio_natural > 0.25) {
+        std::vector<ogl_label> cand, cand_old((size_t)N);
+        rcm_order(N, p.row_ptrs.data(), p.cols.data(), cand);
+        for (ogl_label c = 0; c < N; ++c) cand_old[(size_t)cand[(size_t)c]] = c;
+        const double r = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), cand.data(),
+                                             cand_old.data());
+        if (mode == 1 || r <= 0.9 * rep.ratio_natural) {
+            new_id.swap(cand);
+            old_of.swap(cand_old);
+            rep.ratio_used = r;
+        }
+    }
+    // ---- step 2 (compressed layout only): inside every chunk of CHUNK_ROWS rows, longest rows first,
+    // so that the rows a wavefront runs together have (nearly) the same length and the padding to the
+    // chunk's longest row is never read.  Matters for meshes with mixed cell types; a no-op on hex meshes.
+    if (try_sell) {
+        const double before = sell_read_ratio(N, p.row_ptrs.data(), old_of.empty() ? nullptr : old_of.data());
+        if (before > 1.10) {
+            std::vector<ogl_label> order((size_t)N);
+            for (ogl_label k = 0; k < N; ++k) order[(size_t)k] = old_of.empty() ? k : old_of[(size_t)k];
+            auto len = [&](ogl_label r) { return p.row_ptrs[r + 1] - p.row_ptrs[r]; };
+            for (ogl_label k0 = 0; k0 < N; k0 += CHUNK_ROWS)
+                std::stable_sort(order.begin() + k0, order.begin() + std::min<int64_t>(N, (int64_t)k0 + CHUNK_ROWS),
+                                 [&](ogl_label a, ogl_label b) { return len(a) > len(b); });
+            const double after = sell_read_ratio(N, p.row_ptrs.data(), order.data());
+            if (after <= 0.95 * before) {
+                new_id.assign((size_t)N, 0);
+                for (ogl_label k = 0; k < N; ++k) new_id[(size_t)order[(size_t)k]] = k;
+                rep.sorted_by_length = true;
+            }
+        }
+    }
+    if (new_id.empty()) {  // the caller's numbering stays
+        if (have_natural) hand_over(natural, rep.sell_natural);
         return OGL_OK;
     }
-    rep.ratio_natural = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
     renumber_pattern(p, std::move(new_id));
     rep.applied = true;
     rep.ratio_used = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
+    if (try_sell && sell_out && sell_built) {
+        SellLayout L;
+        const bool ok = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), L);
+        hand_over(L, ok);
+    }
     return OGL_OK;
 }
 
@@ -624,7 +649,14 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
         int32_t width = 0;
-        for (ogl_label r = r0; r < r1; ++r) width = std::max(width, row_ptrs[r + 1] - row_ptrs[r]);
+        for (int wv = 0; wv < CHUNK_ROWS / SELL_WAVE_ROWS; ++wv) {  // what each wavefront has to run to
+            int32_t ww = 0;
+            for (ogl_label r = r0 + wv * SELL_WAVE_ROWS; r < std::min<int64_t>(r1, (int64_t)r0 + (wv + 1) * SELL_WAVE_ROWS); ++r)
+                ww = std::max(ww, row_ptrs[r + 1] - row_ptrs[r]);
+            out.wave_width.push_back(ww);
+            out.read_slots += (int64_t)ww * SELL_WAVE_ROWS;
+            width = std::max(width, ww);
+        }
         // (a) row patterns: one byte per row
         bool pat_mode = width > 0;
         pats.clear();
@@ -739,7 +771,10 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         }
         val_len += (int64_t)width * CHUNK_ROWS;
         code_len = (code_len + 15) / 16 * 16;
-        if ((double)val_len > SELL_MAX_PADDING * (double)nnz + 8.0 * CHUNK_ROWS) return false;
+        // padding that is READ (a wavefront runs to its own longest row) must stay below what CSR's
+        // indices cost; padding that is only allocated (to the chunk's longest row) is bounded too
+        if ((double)out.read_slots > SELL_MAX_PADDING * (double)nnz + 8.0 * CHUNK_ROWS) return false;
+        if ((double)val_len > SELL_MAX_ALLOC * (double)nnz + 8.0 * CHUNK_ROWS) return false;
     }
     out.n_slots = val_len;
     out.codes.assign((size_t)code_len + 16, (uint8_t)255);
@@ -977,11 +1012,11 @@ extern "C" void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_s
 }
 
 extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
-                                   int64_t stats[6])
+                                   int64_t stats[8])
 {
     if (n_rows < 0 || !row_ptrs || !stats || (n_rows > 0 && !cols))
         return fail(OGL_ERR_INVALID, "NULL argument");
-    for (int i = 0; i < 6; ++i) stats[i] = 0;
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
     SellLayout L;
     if (n_rows == 0 || !build_sell_layout(n_rows, row_ptrs, cols, L)) return OGL_OK;
     // decode exactly as k_spmv_sell does: thread t of chunk c owns rows c*CHUNK_ROWS + 2t, +1
@@ -1046,12 +1081,17 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                 if (k != k_end) return fail(OGL_ERR_STATE, "row %ld lost entries", (long)row);
             }
     }
+    if (L.wave_width.size() != 4 * L.chunks.size()) return fail(OGL_ERR_STATE, "wave widths missing");
+    for (ogl_label r = 0; r < n_rows; ++r)
+        if (row_ptrs[r + 1] - row_ptrs[r] > L.wave_width[(size_t)(r / SELL_WAVE_ROWS)])
+            return fail(OGL_ERR_STATE, "row %d is longer than its wavefront's width", r);
     stats[0] = 1;
     stats[1] = L.n_slots;
     stats[2] = (int64_t)L.dict.size();
     stats[3] = (int64_t)L.codes.size() - 16;
     stats[4] = L.n_delta16;
     stats[5] = L.n_col32;
+    stats[6] = L.read_slots;
     return OGL_OK;
 }
 

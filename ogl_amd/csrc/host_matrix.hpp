@@ -74,6 +74,10 @@ struct SellLayout {
     std::vector<int32_t> map;    // value slot -> position in the CSR value array, -1 = padding
     int64_t n_slots = 0;         // padded value slots
     int64_t n_delta16 = 0, n_col32 = 0;  // chunks coded with 16-bit deltas / plain 32-bit columns
+    // slots each wavefront (SELL_WAVE_ROWS rows) of a chunk runs to = its own longest row; the planes
+    // beyond are allocated (to the chunk's longest row) but never read
+    std::vector<int32_t> wave_width;
+    int64_t read_slots = 0;  // sum of wave_width x SELL_WAVE_ROWS
 };
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                        SellLayout &out);
@@ -99,10 +103,13 @@ struct RenumberReport {
     bool applied = false;
     bool sell_natural = false, sell_used = false;  // compressed layout qualifies (only when tried)
     double ratio_natural = 0.0, ratio_used = 0.0;  // gather_sector_ratio before / after
+    bool sorted_by_length = false;  // rows of a chunk reordered longest first (compressed layout)
 };
 // mode 0: keep the caller's numbering; 1: always RCM; 2 (default, "auto"): keep it when the
-// compressed layout qualifies or the gather already coalesces (ratio <= 0.25), else try RCM and
-// adopt it when it makes the compressed layout qualify or cuts the sector ratio by >= 10 %.
+// compressed layout qualifies with 1-byte codes throughout (structured mesh); otherwise RCM when the
+// gather coalesces badly (ratio > 0.25) and RCM cuts the sector ratio by >= 10 %.  With the
+// compressed layout in play (try_sell), modes 1 and 2 also put the rows of every chunk of CHUNK_ROWS
+// rows longest first when that cuts the padding the SpMV would read by >= 5 % (mixed cell types).
 // `sell_out` (may be null) receives the compressed layout of the numbering that was chosen when
 // one was built on the way (sell_built tells), so the caller does not derive it twice.
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,

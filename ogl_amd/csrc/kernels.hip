@@ -879,6 +879,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const int *__restrict__ dict,
                                                      const uint8_t *__restrict__ codes,
                                                      const double *__restrict__ vals,
+                                                     const int *__restrict__ wave_width,
                                                      const double *__restrict__ x,
                                                      const double *__restrict__ b,
                                                      double *__restrict__ y,
@@ -902,6 +903,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     acc.x = acc.y = 0.0;
     if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
     const double *v = vals + h.val_off + t * ROWS_PER_THREAD;
+    // this wavefront runs to the longest of ITS rows: the planes beyond (padding up to the chunk's
+    // longest row) are never touched.  Wave-uniform, so the loops below do not diverge.
+    const int ww = wave_width[chunk * N_WAVES + t / WAVE];
     constexpr int BATCH = 8;
     if (h.dict_len == SELL_MODE_DELTA16) {
         // delta mode: 16 bits per (row, slot), group-major 16-byte words of 4 slots x 2 rows; the
@@ -910,17 +914,17 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
         static_assert(SELL_D16_GROUP * 2 == BATCH, "two code words per batch");
         const uint4 *cw = reinterpret_cast<const uint4 *>(codes + h.code_off) + t;
         int c0 = row + h.dict_off, c1 = row + 1 + h.dict_off;
-        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+        for (int s0 = 0; s0 < ww; s0 += BATCH) {
             const int g = s0 / SELL_D16_GROUP;
             const uint4 wa = cw[(long)g * BLOCK];
             uint4 wb;
             wb.x = wb.y = wb.z = wb.w = 0xffffffffu;
-            if (s0 + SELL_D16_GROUP < h.width) wb = cw[(long)(g + 1) * BLOCK];
+            if (s0 + SELL_D16_GROUP < ww) wb = cw[(long)(g + 1) * BLOCK];
             const unsigned w8[BATCH] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
             double2 vv[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                const int sl = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                const int sl = min(s0 + k, ww - 1);  // clamp: always a valid plane
                 vv[k] = *reinterpret_cast<const double2 *>(v + (long)sl * CHUNK_ROWS);
             }
             int a0[BATCH], a1[BATCH];
@@ -928,8 +932,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 const unsigned d0 = w8[k] & 0xffffu, d1 = w8[k] >> 16;
-                ok0[k] = (s0 + k < h.width) && d0 != 0xffffu;
-                ok1[k] = (s0 + k < h.width) && d1 != 0xffffu;
+                ok0[k] = (s0 + k < ww) && d0 != 0xffffu;
+                ok1[k] = (s0 + k < ww) && d1 != 0xffffu;
                 if (ok0[k]) c0 += (int)d0;
                 if (ok1[k]) c1 += (int)d1;
                 a0[k] = c0;
@@ -957,23 +961,23 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
         // column mode: plain 32-bit columns (-1 = padding), 16-byte words of 2 slots x 2 rows
         static_assert(SELL_C32_GROUP * 4 == BATCH, "four code words per batch");
         const int4 *cw = reinterpret_cast<const int4 *>(codes + h.code_off) + t;
-        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+        for (int s0 = 0; s0 < ww; s0 += BATCH) {
             const int g = s0 / SELL_C32_GROUP;
             int a0[BATCH], a1[BATCH];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 int4 w;
                 w.x = w.y = w.z = w.w = -1;
-                if (s0 + SELL_C32_GROUP * q < h.width) w = cw[(long)(g + q) * BLOCK];
+                if (s0 + SELL_C32_GROUP * q < ww) w = cw[(long)(g + q) * BLOCK];
                 a0[2 * q] = w.x;
                 a1[2 * q] = w.y;
-                a0[2 * q + 1] = (s0 + 2 * q + 1 < h.width) ? w.z : -1;
-                a1[2 * q + 1] = (s0 + 2 * q + 1 < h.width) ? w.w : -1;
+                a0[2 * q + 1] = (s0 + 2 * q + 1 < ww) ? w.z : -1;
+                a1[2 * q + 1] = (s0 + 2 * q + 1 < ww) ? w.w : -1;
             }
             double2 vv[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                const int sl = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                const int sl = min(s0 + k, ww - 1);  // clamp: always a valid plane
                 vv[k] = *reinterpret_cast<const double2 *>(v + (long)sl * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
@@ -999,15 +1003,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
         const unsigned short pp =
             *reinterpret_cast<const unsigned short *>(codes + h.code_off + t * ROWS_PER_THREAD);
         const int p0 = (int)(pp & 0xffu) * h.width, p1 = (int)(pp >> 8) * h.width;
-        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+        for (int s0 = 0; s0 < ww; s0 += BATCH) {
             double2 vv[BATCH];
             int d0[BATCH], d1[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                const int s = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                const int s = min(s0 + k, ww - 1);  // clamp: always a valid plane
                 vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
-                d0[k] = (s0 + k < h.width) ? stab[p0 + s] : SELL_PAD_OFFSET;
-                d1[k] = (s0 + k < h.width) ? stab[p1 + s] : SELL_PAD_OFFSET;
+                d0[k] = (s0 + k < ww) ? stab[p0 + s] : SELL_PAD_OFFSET;
+                d1[k] = (s0 + k < ww) ? stab[p1 + s] : SELL_PAD_OFFSET;
             }
             double x0[BATCH], x1[BATCH];
 #pragma unroll
@@ -1030,13 +1034,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     } else {
         // offset mode: one byte per (row, slot) -> entry of the chunk's offset dictionary
         const uint8_t *c = codes + h.code_off + (long)t * h.code_stride;
-        for (int s0 = 0; s0 < h.width; s0 += BATCH) {
+        for (int s0 = 0; s0 < ww; s0 += BATCH) {
             const uint4 cw = *reinterpret_cast<const uint4 *>(c + 2 * s0);
             const unsigned w4[4] = {cw.x, cw.y, cw.z, cw.w};
             double2 vv[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                const int s = min(s0 + k, h.width - 1);  // clamp: always a valid plane
+                const int s = min(s0 + k, ww - 1);  // clamp: always a valid plane
                 vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
@@ -1046,8 +1050,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 const unsigned pair = (w4[k / 2] >> (16 * (k & 1))) & 0xffffu;
                 const unsigned c0 = pair & 0xffu, c1 = pair >> 8;
                 // padding slots carry code 255; rows past n_rows only have padding slots
-                ok0[k] = (s0 + k < h.width) && c0 != 255u;
-                ok1[k] = (s0 + k < h.width) && c1 != 255u;
+                ok0[k] = (s0 + k < ww) && c0 != 255u;
+                ok1[k] = (s0 + k < ww) && c1 != 255u;
                 x0[k] = ok0[k] ? x[row + stab[c0]] : 0.0;
                 x1[k] = ok1[k] ? x[row + 1 + stab[c1]] : 0.0;
             }
@@ -1820,7 +1824,8 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
 #define OGL_SELL(MODE, NDOT)                                                                     \
     hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
-                       A.dict, A.codes, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+                       A.dict, A.codes, A.vals, A.wave_width, x, b, y, dots.with, dots.part,      \
+                       dots.part_yy, gate)
     if (mode == SPMV_RESIDUAL) {
         OGL_SELL(SPMV_RESIDUAL, 0);
     } else if (dots.part && dots.part_yy) {

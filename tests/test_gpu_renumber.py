@@ -189,3 +189,31 @@ def test_export_is_written_in_the_callers_numbering(reg, tmp_path):
         files[mode] = {n: open(f"{d}/rn_exp{mode}_{n}.mtx").read() for n in ("A_local", "rhs_b_")}
     assert files[0]["A_local"] == files[1]["A_local"]
     assert files[0]["rhs_b_"] == files[1]["rhs_b_"]
+
+
+def test_mixed_row_lengths_run_on_the_compressed_layout_after_the_length_sort(reg, oracle, chunk_rows):
+    """Row lengths 2..15 (a stand-in for mixed cell types): in the caller's order the padding disqualifies
+    the compressed layout (CSR-stream kernel); with `renumber` the rows of a chunk go longest first, the
+    kernel's wavefronts run to their own widths, and everything stays bit-identical to the oracle on the
+    permuted system."""
+    case = synthetic.random_global_case(20000, 4, 300, symmetric=True, seed=2)
+    rng = np.random.default_rng(SEED)
+    x = rng.uniform(-1, 1, case.n_cells)
+    s0 = reg.solver("rn_mixed_off", cfg(renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    assert s0.get_property("spmvLayout") == 0.0
+    for mode in (capi.RENUMBER_ON, capi.RENUMBER_AUTO):
+        s = reg.solver(f"rn_mixed_{mode}", cfg(renumber=mode, preconditioner=capi.PRECOND_BJ, max_iter=30)).set_matrix(case)
+        new_id = s.renumbering()
+        assert new_id is not None and s.get_property("spmvLayout") == 2.0
+        assert s.get_property("rowsSortedByLength") == 1.0
+        assert s.get_property("sellReadSlots") < 1.25 * (case.nnz + 4096) < s.get_property("sellAllocatedSlots")
+        A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, to_new(x, new_id))[new_id])
+        np.testing.assert_allclose(s.spmv(x), s0.spmv(x), rtol=1e-13, atol=1e-13)
+        b = synthetic.apply_case(case, x)
+        xs, perf = s.solve(b, np.zeros_like(b))
+        with blocked(oracle, chunk_rows):
+            ref = oracle.cg(A, to_new(b, new_id), np.zeros_like(b), oracle.jacobi_generate_scalar(rp, cols, vals),
+                            tolerance=0.0, rel_tol=0.0, max_iter=30)
+        np.testing.assert_array_equal(s.history(), ref.history)
+        np.testing.assert_array_equal(xs, ref.x[new_id])
