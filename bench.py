@@ -399,6 +399,36 @@ def main():
     traffic, traffic_src = (pmc_traffic(kernel + "<0, 1>")
                             if (n == 216 and args.format == "Csr" and not args.shuffle) else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
+
+    def turn_model():
+        """Algorithmic bytes of ONE solver turn: the SpMV(s) at the CSR figure + every vector pass the
+        Ginkgo step order needs when neighbouring element-wise steps are fused (what the kernels here
+        do), each vector counted once per read or write.  GKOCG: SURVEY.md §8d.  Others: DESIGN.md §4."""
+        k, m = args.block_size, args.krylov_dim
+        nnz_w = (nnz + N) // 2 if args.precond == "ISAI" else nnz          # tril(A) resp. pattern of A
+        if args.precond == "none":
+            apply_b, materialised = 0, False
+        elif args.precond == "BJ" and k == 1:
+            apply_b, materialised = 8 * N, False                          # inv_diag read, fused
+        elif args.precond == "BJ":
+            apply_b, materialised = (8 * k + 20) * N, True                # block rows + in + out + row->block
+        else:
+            n_spmv = 2 if args.precond == "ISAI" else 1                   # W^T (W r)  resp.  W r
+            apply_b, materialised = n_spmv * (12 * nnz_w + 20 * N), True
+        if args.solver == "GKOCG":
+            # fused: step_1 24 N (+ deferred x update 16 N) , step_2 24 N + partials; materialised z: +16 N
+            vec = 72 * N if not materialised else (24 + 48 + 0) * N
+            return b_spmv + vec + (apply_b if apply_b != 8 * N else 16 * N), "B_spmv + vector passes + M^-1"
+        if args.solver == "GKOBiCGStab":
+            vec = (24 + 24 + 64) * N + (2 * 16 * N if apply_b == 8 * N else 0)   # step_1/2/3 (+ y, z written)
+            return 2 * b_spmv + vec + 2 * (apply_b if materialised else 0), "2 B_spmv + step_1/2/3 + 2 M^-1"
+        # GKOGMRES(m): column `it` of a cycle costs it + 1 modified Gram-Schmidt links of 32 N (w read and
+        # written, v_k-1 and v_k read), the closing link 24 N, the scaling 16 N; per cycle once: update of
+        # x (8 m N + 24 N), the residual SpMV and the restart (24 N)
+        per_col = b_spmv + (apply_b + 16 * N if not materialised else apply_b) + 32 * N * (m + 1) / 2 + 40 * N
+        per_cycle = b_spmv + (8 * m + 48) * N + (apply_b if materialised else 8 * N)
+        return per_col + per_cycle / m, "B_spmv + M^-1 + (m+1)/2 MGS links of 32 N + cycle overhead / m"
+    b_turn, b_turn_what = turn_model()
     if args.solver != "GKOCG" or precond not in (capi.PRECOND_BJ, capi.PRECOND_NONE) or args.block_size != 1:
         b_cg = None              # the per-iteration byte model of SURVEY.md §8d is for CG only
     # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
@@ -458,6 +488,11 @@ def main():
             "algorithmic_bytes": b_cg, "ms": 1e3 * elapsed / max(1, iters),
             "achieved_GBps": None if b_cg is None else b_cg * iters / elapsed / 1e9,
             "frac_of_peak": None if b_cg is None else b_cg * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
+        },
+        "solver_turn": {
+            "algorithmic_bytes": b_turn, "model": b_turn_what, "ms": 1e3 * elapsed / max(1, iters),
+            "achieved_GBps": b_turn * iters / elapsed / 1e9,
+            "frac_of_peak": b_turn * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
         },
         "boundary": {
             "first_set_matrix_s": t_first_matrix, "refresh_set_matrix_s": t_refresh_matrix,

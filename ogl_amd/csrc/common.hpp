@@ -47,34 +47,57 @@ inline int64_t n_chunks(int64_t n_rows) { return (n_rows + CHUNK_ROWS - 1) / CHU
 // Index-compressed chunked ELL ("SELL-512 with diagonal codes"): the layout the Coo/Csr-format path
 // runs on when the sparsity pattern allows it.  Per chunk of CHUNK_ROWS rows: `width` = its longest
 // row, values slot-major [width][CHUNK_ROWS], and the columns coded in one of two ways:
-//   pattern mode (code_stride == ROWS_PER_THREAD): ONE BYTE PER ROW naming one of <= 256 row
+//   pattern mode (SELL_MODE_PATTERN): ONE BYTE PER ROW naming one of <= 256 row
 //     patterns of the chunk; the table holds `width` (column - row) offsets per pattern,
 //     SELL_PAD_OFFSET in the unused tail slots.  8.1 bytes per stored entry on a 7-point stencil;
-//   offset mode (code_stride a multiple of 16): one byte per (row, slot) naming an entry of the
+//   offset mode (SELL_MODE_OFFSET8): one byte per (row, slot) naming an entry of the
 //     chunk's ascending dictionary of <= 255 offsets (255 = padding slot).  9 bytes per entry.
-//   delta mode (dict_len == SELL_MODE_DELTA16; irregular patterns, e.g. an unstructured mesh in
+//   delta mode (mode == SELL_MODE_DELTA16; irregular patterns, e.g. an unstructured mesh in
 //     RCM numbering): 16 bits per (row, slot): the first code of a row is (first column - row) -
 //     dict_off, every later one the distance to the previous column of the row (rows are stored in
 //     ascending column order); 0xFFFF = padding.  10 bytes per entry.  Needs every distance and the
 //     spread of the first offsets over the chunk below 65535;
-//   column mode (dict_len == SELL_MODE_COL32): plain 32-bit columns, -1 = padding.  12 bytes per
+//   column mode (mode == SELL_MODE_COL32): plain 32-bit columns, -1 = padding.  12 bytes per
 //     entry; the fallback that every chunk can take.
 //   Delta / column codes are stored as 16-byte words, group-major: word (g, t) holds the codes of
 //   SELL_D16_GROUP (SELL_C32_GROUP) consecutive slots of thread t's two rows, [slot][row of the pair];
-//   code_stride = 16 x groups.
 // CSR moves 12 + 4 per row.  Rows are still summed in stored column order, so y and the fused dot
 // partials are bit-identical to the CSR kernel's.
-struct SellChunk {
-    int64_t val_off;      // first value of the chunk (doubles)
+#if defined(__HIPCC__)
+#define OGL_HD __host__ __device__
+#else
+#define OGL_HD
+#endif
+constexpr int SELL_WAVE_ROWS = WAVE * ROWS_PER_THREAD;  // rows one wavefront of the SpMV owns
+constexpr int SELL_WAVES = CHUNK_ROWS / SELL_WAVE_ROWS;  // wavefronts of a chunk's workgroup
+enum SellMode : int16_t { SELL_MODE_PATTERN = 0, SELL_MODE_OFFSET8 = 1, SELL_MODE_DELTA16 = 2, SELL_MODE_COL32 = 3 };
+struct SellChunk {  // 32 bytes: one load brings everything a wavefront needs to know about its chunk
+    int64_t val_off;      // first value of the chunk (doubles); planes of CHUNK_ROWS, width() of them
     int64_t code_off;     // first code byte of the chunk
-    int32_t dict_off;     // first dictionary entry of the chunk (delta mode: the base of the first codes)
-    int32_t dict_len;     // table ints (pattern mode: patterns x width; offset mode: <= SELL_MAX_DICT);
-                          // SELL_MODE_DELTA16 / SELL_MODE_COL32 select the table-free modes
-    int32_t width;        // slots per row in this chunk
-    int32_t code_stride;  // code bytes per thread: ROWS_PER_THREAD (pattern mode) or
-                          // ROWS_PER_THREAD x width rounded up to 16 (offset mode)
+    int32_t dict_off;     // first table entry of the chunk (delta mode: the base of the first codes)
+    int16_t mode;         // SellMode
+    uint16_t dict_len;    // table ints (pattern mode: patterns x width; offset mode: <= SELL_MAX_DICT)
+    // slots each wavefront (SELL_WAVE_ROWS rows) runs to = its own longest row; the planes beyond,
+    // up to the chunk's longest row, are allocated but never read
+    uint16_t wave_w[SELL_WAVES];
+    OGL_HD int width() const  // slots allocated per row = the chunk's longest row
+    {
+        int w = wave_w[0];
+        for (int i = 1; i < SELL_WAVES; ++i) w = wave_w[i] > w ? wave_w[i] : w;
+        return w;
+    }
+    // code bytes per thread: ROWS_PER_THREAD (pattern mode), ROWS_PER_THREAD x width rounded up to 16
+    // (offset mode), 16 x groups of SELL_D16_GROUP / SELL_C32_GROUP slots (delta / column mode)
+    OGL_HD int code_stride() const
+    {
+        const int w = width();
+        if (mode == SELL_MODE_PATTERN) return ROWS_PER_THREAD;
+        if (mode == SELL_MODE_OFFSET8) return (ROWS_PER_THREAD * w + 15) / 16 * 16;
+        if (mode == SELL_MODE_DELTA16) return 16 * ((w + 3) / 4);
+        return 16 * ((w + 1) / 2);
+    }
 };
-constexpr int32_t SELL_MODE_DELTA16 = -1, SELL_MODE_COL32 = -2;
+static_assert(sizeof(SellChunk) == 32, "SellChunk is read as two 16-byte words");
 constexpr int SELL_D16_GROUP = 4, SELL_C32_GROUP = 2;  // slots per 16-byte code word
 constexpr int SELL_MAX_DELTA16 = 65534;                // 0xFFFF marks a padding slot
 constexpr int SELL_MAX_DICT = 255;        // offset mode: code 255 marks a padding slot
@@ -83,6 +106,5 @@ constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of 
 constexpr int RENUMBER_AUTO_MIN_ROWS = 16384;  // config renumber = auto: smaller systems keep their numbering
 constexpr double SELL_MAX_PADDING = 1.25;  // value slots READ / nnz above which CSR moves fewer bytes
 constexpr double SELL_MAX_ALLOC = 4.0;     // value slots ALLOCATED / nnz (planes no wavefront reads)
-constexpr int SELL_WAVE_ROWS = WAVE * ROWS_PER_THREAD;  // rows one wavefront of the SpMV owns
 
 }  // namespace ogl

@@ -648,15 +648,16 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     for (int64_t c = 0; c < nc; ++c) {
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
-        int32_t width = 0;
-        for (int wv = 0; wv < CHUNK_ROWS / SELL_WAVE_ROWS; ++wv) {  // what each wavefront has to run to
+        int32_t width = 0, wave_w[SELL_WAVES];
+        for (int wv = 0; wv < SELL_WAVES; ++wv) {  // what each wavefront has to run to
             int32_t ww = 0;
             for (ogl_label r = r0 + wv * SELL_WAVE_ROWS; r < std::min<int64_t>(r1, (int64_t)r0 + (wv + 1) * SELL_WAVE_ROWS); ++r)
                 ww = std::max(ww, row_ptrs[r + 1] - row_ptrs[r]);
-            out.wave_width.push_back(ww);
+            wave_w[wv] = ww;
             out.read_slots += (int64_t)ww * SELL_WAVE_ROWS;
             width = std::max(width, ww);
         }
+        if (width > 65535) return false;  // (a row that long fails the padding rules anyway)
         // (a) row patterns: one byte per row
         bool pat_mode = width > 0;
         pats.clear();
@@ -742,33 +743,30 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         h.val_off = val_len;
         h.code_off = code_len;
         h.dict_off = (int32_t)out.dict.size();
-        h.width = width;
+        h.dict_len = 0;
+        for (int wv = 0; wv < SELL_WAVES; ++wv) h.wave_w[wv] = (uint16_t)wave_w[wv];
         if (pat_mode) {
-            h.dict_len = (int32_t)pats.size();
-            h.code_stride = ROWS_PER_THREAD;
+            h.mode = SELL_MODE_PATTERN;
+            h.dict_len = (uint16_t)pats.size();
             out.dict.insert(out.dict.end(), pats.begin(), pats.end());
             pid_all.insert(pid_all.end(), pid.begin(), pid.end());
-            code_len += (int64_t)h.code_stride * BLOCK;
         } else if (off8_mode) {
-            h.dict_len = (int32_t)ds.size();
-            h.code_stride = (ROWS_PER_THREAD * width + 15) / 16 * 16;
+            h.mode = SELL_MODE_OFFSET8;
+            h.dict_len = (uint16_t)ds.size();
             out.dict.insert(out.dict.end(), ds.begin(), ds.end());
-            code_len += (int64_t)h.code_stride * BLOCK;
-        } else if (width > 0) {
-            // group-major 16-byte words: word (g, t) holds SELL_D16_GROUP (or SELL_C32_GROUP) slots of
-            // thread t's two rows; lane t of a wavefront reads consecutive words
-            const int per = d16_mode ? SELL_D16_GROUP : SELL_C32_GROUP;
-            const int groups = (width + per - 1) / per;
-            h.dict_len = d16_mode ? SELL_MODE_DELTA16 : SELL_MODE_COL32;
-            h.dict_off = d16_mode ? base : 0;
-            h.code_stride = 16 * groups;
-            code_len += (int64_t)h.code_stride * BLOCK;
-            (d16_mode ? out.n_delta16 : out.n_col32) += 1;
+        } else if (d16_mode) {
+            // group-major 16-byte words: word (g, t) holds SELL_D16_GROUP slots of thread t's two rows;
+            // lane t of a wavefront reads consecutive words
+            h.mode = SELL_MODE_DELTA16;
+            h.dict_off = base;
+            out.n_delta16 += 1;
         } else {
-            h.dict_len = 0;
-            h.code_stride = 16;
-            code_len += (int64_t)h.code_stride * BLOCK;
+            h.mode = SELL_MODE_COL32;  // (also what an empty chunk gets: nothing is ever read)
+            h.dict_off = 0;
+            if (width > 0) out.n_col32 += 1;
         }
+        const int cs = h.code_stride();
+        code_len += (int64_t)(cs > 0 ? cs : 16) * BLOCK;
         val_len += (int64_t)width * CHUNK_ROWS;
         code_len = (code_len + 15) / 16 * 16;
         // padding that is READ (a wavefront runs to its own longest row) must stay below what CSR's
@@ -785,8 +783,9 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         const SellChunk &h = out.chunks[(size_t)c];
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
-        const bool d16_mode = h.dict_len == SELL_MODE_DELTA16, c32_mode = h.dict_len == SELL_MODE_COL32;
-        const bool pat_mode = !d16_mode && !c32_mode && h.code_stride == ROWS_PER_THREAD;
+        const bool d16_mode = h.mode == SELL_MODE_DELTA16, c32_mode = h.mode == SELL_MODE_COL32;
+        const bool pat_mode = h.mode == SELL_MODE_PATTERN;
+        const int code_stride = h.code_stride();
         if (pat_mode) {  // rows 2t, 2t+1 of thread t are adjacent bytes
             std::copy(pid_all.begin() + (std::ptrdiff_t)pid_pos, pid_all.begin() + (std::ptrdiff_t)(pid_pos + CHUNK_ROWS),
                       out.codes.begin() + h.code_off);
@@ -795,7 +794,7 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         const int32_t *d0 = (d16_mode || c32_mode) ? nullptr : out.dict.data() + h.dict_off;
         for (ogl_label r = r0; r < r1; ++r) {
             const int32_t lr = r - r0, t = lr / ROWS_PER_THREAD, which = lr % ROWS_PER_THREAD;
-            uint8_t *code = out.codes.data() + h.code_off + (int64_t)t * h.code_stride;
+            uint8_t *code = out.codes.data() + h.code_off + (int64_t)t * code_stride;
             for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s) {
                 out.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS + lr)] = k;
                 if (pat_mode) continue;
@@ -1022,26 +1021,24 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
     // decode exactly as k_spmv_sell does: thread t of chunk c owns rows c*CHUNK_ROWS + 2t, +1
     for (size_t c = 0; c < L.chunks.size(); ++c) {
         const SellChunk &h = L.chunks[c];
-        const bool d16_mode = h.dict_len == SELL_MODE_DELTA16, c32_mode = h.dict_len == SELL_MODE_COL32;
-        const bool pat_mode = !d16_mode && !c32_mode && h.code_stride == ROWS_PER_THREAD;
-        if (h.code_off % 16 != 0) return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
-        if (d16_mode || c32_mode) {
-            const int per = d16_mode ? SELL_D16_GROUP : SELL_C32_GROUP;
-            if (h.width <= 0 || h.code_stride != 16 * ((h.width + per - 1) / per))
-                return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
-        } else if (pat_mode ? (h.width <= 0 || h.dict_len % h.width != 0 || h.dict_len > SELL_TABLE_INTS ||
-                               h.dict_len / h.width > 256)
-                            : (h.dict_len > SELL_MAX_DICT || h.code_stride % 16 != 0 ||
-                               h.code_stride < ROWS_PER_THREAD * h.width))
+        const bool d16_mode = h.mode == SELL_MODE_DELTA16, c32_mode = h.mode == SELL_MODE_COL32;
+        const bool pat_mode = h.mode == SELL_MODE_PATTERN;
+        const int width = h.width(), code_stride = h.code_stride();
+        if (h.code_off % 16 != 0 || h.mode < SELL_MODE_PATTERN || h.mode > SELL_MODE_COL32)
             return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
+        if (pat_mode && (width <= 0 || h.dict_len % width != 0 || h.dict_len > SELL_TABLE_INTS ||
+                         h.dict_len / width > 256))
+            return fail(OGL_ERR_STATE, "chunk %zu: bad pattern table", c);
+        if (h.mode == SELL_MODE_OFFSET8 && h.dict_len > SELL_MAX_DICT)
+            return fail(OGL_ERR_STATE, "chunk %zu: bad dictionary", c);
         for (int t = 0; t < BLOCK; ++t)
             for (int which = 0; which < ROWS_PER_THREAD; ++which) {
                 const int64_t row = (int64_t)c * CHUNK_ROWS + t * ROWS_PER_THREAD + which;
-                const uint8_t *code = L.codes.data() + h.code_off + (int64_t)t * h.code_stride;
+                const uint8_t *code = L.codes.data() + h.code_off + (int64_t)t * code_stride;
                 ogl_label k = row < n_rows ? row_ptrs[row] : 0;
                 const ogl_label k_end = row < n_rows ? row_ptrs[row + 1] : 0;
                 int64_t run = row + h.dict_off;  // delta16: running column
-                for (int s = 0; s < h.width; ++s) {
+                for (int s = 0; s < width; ++s) {
                     const int32_t m = L.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS +
                                                      t * ROWS_PER_THREAD + which)];
                     int64_t col = -1;  // decoded column, -1 = padding
@@ -1060,9 +1057,9 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                         col = v;
                     } else if (pat_mode) {
                         const int32_t id = code[which];
-                        if ((id + 1) * h.width > h.dict_len)
+                        if ((id + 1) * width > h.dict_len)
                             return fail(OGL_ERR_STATE, "row %ld: pattern id out of range", (long)row);
-                        const int32_t off = L.dict[(size_t)h.dict_off + (size_t)id * h.width + s];
+                        const int32_t off = L.dict[(size_t)h.dict_off + (size_t)id * width + s];
                         if (off != SELL_PAD_OFFSET) col = row + off;
                     } else {
                         const uint8_t cd = code[ROWS_PER_THREAD * s + which];
@@ -1081,9 +1078,8 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                 if (k != k_end) return fail(OGL_ERR_STATE, "row %ld lost entries", (long)row);
             }
     }
-    if (L.wave_width.size() != 4 * L.chunks.size()) return fail(OGL_ERR_STATE, "wave widths missing");
     for (ogl_label r = 0; r < n_rows; ++r)
-        if (row_ptrs[r + 1] - row_ptrs[r] > L.wave_width[(size_t)(r / SELL_WAVE_ROWS)])
+        if (row_ptrs[r + 1] - row_ptrs[r] > L.chunks[(size_t)(r / CHUNK_ROWS)].wave_w[(r % CHUNK_ROWS) / SELL_WAVE_ROWS])
             return fail(OGL_ERR_STATE, "row %d is longer than its wavefront's width", r);
     stats[0] = 1;
     stats[1] = L.n_slots;

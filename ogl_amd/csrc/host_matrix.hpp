@@ -74,10 +74,7 @@ struct SellLayout {
     std::vector<int32_t> map;    // value slot -> position in the CSR value array, -1 = padding
     int64_t n_slots = 0;         // padded value slots
     int64_t n_delta16 = 0, n_col32 = 0;  // chunks coded with 16-bit deltas / plain 32-bit columns
-    // slots each wavefront (SELL_WAVE_ROWS rows) of a chunk runs to = its own longest row; the planes
-    // beyond are allocated (to the chunk's longest row) but never read
-    std::vector<int32_t> wave_width;
-    int64_t read_slots = 0;  // sum of wave_width x SELL_WAVE_ROWS
+    int64_t read_slots = 0;  // value slots the kernel reads: sum of SellChunk::wave_w x SELL_WAVE_ROWS
 };
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                        SellLayout &out);

@@ -879,7 +879,6 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const int *__restrict__ dict,
                                                      const uint8_t *__restrict__ codes,
                                                      const double *__restrict__ vals,
-                                                     const int *__restrict__ wave_width,
                                                      const double *__restrict__ x,
                                                      const double *__restrict__ b,
                                                      double *__restrict__ y,
@@ -895,7 +894,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
-    for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];  // (none in delta / column mode)
+    if (h.mode <= SELL_MODE_OFFSET8)  // (no table in delta / column mode)
+        for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];
     __syncthreads();
     const RowPair rp = my_rows(chunk, n_rows);
     const int row = chunk * CHUNK_ROWS + t * ROWS_PER_THREAD;
@@ -905,9 +905,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     const double *v = vals + h.val_off + t * ROWS_PER_THREAD;
     // this wavefront runs to the longest of ITS rows: the planes beyond (padding up to the chunk's
     // longest row) are never touched.  Wave-uniform, so the loops below do not diverge.
-    const int ww = wave_width[chunk * N_WAVES + t / WAVE];
+    const int ww = h.wave_w[t / WAVE], width = h.width();
     constexpr int BATCH = 8;
-    if (h.dict_len == SELL_MODE_DELTA16) {
+    if (h.mode == SELL_MODE_DELTA16) {
         // delta mode: 16 bits per (row, slot), group-major 16-byte words of 4 slots x 2 rows; the
         // column of a slot is the running sum of the row's codes (first code relative to
         // row + dict_off).  The eight columns of a batch are formed first, then the eight gathers.
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 }
             }
         }
-    } else if (h.dict_len == SELL_MODE_COL32) {
+    } else if (h.mode == SELL_MODE_COL32) {
         // column mode: plain 32-bit columns (-1 = padding), 16-byte words of 2 slots x 2 rows
         static_assert(SELL_C32_GROUP * 4 == BATCH, "four code words per batch");
         const int4 *cw = reinterpret_cast<const int4 *>(codes + h.code_off) + t;
@@ -998,11 +998,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 }
             }
         }
-    } else if (h.code_stride == ROWS_PER_THREAD) {
+    } else if (h.mode == SELL_MODE_PATTERN) {
         // pattern mode: one byte per row -> `width` offsets of the row in the LDS table
         const unsigned short pp =
             *reinterpret_cast<const unsigned short *>(codes + h.code_off + t * ROWS_PER_THREAD);
-        const int p0 = (int)(pp & 0xffu) * h.width, p1 = (int)(pp >> 8) * h.width;
+        const int p0 = (int)(pp & 0xffu) * width, p1 = (int)(pp >> 8) * width;
         for (int s0 = 0; s0 < ww; s0 += BATCH) {
             double2 vv[BATCH];
             int d0[BATCH], d1[BATCH];
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
         }
     } else {
         // offset mode: one byte per (row, slot) -> entry of the chunk's offset dictionary
-        const uint8_t *c = codes + h.code_off + (long)t * h.code_stride;
+        const uint8_t *c = codes + h.code_off + (long)t * h.code_stride();
         for (int s0 = 0; s0 < ww; s0 += BATCH) {
             const uint4 cw = *reinterpret_cast<const uint4 *>(c + 2 * s0);
             const unsigned w4[4] = {cw.x, cw.y, cw.z, cw.w};
@@ -1116,7 +1116,8 @@ __global__ __launch_bounds__(BLOCK) void k_gather_sell(int n_chunks, const SellC
     const int chunk = blockIdx.x;
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
-    for (int s = 0; s < h.width; ++s) {
+    const int width = h.width();
+    for (int s = 0; s < width; ++s) {
         const long i = h.val_off + (long)s * CHUNK_ROWS + threadIdx.x * ROWS_PER_THREAD;
         const int2 m = *reinterpret_cast<const int2 *>(map + i);
         double2 v;
@@ -1824,7 +1825,7 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
 #define OGL_SELL(MODE, NDOT)                                                                     \
     hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
-                       A.dict, A.codes, A.vals, A.wave_width, x, b, y, dots.with, dots.part,      \
+                       A.dict, A.codes, A.vals, x, b, y, dots.with, dots.part,      \
                        dots.part_yy, gate)
     if (mode == SPMV_RESIDUAL) {
         OGL_SELL(SPMV_RESIDUAL, 0);

@@ -88,7 +88,6 @@ struct DevSell {
     const int32_t *dict = nullptr;      // column - row offsets, ascending per chunk
     const uint8_t *codes = nullptr;     // thread-major: [thread][slot][row of the pair]
     const double *vals = nullptr;
-    const int32_t *wave_width = nullptr;  // [4 n_chunks] slots each wavefront of a chunk runs to
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
                       double *y, const SpmvDots &dots, const DevScalars *gate);

@@ -423,7 +423,6 @@ DevSell ogl_solver::sell() const
     S.dict = d_sell_dict.p;
     S.codes = d_sell_codes.p;
     S.vals = d_sell_vals.p;
-    S.wave_width = d_sell_wave.p;
     return S;
 }
 
@@ -442,8 +441,6 @@ int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label 
     OGL_TRY(stager.h2d(dict.p, L.dict.data(), L.dict.size() * sizeof(int32_t), st));
     OGL_TRY(stager.h2d(codes.p, L.codes.data(), L.codes.size(), st));
     OGL_TRY(stager.h2d(map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
-    OGL_TRY(wave_width.alloc(L.wave_width.size(), st));
-    OGL_TRY(stager.h2d(wave_width.p, L.wave_width.data(), L.wave_width.size() * sizeof(int32_t), st));
     slots = L.n_slots;
     ready = true;
     return OGL_OK;
@@ -472,15 +469,13 @@ int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
     OGL_TRY(reg->stager.h2d(d_sell_dict.p, L.dict.data(), L.dict.size() * sizeof(int32_t), st));
     OGL_TRY(reg->stager.h2d(d_sell_codes.p, L.codes.data(), L.codes.size(), st));
     OGL_TRY(reg->stager.h2d(d_sell_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
-    OGL_TRY(d_sell_wave.alloc(L.wave_width.size(), st));
-    OGL_TRY(reg->stager.h2d(d_sell_wave.p, L.wave_width.data(), L.wave_width.size() * sizeof(int32_t), st));
     sell_slots = L.n_slots;
     sell_state = 1;
     // bytes one SpMV reads of this layout (bench.py's moved-bytes model): the value planes and codes
     // up to every wavefront's own width (planes beyond it are allocated, not read), headers, tables
     const double read_frac = L.n_slots ? (double)L.read_slots / (double)L.n_slots : 1.0;
     props["sellMatrixBytes"] = 8.0 * (double)L.read_slots + read_frac * (double)(L.codes.size() - 16) +
-                               (double)(L.chunks.size() * (sizeof(SellChunk) + 16)) + 4.0 * (double)L.dict.size();
+                               (double)(L.chunks.size() * sizeof(SellChunk)) + 4.0 * (double)L.dict.size();
     props["sellReadSlots"] = (double)L.read_slots;
     props["sellAllocatedSlots"] = (double)L.n_slots;
     props["sellChunksDelta16"] = (double)L.n_delta16;
@@ -1369,7 +1364,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_part0.p, (uintptr_t)d_part1.p, (uintptr_t)s, (uintptr_t)d_history.p,
             (uintptr_t)d_row_ptrs.p, (uintptr_t)d_cols.p, (uintptr_t)d_vals.p,
             (uintptr_t)d_sell_chunks.p, (uintptr_t)d_sell_dict.p, (uintptr_t)d_sell_codes.p,
-            (uintptr_t)d_sell_vals.p, (uintptr_t)d_sell_wave.p, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
+            (uintptr_t)d_sell_vals.p, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);

@@ -80,7 +80,7 @@ class Stager;
 // values live elsewhere: pattern once (`build`), values by `refresh` from the CSR value array.
 struct SellDev {
     DevBuf<SellChunk> chunks;
-    DevBuf<int32_t> dict, map, wave_width;
+    DevBuf<int32_t> dict, map;
     DevBuf<uint8_t> codes;
     DevBuf<double> vals;
     int64_t slots = 0;
@@ -99,7 +99,6 @@ struct SellDev {
         S.dict = dict.p;
         S.codes = codes.p;
         S.vals = vals.p;
-        S.wave_width = wave_width.p;
         return S;
     }
 };
@@ -203,7 +202,7 @@ struct ogl_solver {
     // cfg.compress_indices is set and the pattern qualifies.  sell_state: 0 = not tried for this
     // pattern, 1 = built, -1 = pattern does not qualify (CSR-stream kernel runs)
     ogl::DevBuf<ogl::SellChunk> d_sell_chunks;
-    ogl::DevBuf<int32_t> d_sell_dict, d_sell_map, d_sell_wave;
+    ogl::DevBuf<int32_t> d_sell_dict, d_sell_map;
     ogl::DevBuf<uint8_t> d_sell_codes;
     ogl::DevBuf<double> d_sell_vals;
     int64_t sell_slots = 0;

@@ -89,14 +89,20 @@ def test_unstructured_pattern_runs_on_16_bit_deltas(reg, oracle):
 
 
 def test_far_couplings_take_32_bit_columns_in_their_chunk(reg, oracle):
-    # 70,000 cells; cells 600..1100 also couple to a cell ~66,000 further on: those chunks store plain
+    # 80,000 cells; cells 600..1100 also couple to a cell 70,000 further on: those chunks store plain
     # 32-bit columns, the rest 16-bit deltas; all of it in one launch
-    n = 70_000
+    n = 80_000
     rng = np.random.default_rng(4)
-    lo = np.arange(n - 1, dtype=np.int32)
-    pairs = {(int(a), int(a) + 1) for a in lo}
-    pairs |= {(int(a), min(n - 1, int(a) + int(d))) for a, d in zip(rng.integers(0, n - 400, 3 * n), rng.integers(2, 400, 3 * n))}
-    pairs |= {(a, a + 66_000) for a in range(600, 1100)}
+    # every cell couples to three later cells at a distance that grows along its block of 512 cells:
+    # 512 distinct offsets per leg and chunk (no 1-byte dictionary fits), one incoming edge per leg and
+    # cell (row lengths stay uniform)
+    pairs = set()
+    for j in (1, 2, 3):
+        for a in range(n):
+            b_ = a + 600 * j + (a % 512) + (a // 512) % 2
+            if b_ < n:
+                pairs.add((a, b_))
+    pairs |= {(a, a + 70_000) for a in range(600, 1100)}
     pairs = np.array(sorted(p for p in pairs if p[0] < p[1]), dtype=np.int32)
     f = len(pairs)
     case = synthetic.LduCase(n, pairs[:, 0].copy(), pairs[:, 1].copy(), rng.uniform(20, 30, n),

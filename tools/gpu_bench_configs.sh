@@ -1,14 +1,21 @@
 #!/bin/bash
-# Single-GPU measurements of the other BASELINE.json configs' solver/preconditioner pairs
+# Single-GPU measurements of the other BASELINE.json configs' solver / preconditioner pairs, each against
+# the byte model of one solver turn (bench.py turn_model).  Writes gpurun_out/${TAG}_configs.txt
+TAG=${1:-r02}
 mkdir -p gpurun_out
+OUT=gpurun_out/${TAG}_configs.txt
+echo "# tools/gpu_bench_configs.sh on one MI355X (bench.py --steps 3 --warmup 2, HBM-resident, fixed turn count)" > $OUT
+echo "# turn = one solver iteration (BiCGStab: two SpMVs); spmv = in-loop SpMV (HIP event pairs); frac = turn byte model / time / 8 TB/s" >> $OUT
 run() {
-  TAG=$1; shift
-  python bench.py --steps 3 --warmup 2 --cpu-iters 0 "$@" > gpurun_out/cfg_$TAG.json 2> gpurun_out/cfg_$TAG.err || { echo "$TAG FAILED"; tail -3 gpurun_out/cfg_$TAG.err; return; }
-  python - "$TAG" <<'PY'
+  T=$1; shift
+  python bench.py --steps 3 --warmup 2 --cpu-iters 0 "$@" > gpurun_out/cfg_$T.json 2> gpurun_out/cfg_$T.err || { echo "$T FAILED" | tee -a $OUT; tail -3 gpurun_out/cfg_$T.err; return; }
+  python - "$T" <<'PY' | tee -a $OUT
 import json,sys
 d=json.load(open(f"gpurun_out/cfg_{sys.argv[1]}.json"))
-r=d["roofline"]
-print("%-26s turns/s=%8.1f  ms/turn=%.4f  spmv_ms=%.4f  | %s" % (sys.argv[1], d["value"], d["cg_iteration"]["ms"], r["avg_kernel_ms"], d["config"]["workload"][:110]))
+r=d["roofline"]; t=d["solver_turn"]
+print("%-18s turns/s=%8.1f  ms/turn=%.4f  spmv_us=%6.1f (frac %.3f, %s)  turn bytes=%.3f GB -> %.0f GB/s = %.3f of 8 TB/s | %s" % (
+    sys.argv[1], d["value"], t["ms"], 1e3*r["avg_kernel_ms"], r["frac"], r["layout"], t["algorithmic_bytes"]/1e9,
+    t["achieved_GBps"], t["frac_of_peak"], d["config"]["workload"][:96]))
 PY
 }
 run cg_bj_216        --iters 100
@@ -19,6 +26,6 @@ run bicg_bj_128a     --iters 100 --solver GKOBiCGStab --asym --edge 128
 run bicg_gisai_128a  --iters 100 --solver GKOBiCGStab --asym --edge 128 --precond GISAI
 run bicg_bj_216a     --iters 50 --solver GKOBiCGStab --asym
 run gmres30_bj_216   --iters 60 --solver GKOGMRES --krylov-dim 30
+run gmres30_bj_216s  --iters 60 --solver GKOGMRES --krylov-dim 30 --shuffle 65536
 run gmres30_bj_368   --iters 60 --solver GKOGMRES --krylov-dim 30 --edge 368
-run gmres30_bj_368e  --iters 60 --solver GKOGMRES --krylov-dim 30 --edge 368 --format Ell
 run cg_bj_368        --iters 50 --edge 368
