@@ -92,7 +92,7 @@ static void run_case(int nx, int ny, int nz, bool symmetric, bool with_interface
     std::vector<ogl_label> rp(N + 1, 0);
     for (int e = 0; e < d.local_nnz; ++e) ++rp[rows[e] + 1];
     for (int r = 0; r < N; ++r) rp[r + 1] += rp[r];
-    int64_t stats[4];
+    int64_t stats[8];
     CHECK(ogl_host_sell_check(N, rp.data(), cols.data(), stats) == OGL_OK);
     CHECK(stats[0] == 1 && stats[1] >= d.local_nnz);
     // update functions on the plain (interface-free) pattern
