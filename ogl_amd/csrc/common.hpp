@@ -70,20 +70,24 @@ inline int64_t n_chunks(int64_t n_rows) { return (n_rows + CHUNK_ROWS - 1) / CHU
 #endif
 constexpr int SELL_WAVE_ROWS = WAVE * ROWS_PER_THREAD;  // rows one wavefront of the SpMV owns
 constexpr int SELL_WAVES = CHUNK_ROWS / SELL_WAVE_ROWS;  // wavefronts of a chunk's workgroup
-enum SellMode : int16_t { SELL_MODE_PATTERN = 0, SELL_MODE_OFFSET8 = 1, SELL_MODE_DELTA16 = 2, SELL_MODE_COL32 = 3 };
-struct SellChunk {  // 32 bytes: one load brings everything a wavefront needs to know about its chunk
+enum SellMode : int { SELL_MODE_PATTERN = 0, SELL_MODE_OFFSET8 = 1, SELL_MODE_DELTA16 = 2, SELL_MODE_COL32 = 3 };
+struct SellChunk {  // 32 bytes of 32/64-bit words: the whole header arrives by scalar loads (a 16-bit
+                    // member would cost a vector load and a full memory round trip in the prologue)
     int64_t val_off;      // first value of the chunk (doubles); planes of CHUNK_ROWS, width() of them
     int64_t code_off;     // first code byte of the chunk
     int32_t dict_off;     // first table entry of the chunk (delta mode: the base of the first codes)
-    int16_t mode;         // SellMode
-    uint16_t dict_len;    // table ints (pattern mode: patterns x width; offset mode: <= SELL_MAX_DICT)
+    uint32_t mode_len;    // SellMode | table ints << 16 (pattern mode: patterns x width; offset mode:
+                          // <= SELL_MAX_DICT)
     // slots each wavefront (SELL_WAVE_ROWS rows) runs to = its own longest row; the planes beyond,
     // up to the chunk's longest row, are allocated but never read
-    uint16_t wave_w[SELL_WAVES];
+    uint32_t w01, w23;    // wavefront 0 | wavefront 1 << 16,  wavefront 2 | wavefront 3 << 16
+    OGL_HD int mode() const { return (int)(mode_len & 0xffffu); }
+    OGL_HD int dict_len() const { return (int)(mode_len >> 16); }
+    OGL_HD int wave_width(int wv) const { return (int)(((wv & 2 ? w23 : w01) >> (16 * (wv & 1))) & 0xffffu); }
     OGL_HD int width() const  // slots allocated per row = the chunk's longest row
     {
-        int w = wave_w[0];
-        for (int i = 1; i < SELL_WAVES; ++i) w = wave_w[i] > w ? wave_w[i] : w;
+        int w = wave_width(0);
+        for (int i = 1; i < SELL_WAVES; ++i) w = wave_width(i) > w ? wave_width(i) : w;
         return w;
     }
     // code bytes per thread: ROWS_PER_THREAD (pattern mode), ROWS_PER_THREAD x width rounded up to 16
@@ -91,10 +95,16 @@ struct SellChunk {  // 32 bytes: one load brings everything a wavefront needs to
     OGL_HD int code_stride() const
     {
         const int w = width();
-        if (mode == SELL_MODE_PATTERN) return ROWS_PER_THREAD;
-        if (mode == SELL_MODE_OFFSET8) return (ROWS_PER_THREAD * w + 15) / 16 * 16;
-        if (mode == SELL_MODE_DELTA16) return 16 * ((w + 3) / 4);
+        if (mode() == SELL_MODE_PATTERN) return ROWS_PER_THREAD;
+        if (mode() == SELL_MODE_OFFSET8) return (ROWS_PER_THREAD * w + 15) / 16 * 16;
+        if (mode() == SELL_MODE_DELTA16) return 16 * ((w + 3) / 4);
         return 16 * ((w + 1) / 2);
+    }
+    void set(int mode, int dict_len, const int32_t (&wave_w)[SELL_WAVES])
+    {
+        mode_len = (uint32_t)mode | ((uint32_t)dict_len << 16);
+        w01 = (uint32_t)wave_w[0] | ((uint32_t)wave_w[1] << 16);
+        w23 = (uint32_t)wave_w[2] | ((uint32_t)wave_w[3] << 16);
     }
 };
 static_assert(sizeof(SellChunk) == 32, "SellChunk is read as two 16-byte words");

@@ -743,25 +743,21 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         h.val_off = val_len;
         h.code_off = code_len;
         h.dict_off = (int32_t)out.dict.size();
-        h.dict_len = 0;
-        for (int wv = 0; wv < SELL_WAVES; ++wv) h.wave_w[wv] = (uint16_t)wave_w[wv];
         if (pat_mode) {
-            h.mode = SELL_MODE_PATTERN;
-            h.dict_len = (uint16_t)pats.size();
+            h.set(SELL_MODE_PATTERN, (int)pats.size(), wave_w);
             out.dict.insert(out.dict.end(), pats.begin(), pats.end());
             pid_all.insert(pid_all.end(), pid.begin(), pid.end());
         } else if (off8_mode) {
-            h.mode = SELL_MODE_OFFSET8;
-            h.dict_len = (uint16_t)ds.size();
+            h.set(SELL_MODE_OFFSET8, (int)ds.size(), wave_w);
             out.dict.insert(out.dict.end(), ds.begin(), ds.end());
         } else if (d16_mode) {
             // group-major 16-byte words: word (g, t) holds SELL_D16_GROUP slots of thread t's two rows;
             // lane t of a wavefront reads consecutive words
-            h.mode = SELL_MODE_DELTA16;
+            h.set(SELL_MODE_DELTA16, 0, wave_w);
             h.dict_off = base;
             out.n_delta16 += 1;
         } else {
-            h.mode = SELL_MODE_COL32;  // (also what an empty chunk gets: nothing is ever read)
+            h.set(SELL_MODE_COL32, 0, wave_w);  // (also what an empty chunk gets: nothing is ever read)
             h.dict_off = 0;
             if (width > 0) out.n_col32 += 1;
         }
@@ -783,8 +779,8 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         const SellChunk &h = out.chunks[(size_t)c];
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
-        const bool d16_mode = h.mode == SELL_MODE_DELTA16, c32_mode = h.mode == SELL_MODE_COL32;
-        const bool pat_mode = h.mode == SELL_MODE_PATTERN;
+        const bool d16_mode = h.mode() == SELL_MODE_DELTA16, c32_mode = h.mode() == SELL_MODE_COL32;
+        const bool pat_mode = h.mode() == SELL_MODE_PATTERN;
         const int code_stride = h.code_stride();
         if (pat_mode) {  // rows 2t, 2t+1 of thread t are adjacent bytes
             std::copy(pid_all.begin() + (std::ptrdiff_t)pid_pos, pid_all.begin() + (std::ptrdiff_t)(pid_pos + CHUNK_ROWS),
@@ -814,7 +810,7 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
                 } else {
                     const int32_t d = cols[k] - r;
                     code[ROWS_PER_THREAD * s + which] =
-                        (uint8_t)(std::lower_bound(d0, d0 + h.dict_len, d) - d0);
+                        (uint8_t)(std::lower_bound(d0, d0 + h.dict_len(), d) - d0);
                 }
             }
         }
@@ -1021,15 +1017,15 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
     // decode exactly as k_spmv_sell does: thread t of chunk c owns rows c*CHUNK_ROWS + 2t, +1
     for (size_t c = 0; c < L.chunks.size(); ++c) {
         const SellChunk &h = L.chunks[c];
-        const bool d16_mode = h.mode == SELL_MODE_DELTA16, c32_mode = h.mode == SELL_MODE_COL32;
-        const bool pat_mode = h.mode == SELL_MODE_PATTERN;
+        const bool d16_mode = h.mode() == SELL_MODE_DELTA16, c32_mode = h.mode() == SELL_MODE_COL32;
+        const bool pat_mode = h.mode() == SELL_MODE_PATTERN;
         const int width = h.width(), code_stride = h.code_stride();
-        if (h.code_off % 16 != 0 || h.mode < SELL_MODE_PATTERN || h.mode > SELL_MODE_COL32)
+        if (h.code_off % 16 != 0 || h.mode() < SELL_MODE_PATTERN || h.mode() > SELL_MODE_COL32)
             return fail(OGL_ERR_STATE, "chunk %zu: bad header", c);
-        if (pat_mode && (width <= 0 || h.dict_len % width != 0 || h.dict_len > SELL_TABLE_INTS ||
-                         h.dict_len / width > 256))
+        if (pat_mode && (width <= 0 || h.dict_len() % width != 0 || h.dict_len() > SELL_TABLE_INTS ||
+                         h.dict_len() / width > 256))
             return fail(OGL_ERR_STATE, "chunk %zu: bad pattern table", c);
-        if (h.mode == SELL_MODE_OFFSET8 && h.dict_len > SELL_MAX_DICT)
+        if (h.mode() == SELL_MODE_OFFSET8 && h.dict_len() > SELL_MAX_DICT)
             return fail(OGL_ERR_STATE, "chunk %zu: bad dictionary", c);
         for (int t = 0; t < BLOCK; ++t)
             for (int which = 0; which < ROWS_PER_THREAD; ++which) {
@@ -1057,13 +1053,13 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                         col = v;
                     } else if (pat_mode) {
                         const int32_t id = code[which];
-                        if ((id + 1) * width > h.dict_len)
+                        if ((id + 1) * width > h.dict_len())
                             return fail(OGL_ERR_STATE, "row %ld: pattern id out of range", (long)row);
                         const int32_t off = L.dict[(size_t)h.dict_off + (size_t)id * width + s];
                         if (off != SELL_PAD_OFFSET) col = row + off;
                     } else {
                         const uint8_t cd = code[ROWS_PER_THREAD * s + which];
-                        if (cd != 255 && cd >= h.dict_len)
+                        if (cd != 255 && cd >= h.dict_len())
                             return fail(OGL_ERR_STATE, "row %ld: code out of range", (long)row);
                         if (cd != 255) col = row + L.dict[(size_t)h.dict_off + cd];
                     }
@@ -1079,7 +1075,7 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
             }
     }
     for (ogl_label r = 0; r < n_rows; ++r)
-        if (row_ptrs[r + 1] - row_ptrs[r] > L.chunks[(size_t)(r / CHUNK_ROWS)].wave_w[(r % CHUNK_ROWS) / SELL_WAVE_ROWS])
+        if (row_ptrs[r + 1] - row_ptrs[r] > L.chunks[(size_t)(r / CHUNK_ROWS)].wave_width((r % CHUNK_ROWS) / SELL_WAVE_ROWS))
             return fail(OGL_ERR_STATE, "row %d is longer than its wavefront's width", r);
     stats[0] = 1;
     stats[1] = L.n_slots;

@@ -894,8 +894,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
-    if (h.mode <= SELL_MODE_OFFSET8)  // (no table in delta / column mode)
-        for (int i = t; i < h.dict_len; i += BLOCK) stab[i] = dict[h.dict_off + i];
+    if (h.mode() <= SELL_MODE_OFFSET8)  // (no table in delta / column mode)
+        for (int i = t; i < h.dict_len(); i += BLOCK) stab[i] = dict[h.dict_off + i];
     __syncthreads();
     const RowPair rp = my_rows(chunk, n_rows);
     const int row = chunk * CHUNK_ROWS + t * ROWS_PER_THREAD;
@@ -905,9 +905,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     const double *v = vals + h.val_off + t * ROWS_PER_THREAD;
     // this wavefront runs to the longest of ITS rows: the planes beyond (padding up to the chunk's
     // longest row) are never touched.  Wave-uniform, so the loops below do not diverge.
-    const int ww = h.wave_w[t / WAVE], width = h.width();
+    const int ww = h.wave_width(__builtin_amdgcn_readfirstlane(t / WAVE)), width = h.width();
     constexpr int BATCH = 8;
-    if (h.mode == SELL_MODE_DELTA16) {
+    if (h.mode() == SELL_MODE_DELTA16) {
         // delta mode: 16 bits per (row, slot), group-major 16-byte words of 4 slots x 2 rows; the
         // column of a slot is the running sum of the row's codes (first code relative to
         // row + dict_off).  The eight columns of a batch are formed first, then the eight gathers.
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 }
             }
         }
-    } else if (h.mode == SELL_MODE_COL32) {
+    } else if (h.mode() == SELL_MODE_COL32) {
         // column mode: plain 32-bit columns (-1 = padding), 16-byte words of 2 slots x 2 rows
         static_assert(SELL_C32_GROUP * 4 == BATCH, "four code words per batch");
         const int4 *cw = reinterpret_cast<const int4 *>(codes + h.code_off) + t;
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 }
             }
         }
-    } else if (h.mode == SELL_MODE_PATTERN) {
+    } else if (h.mode() == SELL_MODE_PATTERN) {
         // pattern mode: one byte per row -> `width` offsets of the row in the LDS table
         const unsigned short pp =
             *reinterpret_cast<const unsigned short *>(codes + h.code_off + t * ROWS_PER_THREAD);
