@@ -401,19 +401,14 @@ void rcm_order(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *col
     size_t filled = 0;
     for (ogl_label seed = 0; seed < n; ++seed) {
         if (placed[(size_t)seed]) continue;
-        // pseudo-peripheral start of this component (at most three sweeps)
-        ogl_label start = seed, far_node = seed;
-        int ecc = sweep(start, far_node);
-        for (int tries = 0; tries < 2 && far_node != start; ++tries) {
-            ogl_label far2 = far_node;
-            const int e2 = sweep(far_node, far2);
-            if (e2 <= ecc) {
-                if (degree(far_node) < degree(start)) start = far_node;
-                break;
-            }
+        // start of this component: the node of smallest degree in the last level of a breadth-first
+        // sweep from the seed (one step of the George-Liu pseudo-peripheral search; more sweeps gain
+        // little on mesh graphs and each costs a traversal of the whole component)
+        ogl_label start = seed;
+        if (degree(seed) > 1) {  // (isolated cells and chain ends are peripheral already)
+            ogl_label far_node = seed;
+            (void)sweep(seed, far_node);
             start = far_node;
-            ecc = e2;
-            far_node = far2;
         }
         // Cuthill-McKee from `start`
         size_t head = filled;

@@ -75,10 +75,22 @@ struct InstallCommHook {
                 rc = ogl_registry_init_rccl(reg, Pstream::myProcNo(), Pstream::nProcs(), id.begin());
             }
             if (rc != OGL_OK) FatalErrorInFunction << ogl_last_error() << abort(FatalError);
-            // scalar all-reduces through peer-written mailboxes over xGMI (single node, <= 16
-            // ranks): all-gather the 64-byte IPC handles, connect (collective self-test), and keep
-            // the transport's own all-reduce if any rank cannot join
-            if (controls.lookupOrDefault<Switch>("peerAllReduce", true) &&
+            // Scalar all-reduces and halo puts through peer-written memory over xGMI (hipIpc): opt-in
+            // (`peerAllReduce true`) until a run with one rank per device is on record -- RCCL is the
+            // default transport.  Only tried when every rank sits on the same host (hipIpc does not
+            // cross nodes; without this check the ranks of a multi-node run would sit in the 60 s
+            // self-test time-out before falling back) and with at most 16 ranks.  All-gather the
+            // 64-byte IPC handles, connect (collective self-test), and keep the transport's own
+            // all-reduce and halo exchange if any rank cannot join.
+            bool one_host = true;
+            {
+                List<word> hosts(Pstream::nProcs());
+                hosts[Pstream::myProcNo()] = hostName();
+                Pstream::gatherList(hosts);
+                Pstream::scatterList(hosts);
+                forAll(hosts, p) one_host = one_host && hosts[p] == hosts[0];
+            }
+            if (controls.lookupOrDefault<Switch>("peerAllReduce", false) && one_host &&
                 Pstream::nProcs() <= 16) {
                 List<List<char>> handles(Pstream::nProcs());
                 handles[Pstream::myProcNo()].setSize(OGL_PEER_HANDLE_BYTES, '\0');
