@@ -354,6 +354,47 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
     return OGL_OK;
 }
 
+bool isai_pattern(const HostPattern &p, bool spd, int power, int max_row, std::vector<ogl_label> &w_row_ptrs,
+                  std::vector<ogl_label> &w_cols, ogl_label &first_wide_row)
+{
+    const ogl_label N = p.n_rows;
+    w_row_ptrs.assign((size_t)N + 1, 0);
+    w_cols.clear();
+    w_cols.reserve((size_t)p.local_nnz);
+    std::vector<ogl_label> seen((size_t)N, -1), row, next;
+    auto in_s = [&](ogl_label r, ogl_label c) { return !spd || c <= r; };
+    for (ogl_label i = 0; i < N; ++i) {
+        row.clear();
+        for (ogl_label k = p.row_ptrs[i]; k < p.row_ptrs[i + 1]; ++k) {
+            const ogl_label c = p.cols[k];
+            if (in_s(i, c) && seen[(size_t)c] != i) {  // (cyclic patches can repeat a column)
+                seen[(size_t)c] = i;
+                row.push_back(c);
+            }
+        }
+        for (int pw = 1; pw < power && (int)row.size() <= max_row; ++pw) {
+            next = row;
+            for (ogl_label j : row)
+                for (ogl_label k = p.row_ptrs[j]; k < p.row_ptrs[j + 1]; ++k) {
+                    const ogl_label c = p.cols[k];
+                    if (in_s(j, c) && seen[(size_t)c] != i) {
+                        seen[(size_t)c] = i;
+                        next.push_back(c);
+                    }
+                }
+            row.swap(next);
+        }
+        if ((int)row.size() > max_row) {
+            first_wide_row = i;
+            return false;
+        }
+        std::sort(row.begin(), row.end());
+        w_cols.insert(w_cols.end(), row.begin(), row.end());
+        w_row_ptrs[(size_t)i + 1] = (ogl_label)w_cols.size();
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // Renumbering
 // ---------------------------------------------------------------------------------------

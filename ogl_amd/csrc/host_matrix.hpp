@@ -112,6 +112,12 @@ struct RenumberReport {
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
                      RenumberReport &rep);
 
+// Pattern of the ISAI approximate inverse W (keyword sparsityPower, Preconditioner.H:227): rows of
+// S^power in ascending column order, S = tril(A) (spd = ISAI) or A (general = GISAI).  Returns false
+// (first_wide_row set) when a row would get more than `max_row` entries.
+bool isai_pattern(const HostPattern &p, bool spd, int power, int max_row, std::vector<ogl_label> &w_row_ptrs,
+                  std::vector<ogl_label> &w_cols, ogl_label &first_wide_row);
+
 // HostMatrix.C:180-207: concatenated bouCoeffs of the (non-)processor interfaces, times -1.
 void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *out);
 

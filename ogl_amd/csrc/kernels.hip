@@ -376,6 +376,7 @@ __global__ __launch_bounds__(64) void k_isai_generate(int n_rows, const int *__r
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_rows) return;
     const int w0 = w_row_ptrs[i], bs = w_row_ptrs[i + 1] - w0;
+    if (bs > LD) return;  // a wide row: k_isai_generate_wide takes it
     int J[LD], pos = -1;
     for (int r = 0; r < bs; ++r) {
         J[r] = w_cols[w0 + r];
@@ -419,6 +420,96 @@ __global__ __launch_bounds__(64) void k_isai_generate(int n_rows, const int *__r
     }
     const double scale = spd ? sqrt(rhs[pos]) : 1.0;
     for (int r = 0; r < bs; ++r) w_vals[w0 + r] = spd ? rhs[r] / scale : rhs[r];
+}
+
+// The same solve for one WIDE row (ISAI_THREAD_ROW < entries <= MAX_ISAI_ROW) per wavefront: the
+// dense system sits in LDS, lane c owns column c.  Every element sees the operations of the
+// thread-per-row kernel (and of the oracle's solve_dense) in the same order, so the bits agree.
+__global__ __launch_bounds__(WAVE) void k_isai_generate_wide(int n_wide, const int *__restrict__ wide_rows,
+                                                           const int *__restrict__ row_ptrs,
+                                                           const int *__restrict__ cols,
+                                                           const double *__restrict__ vals, int spd,
+                                                           const int *__restrict__ w_row_ptrs,
+                                                           const int *__restrict__ w_cols,
+                                                           double *__restrict__ w_vals)
+{
+    constexpr int LD = MAX_ISAI_ROW + 1;  // odd leading dimension: column walks hit distinct banks
+    __shared__ double a[MAX_ISAI_ROW * LD];
+    __shared__ double rhs[MAX_ISAI_ROW];
+    __shared__ int Js[MAX_ISAI_ROW];
+    __shared__ int piv_s;
+    if ((int)blockIdx.x >= n_wide) return;
+    const int i = wide_rows[blockIdx.x];
+    const int w0 = w_row_ptrs[i], bs = w_row_ptrs[i + 1] - w0;
+    const int c = threadIdx.x;  // this lane's column (and, where rows are walked in parallel, its row)
+    const bool on = c < bs;
+    const int Jc = on ? w_cols[w0 + c] : -1;
+    if (on) {
+        Js[c] = Jc;
+        rhs[c] = Jc == i ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int r = 0; r < bs; ++r)
+        if (on) a[r * LD + c] = spd ? csr_entry(row_ptrs, cols, vals, Js[r], Jc) : csr_entry(row_ptrs, cols, vals, Jc, Js[r]);
+    __syncthreads();
+    for (int k = 0; k < bs; ++k) {
+        // pivot: the first row >= k with the largest |a[r][k]| (lane r looks at row r)
+        double mine = (on && c >= k) ? fabs(a[c * LD + k]) : -1.0;
+        int idx = c;
+#pragma unroll
+        for (int off = WAVE / 2; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(mine, off, WAVE);
+            const int oi = __shfl_xor(idx, off, WAVE);
+            if (ov > mine || (ov == mine && oi < idx)) {
+                mine = ov;
+                idx = oi;
+            }
+        }
+        if (c == 0) piv_s = idx;
+        __syncthreads();
+        const int piv = piv_s;
+        if (piv != k) {
+            if (on) {
+                const double tv = a[k * LD + c];
+                a[k * LD + c] = a[piv * LD + c];
+                a[piv * LD + c] = tv;
+            }
+            if (c == 0) {
+                const double tv = rhs[k];
+                rhs[k] = rhs[piv];
+                rhs[piv] = tv;
+            }
+        }
+        __syncthreads();
+        // eliminate below the pivot: lane c updates column c (> k) of every row; lane k the right-hand side
+        const double akk = a[k * LD + k];
+        const double akc = on ? a[k * LD + c] : 0.0;
+        const double rk = rhs[k];
+        for (int r = k + 1; r < bs; ++r) {
+            const double f = a[r * LD + k] / akk;
+            if (on && c > k) a[r * LD + c] -= f * akc;
+            if (c == k) rhs[r] -= f * rk;
+        }
+        __syncthreads();
+    }
+    if (c == 0) {  // back substitution, left to right like the oracle
+        for (int r = bs - 1; r >= 0; --r) {
+            double tv = rhs[r];
+            for (int j = r + 1; j < bs; ++j) tv -= a[r * LD + j] * rhs[j];
+            rhs[r] = tv / a[r * LD + r];
+        }
+    }
+    __syncthreads();
+    if (on) {
+        double scale = 1.0;
+        if (spd) {
+            int pos = 0;
+            for (int r = 0; r < bs; ++r)
+                if (Js[r] == i) pos = r;
+            scale = sqrt(rhs[pos]);
+        }
+        w_vals[w0 + c] = spd ? rhs[c] / scale : rhs[c];
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_permute_scatter(int n, const int *__restrict__ new_id,
@@ -1933,7 +2024,8 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
 }
 
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
-                          const int32_t *w_cols, double *w_vals, int32_t max_row)
+                          const int32_t *w_cols, double *w_vals, int32_t max_row,
+                          const int32_t *wide_rows, int32_t n_wide)
 {
     if (A.n_rows == 0) return;
     const dim3 grid((A.n_rows + 63) / 64), block(64);
@@ -1947,6 +2039,9 @@ void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_
     else
         OGL_ISAI(32);
 #undef OGL_ISAI
+    if (n_wide > 0)
+        hipLaunchKernelGGL(k_isai_generate_wide, dim3(n_wide), dim3(WAVE), 0, st, n_wide, wide_rows,
+                           A.row_ptrs, A.cols, A.vals, spd, w_row_ptrs, w_cols, w_vals);
 }
 
 void launch_permute_scatter(hipStream_t st, int32_t n, const int32_t *new_id, const double *in, double *out)

@@ -130,14 +130,19 @@ void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
                      double *dot_part, const DevScalars *gate);
 
-// ISAI / GISAI with sparsityPower 1 (Preconditioner.H:225-258): row i of the approximate inverse W
-// solves a dense system over its own pattern (<= 32 entries), one thread per row, Gaussian
-// elimination with partial pivoting.  spd: pattern tril(A), A(J,J) y = e_i, W(i,J) = y / sqrt(y_i);
-// general: pattern of A, A(J,J)^T y = e_i, W(i,J) = y.
-constexpr int MAX_ISAI_ROW = 32;
-// max_row = longest row of W (selects the per-thread scratch size: 8, 16 or 32)
+// ISAI / GISAI (Preconditioner.H:225-258): row i of the approximate inverse W lives on the pattern J of
+// row i of S^sparsityPower (S = tril(A) resp. A, built on the host) and solves a dense system over it by
+// Gaussian elimination with partial pivoting.  spd: A(J,J) y = e_i, W(i,J) = y / sqrt(y_i); general:
+// A(J,J)^T y = e_i, W(i,J) = y.  Rows of up to ISAI_THREAD_ROW entries: one thread per row (per-thread
+// arrays); longer ones, up to MAX_ISAI_ROW: one wavefront per row, the system in LDS, lane = column --
+// the same operations on every element in the same order, so both give the oracle's bits.
+constexpr int ISAI_THREAD_ROW = 32;
+constexpr int MAX_ISAI_ROW = 64;
+// max_row = longest row of W (selects the per-thread scratch size: 8, 16 or 32);
+// wide_rows[n_wide] = the rows longer than ISAI_THREAD_ROW
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
-                          const int32_t *w_cols, double *w_vals, int32_t max_row);
+                          const int32_t *w_cols, double *w_vals, int32_t max_row,
+                          const int32_t *wide_rows, int32_t n_wide);
 
 // renumbering (keyword `renumber`): host vectors arrive in the caller's cell order
 //   scatter: out[new_id[i]] = in[i]   (b, x on upload)      gather: out[i] = in[new_id[i]]   (x on copy-back)

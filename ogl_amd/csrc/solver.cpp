@@ -776,20 +776,25 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         const bool spd = cfg.preconditioner == OGL_PRECOND_ISAI;
         const int32_t N = pat.n_rows;
         const int kind = spd ? 3 : 4;
-        if (!P.has_structure(pat_id, kind, 0)) {
+        if (!P.has_structure(pat_id, kind, cfg.sparsity_power)) {
             P.struct_pat_id = 0;
-            std::vector<int32_t> wrp((size_t)N + 1, 0), wc;
-            wc.reserve((size_t)pat.local_nnz);
+            std::vector<int32_t> wrp, wc;
+            ogl_label wide = -1;
+            if (!isai_pattern(pat, spd, cfg.sparsity_power, MAX_ISAI_ROW, wrp, wc, wide))
+                return fail(OGL_ERR_UNSUPPORTED,
+                            "ISAI sparsityPower %d: row %d of the approximate inverse has more than %d "
+                            "pattern entries", cfg.sparsity_power, wide, MAX_ISAI_ROW);
             int32_t max_row = 0;
+            std::vector<int32_t> wide_rows;  // rows solved by one wavefront each (the others: one thread)
             for (int32_t r = 0; r < N; ++r) {
-                for (int32_t k = pat.row_ptrs[r]; k < pat.row_ptrs[r + 1]; ++k)
-                    if (!spd || pat.cols[k] <= r) wc.push_back(pat.cols[k]);
-                wrp[r + 1] = (int32_t)wc.size();
-                max_row = std::max(max_row, wrp[r + 1] - wrp[r]);
-                if (wrp[r + 1] - wrp[r] > MAX_ISAI_ROW)
-                    return fail(OGL_ERR_UNSUPPORTED, "ISAI: row %d has more than %d pattern entries",
-                                r, MAX_ISAI_ROW);
+                const int32_t len = wrp[(size_t)r + 1] - wrp[(size_t)r];
+                max_row = std::max(max_row, len);
+                if (len > ISAI_THREAD_ROW) wide_rows.push_back(r);
             }
+            P.n_wide_rows = (int32_t)wide_rows.size();
+            OGL_TRY(P.wide_rows.alloc(std::max<size_t>(1, wide_rows.size()), st));
+            if (!wide_rows.empty())
+                OGL_TRY(reg->stager.h2d(P.wide_rows.p, wide_rows.data(), wide_rows.size() * sizeof(int32_t), st));
             const size_t wn = wc.size();
             OGL_TRY(P.w_row_ptrs.alloc((size_t)N + 1, st));
             OGL_TRY(P.w_cols.alloc(wn + NNZ_PAD, st));
@@ -824,15 +829,15 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             P.w_max_row = max_row;
             P.struct_pat_id = pat_id;
             P.struct_kind = kind;
-            P.struct_stride = 0;
+            P.struct_stride = cfg.sparsity_power;
         }
         launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p,
-                             P.w_max_row);
+                             P.w_max_row, P.wide_rows.p, P.n_wide_rows);
         if (spd) launch_gather_coeffs(st, P.w_nnz, P.wt_map.p, P.w_vals.p, P.wt_vals.p);
         P.w_sell.refresh(P.w_vals.p, st);
         if (spd) P.wt_sell.refresh(P.wt_vals.p, st);
         P.kind = spd ? 3 : 4;
-        P.stride = 0;
+        P.stride = cfg.sparsity_power;
     } else if (cfg.max_block_size == 1) {  // scalar Jacobi: 1 / diag
         OGL_TRY(P.values.alloc(n + 2, st));
         launch_jacobi_generate_pos(st, csr(), d_diag_pos.p, P.values.p);
@@ -926,8 +931,8 @@ int ogl_solver::init_preconditioner()
     const bool isai = cfg.preconditioner == OGL_PRECOND_ISAI || cfg.preconditioner == OGL_PRECOND_GISAI;
     if (cfg.preconditioner != OGL_PRECOND_BJ && !isai)
         return fail(OGL_ERR_UNSUPPORTED, "preconditioner kind %d is not built", cfg.preconditioner);
-    if (isai && cfg.sparsity_power != 1)
-        return fail(OGL_ERR_UNSUPPORTED, "ISAI sparsityPower %d: only 1 is built", cfg.sparsity_power);
+    if (isai && (cfg.sparsity_power < 1 || cfg.sparsity_power > 8))
+        return fail(OGL_ERR_INVALID, "ISAI sparsityPower %d outside [1, 8]", cfg.sparsity_power);
     if (!isai && (cfg.max_block_size < 1 || cfg.max_block_size > MAX_JACOBI_BLOCK))
         return fail(OGL_ERR_INVALID, "BJ maxBlockSize %d outside [1, %d]", cfg.max_block_size,
                     MAX_JACOBI_BLOCK);
@@ -935,7 +940,7 @@ int ogl_solver::init_preconditioner()
         OGL_TRY(d_isai_tmp.alloc((size_t)pat.n_rows + 2, reg->stream));
     const int kind = isai ? (cfg.preconditioner == OGL_PRECOND_ISAI ? 3 : 4)
                           : (cfg.max_block_size == 1 ? 1 : 2);
-    const int stride = kind == 2 ? cfg.max_block_size : 0;
+    const int stride = kind == 2 ? cfg.max_block_size : (isai ? cfg.sparsity_power : 0);
     const int cache = (int)prop("preconditionerCaching", 0);
     const bool stored =
         reg->has_cached_precond && reg->cached_precond.matches(kind, (size_t)pat.n_rows, stride);

@@ -768,7 +768,7 @@ void orc_jacobi_generate_blocks(orc_label n, const orc_label *rowptr, const orc_
     }
 }
 
-/* ---- ISAI ([UPSTREAM] gko::preconditioner::Isai, sparsity power 1) ------------------------- */
+/* ---- ISAI ([UPSTREAM] gko::preconditioner::Isai) --------------------------------------------- */
 static orc_scalar csr_entry(const orc_label *rowptr, const orc_label *cols, const orc_scalar *vals,
                             orc_label r, orc_label c) {
     for (orc_label k = rowptr[r]; k < rowptr[r + 1]; ++k)
@@ -809,40 +809,89 @@ static void solve_dense(orc_label bs, orc_scalar *a, orc_label ld, orc_scalar *r
     }
 }
 
-orc_label orc_isai_generate(orc_label n, const orc_label *rowptr, const orc_label *cols,
-                            const orc_scalar *vals, int spd, orc_label *w_rowptr, orc_label *w_cols,
-                            orc_scalar *w_vals) {
-    w_rowptr[0] = 0;
+/* Pattern of S^power, rows in ascending column order, S = tril(A) (spd) or A (general)
+ * ([UPSTREAM] isai extend_sparsity; Preconditioner.H:227 `sparsityPower`).  Returns the number of
+ * entries, -1 if a row gets more than ORC_ISAI_MAX_ROW of them; p_cols == NULL: sizes only. */
+#define ORC_ISAI_MAX_ROW 64
+static orc_label isai_pattern(orc_label n, const orc_label *rowptr, const orc_label *cols, int spd,
+                              int power, orc_label *p_rowptr, orc_label *p_cols) {
+    orc_label *mark = (orc_label *)xmalloc(sizeof(orc_label) * ((size_t)n + 1));
+    orc_label row[ORC_ISAI_MAX_ROW + 1], next[ORC_ISAI_MAX_ROW + 1];
+    for (orc_label i = 0; i < n; ++i) mark[i] = -1;
+    p_rowptr[0] = 0;
     for (orc_label i = 0; i < n; ++i) {
-        orc_label cnt = 0;
+        orc_label len = 0;
         for (orc_label k = rowptr[i]; k < rowptr[i + 1]; ++k)
-            if (!spd || cols[k] <= i) ++cnt;
-        if (cnt > 32) return -1;
-        w_rowptr[i + 1] = w_rowptr[i] + cnt;
-    }
-    if (!w_vals) return w_rowptr[n];
-    for (orc_label i = 0; i < n; ++i) {
-        orc_label J[32], bs = 0, pos = -1;
-        for (orc_label k = rowptr[i]; k < rowptr[i + 1]; ++k)
-            if (!spd || cols[k] <= i) {
-                if (cols[k] == i) pos = bs;
-                J[bs++] = cols[k];
+            if ((!spd || cols[k] <= i) && mark[cols[k]] != i) { /* S(i,:), duplicates once */
+                if (len == ORC_ISAI_MAX_ROW) { free(mark); return -1; }
+                mark[cols[k]] = i;
+                row[len++] = cols[k];
             }
-        orc_scalar a[32 * 32], rhs[32];
+        for (int pw = 1; pw < power; ++pw) { /* row of S^(pw+1) = union of S(j,:) over the row of S^pw */
+            orc_label nl = 0;
+            for (orc_label e = 0; e < len; ++e) next[nl++] = row[e];
+            for (orc_label e = 0; e < len; ++e) {
+                const orc_label j = row[e];
+                for (orc_label k = rowptr[j]; k < rowptr[j + 1]; ++k)
+                    if ((!spd || cols[k] <= j) && mark[cols[k]] != i) {
+                        if (nl == ORC_ISAI_MAX_ROW) { free(mark); return -1; }
+                        mark[cols[k]] = i;
+                        next[nl++] = cols[k];
+                    }
+            }
+            len = nl;
+            for (orc_label e = 0; e < len; ++e) row[e] = next[e];
+        }
+        for (orc_label a = 1; a < len; ++a) { /* ascending columns */
+            const orc_label c = row[a];
+            orc_label bpos = a;
+            while (bpos > 0 && row[bpos - 1] > c) { row[bpos] = row[bpos - 1]; --bpos; }
+            row[bpos] = c;
+        }
+        if (p_cols)
+            for (orc_label e = 0; e < len; ++e) p_cols[p_rowptr[i] + e] = row[e];
+        p_rowptr[i + 1] = p_rowptr[i] + len;
+    }
+    free(mark);
+    return p_rowptr[n];
+}
+
+/* ISAI with `sparsityPower` power: row i of W lives on the pattern J of row i of S^power and solves
+ * A(J,J) y = e_i (spd; then W(i,J) = y / sqrt(y_i)) or A(J,J)^T y = e_i (general).  Rows of up to
+ * ORC_ISAI_MAX_ROW entries, each by one dense solve. */
+orc_label orc_isai_generate_p(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                              const orc_scalar *vals, int spd, int power, orc_label *w_rowptr,
+                              orc_label *w_cols, orc_scalar *w_vals) {
+    if (power < 1) return -1;
+    if (!w_vals) return isai_pattern(n, rowptr, cols, spd, power, w_rowptr, 0);
+    if (isai_pattern(n, rowptr, cols, spd, power, w_rowptr, w_cols) < 0) return -1;
+    enum { LD = ORC_ISAI_MAX_ROW };
+    orc_scalar *a = (orc_scalar *)xmalloc(sizeof(orc_scalar) * LD * LD);
+    orc_scalar rhs[LD];
+    for (orc_label i = 0; i < n; ++i) {
+        const orc_label *J = w_cols + w_rowptr[i];
+        const orc_label bs = w_rowptr[i + 1] - w_rowptr[i];
+        orc_label pos = -1;
+        for (orc_label r = 0; r < bs; ++r)
+            if (J[r] == i) pos = r;
         for (orc_label r = 0; r < bs; ++r) {
             for (orc_label c = 0; c < bs; ++c)
-                a[r * 32 + c] = spd ? csr_entry(rowptr, cols, vals, J[r], J[c])
+                a[r * LD + c] = spd ? csr_entry(rowptr, cols, vals, J[r], J[c])
                                     : csr_entry(rowptr, cols, vals, J[c], J[r]);
             rhs[r] = (r == pos) ? 1.0 : 0.0;
         }
-        solve_dense(bs, a, 32, rhs);
+        solve_dense(bs, a, LD, rhs);
         const orc_scalar scale = spd ? sqrt(rhs[pos]) : 1.0;
-        for (orc_label r = 0; r < bs; ++r) {
-            w_cols[w_rowptr[i] + r] = J[r];
-            w_vals[w_rowptr[i] + r] = spd ? rhs[r] / scale : rhs[r];
-        }
+        for (orc_label r = 0; r < bs; ++r) w_vals[w_rowptr[i] + r] = spd ? rhs[r] / scale : rhs[r];
     }
+    free(a);
     return w_rowptr[n];
+}
+
+orc_label orc_isai_generate(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                            const orc_scalar *vals, int spd, orc_label *w_rowptr, orc_label *w_cols,
+                            orc_scalar *w_vals) {
+    return orc_isai_generate_p(n, rowptr, cols, vals, spd, 1, w_rowptr, w_cols, w_vals);
 }
 
 void orc_csr_transpose(orc_label n, const orc_label *rowptr, const orc_label *cols,

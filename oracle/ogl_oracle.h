@@ -256,6 +256,10 @@ typedef struct {
  * spd == 0 (GISAI): W has A's pattern; row i solves A(J,J)^T y = e_i, M^-1 = W.
  * Step 1 (vals == NULL): returns nnz(W) and fills w_rowptr[n+1]; step 2: fills w_cols / w_vals.
  * Rows with more than 32 pattern entries are not handled (returns -1). */
+/* the same on the pattern of S^power (keyword sparsityPower, Preconditioner.H:227), rows <= 64 entries */
+orc_label orc_isai_generate_p(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                              const orc_scalar *vals, int spd, int power, orc_label *w_rowptr,
+                              orc_label *w_cols, orc_scalar *w_vals);
 orc_label orc_isai_generate(orc_label n, const orc_label *rowptr, const orc_label *cols,
                             const orc_scalar *vals, int spd, orc_label *w_rowptr, orc_label *w_cols,
                             orc_scalar *w_vals);

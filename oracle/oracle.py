@@ -350,7 +350,7 @@ class _CPrecond(C.Structure):
 class Precond:
     """Jacobi preconditioner object: scalar (maxBlockSize 1) or block (maxBlockSize k > 1)."""
 
-    def __init__(self, rowptr, cols, vals, max_block_size=1, isai=None):
+    def __init__(self, rowptr, cols, vals, max_block_size=1, isai=None, sparsity_power=1):
         """isai: None (Jacobi), "spd" (keyword ISAI) or "general" (keyword GISAI)."""
         rowptr, prp = _l(rowptr)
         cols, pc = _l(cols)
@@ -359,15 +359,16 @@ class Precond:
         self.max_block_size = int(max_block_size)
         if isai is not None:
             spd = C.c_int(isai == "spd")
-            lib().orc_isai_generate.restype = C.c_int32
+            lib().orc_isai_generate_p.restype = C.c_int32
+            pw = C.c_int(int(sparsity_power))
             self.w_rowptr = np.zeros(n + 1, label)
-            nnz = lib().orc_isai_generate(C.c_int32(n), prp, pc, pv, spd,
-                                          self.w_rowptr.ctypes.data_as(_LP), None, None)
+            nnz = lib().orc_isai_generate_p(C.c_int32(n), prp, pc, pv, spd, pw,
+                                            self.w_rowptr.ctypes.data_as(_LP), None, None)
             if nnz < 0:
-                raise ValueError("ISAI row wider than 32")
+                raise ValueError("ISAI row wider than 64")
             self.w_cols, self.w_vals = np.zeros(max(1, nnz), label), np.zeros(max(1, nnz), scalar)
-            lib().orc_isai_generate(C.c_int32(n), prp, pc, pv, spd, self.w_rowptr.ctypes.data_as(_LP),
-                                    self.w_cols.ctypes.data_as(_LP), self.w_vals.ctypes.data_as(_SP))
+            lib().orc_isai_generate_p(C.c_int32(n), prp, pc, pv, spd, pw, self.w_rowptr.ctypes.data_as(_LP),
+                                      self.w_cols.ctypes.data_as(_LP), self.w_vals.ctypes.data_as(_SP))
             self.wt_rowptr = np.zeros(n + 1, label)
             self.wt_cols, self.wt_vals = np.zeros_like(self.w_cols), np.zeros_like(self.w_vals)
             lib().orc_csr_transpose(C.c_int32(n), self.w_rowptr.ctypes.data_as(_LP),

@@ -581,9 +581,47 @@ def test_isai(reg, oracle, chunk_rows, precond, kind, sym, solver):
         assert perf.n_iterations < perf0.n_iterations
 
 
-def test_isai_unsupported_power(reg):
-    case = synthetic.poisson_case(4)
-    s = reg.solver("isai_p2", cg_cfg(preconditioner=capi.PRECOND_ISAI, sparsity_power=2)).set_matrix(case)
-    with pytest.raises(capi.OglError) as e:
+@pytest.mark.parametrize("precond,kind,sym,solver,power,widest", [
+    (capi.PRECOND_ISAI, "spd", True, "cg", 2, 10),          # tril(A)^2 on the 7-point box
+    (capi.PRECOND_ISAI, "spd", True, "cg", 3, 20),
+    (capi.PRECOND_GISAI, "general", False, "bicgstab", 2, 25),   # A^2: 25 entries, one thread per row
+    (capi.PRECOND_GISAI, "general", False, "bicgstab", 3, 63),   # A^3: 63 entries, one wavefront per row
+    (capi.PRECOND_GISAI, "general", True, "cg", 3, 63),
+], ids=["ISAI-p2", "ISAI-p3", "GISAI-p2", "GISAI-p3-wide", "GISAI-p3-wide-cg"])
+def test_isai_sparsity_power(reg, oracle, chunk_rows, precond, kind, sym, solver, power, widest):
+    """Preconditioner.H:227 `sparsityPower`: W lives on the pattern of S^power.  Rows of up to 32 entries
+    are solved by one thread each, wider ones (up to 64) by one wavefront each with the system in LDS;
+    both must give the oracle's bits (same dense solve, same order of operations per element)."""
+    case = synthetic.poisson_case(9, symmetric=sym)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    sk = {"cg": capi.SOLVER_CG, "bicgstab": capi.SOLVER_BICGSTAB}[solver]
+    kw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=200)
+    s = reg.solver(f"isaip_{kind}_{sym}_{power}", cg_cfg(solver=sk, preconditioner=precond,
+                                                          sparsity_power=power, **kw)).set_matrix(case)
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    P = oracle.Precond(rp, cols, vals, isai=kind, sparsity_power=power)
+    assert int(np.diff(P.w_rowptr).max()) == widest
+    with blocked(oracle, chunk_rows):
+        ref = (oracle.cg if solver == "cg" else oracle.bicgstab)(A, b, np.zeros_like(b), P, **kw)
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x)
+    np.testing.assert_allclose(x, xs, atol=1e-7, rtol=0)
+    # a larger pattern is a better preconditioner: fewer checks than with sparsityPower 1
+    s1 = reg.solver(f"isaip1_{kind}_{sym}", cg_cfg(solver=sk, preconditioner=precond, **kw)).set_matrix(case)
+    s1.upload_solution(None)
+    _, perf1 = s1.solve(b, np.zeros_like(b))
+    assert perf.n_iterations < perf1.n_iterations
+
+
+def test_isai_rows_wider_than_64_are_refused(reg):
+    case = synthetic.poisson_case(9)
+    s = reg.solver("isai_p4", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=4)).set_matrix(case)
+    with pytest.raises(capi.OglError) as e:                 # A^4 on the 7-point box: 129 entries per row
         s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
     assert e.value.status == capi.ERR_UNSUPPORTED
+    s = reg.solver("isai_p0", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=0)).set_matrix(case)
+    with pytest.raises(capi.OglError) as e:
+        s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
+    assert e.value.status == capi.ERR_INVALID

@@ -136,3 +136,32 @@ def test_adaptive_policy(oracle):
     assert mi == 60 and fr == int(1 / np.sqrt(1.0 / (100 * 0.4)))
     mi, fr = oracle.adapt_criterion(0, 1, False, 100000, prev_rel_cost=1.0)
     assert fr == 100                                                                # normEvalLimit
+
+
+@pytest.mark.parametrize("sym", [True, False])
+@pytest.mark.parametrize("power", [1, 2, 3])
+def test_isai_defining_property_with_sparsity_power(oracle, sym, power):
+    """Preconditioner.H:227 `sparsityPower`: W lives on the pattern of S^power (S = tril(A) for ISAI, A for
+    GISAI).  General: (W A)(i, j) = delta_ij for every (i, j) of W's pattern -- the defining property of
+    the incomplete sparse approximate inverse.  SPD: W is lower triangular and (W A W^T)(i, i) = 1."""
+    import scipy.sparse as sp
+    from ogl_amd import synthetic
+    from helpers import oracle_csr
+    case = synthetic.poisson_case(6, symmetric=sym)
+    rp, cols, vals = oracle_csr(oracle, case)
+    A = sp.csr_matrix((vals, cols, rp))
+    P = oracle.Precond(rp, cols, vals, isai="spd" if sym else "general", sparsity_power=power)
+    nnz = P.w_rowptr[-1]
+    W = sp.csr_matrix((P.w_vals[:nnz], P.w_cols[:nnz], P.w_rowptr))
+    S = sp.tril(A) if sym else A
+    pat = (abs(S) ** power).tocsr()
+    pat.sum_duplicates()
+    assert np.array_equal(pat.indptr, P.w_rowptr) and np.array_equal(pat.indices, P.w_cols[:nnz])
+    if sym:
+        assert sp.triu(W, 1).nnz == 0
+        np.testing.assert_allclose((W @ A @ W.T).diagonal(), 1.0, rtol=1e-12)
+    else:
+        R = (W @ A - sp.identity(A.shape[0])).toarray()
+        assert np.abs(R[(W != 0).toarray()]).max() < 1e-13
+    with pytest.raises(ValueError):
+        oracle.Precond(rp, cols, vals, isai="general", sparsity_power=5)      # rows wider than 64
