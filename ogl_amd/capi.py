@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libogl_amd.so")
+# (OGL_AMD_LIB: another build of the same library, for A/B runs during development)
+LIB_PATH = os.environ.get("OGL_AMD_LIB") or os.path.join(_HERE, "lib", "libogl_amd.so")
 
 OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_COMM, ERR_STATE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6

@@ -1,5 +1,7 @@
 #include "common.hpp"
 
+#include <cstdlib>
+
 #include <dlfcn.h>
 
 #include <mutex>
@@ -67,3 +69,30 @@ int fail(int status, const char *fmt, ...)
 
 extern "C" const char *ogl_last_error(void) { return ogl::last_error().c_str(); }
 extern "C" int ogl_abi_version(void) { return OGL_AMD_ABI_VERSION; }
+
+// OGL_SEGV_TRACE=1: print a native backtrace on SIGSEGV / SIGABRT (the GPU boxes have no debugger)
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void segv_trace(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "libogl_amd: fatal signal, native backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct InstallSegvTrace {
+    InstallSegvTrace()
+    {
+        const char *e = getenv("OGL_SEGV_TRACE");
+        if (e && *e == '1') {
+            signal(SIGSEGV, segv_trace);
+            signal(SIGABRT, segv_trace);
+        }
+    }
+} install_segv_trace;
+}  // namespace

@@ -483,7 +483,8 @@ def _solve(fn_name, A, b, x0, inv_diag, tolerance, rel_tol, min_iter, max_iter, 
     elif inv_diag is not None:
         inv_diag, pinv = _s(inv_diag)
     crit = _CCriterion(tolerance, rel_tol, min_iter, max_iter, frequency, int(bool(export_res)))
-    hist = np.zeros(max_iter + 2, scalar)
+    # the criterion stops at the first evaluated check at or after max(maxIter, minIter)
+    hist = np.zeros(2 * max(max_iter, min_iter) + frequency + 4, scalar)   # (x2: orc_bicgstab doubles maxIter)
     st = _CState()
     st.history = hist.ctypes.data_as(_SP)
     if omp_threads is None:
@@ -517,7 +518,7 @@ def gmres(A, b, x0, precond=None, tolerance=1e-6, rel_tol=1e-6, min_iter=0, max_
     b, pb = _s(b)
     x = np.array(x0, dtype=scalar, copy=True)
     crit = _CCriterion(tolerance, rel_tol, min_iter, max_iter, frequency, int(bool(export_res)))
-    hist = np.zeros(max_iter + frequency + 4, scalar)
+    hist = np.zeros(max(max_iter, min_iter) + frequency + 4, scalar)
     st = _CState()
     st.history = hist.ctypes.data_as(_SP)
     lib().orc_gmres_p.restype = C.c_int32

@@ -95,6 +95,32 @@ static void run_case(int nx, int ny, int nz, bool symmetric, bool with_interface
     int64_t stats[8];
     CHECK(ogl_host_sell_check(N, rp.data(), cols.data(), stats) == OGL_OK);
     CHECK(stats[0] == 1 && stats[1] >= d.local_nnz);
+    // renumbering: forced (RCM + length sort) and auto; the outputs must be a permutation and a sorted pattern
+    for (int mode = 1; mode <= 2; ++mode) {
+        std::vector<ogl_label> new_id(N + 1, -1), rr(d.local_nnz), cc(d.local_nnz), mm(d.local_nnz);
+        ogl_matrix_dims d2{};
+        const int rc = ogl_host_pattern_renumbered(&v, mode, 1, &d2, rr.data(), cc.data(), mm.data(), nr.data(),
+                                                   nc.data(), nm.data(), tid.data(), tsz.data(), snd.data(),
+                                                   new_id.data());
+        CHECK(rc == 0 || rc == 1);
+        std::vector<int> seen(N, 0);
+        for (int c = 0; c < N; ++c) {
+            CHECK(new_id[c] >= 0 && new_id[c] < N);
+            if (new_id[c] >= 0 && new_id[c] < N) ++seen[new_id[c]];
+        }
+        for (int c = 0; c < N; ++c) CHECK(seen[c] == 1);
+        for (int e = 1; e < d2.local_nnz; ++e)
+            CHECK(rr[e] > rr[e - 1] || (rr[e] == rr[e - 1] && cc[e] >= cc[e - 1]));
+        std::vector<ogl_label> rp2(N + 1, 0);
+        for (int e = 0; e < d2.local_nnz; ++e) ++rp2[rr[e] + 1];
+        for (int r = 0; r < N; ++r) rp2[r + 1] += rp2[r];
+        int64_t st2[8];
+        CHECK(ogl_host_sell_check(N, rp2.data(), cc.data(), st2) == OGL_OK);
+        std::vector<ogl_label> rcm(N + 1);
+        CHECK(ogl_host_rcm(N, rp.data(), cols.data(), rcm.data()) == OGL_OK);
+        (void)ogl_host_gather_sector_ratio(N, rp.data(), cols.data(), rcm.data());
+    }
+    (void)ogl_host_addressing_fingerprint(&v);
     // update functions on the plain (interface-free) pattern
     if (!with_interfaces) {
         std::vector<ogl_label> r2(N + 2 * F), c2(N + 2 * F), p2(N + 2 * F);
@@ -119,6 +145,7 @@ int main()
             run_case(5, 4, 3, sym, ifs);
             run_case(33, 17, 9, sym, ifs);   // 5049 cells: ten chunks, the last one partial
             run_case(600, 1, 1, sym, false);
+            run_case(40, 30, 20, sym, ifs);  // 24,000 cells: past the auto policy's size threshold
         }
     // bad input must be refused, not read
     ogl_ldu_view bad{};
