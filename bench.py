@@ -84,14 +84,14 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, variant=""):
     """HBM-side bytes per launch of `kernel` from the committed PMC passes of this same command
     (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs).  Units and the
     gfx950 correction per MI355X_MICROARCH.md "HBM": counters are KiB, FETCH_SIZE reads half the
     bytes of a wide coalesced stream (calibrated here on k_cg_step1: 2 x 118,111 KiB = 241.9 MB
     measured vs 24 N = 241.9 MB algorithmic)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{variant}_summary.json")))
     if not files:
         return None, None
     with open(files[-1]) as fh:
@@ -121,6 +121,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in libogl_amd")
+    # a rank that never shows up on the peer mesh ends a wait after this many seconds (library default
+    # 60): the ladder below may have to sit out two failed rungs before it reaches a working transport
+    os.environ.setdefault("OGL_PEER_TIMEOUT_S", "15")
     # one rank per GPU; on a box with fewer GPUs than ranks (development only) ranks share devices
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -396,8 +399,9 @@ def main():
     kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell"}[layout]
     # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
     b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout == "sell" else b_spmv
-    traffic, traffic_src = (pmc_traffic(kernel + "<0, 1>")
-                            if (n == 216 and args.format == "Csr" and not args.shuffle) else (None, None))
+    traffic, traffic_src = (pmc_traffic(kernel + "<0, 1>", "_shuffle65536" if args.shuffle == 65536 else "")
+                            if (n == 216 and args.format == "Csr" and args.shuffle in (0, 65536)
+                                and args.renumber == "auto" and not args.rcm) else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
 
     def turn_model():

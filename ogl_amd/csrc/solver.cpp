@@ -557,7 +557,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     const double t0 = now_ms();
     const bool try_sell = cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices;
     bool first = !have_pattern || !same_shape(ldu, pat) || pat_renumber_mode != cfg.renumber ||
-                 (cfg.renumber == 2 && pat_try_sell != try_sell);
+                 (cfg.renumber != 0 && pat_try_sell != try_sell);
     if (reg->comm->multi()) {
         // a rebuild is collective once the peer mesh is up (setup_peer_halo): every rank rebuilds
         // when any rank's addressing changed
