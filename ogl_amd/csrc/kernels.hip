@@ -585,6 +585,7 @@ __global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply(int n_rows,
                                                          const int *__restrict__ block_ptrs,
                                                          const int *__restrict__ row_block,
                                                          const double *__restrict__ blocks, int ld,
+                                                         int uniform,
                                                          const double *__restrict__ in,
                                                          double *__restrict__ out,
                                                          double *__restrict__ dot_part,
@@ -597,8 +598,16 @@ __global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply(int n_rows,
     const int row = chunk * CHUNK_ROWS + threadIdx.x;
     double sum = 0.0, mine = 0.0;
     if (row < n_rows) {
-        const int b = row_block[row];
-        const int r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
+        int b, r0, bs;
+        if (uniform) {  // blocks of exactly `ld` rows (the last one may be shorter)
+            b = row / ld;
+            r0 = b * ld;
+            bs = min(ld, n_rows - r0);
+        } else {
+            b = row_block[row];
+            r0 = block_ptrs[b];
+            bs = block_ptrs[b + 1] - r0;
+        }
         const double *a = blocks + (size_t)b * ld * ld + (size_t)(row - r0) * ld;
         for (int j = 0; j < bs; ++j) sum += a[j] * in[r0 + j];
         out[row] = sum;
@@ -2017,10 +2026,10 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
     const dim3 grid((unsigned)n_chunks(J.n_rows)), block(CHUNK_ROWS);
     if (dot_part)
         hipLaunchKernelGGL((k_bj_apply<1>), grid, block, 0, st, J.n_rows, J.block_ptrs, J.row_block,
-                           J.blocks, J.stride, in, out, dot_part, gate);
+                           J.blocks, J.stride, J.uniform, in, out, dot_part, gate);
     else
         hipLaunchKernelGGL((k_bj_apply<0>), grid, block, 0, st, J.n_rows, J.block_ptrs, J.row_block,
-                           J.blocks, J.stride, in, out, dot_part, gate);
+                           J.blocks, J.stride, J.uniform, in, out, dot_part, gate);
 }
 
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,

@@ -121,6 +121,9 @@ struct DevBlockJacobi {
     const int32_t *block_ptrs = nullptr; // [n_blocks + 1] first row of each block
     const int32_t *row_block = nullptr;  // [n_rows] block of each row
     double *blocks = nullptr;            // [n_blocks * stride * stride]
+    // every block but the last holds exactly `stride` rows (what agglomeration gives on a mesh without
+    // repeated row patterns): block and first row follow from the row index, no index loads in the apply
+    int32_t uniform = 0;
 };
 constexpr int MAX_JACOBI_BLOCK = 32;
 // blocks[b] = inverse of A(block b, block b) by Gauss-Jordan with partial pivoting

@@ -851,6 +851,11 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             std::vector<int32_t> ptrs, row_block;
             find_jacobi_blocks(pat, cfg.max_block_size, ptrs, row_block);
             P.n_blocks = (int32_t)ptrs.size() - 1;
+            P.uniform_blocks = true;
+            for (int32_t b = 0; b + 1 < P.n_blocks; ++b)
+                P.uniform_blocks = P.uniform_blocks && ptrs[(size_t)b + 1] - ptrs[(size_t)b] == cfg.max_block_size;
+            if (P.n_blocks > 0)
+                P.uniform_blocks = P.uniform_blocks && ptrs[(size_t)P.n_blocks - 1] == (P.n_blocks - 1) * cfg.max_block_size;
             OGL_TRY(P.block_ptrs.alloc(ptrs.size(), st));
             OGL_TRY(P.row_block.alloc(std::max<size_t>(1, row_block.size()), st));
             OGL_TRY(P.values.alloc(std::max<size_t>(1, (size_t)P.n_blocks * k * k), st));
@@ -920,6 +925,7 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
     J.block_ptrs = precond_data->block_ptrs.p;
     J.row_block = precond_data->row_block.p;
     J.blocks = precond_data->values.p;
+    J.uniform = precond_data->uniform_blocks ? 1 : 0;
     launch_bj_apply(st, J, in, out, dot_part, gate);
 }
 

@@ -109,6 +109,7 @@ struct PrecondData {
     size_t n_rows = 0;
     int stride = 0;  // block Jacobi: maxBlockSize
     int32_t n_blocks = 0;
+    bool uniform_blocks = false;  // block Jacobi: every block but the last has exactly `stride` rows
     DevBuf<double> values;  // inverse diagonal (n_rows + 2) or inverted blocks
     DevBuf<int32_t> block_ptrs, row_block;
     // ISAI (kind 3: spd, M^-1 = W^T W; kind 4: general, M^-1 = W): CSR arrays padded like the

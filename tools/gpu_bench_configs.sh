@@ -29,3 +29,9 @@ run gmres30_bj_216   --iters 60 --solver GKOGMRES --krylov-dim 30
 run gmres30_bj_216s  --iters 60 --solver GKOGMRES --krylov-dim 30 --shuffle 65536
 run gmres30_bj_368   --iters 60 --solver GKOGMRES --krylov-dim 30 --edge 368
 run cg_bj_368        --iters 50 --edge 368
+# proxies of the unstructured configs (cells renumbered at random in windows of 65536; the backend renumbers itself)
+run c3_cg_bj_128s     --iters 100 --edge 128 --shuffle 65536
+run c3_bicg_isai_128s --iters 100 --edge 128 --shuffle 65536 --solver GKOBiCGStab --asym --precond ISAI
+run c4_cg_bj_136      --iters 100 --edge 136
+run c5_gmres_csr_184s --iters 60 --edge 184 --shuffle 65536 --solver GKOGMRES --krylov-dim 30
+run c5_gmres_ell_184s --iters 60 --edge 184 --shuffle 65536 --solver GKOGMRES --krylov-dim 30 --format Ell
