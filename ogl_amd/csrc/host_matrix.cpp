@@ -195,15 +195,19 @@ uint64_t addressing_fingerprint(const ogl_ldu_view &ldu)
     return h;
 }
 
-bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p)
+bool same_counts(const ogl_ldu_view &ldu, const HostPattern &p)
 {
     if (ldu.n_cells != p.n_rows || ldu.n_faces != p.upper_nnz) return false;
     if ((ldu.lower == nullptr) != p.symmetric) return false;
     int64_t loc = 0, nl = 0;
     for (ogl_label i = 0; i < ldu.n_interfaces; ++i)
         (ldu.interfaces[i].kind == OGL_IFACE_PROCESSOR ? nl : loc) += ldu.interfaces[i].size;
-    if (loc != p.local_iface_nnz || nl != p.non_local_nnz) return false;
-    return addressing_fingerprint(ldu) == p.fingerprint;
+    return loc == p.local_iface_nnz && nl == p.non_local_nnz;
+}
+
+bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p)
+{
+    return same_counts(ldu, p) && addressing_fingerprint(ldu) == p.fingerprint;
 }
 
 int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)

@@ -58,6 +58,8 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p);
 uint64_t addressing_fingerprint(const ogl_ldu_view &ldu);
 // same counts and same addressing (full hash) as the view the pattern was built from
 bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p);
+// the cheap half of it: sizes and symmetry only
+bool same_counts(const ogl_ldu_view &ldu, const HostPattern &p);
 
 // Jacobi block pointers for maxBlockSize > 1 ([UPSTREAM] gko::preconditioner::Jacobi
 // find_blocks): natural blocks = runs of consecutive rows with identical column pattern (capped at

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <future>
 #include <thread>
 
 using namespace ogl;
@@ -556,8 +557,81 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     TraceRange trace("update_matrix", field);
     const double t0 = now_ms();
     const bool try_sell = cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices;
-    bool first = !have_pattern || !same_shape(ldu, pat) || pat_renumber_mode != cfg.renumber ||
-                 (cfg.renumber != 0 && pat_try_sell != try_sell);
+    // ---- coefficients (update_local_matrix_data :592-705) ----
+    // MatrixInitFunctor::update only overwrites the matrix values when updateSysMatrix is set
+    // (CsrMatrixWrapper.H:259); the fresh coefficients have no other consumer, so the transfer
+    // is skipped altogether in that case.
+    auto upload_coefficients = [&]() -> int {
+        const int32_t N = pat.n_rows, F = pat.upper_nnz;
+        const size_t nnz = (size_t)pat.local_nnz;
+        std::vector<double> iface;
+        if (pat.local_iface_nnz) {
+            iface.resize(pat.local_iface_nnz);
+            collect_interface_coeffs(ldu, true, iface.data());
+        }
+        if (cfg.reorder_on_host) {  // :608-633, scaling applied by the host update functions
+            std::vector<double> sorted(nnz);
+            if (pat.local_iface_nnz) {
+                if (pat.symmetric)
+                    ogl_host_symmetric_update_w_interface(pat.local_nnz, N, F, pat.ldu_mapping.data(),
+                                                          cfg.scaling, ldu.diag, ldu.upper,
+                                                          iface.data(), sorted.data());
+                else
+                    ogl_host_non_symmetric_update_w_interface(
+                        pat.local_nnz, N, F, pat.ldu_mapping.data(), cfg.scaling, ldu.diag,
+                        ldu.upper, ldu.lower, iface.data(), sorted.data());
+            } else if (pat.symmetric) {
+                ogl_host_symmetric_update(pat.local_nnz, F, pat.ldu_mapping.data(), cfg.scaling,
+                                          ldu.diag, ldu.upper, sorted.data());
+            } else {
+                ogl_host_non_symmetric_update(pat.local_nnz, F, pat.ldu_mapping.data(), cfg.scaling,
+                                              ldu.diag, ldu.upper, ldu.lower, sorted.data());
+            }
+            OGL_TRY(reg->stager.h2d(d_vals.p, sorted.data(), nnz * sizeof(double), st));
+        } else {  // :634-704 -- H2D into the unsorted slots, then the device permutation (K9)
+            double *src = d_source.p;
+            OGL_TRY(reg->stager.h2d(src, ldu.upper, (size_t)F * sizeof(double), st));          // :644-650
+            if (!pat.symmetric)
+                OGL_TRY(reg->stager.h2d(src + F, ldu.lower, (size_t)F * sizeof(double), st));  // :653-660
+            OGL_TRY(reg->stager.h2d(src + pat.diag_start(), ldu.diag, (size_t)N * sizeof(double),
+                                    st));                                                     // :663-669
+            if (pat.local_iface_nnz)
+                OGL_TRY(reg->stager.h2d(src + pat.diag_start() + N, iface.data(),
+                                        iface.size() * sizeof(double), st));                  // :672-682
+            launch_gather_coeffs(st, pat.local_nnz, d_ldu_mapping.p, src, d_vals.p);          // :700-703
+        }
+        // ---- non-local coefficients (:708-732): tiny, permuted on the host ----
+        if (pat.non_local_nnz) {
+            std::vector<double> cc(pat.non_local_nnz);
+            collect_interface_coeffs(ldu, false, cc.data());
+            h_nl_vals.resize(pat.non_local_nnz);
+            for (int32_t e = 0; e < pat.non_local_nnz; ++e) h_nl_vals[e] = cc[pat.nl_ldu_mapping[e]];
+            OGL_TRY(reg->stager.h2d(d_nl_vals.p, h_nl_vals.data(),
+                                    h_nl_vals.size() * sizeof(double), st));
+        }
+        matrix_set = true;
+        ell_values_stale = true;
+        sell_values_stale = true;
+        return OGL_OK;
+    };
+    // Has the addressing changed?  Counts first (free); then the hash of every face and interface cell,
+    // which runs on helper threads WHILE the coefficients of the (presumably unchanged) pattern are
+    // staged to the device: the arrays have the right sizes either way, and if the hash disagrees the
+    // pattern is rebuilt and the coefficients go up again.
+    const bool config_same = have_pattern && pat_renumber_mode == cfg.renumber &&
+                             !(cfg.renumber != 0 && pat_try_sell != try_sell);
+    bool first = true, coefficients_done = false;
+    if (config_same && same_counts(ldu, pat)) {
+        auto fp = std::async(std::launch::async, [&ldu] { return addressing_fingerprint(ldu); });
+        int rc = OGL_OK;
+        if (!matrix_set || cfg.update_sys_matrix || cfg.regenerate) {
+            rc = upload_coefficients();
+            coefficients_done = rc == OGL_OK;
+        }
+        first = fp.get() != pat.fingerprint;  // (joined before any return)
+        if (rc != OGL_OK) return rc;
+        if (first) coefficients_done = false;
+    }
     if (reg->comm->multi()) {
         // a rebuild is collective once the peer mesh is up (setup_peer_halo): every rank rebuilds
         // when any rank's addressing changed
@@ -678,62 +752,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         OGL_TRY(setup_peer_halo());  // collective when the peer mesh is up (every rank, every pattern)
     }
 
-    // ---- coefficients (update_local_matrix_data :592-705) ----
-    // MatrixInitFunctor::update only overwrites the matrix values when updateSysMatrix is set
-    // (CsrMatrixWrapper.H:259); the fresh coefficients have no other consumer, so the transfer
-    // is skipped altogether in that case.
-    if (!matrix_set || cfg.update_sys_matrix || cfg.regenerate) {
-        const int32_t N = pat.n_rows, F = pat.upper_nnz;
-        const size_t nnz = (size_t)pat.local_nnz;
-        std::vector<double> iface;
-        if (pat.local_iface_nnz) {
-            iface.resize(pat.local_iface_nnz);
-            collect_interface_coeffs(ldu, true, iface.data());
-        }
-        if (cfg.reorder_on_host) {  // :608-633, scaling applied by the host update functions
-            std::vector<double> sorted(nnz);
-            if (pat.local_iface_nnz) {
-                if (pat.symmetric)
-                    ogl_host_symmetric_update_w_interface(pat.local_nnz, N, F, pat.ldu_mapping.data(),
-                                                          cfg.scaling, ldu.diag, ldu.upper,
-                                                          iface.data(), sorted.data());
-                else
-                    ogl_host_non_symmetric_update_w_interface(
-                        pat.local_nnz, N, F, pat.ldu_mapping.data(), cfg.scaling, ldu.diag,
-                        ldu.upper, ldu.lower, iface.data(), sorted.data());
-            } else if (pat.symmetric) {
-                ogl_host_symmetric_update(pat.local_nnz, F, pat.ldu_mapping.data(), cfg.scaling,
-                                          ldu.diag, ldu.upper, sorted.data());
-            } else {
-                ogl_host_non_symmetric_update(pat.local_nnz, F, pat.ldu_mapping.data(), cfg.scaling,
-                                              ldu.diag, ldu.upper, ldu.lower, sorted.data());
-            }
-            OGL_TRY(reg->stager.h2d(d_vals.p, sorted.data(), nnz * sizeof(double), st));
-        } else {  // :634-704 -- H2D into the unsorted slots, then the device permutation (K9)
-            double *src = d_source.p;
-            OGL_TRY(reg->stager.h2d(src, ldu.upper, (size_t)F * sizeof(double), st));          // :644-650
-            if (!pat.symmetric)
-                OGL_TRY(reg->stager.h2d(src + F, ldu.lower, (size_t)F * sizeof(double), st));  // :653-660
-            OGL_TRY(reg->stager.h2d(src + pat.diag_start(), ldu.diag, (size_t)N * sizeof(double),
-                                    st));                                                     // :663-669
-            if (pat.local_iface_nnz)
-                OGL_TRY(reg->stager.h2d(src + pat.diag_start() + N, iface.data(),
-                                        iface.size() * sizeof(double), st));                  // :672-682
-            launch_gather_coeffs(st, pat.local_nnz, d_ldu_mapping.p, src, d_vals.p);          // :700-703
-        }
-        // ---- non-local coefficients (:708-732): tiny, permuted on the host ----
-        if (pat.non_local_nnz) {
-            std::vector<double> cc(pat.non_local_nnz);
-            collect_interface_coeffs(ldu, false, cc.data());
-            h_nl_vals.resize(pat.non_local_nnz);
-            for (int32_t e = 0; e < pat.non_local_nnz; ++e) h_nl_vals[e] = cc[pat.nl_ldu_mapping[e]];
-            OGL_TRY(reg->stager.h2d(d_nl_vals.p, h_nl_vals.data(),
-                                    h_nl_vals.size() * sizeof(double), st));
-        }
-        matrix_set = true;
-        ell_values_stale = true;
-        sell_values_stale = true;
-    }
+    if (!coefficients_done && (!matrix_set || cfg.update_sys_matrix || cfg.regenerate)) OGL_TRY(upload_coefficients());
     if (cfg.matrix_format == OGL_FORMAT_ELL) {
         if (!ell_ready) OGL_TRY(build_ell());
         if (ell_values_stale) {
