@@ -61,6 +61,9 @@ def parse():
                     help="renumber the cells at random inside windows of this many cells (a stand-in for "
                          "an unstructured mesh: the compressed layouts do not qualify, the CSR-stream "
                          "kernel runs); single rank only")
+    ap.add_argument("--drop-faces", type=float, default=0.0,
+                    help="remove this fraction of the internal faces at random (row lengths 1..7: a stand-in "
+                         "for a mesh of mixed cell types); single rank only")
     ap.add_argument("--rcm", action="store_true",
                     help="after --shuffle: renumber the CASE with reverse Cuthill-McKee (scipy), as "
                          "renumberMesh would, before the library sees it")
@@ -141,6 +144,9 @@ def main():
                                        off_upper=-0.9, off_lower=-1.1)
     else:
         case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
+    if args.drop_faces:
+        assert world == 1, "--drop-faces is a single-rank option"
+        case = synthetic.drop_faces_case(case, args.drop_faces)
     if args.shuffle:
         assert world == 1, "--shuffle is a single-rank option"
         case = synthetic.renumber_case(case, args.shuffle)
@@ -450,6 +456,7 @@ def main():
         "config": {
             "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix"
                         f"{' (non-symmetric)' if args.asym else ''}"
+                        f"{f' ({args.drop_faces:.0%} of the faces removed at random)' if args.drop_faces else ''}"
                         f"{f' (cells shuffled within windows of {args.shuffle}' + (', then RCM' if args.rcm else '') + ')' if args.shuffle else ''}, {args.solver}"
                         f"{'(' + str(args.krylov_dim) + ')' if args.solver == 'GKOGMRES' else ''} + "
                         f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
@@ -461,6 +468,7 @@ def main():
                         + " (BASELINE.json configs[1])",
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
+            "rows_sorted_by_length": s.get_property("rowsSortedByLength") == 1.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
                                          "in_use": s.get_property("gatherSectorRatio")},
             "parallelism": f"rows sharded into {world} z-slab(s), {transport}"

@@ -216,6 +216,23 @@ def renumber_case(case: LduCase, window: int, seed: int = 20241016) -> LduCase:
     return permute_case(case, new_id)
 
 
+def drop_faces_case(case: LduCase, fraction: float, seed: int = 20241016) -> LduCase:
+    """A stand-in for a mesh of mixed cell types: a random `fraction` of the internal faces is removed
+    (row lengths then vary from 1 to 7 on the box) and the diagonal is reduced by the couplings that
+    went, so the matrix stays diagonally dominant.  Single-rank cases only."""
+    assert not case.interfaces
+    rng = np.random.default_rng(seed)
+    keep = rng.random(case.n_faces) >= fraction
+    gone = ~keep
+    diag = case.diag.copy()
+    low = case.upper if case.lower is None else case.lower
+    np.add.at(diag, case.lower_addr[gone], -np.abs(case.upper[gone]))
+    np.add.at(diag, case.upper_addr[gone], -np.abs(low[gone]))
+    return LduCase(case.n_cells, case.lower_addr[keep].copy(), case.upper_addr[keep].copy(), diag,
+                   case.upper[keep].copy(), None if case.lower is None else case.lower[keep].copy(), [],
+                   case.global_index, case.global_n)
+
+
 def rcm_case(case: LduCase) -> LduCase:
     """What OpenFOAM's renumberMesh does: reverse Cuthill-McKee ordering of the cell graph (scipy)."""
     import scipy.sparse as sp
