@@ -527,16 +527,29 @@ void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
         rp[(size_t)k + 1] = rp[(size_t)k] + (p.row_ptrs[r + 1] - p.row_ptrs[r]);
     }
     std::vector<ogl_label> rows((size_t)nnz), cols((size_t)nnz), map((size_t)nnz);
-    for (ogl_label k = 0; k < N; ++k) {
-        const ogl_label r = old_of[(size_t)k];
-        const ogl_label len = p.row_ptrs[r + 1] - p.row_ptrs[r];
-        ogl_label *c = cols.data() + rp[(size_t)k], *m = map.data() + rp[(size_t)k];
-        for (ogl_label i = 0; i < len; ++i) {
-            rows[(size_t)rp[(size_t)k] + i] = k;
-            c[i] = new_id[(size_t)p.cols[(size_t)p.row_ptrs[r] + i]];
-            m[i] = p.ldu_mapping[(size_t)p.row_ptrs[r] + i];
+    auto fill_rows = [&](ogl_label k0, ogl_label k1) {  // new rows [k0, k1): independent of each other
+        for (ogl_label k = k0; k < k1; ++k) {
+            const ogl_label r = old_of[(size_t)k];
+            const ogl_label len = p.row_ptrs[r + 1] - p.row_ptrs[r];
+            ogl_label *c = cols.data() + rp[(size_t)k], *m = map.data() + rp[(size_t)k];
+            for (ogl_label i = 0; i < len; ++i) {
+                rows[(size_t)rp[(size_t)k] + i] = k;
+                c[i] = new_id[(size_t)p.cols[(size_t)p.row_ptrs[r] + i]];
+                m[i] = p.ldu_mapping[(size_t)p.row_ptrs[r] + i];
+            }
+            sort_segment(c, m, len);  // stable: equal columns keep the reference's order
         }
-        sort_segment(c, m, len);  // stable: equal columns keep the reference's order
+    };
+    {
+        const char *e = std::getenv("OGL_STAGE_THREADS");
+        const int n_threads = N < (1 << 18) ? 1 : std::max(1, std::min(16, e ? atoi(e) : 4));
+        const ogl_label part = (N + n_threads - 1) / n_threads;
+        std::vector<std::thread> helpers;
+        for (int t = 1; t < n_threads; ++t)
+            if ((int64_t)t * part < N)
+                helpers.emplace_back(fill_rows, (ogl_label)(t * part), (ogl_label)std::min<int64_t>(N, (int64_t)(t + 1) * part));
+        fill_rows(0, std::min(part, N));
+        for (auto &h : helpers) h.join();
     }
     p.rows.swap(rows);
     p.cols.swap(cols);
@@ -698,16 +711,23 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             width = std::max(width, ww);
         }
         if (width > 65535) return false;  // (a row that long fails the padding rules anyway)
-        // (a) row patterns: one byte per row
+        // (a) row patterns: one byte per row.  Known patterns are found through a small hash table
+        // (an irregular chunk would otherwise compare every row with up to 256 patterns before giving up)
         bool pat_mode = width > 0;
         pats.clear();
         size_t last_pat = 0;
+        constexpr int PAT_HASH = 1024;  // > 2 x 256 patterns, power of two
+        int16_t pat_slot[PAT_HASH];
+        for (int i = 0; i < PAT_HASH; ++i) pat_slot[i] = -1;
         for (ogl_label lr = 0; lr < CHUNK_ROWS && pat_mode; ++lr) {
             const ogl_label r = r0 + lr;
             pat.assign((size_t)width, SELL_PAD_OFFSET);
+            uint32_t hsh = 2166136261u;
             if (r < r1)
-                for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s)
+                for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s) {
                     pat[(size_t)s] = cols[k] - r;
+                    hsh = (hsh ^ (uint32_t)pat[(size_t)s]) * 16777619u;
+                }
             const size_t n_pat = pats.size() / (size_t)width;
             auto same = [&](size_t i) {
                 return std::equal(pat.begin(), pat.end(), pats.begin() + (std::ptrdiff_t)(i * width));
@@ -716,18 +736,18 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             if (n_pat && same(last_pat)) {
                 id = last_pat;
             } else {
-                for (size_t i = 0; i < n_pat; ++i)
-                    if (same(i)) {
-                        id = i;
+                uint32_t slot = (hsh ^ (hsh >> 15)) & (PAT_HASH - 1);
+                while (pat_slot[slot] >= 0 && !same((size_t)pat_slot[slot])) slot = (slot + 1) & (PAT_HASH - 1);
+                if (pat_slot[slot] >= 0) {
+                    id = (size_t)pat_slot[slot];
+                } else {
+                    if (n_pat == 256 || (n_pat + 1) * (size_t)width > (size_t)SELL_TABLE_INTS) {
+                        pat_mode = false;
                         break;
                     }
-            }
-            if (id == n_pat) {
-                if (n_pat == 256 || (n_pat + 1) * (size_t)width > (size_t)SELL_TABLE_INTS) {
-                    pat_mode = false;
-                    break;
+                    pat_slot[slot] = (int16_t)n_pat;
+                    pats.insert(pats.end(), pat.begin(), pat.end());
                 }
-                pats.insert(pats.end(), pat.begin(), pat.end());
             }
             last_pat = id;
             pid[(size_t)lr] = (uint8_t)id;
