@@ -49,6 +49,7 @@ def main():
     from ogl_amd import synthetic          # numpy-only input generator (no device code)
     from oracle import oracle as orc
     orc.build()
+    omp_build = orc.use_native_omp_build()     # the OpenMP legs (probe, CG) may use this host's vector units
 
     def probe():
         """The thread count that moves the most bytes here: affinity masks say nothing about cgroup CPU
@@ -64,7 +65,7 @@ def main():
 
     if args.probe:
         gbps, t = probe()
-        print(json.dumps({"threads": t, "GBps": gbps, "bind": args.bind, "host_cpus": cores}))
+        print(json.dumps({"threads": t, "GBps": gbps, "bind": args.bind, "host_cpus": cores, "build": omp_build}))
         return
 
     case = synthetic.poisson_case(args.edge)
@@ -107,7 +108,7 @@ def main():
     done = res.n_iterations - 1
     out["omp"] = {"value": done / t_loop, "unit": "iter/s", "cores": threads, "kind": "port",
                   "GBps": b_cg * done / t_loop / 1e9, "stream_triad_GBps": triad,
-                  "host_cpus": cores,
+                  "host_cpus": cores, "build": omp_build,
                   "thread_binding": (f"OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} OMP_PLACES="
                                      f"{os.environ['OMP_PLACES']} (set before libgomp loads)") if args.bind
                   else "none (scheduler)",

@@ -87,6 +87,33 @@ def lib(omp=False):
     return _libs[key]
 
 
+def use_native_omp_build():
+    """CPU-baseline leg only: rebuild the OpenMP variant for THIS host's CPU (-march=native) into the
+    temporary directory and use it as lib(True) from now on.  The in-tree liboracle_omp.so is generic
+    x86-64 because it travels between machines; a baseline timed on a host should be allowed that
+    host's vector units.  Returns a description of what is in use."""
+    import tempfile
+    if "liboracle_omp.so" in _libs:
+        return "generic x86-64 build (already loaded)"
+    out = os.path.join(tempfile.gettempdir(), f"liboracle_omp_native_{os.getpid()}.so")
+    cmd = ["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11", "-fopenmp",
+           "-shared", "-o", out, os.path.join(_HERE, "ogl_oracle.c"), "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        native = C.CDLL(out)
+    except (subprocess.CalledProcessError, OSError):
+        return "generic x86-64 build (native build failed)"
+    finally:
+        if os.path.exists(out):
+            os.unlink(out)                      # the mapping stays valid; nothing is left behind
+    generic = _load("liboracle_omp.so")         # restype declarations
+    for f in ("orc_cg_omp_timed", "orc_omp_max_threads"):
+        getattr(native, f).restype = getattr(generic, f).restype
+    native.orc_stream_triad_omp.restype = C.c_double
+    _libs["liboracle_omp.so"] = native
+    return "gcc -O3 -march=native build for this host"
+
+
 def _l(a):
     a = np.ascontiguousarray(a, dtype=label)
     return a, a.ctypes.data_as(_LP)
