@@ -100,29 +100,28 @@ def main():
     else:
         triad, threads = probe()
     # The triad names the thread count that streams best; CG also gathers (latency-bound), where SMT
-    # siblings can hurt.  Try that count, half and a quarter of it on 3 iterations each and keep the
-    # fastest; then size the run to about --seconds of work.
-    trials = {}
-    for t in sorted({threads, max(1, threads // 2), max(1, threads // 4)}, reverse=True):
-        orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=1, threads=t)      # (spawns / wakes the team)
+    # siblings can hurt, and the hosts of this pool are shared (short trials mislead).  So the whole leg
+    # is run for that count and for half of it, each for about half of --seconds, and the faster is kept.
+    runs = {}
+    for t in sorted({threads, max(1, threads // 2)}, reverse=True):
         _, _, t3 = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=3, threads=t)
-        trials[t] = t3
-    threads = min(trials, key=trials.get)
-    t_loop = trials[threads]
-    omp_iters = int(max(3, min(args.iters, args.seconds / max(t_loop / 4.0, 1e-6))))
-    res, t_setup, t_loop = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=omp_iters, threads=threads)
+        its = int(max(3, min(args.iters, 0.5 * args.seconds / max(t3 / 4.0, 1e-6))))
+        runs[t] = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=its, threads=t)
+    threads = max(runs, key=lambda t: (runs[t][0].n_iterations - 1) / runs[t][2])
+    res, t_setup, t_loop = runs[threads]
+    trials = {t: (r[0].n_iterations - 1) / r[2] for t, r in runs.items()}
     if triad is None:
         triad = orc.stream_triad_omp(1 << 26, 3, threads)
     done = res.n_iterations - 1
     out["omp"] = {"value": done / t_loop, "unit": "iter/s", "cores": threads, "kind": "port",
                   "GBps": b_cg * done / t_loop / 1e9, "stream_triad_GBps": triad,
                   "host_cpus": cores, "build": omp_build,
-                  "thread_count_trials_s_per_4_checks": {str(k): v for k, v in trials.items()},
+                  "iters_per_s_by_thread_count": {str(k): v for k, v in trials.items()},
                   "thread_binding": (f"OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} OMP_PLACES="
                                      f"{os.environ['OMP_PLACES']} (set before libgomp loads)") if args.bind
                   else "none (scheduler)",
-                  "sample": f"{done} iterations, OpenMP variant on {threads} threads (fastest of the triad-optimal count, its half "
-                            f"and its quarter; {cores} CPUs), loop {t_loop:.2f} s "
+                  "sample": f"{done} iterations, OpenMP variant on {threads} threads (the faster of the triad-optimal count and its "
+                            f"half; {cores} CPUs), loop {t_loop:.2f} s "
                             f"(first-touch copy of the matrix {t_setup:.2f} s, not counted)"}
     print(json.dumps(out))
 
