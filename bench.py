@@ -131,7 +131,10 @@ def main():
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        # gloo is the control plane only (agreeing on transports, the final MAX over ranks); a rank that dies
+        # must not leave the others waiting for the default 30 minutes
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=8))
 
     def barrier():
         torch.cuda.synchronize()
