@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--drop-faces", type=float, default=0.0,
                     help="remove this fraction of the internal faces at random (row lengths 1..7: a stand-in "
                          "for a mesh of mixed cell types); single rank only")
+    ap.add_argument("--long-rows", type=float, default=0.0,
+                    help="give this fraction of the cells five extra couplings (rows of 12 entries among rows "
+                         "of 7: a stand-in for a hex-dominant mesh); single rank only")
     ap.add_argument("--rcm", action="store_true",
                     help="after --shuffle: renumber the CASE with reverse Cuthill-McKee (scipy), as "
                          "renumberMesh would, before the library sees it")
@@ -150,6 +153,9 @@ def main():
     if args.drop_faces:
         assert world == 1, "--drop-faces is a single-rank option"
         case = synthetic.drop_faces_case(case, args.drop_faces)
+    if args.long_rows:
+        assert world == 1, "--long-rows is a single-rank option"
+        case = synthetic.long_rows_case(case, args.long_rows, n)
     if args.shuffle:
         assert world == 1, "--shuffle is a single-rank option"
         case = synthetic.renumber_case(case, args.shuffle)
@@ -398,6 +404,11 @@ def main():
         spmv_src = (f"{launches} in-loop launches of the timed steps (every "
                     f"{args.profile_stride}th turn), HIP event pairs")
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
+    def prop_or(name, default):
+        try:
+            return s.get_property(name)
+        except capi.OglError:
+            return default
     layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[s.get_property("spmvLayout")]
     renumbered = s.get_property("renumbered") == 1.0
     if world > 1 and s.get_property("peerHalo") == 1.0:
@@ -460,6 +471,7 @@ def main():
             "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix"
                         f"{' (non-symmetric)' if args.asym else ''}"
                         f"{f' ({args.drop_faces:.0%} of the faces removed at random)' if args.drop_faces else ''}"
+                        f"{f' ({args.long_rows:.0%} of the cells with 5 extra couplings)' if args.long_rows else ''}"
                         f"{f' (cells shuffled within windows of {args.shuffle}' + (', then RCM' if args.rcm else '') + ')' if args.shuffle else ''}, {args.solver}"
                         f"{'(' + str(args.krylov_dim) + ')' if args.solver == 'GKOGMRES' else ''} + "
                         f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
@@ -472,6 +484,7 @@ def main():
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
             "rows_sorted_by_length": s.get_property("rowsSortedByLength") == 1.0,
+            "spilled_entries": prop_or("sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
                                          "in_use": s.get_property("gatherSectorRatio")},
             "parallelism": f"rows sharded into {world} z-slab(s), {transport}"

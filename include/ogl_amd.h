@@ -364,7 +364,8 @@ void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,
  * bytes, stats[4] / stats[5] = chunks coded with 16-bit deltas / with plain 32-bit columns (the
  * others use 1-byte pattern or offset codes), stats[6] = value slots the kernel reads (a wavefront
  * runs to the longest of ITS 128 rows; stats[1] counts what is allocated, to the chunk's longest
- * row).  OGL_ERR_STATE if the decoded pattern differs from the input. */
+ * row), stats[7] = entries spilled (tails of rows longer than their chunk's cap, added by a second
+ * small kernel).  OGL_ERR_STATE if the decoded pattern differs from the input. */
 int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                         int64_t stats[8]);
 

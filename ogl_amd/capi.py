@@ -498,6 +498,15 @@ def host_sell_read_slots(row_ptrs, cols):
     return bool(stats[0]), int(stats[1]), int(stats[6])
 
 
+def host_sell_spilled(row_ptrs, cols):
+    """(qualifies, value slots read, entries spilled into the second pass)."""
+    rp, cc = _l(row_ptrs), _l(cols)
+    stats = (C.c_int64 * 8)()
+    _check(lib().ogl_host_sell_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
+                                     cc.ctypes.data_as(C.c_void_p), stats))
+    return bool(stats[0]), int(stats[6]), int(stats[7])
+
+
 def host_adapt_criterion(cfg, prev_solve_iters, prev_rel_cost):
     mi, fr = C.c_int32(), C.c_int32()
     lib().ogl_host_adapt_criterion(C.byref(cfg), C.c_int32(prev_solve_iters),

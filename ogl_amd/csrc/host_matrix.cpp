@@ -578,22 +578,78 @@ void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
     p.old_of = std::move(old_of);
 }
 
-// Value slots the compressed SpMV READS per stored entry when the rows are taken in the order
-// order[0], order[1], ... (order == nullptr: the pattern's own): a wavefront of SELL_WAVE_ROWS rows
-// runs to the longest of its rows, shorter rows idle.  1 = no padding read.
+// Slots a chunk's rows get in the value planes (its "cap"), chosen from the row lengths alone: the cap
+// that minimises  slots read (every wavefront to the longest of its rows, capped) + SELL_SPILL_COST x
+// entries spilled beyond the cap.  Equal to the longest row when lengths are uniform.  lens[n], n <=
+// CHUNK_ROWS, in the order the rows take in the chunk.
+static int32_t sell_chunk_cap_lens(const int32_t *lens, int n, double *cost_out)
+{
+    int32_t hist_max = 0, wave_max[SELL_WAVES] = {}, wave_rows[SELL_WAVES] = {};
+    for (int i = 0; i < n; ++i) {
+        hist_max = std::max(hist_max, lens[i]);
+        wave_max[i / SELL_WAVE_ROWS] = std::max(wave_max[i / SELL_WAVE_ROWS], lens[i]);
+        ++wave_rows[i / SELL_WAVE_ROWS];
+    }
+    std::vector<int64_t> longer((size_t)hist_max + 2, 0);  // longer[w] = sum max(0, len - w)
+    std::vector<int32_t> cnt((size_t)hist_max + 2, 0);
+    for (int i = 0; i < n; ++i) ++cnt[(size_t)lens[i]];
+    int64_t rows_longer = 0;
+    for (int32_t w = hist_max; w >= 0; --w) {  // longer[w] = longer[w + 1] + #rows with len > w
+        longer[(size_t)w] = longer[(size_t)w + 1] + rows_longer;
+        rows_longer += cnt[(size_t)w];
+    }
+    auto cost_of = [&](int32_t w) {
+        double read = 0;
+        for (int wv = 0; wv < SELL_WAVES; ++wv) read += (double)std::min(wave_max[wv], w) * wave_rows[wv];
+        return read + SELL_SPILL_COST * (double)longer[(size_t)w];
+    };
+    const double full = hist_max ? cost_of(hist_max) : 0.0;
+    int32_t best_w = hist_max;
+    double best = full;
+    for (int32_t w = hist_max - 1; w >= 1; --w) {
+        const double cost = cost_of(w);
+        if (cost < best) {
+            best = cost;
+            best_w = w;
+        }
+    }
+    // spilling is for heavy tails (a few long rows among many): a saving below 10 % is not worth the
+    // second pass, the chunk keeps all its entries in the planes
+    if (best > 0.9 * full) {
+        best = full;
+        best_w = hist_max;
+    }
+    if (cost_out) *cost_out = best;
+    return best_w;
+}
+
+static int32_t sell_chunk_cap(const ogl_label *row_ptrs, ogl_label r0, ogl_label r1)
+{
+    int32_t lens[CHUNK_ROWS];
+    for (ogl_label r = r0; r < r1; ++r) lens[r - r0] = row_ptrs[r + 1] - row_ptrs[r];
+    return sell_chunk_cap_lens(lens, (int)(r1 - r0), nullptr);
+}
+
+// Cost of the compressed layout per stored entry when the rows are taken in the order order[0],
+// order[1], ... (order == nullptr: the pattern's own): value slots READ (a wavefront of SELL_WAVE_ROWS
+// rows runs to the longest of its rows, capped at the chunk's cap) + SELL_SPILL_COST x entries spilled
+// beyond the caps, over the stored entries.  1 = no padding read, nothing spilled.
 static double sell_read_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *order)
 {
     if (n_rows <= 0 || row_ptrs[n_rows] == 0) return 1.0;
-    int64_t read = 0;
-    for (ogl_label k0 = 0; k0 < n_rows; k0 += SELL_WAVE_ROWS) {
-        ogl_label w = 0;
-        for (ogl_label k = k0; k < std::min<int64_t>(n_rows, (int64_t)k0 + SELL_WAVE_ROWS); ++k) {
-            const ogl_label r = order ? order[k] : k;
-            w = std::max(w, row_ptrs[r + 1] - row_ptrs[r]);
+    double total = 0;
+    int32_t lens[CHUNK_ROWS];
+    for (ogl_label k0 = 0; k0 < n_rows; k0 += CHUNK_ROWS) {
+        const int n = (int)std::min<int64_t>(CHUNK_ROWS, (int64_t)n_rows - k0);
+        for (int i = 0; i < n; ++i) {
+            const ogl_label r = order ? order[k0 + i] : k0 + i;
+            lens[i] = row_ptrs[r + 1] - row_ptrs[r];
         }
-        read += (int64_t)w * SELL_WAVE_ROWS;
+        double cost = 0;
+        (void)sell_chunk_cap_lens(lens, n, &cost);
+        total += cost;
     }
-    return (double)read / (double)row_ptrs[n_rows];
+    return total / (double)row_ptrs[n_rows];
 }
 
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
@@ -685,7 +741,7 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
 // the chunk's longest row stays below SELL_MAX_PADDING x nnz.
 // ---------------------------------------------------------------------------------------
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
-                       SellLayout &out)
+                       SellLayout &out, bool allow_spill)
 {
     out = SellLayout{};
     const int64_t nc = n_chunks(n_rows);
@@ -701,15 +757,31 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     for (int64_t c = 0; c < nc; ++c) {
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+        // Cap of the chunk: the slots its rows get in the planes.  Entries beyond it (the tails of a
+        // few long rows: split / polyhedral cells of a hex-dominant mesh) are "spilled" into a short
+        // row-sorted list that the chunk's workgroup adds after the planes, continuing every row's sum
+        // in stored order -- so one long row does not make 127 others read padding.
+        const int32_t cap = allow_spill ? sell_chunk_cap(row_ptrs, r0, r1) : INT32_MAX;
+        auto row_end = [&](ogl_label r) { return std::min(row_ptrs[r + 1], row_ptrs[r] + cap); };
         int32_t width = 0, wave_w[SELL_WAVES];
         for (int wv = 0; wv < SELL_WAVES; ++wv) {  // what each wavefront has to run to
             int32_t ww = 0;
             for (ogl_label r = r0 + wv * SELL_WAVE_ROWS; r < std::min<int64_t>(r1, (int64_t)r0 + (wv + 1) * SELL_WAVE_ROWS); ++r)
-                ww = std::max(ww, row_ptrs[r + 1] - row_ptrs[r]);
+                ww = std::max(ww, row_end(r) - row_ptrs[r]);
             wave_w[wv] = ww;
             out.read_slots += (int64_t)ww * SELL_WAVE_ROWS;
             width = std::max(width, ww);
         }
+        out.spill_chunk_ptr.push_back((int32_t)out.spill_rows.size());
+        for (ogl_label r = r0; r < r1; ++r)
+            if (row_end(r) < row_ptrs[r + 1]) {
+                out.spill_rows.push_back(r);
+                out.spill_ptrs.push_back((int32_t)out.spill_cols.size());
+                for (ogl_label k = row_end(r); k < row_ptrs[r + 1]; ++k) {
+                    out.spill_cols.push_back(cols[k]);
+                    out.spill_map.push_back(k);
+                }
+            }
         if (width > 65535) return false;  // (a row that long fails the padding rules anyway)
         // (a) row patterns: one byte per row.  Known patterns are found through a small hash table
         // (an irregular chunk would otherwise compare every row with up to 256 patterns before giving up)
@@ -724,7 +796,7 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             pat.assign((size_t)width, SELL_PAD_OFFSET);
             uint32_t hsh = 2166136261u;
             if (r < r1)
-                for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s) {
+                for (ogl_label k = row_ptrs[r], s = 0; k < row_end(r); ++k, ++s) {
                     pat[(size_t)s] = cols[k] - r;
                     hsh = (hsh ^ (uint32_t)pat[(size_t)s]) * 16777619u;
                 }
@@ -758,7 +830,7 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         if (off8_mode) {
             size_t last = 0;
             for (ogl_label r = r0; r < r1 && off8_mode; ++r)
-                for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                for (ogl_label k = row_ptrs[r]; k < row_end(r); ++k) {
                     const int32_t d = cols[k] - r;
                     if (!ds.empty()) {
                         if (ds[last] == d) continue;
@@ -785,11 +857,11 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         if (d16_mode) {
             int64_t lo = INT64_MAX, hi = INT64_MIN;
             for (ogl_label r = r0; r < r1 && d16_mode; ++r) {
-                if (row_ptrs[r] == row_ptrs[r + 1]) continue;
+                if (row_ptrs[r] == row_end(r)) continue;
                 const int64_t first = (int64_t)cols[row_ptrs[r]] - r;
                 lo = std::min(lo, first);
                 hi = std::max(hi, first);
-                for (ogl_label k = row_ptrs[r] + 1; k < row_ptrs[r + 1]; ++k) {
+                for (ogl_label k = row_ptrs[r] + 1; k < row_end(r); ++k) {
                     const int64_t d = (int64_t)cols[k] - cols[k - 1];
                     if (d < 0 || d > SELL_MAX_DELTA16) d16_mode = false;
                 }
@@ -827,10 +899,14 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         code_len = (code_len + 15) / 16 * 16;
         // padding that is READ (a wavefront runs to its own longest row) must stay below what CSR's
         // indices cost; padding that is only allocated (to the chunk's longest row) is bounded too
-        if ((double)out.read_slots > SELL_MAX_PADDING * (double)nnz + 8.0 * CHUNK_ROWS) return false;
+        if ((double)out.read_slots + SELL_SPILL_COST * (double)out.spill_cols.size() >
+            SELL_MAX_PADDING * (double)nnz + 8.0 * CHUNK_ROWS)
+            return false;
         if ((double)val_len > SELL_MAX_ALLOC * (double)nnz + 8.0 * CHUNK_ROWS) return false;
     }
     out.n_slots = val_len;
+    out.spill_ptrs.push_back((int32_t)out.spill_cols.size());
+    out.spill_chunk_ptr.push_back((int32_t)out.spill_rows.size());
     out.codes.assign((size_t)code_len + 16, (uint8_t)255);
     out.map.assign((size_t)val_len + 2, -1);
     // pass 2: codes and the value map
@@ -851,7 +927,8 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         for (ogl_label r = r0; r < r1; ++r) {
             const int32_t lr = r - r0, t = lr / ROWS_PER_THREAD, which = lr % ROWS_PER_THREAD;
             uint8_t *code = out.codes.data() + h.code_off + (int64_t)t * code_stride;
-            for (ogl_label k = row_ptrs[r], s = 0; k < row_ptrs[r + 1]; ++k, ++s) {
+            const ogl_label k_end = std::min(row_ptrs[r + 1], row_ptrs[r] + h.width());  // (the rest is spilled)
+            for (ogl_label k = row_ptrs[r], s = 0; k < k_end; ++k, ++s) {
                 out.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS + lr)] = k;
                 if (pat_mode) continue;
                 if (d16_mode) {
@@ -1092,7 +1169,8 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                 const int64_t row = (int64_t)c * CHUNK_ROWS + t * ROWS_PER_THREAD + which;
                 const uint8_t *code = L.codes.data() + h.code_off + (int64_t)t * code_stride;
                 ogl_label k = row < n_rows ? row_ptrs[row] : 0;
-                const ogl_label k_end = row < n_rows ? row_ptrs[row + 1] : 0;
+                // the planes hold the first width() entries of a row; the rest is in the spill list
+                const ogl_label k_end = row < n_rows ? std::min(row_ptrs[row + 1], row_ptrs[row] + width) : 0;
                 int64_t run = row + h.dict_off;  // delta16: running column
                 for (int s = 0; s < width; ++s) {
                     const int32_t m = L.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS +
@@ -1134,9 +1212,33 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                 if (k != k_end) return fail(OGL_ERR_STATE, "row %ld lost entries", (long)row);
             }
     }
-    for (ogl_label r = 0; r < n_rows; ++r)
-        if (row_ptrs[r + 1] - row_ptrs[r] > L.chunks[(size_t)(r / CHUNK_ROWS)].wave_width((r % CHUNK_ROWS) / SELL_WAVE_ROWS))
-            return fail(OGL_ERR_STATE, "row %d is longer than its wavefront's width", r);
+    {   // every row is either fully in the planes (within its wavefront's width) or continues in the spill list
+        size_t sp = 0;
+        for (ogl_label r = 0; r < n_rows; ++r) {
+            const SellChunk &h = L.chunks[(size_t)(r / CHUNK_ROWS)];
+            const int len = row_ptrs[r + 1] - row_ptrs[r], cap = h.width();
+            if (std::min(len, cap) > h.wave_width((r % CHUNK_ROWS) / SELL_WAVE_ROWS))
+                return fail(OGL_ERR_STATE, "row %d is longer than its wavefront's width", r);
+            if (len <= cap) continue;
+            if (sp >= L.spill_rows.size() || L.spill_rows[sp] != r ||
+                L.spill_ptrs[sp + 1] - L.spill_ptrs[sp] != len - cap)
+                return fail(OGL_ERR_STATE, "row %d: spill list does not hold its tail", r);
+            for (int i = 0; i < len - cap; ++i)
+                if (L.spill_cols[(size_t)L.spill_ptrs[sp] + i] != cols[row_ptrs[r] + cap + i] ||
+                    L.spill_map[(size_t)L.spill_ptrs[sp] + i] != row_ptrs[r] + cap + i)
+                    return fail(OGL_ERR_STATE, "row %d: spilled entry %d is wrong", r, i);
+            ++sp;
+        }
+        if (sp != L.spill_rows.size()) return fail(OGL_ERR_STATE, "spill list holds rows that do not spill");
+        // the kernel finds a chunk's spilled rows through spill_chunk_ptr
+        if (L.spill_chunk_ptr.size() != L.chunks.size() + 1 || L.spill_chunk_ptr.front() != 0 ||
+            L.spill_chunk_ptr.back() != (int32_t)L.spill_rows.size())
+            return fail(OGL_ERR_STATE, "spill_chunk_ptr does not cover the spill list");
+        for (size_t c = 0; c < L.chunks.size(); ++c)
+            for (int32_t j = L.spill_chunk_ptr[c]; j < L.spill_chunk_ptr[c + 1]; ++j)
+                if (j < 0 || j >= (int32_t)L.spill_rows.size() || L.spill_rows[(size_t)j] / CHUNK_ROWS != (int32_t)c)
+                    return fail(OGL_ERR_STATE, "spill_chunk_ptr: row %d is not in chunk %zu", L.spill_rows[(size_t)j], c);
+    }
     stats[0] = 1;
     stats[1] = L.n_slots;
     stats[2] = (int64_t)L.dict.size();
@@ -1144,6 +1246,7 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
     stats[4] = L.n_delta16;
     stats[5] = L.n_col32;
     stats[6] = L.read_slots;
+    stats[7] = (int64_t)L.spill_cols.size();
     return OGL_OK;
 }
 

@@ -77,9 +77,15 @@ struct SellLayout {
     int64_t n_slots = 0;         // padded value slots
     int64_t n_delta16 = 0, n_col32 = 0;  // chunks coded with 16-bit deltas / plain 32-bit columns
     int64_t read_slots = 0;  // value slots the kernel reads: sum of SellChunk::wave_w x SELL_WAVE_ROWS
+    // spill: the tails of the rows that are longer than their chunk's cap, row-sorted; the workgroup of the
+    // chunk adds them after the planes, continuing every row's sum in stored order
+    std::vector<int32_t> spill_rows, spill_ptrs, spill_cols, spill_map;  // map = position in the CSR values
+    std::vector<int32_t> spill_chunk_ptr;  // [n_chunks + 1] range of spill_rows that belongs to each chunk
 };
+// allow_spill false: every row keeps all its entries in the planes (layouts of matrices whose apply has no
+// second pass, e.g. the ISAI factors)
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
-                       SellLayout &out);
+                       SellLayout &out, bool allow_spill = true);
 
 // ---- renumbering (no reference counterpart: OpenFOAM users run `renumberMesh`; here the backend
 // does it for itself when the numbering it is handed gathers x badly) ----

@@ -979,6 +979,11 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const int *__restrict__ dict,
                                                      const uint8_t *__restrict__ codes,
                                                      const double *__restrict__ vals,
+                                                     const int *__restrict__ spill_chunk_ptr,
+                                                     const int *__restrict__ spill_rows,
+                                                     const int *__restrict__ spill_ptrs,
+                                                     const int *__restrict__ spill_cols,
+                                                     const double *__restrict__ spill_vals,
                                                      const double *__restrict__ x,
                                                      const double *__restrict__ b,
                                                      double *__restrict__ y,
@@ -994,6 +999,18 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
+    // spill (the tails of this chunk's long rows): which row this thread will finish and where its
+    // tail sits -- asked for now, so that the answers arrive while the planes are being worked on
+    int sp0 = 0, sp1 = 0, s_row = 0, s_k0 = 0, s_k1 = 0;
+    if (spill_chunk_ptr) {
+        sp0 = spill_chunk_ptr[chunk];
+        sp1 = spill_chunk_ptr[chunk + 1];
+        if (sp0 + t < sp1) {
+            s_row = spill_rows[sp0 + t];
+            s_k0 = spill_ptrs[sp0 + t];
+            s_k1 = spill_ptrs[sp0 + t + 1];
+        }
+    }
     if (h.mode() <= SELL_MODE_OFFSET8)  // (no table in delta / column mode)
         for (int i = t; i < h.dict_len(); i += BLOCK) stab[i] = dict[h.dict_off + i];
     __syncthreads();
@@ -1167,6 +1184,48 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 }
             }
         }
+    }
+    // spill: the tails of this chunk's long rows (beyond the chunk's cap).  The row sums go through LDS
+    // to the threads that walk the tails -- one row each, entries in stored order, so every row is still
+    // summed left to right -- and back.  Workgroup-uniform branch; chunks without long rows skip it.
+    if (sp1 > sp0) {
+        double *ys = reinterpret_cast<double *>(stab);  // the table is not needed any more
+        __syncthreads();
+        ys[ROWS_PER_THREAD * t] = acc.x;
+        ys[ROWS_PER_THREAD * t + 1] = acc.y;
+        __syncthreads();
+        for (int j = sp0 + t; j < sp1; j += BLOCK) {
+            if (j != sp0 + t) {  // (more than BLOCK long rows in one chunk: the later ones were not prefetched)
+                s_row = spill_rows[j];
+                s_k0 = spill_ptrs[j];
+                s_k1 = spill_ptrs[j + 1];
+            }
+            const int li = s_row - chunk * CHUNK_ROWS;
+            double a = ys[li];
+            constexpr int SB = 4;  // values, columns and x of SB entries in flight; the adds stay in order
+            for (int k0 = s_k0; k0 < s_k1; k0 += SB) {
+                double sv[SB], sx[SB];
+                int sc[SB];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    const int k = min(k0 + i, s_k1 - 1);
+                    sv[i] = spill_vals[k];
+                    sc[i] = spill_cols[k];
+                }
+#pragma unroll
+                for (int i = 0; i < SB; ++i) sx[i] = x[sc[i]];
+#pragma unroll
+                for (int i = 0; i < SB; ++i)
+                    if (k0 + i < s_k1) {
+                        const double p = sv[i] * sx[i];
+                        a = (MODE == SPMV_RESIDUAL) ? a - p : a + p;
+                    }
+            }
+            ys[li] = a;
+        }
+        __syncthreads();
+        acc.x = ys[ROWS_PER_THREAD * t];
+        acc.y = ys[ROWS_PER_THREAD * t + 1];
     }
     st2(y, rp, acc);
     if (NDOT >= 1) {
@@ -1925,8 +1984,8 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
 #define OGL_SELL(MODE, NDOT)                                                                     \
     hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
-                       A.dict, A.codes, A.vals, x, b, y, dots.with, dots.part,      \
-                       dots.part_yy, gate)
+                       A.dict, A.codes, A.vals, A.spill_chunk_ptr, A.spill_rows, A.spill_ptrs,  \
+                       A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
     if (mode == SPMV_RESIDUAL) {
         OGL_SELL(SPMV_RESIDUAL, 0);
     } else if (dots.part && dots.part_yy) {

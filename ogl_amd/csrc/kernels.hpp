@@ -88,6 +88,11 @@ struct DevSell {
     const int32_t *dict = nullptr;      // column - row offsets, ascending per chunk
     const uint8_t *codes = nullptr;     // thread-major: [thread][slot][row of the pair]
     const double *vals = nullptr;
+    // spill (nullptr: none): tails of the rows longer than their chunk's cap, added by the chunk's
+    // workgroup after the planes.  spill_chunk_ptr[c] .. [c + 1] = this chunk's range of spill_rows;
+    // spill_ptrs = their entry ranges in spill_cols / spill_vals
+    const int32_t *spill_chunk_ptr = nullptr, *spill_rows = nullptr, *spill_ptrs = nullptr, *spill_cols = nullptr;
+    const double *spill_vals = nullptr;
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
                       double *y, const SpmvDots &dots, const DevScalars *gate);

@@ -424,6 +424,13 @@ DevSell ogl_solver::sell() const
     S.dict = d_sell_dict.p;
     S.codes = d_sell_codes.p;
     S.vals = d_sell_vals.p;
+    if (n_spill) {
+        S.spill_chunk_ptr = d_spill_chunks.p;
+        S.spill_rows = d_spill_rows.p;
+        S.spill_ptrs = d_spill_ptrs.p;
+        S.spill_cols = d_spill_cols.p;
+        S.spill_vals = d_spill_vals.p;
+    }
     return S;
 }
 
@@ -432,7 +439,7 @@ int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label 
 {
     ready = false;
     SellLayout L;
-    if (n_rows == 0 || !build_sell_layout(n_rows, row_ptrs, cols, L)) return OGL_OK;
+    if (n_rows == 0 || !build_sell_layout(n_rows, row_ptrs, cols, L, /*allow_spill*/ false)) return OGL_OK;
     OGL_TRY(chunks.alloc(L.chunks.size(), st));
     OGL_TRY(dict.alloc(L.dict.size(), st));
     OGL_TRY(codes.alloc(L.codes.size(), st));
@@ -454,6 +461,7 @@ int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
     hipStream_t st = reg->stream;
     SellLayout own;
     SellLayout &L = pre ? *pre : own;
+    n_spill = n_spill_rows = 0;
     const bool ok = pre ? pre_qualifies
                         : (pat.n_rows > 0 &&
                            build_sell_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), own));
@@ -470,13 +478,31 @@ int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
     OGL_TRY(reg->stager.h2d(d_sell_dict.p, L.dict.data(), L.dict.size() * sizeof(int32_t), st));
     OGL_TRY(reg->stager.h2d(d_sell_codes.p, L.codes.data(), L.codes.size(), st));
     OGL_TRY(reg->stager.h2d(d_sell_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
+    // spill: tails of the rows longer than their chunk's cap (row-sorted), added by a second pass
+    n_spill_rows = (int32_t)L.spill_rows.size();
+    n_spill = (int32_t)L.spill_cols.size();
+    if (n_spill) {
+        OGL_TRY(d_spill_rows.alloc(L.spill_rows.size(), st));
+        OGL_TRY(d_spill_ptrs.alloc(L.spill_ptrs.size(), st));
+        OGL_TRY(d_spill_cols.alloc(L.spill_cols.size(), st));
+        OGL_TRY(d_spill_map.alloc(L.spill_map.size() + NNZ_PAD, st));
+        OGL_TRY(d_spill_vals.alloc(L.spill_cols.size() + NNZ_PAD, st));
+        OGL_TRY(d_spill_chunks.alloc(L.spill_chunk_ptr.size(), st));
+        OGL_TRY(reg->stager.h2d(d_spill_rows.p, L.spill_rows.data(), L.spill_rows.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_spill_ptrs.p, L.spill_ptrs.data(), L.spill_ptrs.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_spill_cols.p, L.spill_cols.data(), L.spill_cols.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_spill_map.p, L.spill_map.data(), L.spill_map.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_spill_chunks.p, L.spill_chunk_ptr.data(), L.spill_chunk_ptr.size() * sizeof(int32_t), st));
+    }
+    props["sellSpilledEntries"] = (double)n_spill;
     sell_slots = L.n_slots;
     sell_state = 1;
     // bytes one SpMV reads of this layout (bench.py's moved-bytes model): the value planes and codes
     // up to every wavefront's own width (planes beyond it are allocated, not read), headers, tables
     const double read_frac = L.n_slots ? (double)L.read_slots / (double)L.n_slots : 1.0;
     props["sellMatrixBytes"] = 8.0 * (double)L.read_slots + read_frac * (double)(L.codes.size() - 16) +
-                               (double)(L.chunks.size() * sizeof(SellChunk)) + 4.0 * (double)L.dict.size();
+                               (double)(L.chunks.size() * sizeof(SellChunk)) + 4.0 * (double)L.dict.size() +
+                               16.0 * (double)L.spill_cols.size();  // spilled entries: value + column + their share of row data
     props["sellReadSlots"] = (double)L.read_slots;
     props["sellAllocatedSlots"] = (double)L.n_slots;
     props["sellChunksDelta16"] = (double)L.n_delta16;
@@ -765,6 +791,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         if (sell_state == 1 && sell_values_stale) {
             launch_gather_sell(st, (int32_t)d_sell_chunks.n, d_sell_chunks.p, d_sell_map.p, d_vals.p,
                                d_sell_vals.p);
+            if (n_spill) launch_gather_coeffs(st, n_spill, d_spill_map.p, d_vals.p, d_spill_vals.p);
             sell_values_stale = false;
         }
     }
@@ -1394,7 +1421,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_part0.p, (uintptr_t)d_part1.p, (uintptr_t)s, (uintptr_t)d_history.p,
             (uintptr_t)d_row_ptrs.p, (uintptr_t)d_cols.p, (uintptr_t)d_vals.p,
             (uintptr_t)d_sell_chunks.p, (uintptr_t)d_sell_dict.p, (uintptr_t)d_sell_codes.p,
-            (uintptr_t)d_sell_vals.p, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
+            (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);

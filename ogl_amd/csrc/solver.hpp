@@ -210,6 +210,10 @@ struct ogl_solver {
     ogl::DevBuf<double> d_sell_vals;
     int64_t sell_slots = 0;
     int sell_state = 0;
+    // spill of the compressed copy: tails of the rows longer than their chunk's cap (SellLayout)
+    ogl::DevBuf<int32_t> d_spill_rows, d_spill_ptrs, d_spill_cols, d_spill_map, d_spill_chunks;
+    ogl::DevBuf<double> d_spill_vals;
+    int32_t n_spill_rows = 0, n_spill = 0;   // (d_spill_chunks holds the per-chunk ranges of d_spill_rows)
     bool sell_values_stale = true;
     // `pre` != nullptr: the layout choose_numbering already derived for this pattern
     // (`pre_qualifies` tells whether it is usable)

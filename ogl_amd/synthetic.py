@@ -233,6 +233,32 @@ def drop_faces_case(case: LduCase, fraction: float, seed: int = 20241016) -> Ldu
                    case.global_index, case.global_n)
 
 
+def long_rows_case(case: LduCase, fraction: float, nx: int, seed: int = 20241016) -> LduCase:
+    """A stand-in for a hex-dominant mesh (snappyHexMesh): a random `fraction` of the cells of an nx-wide
+    box gets five extra couplings (offsets 2, nx+1, 2 nx, nx^2+1, nx^2+nx: none of them a stencil leg), so
+    that a few rows have 12 entries among many with 7.  Coefficient -0.25 each, the diagonal grows
+    accordingly.  Single-rank cases only."""
+    assert not case.interfaces
+    rng = np.random.default_rng(seed)
+    n = case.n_cells
+    cells = np.flatnonzero(rng.random(n) < fraction).astype(np.int64)
+    offs = np.array([2, nx + 1, 2 * nx, nx * nx + 1, nx * nx + nx], dtype=np.int64)
+    a = np.repeat(cells, offs.size)
+    b = a + np.tile(offs, cells.size)
+    ok = b < n
+    a, b = a[ok], b[ok]
+    lo = np.concatenate([case.lower_addr.astype(np.int64), a])
+    up = np.concatenate([case.upper_addr.astype(np.int64), b])
+    coef = np.concatenate([case.upper, np.full(a.size, -0.25)])
+    low = None if case.lower is None else np.concatenate([case.lower, np.full(a.size, -0.25)])
+    order = np.lexsort((up, lo))
+    diag = case.diag.copy()
+    np.add.at(diag, a, 0.25)
+    np.add.at(diag, b, 0.25)
+    return LduCase(n, lo[order].astype(np.int32), up[order].astype(np.int32), diag, coef[order],
+                   None if low is None else low[order], [], case.global_index, case.global_n)
+
+
 def rcm_case(case: LduCase) -> LduCase:
     """What OpenFOAM's renumberMesh does: reverse Cuthill-McKee ordering of the cell graph (scipy)."""
     import scipy.sparse as sp

@@ -116,8 +116,9 @@ def test_far_couplings_take_32_bit_columns_in_their_chunk(reg, oracle):
     np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
 
 
-def test_one_long_row_per_chunk_falls_back_to_csr_stream(reg, oracle):
-    # padding to the chunk's longest row would cost more than CSR's indices: the CSR-stream kernel runs
+def test_one_long_row_per_chunk_is_spilled(reg, oracle):
+    # padding every row to the chunk's longest would cost far more than CSR's indices: the chunk keeps 3 slots
+    # per row and the long row's tail is added by the spill pass
     n = 2048
     lower = [r for r in range(n - 1)] + [r for r in range(7, n, 512) for _ in range(2, 200) if r + 199 < n]
     upper = [r + 1 for r in range(n - 1)] + [r + d for r in range(7, n, 512) for d in range(2, 200) if r + 199 < n]
@@ -125,9 +126,39 @@ def test_one_long_row_per_chunk_falls_back_to_csr_stream(reg, oracle):
     lower, upper = np.array(lower, np.int32)[order], np.array(upper, np.int32)[order]
     rng = np.random.default_rng(3)
     case = synthetic.LduCase(n, lower, upper, rng.uniform(300, 400, n), rng.uniform(-1, 1, len(lower)), None)
-    s = reg.solver("sell_longrow", cfg(1)).set_matrix(case)
-    assert s.get_property("spmvLayout") == LAYOUT_CSR
+    s = reg.solver("sell_longrow", cfg(1, renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL and s.get_property("sellSpilledEntries") > 0
     rp, cols, vals = oracle_csr(oracle, case)
+    x = rng.uniform(-1, 1, n)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+    # the fused dot partials of the chunks that hold spilled rows are redone: whole solves stay bit-identical
+    b = oracle.spmv(rp, cols, vals, x)
+    A, _ = oracle_matrix(oracle, case)
+    for solver, fn in ((capi.SOLVER_CG, oracle.cg), (capi.SOLVER_BICGSTAB, oracle.bicgstab)):
+        sv = reg.solver(f"sell_longrow_{solver}", cfg(1, solver=solver, renumber=capi.RENUMBER_OFF, max_iter=60)).set_matrix(case)
+        xs, perf = sv.solve(b, np.zeros_like(b))
+        with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+            ref = fn(A, b, np.zeros_like(b), oracle.jacobi_generate_scalar(rp, cols, vals), tolerance=1e-11,
+                     rel_tol=0.0, max_iter=60)
+        np.testing.assert_array_equal(sv.history(), ref.history)
+        np.testing.assert_array_equal(xs, ref.x)
+
+
+def test_alternating_short_and_long_rows_fall_back_to_csr_stream(reg, oracle):
+    # rows of 2 and 10 entries alternate: half of the rows are long, no cap helps and the padding would cost
+    # more than CSR's indices; with `renumber off` nothing is sorted either -> the CSR-stream kernel runs
+    n = 4096
+    lower = [r for r in range(0, n - 8, 2) for d in range(1, 9)]
+    upper = [r + d for r in range(0, n - 8, 2) for d in range(1, 9)]
+    lower, upper = np.array(lower, np.int32), np.array(upper, np.int32)
+    keep = (upper % 2 == 1)                      # even rows couple to odd rows only: odd rows stay short-ish
+    lower, upper = lower[keep], upper[keep]
+    rng = np.random.default_rng(3)
+    case = synthetic.LduCase(n, lower, upper, rng.uniform(30, 40, n), rng.uniform(-1, 1, len(lower)), None)
+    s = reg.solver("sell_altrows", cfg(1, renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    rp, cols, vals = oracle_csr(oracle, case)
+    if not capi.host_sell_check(rp, cols)[0]:
+        assert s.get_property("spmvLayout") == LAYOUT_CSR
     x = rng.uniform(-1, 1, n)
     np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
 

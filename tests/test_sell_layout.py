@@ -118,15 +118,46 @@ def test_unsorted_rows_take_32_bit_columns():
     assert capi.host_sell_modes(rp, cols) == (True, 1, 1)
 
 
-def test_one_long_row_per_chunk_is_too_much_padding():
-    # tridiagonal matrix + a 200-wide row in every chunk: padded slots ~ 200/3 x nnz
-    n = 2048
+def test_one_long_row_per_chunk_is_spilled():
+    # tridiagonal matrix + a 200-wide row in every chunk: padding every row to 200 slots is out of the
+    # question; the chunk keeps 3 slots per row and the long row's tail (198 entries) goes to the spill list
+    n = 8192
     rows = []
     for r in range(n):
         c = {max(r - 1, 0), r, min(r + 1, n - 1)}
         if r % CHUNK == 7:
             c |= set(range(r, min(n, r + 200)))
         rows.append(np.array(sorted(c)))
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    cols = np.concatenate(rows).astype(np.int32)
+    ok, read, spilled = capi.host_sell_spilled(rp, cols)
+    assert ok and read == 3 * n and spilled == (n // CHUNK) * 198      # 201 entries, 3 stay in the planes
+    assert capi.host_sell_check(rp, cols)[1] == 3 * n          # allocated = 3 planes per chunk
+
+
+def test_a_few_long_rows_among_many_are_spilled_not_padded():
+    # hex-dominant mesh stand-in: 7 entries per row, 3 % of the rows have 12: without the spill every
+    # wavefront would run to 12 slots (1.7 x the entries)
+    rng = np.random.default_rng(12)
+    n = 16 * CHUNK
+    rows = []
+    for r in range(n):
+        k = 12 if rng.random() < 0.03 else 7
+        c = np.unique(np.clip(r + np.arange(-(k // 2), k - k // 2) * 3, 0, n - 1))
+        rows.append(c)
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    cols = np.concatenate(rows).astype(np.int32)
+    nnz = int(rp[-1])
+    ok, read, spilled = capi.host_sell_spilled(rp, cols)
+    assert ok and 0 < spilled < 0.03 * nnz and read + 4 * spilled < 1.1 * nnz
+
+
+def test_alternating_short_and_long_rows_are_too_much_padding():
+    # rows of 1 and 9 entries alternate: no cap helps (half of the rows are long), the padding to 9 slots
+    # costs more than CSR's indices -> the layout does not qualify (the CSR-stream kernel runs; with
+    # `renumber` the rows of a chunk would be sorted by length instead)
+    n = 4096
+    rows = [np.array([r]) if r % 2 else np.unique(np.clip(r + np.arange(-4, 5), 0, n - 1)) for r in range(n)]
     rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
     cols = np.concatenate(rows).astype(np.int32)
     assert capi.host_sell_check(rp, cols)[0] is False
