@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--long-rows", type=float, default=0.0,
                     help="give this fraction of the cells five extra couplings (rows of 12 entries among rows "
                          "of 7: a stand-in for a hex-dominant mesh); single rank only")
+    ap.add_argument("--voronoi", type=int, default=0,
+                    help="instead of the box: the Voronoi cells of this many random points (a polyhedral mesh, "
+                         "15.5 faces per cell on average, random numbering); single rank only; scipy Delaunay "
+                         "takes about a minute per million points")
     ap.add_argument("--rcm", action="store_true",
                     help="after --shuffle: renumber the CASE with reverse Cuthill-McKee (scipy), as "
                          "renumberMesh would, before the library sees it")
@@ -150,6 +154,9 @@ def main():
                                        off_upper=-0.9, off_lower=-1.1)
     else:
         case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
+    if args.voronoi:
+        assert world == 1, "--voronoi is a single-rank option"
+        case = synthetic.voronoi_case(args.voronoi)
     if args.drop_faces:
         assert world == 1, "--drop-faces is a single-rank option"
         case = synthetic.drop_faces_case(case, args.drop_faces)
@@ -468,22 +475,23 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"{n}^3-per-GPU 7-pt Poisson lduMatrix"
+            "workload": (f"Voronoi mesh of {args.voronoi} random points (polyhedral cells, random numbering) lduMatrix"
+                         if args.voronoi else f"{n}^3-per-GPU 7-pt Poisson lduMatrix") +
                         f"{' (non-symmetric)' if args.asym else ''}"
                         f"{f' ({args.drop_faces:.0%} of the faces removed at random)' if args.drop_faces else ''}"
                         f"{f' ({args.long_rows:.0%} of the cells with 5 extra couplings)' if args.long_rows else ''}"
                         f"{f' (cells shuffled within windows of {args.shuffle}' + (', then RCM' if args.rcm else '') + ')' if args.shuffle else ''}, {args.solver}"
                         f"{'(' + str(args.krylov_dim) + ')' if args.solver == 'GKOGMRES' else ''} + "
                         f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
-                        + {"sell": "fp64 SpMV on the index-compressed SELL copy (1-byte column codes) of the "
-                                   "persistent fp64/int32 device CSR",
+                        + {"sell": "fp64 SpMV on the index-compressed SELL copy (1-byte / 16-bit column codes) of "
+                                   "the persistent fp64/int32 device CSR",
                            "csr": "fp64/int32 persistent device CSR (CSR-stream SpMV)",
                            "ell": "fp64/int32 ELL copy of the persistent device CSR"}[layout]
                         + (", device copy renumbered by the library (RCM)" if renumbered else "")
-                        + " (BASELINE.json configs[1])",
+                        + (" (BASELINE.json configs[1])" if not (args.voronoi or args.shuffle or args.drop_faces
+                                                                or args.long_rows) else " (proxy of an unstructured mesh)"),
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
-            "rows_sorted_by_length": s.get_property("rowsSortedByLength") == 1.0,
             "spilled_entries": prop_or("sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
                                          "in_use": s.get_property("gatherSectorRatio")},

@@ -114,7 +114,8 @@ constexpr int SELL_MAX_DICT = 255;        // offset mode: code 255 marks a paddi
 constexpr int SELL_TABLE_INTS = 2048;     // LDS table of the SpMV kernel (8 KB)
 constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of a pattern
 constexpr int RENUMBER_AUTO_MIN_ROWS = 16384;  // config renumber = auto: smaller systems keep their numbering
-constexpr double SELL_MAX_PADDING = 1.25;  // value slots READ / nnz above which CSR moves fewer bytes
+constexpr double SELL_MAX_PADDING = 1.15;  // (value slots READ + 4 x spilled) / nnz above which the
+                                           // CSR-stream kernel is at least as fast (12 B per entry, no padding)
 constexpr double SELL_SPILL_COST = 4.0;     // cost of one spilled entry in units of one plane slot read
 constexpr double SELL_MAX_ALLOC = 4.0;     // value slots ALLOCATED / nnz (planes no wavefront reads)
 

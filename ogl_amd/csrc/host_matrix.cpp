@@ -630,28 +630,6 @@ static int32_t sell_chunk_cap(const ogl_label *row_ptrs, ogl_label r0, ogl_label
     return sell_chunk_cap_lens(lens, (int)(r1 - r0), nullptr);
 }
 
-// Cost of the compressed layout per stored entry when the rows are taken in the order order[0],
-// order[1], ... (order == nullptr: the pattern's own): value slots READ (a wavefront of SELL_WAVE_ROWS
-// rows runs to the longest of its rows, capped at the chunk's cap) + SELL_SPILL_COST x entries spilled
-// beyond the caps, over the stored entries.  1 = no padding read, nothing spilled.
-static double sell_read_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *order)
-{
-    if (n_rows <= 0 || row_ptrs[n_rows] == 0) return 1.0;
-    double total = 0;
-    int32_t lens[CHUNK_ROWS];
-    for (ogl_label k0 = 0; k0 < n_rows; k0 += CHUNK_ROWS) {
-        const int n = (int)std::min<int64_t>(CHUNK_ROWS, (int64_t)n_rows - k0);
-        for (int i = 0; i < n; ++i) {
-            const ogl_label r = order ? order[k0 + i] : k0 + i;
-            lens[i] = row_ptrs[r + 1] - row_ptrs[r];
-        }
-        double cost = 0;
-        (void)sell_chunk_cap_lens(lens, n, &cost);
-        total += cost;
-    }
-    return total / (double)row_ptrs[n_rows];
-}
-
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
                      RenumberReport &rep)
 {
@@ -697,26 +675,6 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
             new_id.swap(cand);
             old_of.swap(cand_old);
             rep.ratio_used = r;
-        }
-    }
-    // ---- step 2 (compressed layout only): inside every chunk of CHUNK_ROWS rows, longest rows first,
-    // so that the rows a wavefront runs together have (nearly) the same length and the padding to the
-    // chunk's longest row is never read.  Matters for meshes with mixed cell types; a no-op on hex meshes.
-    if (try_sell) {
-        const double before = sell_read_ratio(N, p.row_ptrs.data(), old_of.empty() ? nullptr : old_of.data());
-        if (before > 1.10) {
-            std::vector<ogl_label> order((size_t)N);
-            for (ogl_label k = 0; k < N; ++k) order[(size_t)k] = old_of.empty() ? k : old_of[(size_t)k];
-            auto len = [&](ogl_label r) { return p.row_ptrs[r + 1] - p.row_ptrs[r]; };
-            for (ogl_label k0 = 0; k0 < N; k0 += CHUNK_ROWS)
-                std::stable_sort(order.begin() + k0, order.begin() + std::min<int64_t>(N, (int64_t)k0 + CHUNK_ROWS),
-                                 [&](ogl_label a, ogl_label b) { return len(a) > len(b); });
-            const double after = sell_read_ratio(N, p.row_ptrs.data(), order.data());
-            if (after <= 0.95 * before) {
-                new_id.assign((size_t)N, 0);
-                for (ogl_label k = 0; k < N; ++k) new_id[(size_t)order[(size_t)k]] = k;
-                rep.sorted_by_length = true;
-            }
         }
     }
     if (new_id.empty()) {  // the caller's numbering stays

@@ -108,13 +108,12 @@ struct RenumberReport {
     bool applied = false;
     bool sell_natural = false, sell_used = false;  // compressed layout qualifies (only when tried)
     double ratio_natural = 0.0, ratio_used = 0.0;  // gather_sector_ratio before / after
-    bool sorted_by_length = false;  // rows of a chunk reordered longest first (compressed layout)
 };
 // mode 0: keep the caller's numbering; 1: always RCM; 2 (default, "auto"): keep it when the
 // compressed layout qualifies with 1-byte codes throughout (structured mesh); otherwise RCM when the
-// gather coalesces badly (ratio > 0.25) and RCM cuts the sector ratio by >= 10 %.  With the
-// compressed layout in play (try_sell), modes 1 and 2 also put the rows of every chunk of CHUNK_ROWS
-// rows longest first when that cuts the padding the SpMV would read by >= 5 % (mixed cell types).
+// gather coalesces badly (ratio > 0.25) and RCM cuts the sector ratio by >= 10 %.  (Sorting the rows of a
+// chunk by length to save padding was tried and dropped: it scatters the gather inside the chunk and was
+// never faster than the CSR-stream kernel on the same rows, profiles/r02_unstructured_proxy.txt.)
 // `sell_out` (may be null) receives the compressed layout of the numbering that was chosen when
 // one was built on the way (sell_built tells), so the caller does not derive it twice.
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,

@@ -684,7 +684,6 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         props["renumbered"] = rep.applied ? 1.0 : 0.0;
         props["gatherSectorRatioNatural"] = rep.ratio_natural;
         props["gatherSectorRatio"] = rep.ratio_used;
-        props["rowsSortedByLength"] = rep.sorted_by_length ? 1.0 : 0.0;
         pat = std::move(np);
         have_pattern = true;
         static std::atomic<uint64_t> pattern_counter{0};  // registries may live on different threads

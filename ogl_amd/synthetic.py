@@ -259,6 +259,36 @@ def long_rows_case(case: LduCase, fraction: float, nx: int, seed: int = 20241016
                    None if low is None else low[order], [], case.global_index, case.global_n)
 
 
+def voronoi_case(n_points: int, seed: int = 20241016) -> LduCase:
+    """A genuinely unstructured finite-volume pattern: the cells are the Voronoi cells of `n_points`
+    random points in the unit cube, two cells share a face when their points share a Delaunay edge
+    (scipy.spatial.Delaunay) -- a polyhedral mesh with 15.5 faces per cell on average (5 ... ~60), numbered
+    in the random order of the points.  upper = -1, diag = #faces + delta.  Single-rank cases only.
+    The triangulation takes ~1 min per million points: with OGL_CASE_CACHE_DIR set the addressing is kept
+    there between calls (profiling scripts run the same case several times)."""
+    import os
+    cache = os.environ.get("OGL_CASE_CACHE_DIR")
+    path = os.path.join(cache, f"voronoi_{n_points}_{seed}.npz") if cache else None
+    if path and os.path.exists(path):
+        z = np.load(path)
+        lo, up, n_faces = z["lo"], z["up"], z["n_faces"]
+    else:
+        from scipy.spatial import Delaunay
+        rng = np.random.default_rng(seed)
+        tri = Delaunay(rng.random((n_points, 3)))
+        indptr, indices = tri.vertex_neighbor_vertices
+        own = np.repeat(np.arange(n_points, dtype=np.int64), np.diff(indptr))
+        keep = own < indices                                 # every face once, owner < neighbour
+        lo, up = own[keep], indices[keep].astype(np.int64)
+        order = np.lexsort((up, lo))
+        lo, up, n_faces = lo[order].astype(np.int32), up[order].astype(np.int32), np.diff(indptr)
+        if path:
+            np.savez(path, lo=lo, up=up, n_faces=n_faces)
+    gi = np.arange(n_points, dtype=np.int64)
+    diag = n_faces.astype(np.float64) + _delta(gi)
+    return LduCase(n_points, lo, up, diag, np.full(lo.size, -1.0), None, [], gi, n_points)
+
+
 def rcm_case(case: LduCase) -> LduCase:
     """What OpenFOAM's renumberMesh does: reverse Cuthill-McKee ordering of the cell graph (scipy)."""
     import scipy.sparse as sp

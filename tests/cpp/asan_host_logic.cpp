@@ -95,7 +95,7 @@ static void run_case(int nx, int ny, int nz, bool symmetric, bool with_interface
     int64_t stats[8];
     CHECK(ogl_host_sell_check(N, rp.data(), cols.data(), stats) == OGL_OK);
     CHECK(stats[0] == 1 && stats[1] >= d.local_nnz);
-    // renumbering: forced (RCM + length sort) and auto; the outputs must be a permutation and a sorted pattern
+    // renumbering: forced (RCM) and auto; the outputs must be a permutation and a sorted pattern
     for (int mode = 1; mode <= 2; ++mode) {
         std::vector<ogl_label> new_id(N + 1, -1), rr(d.local_nnz), cc(d.local_nnz), mm(d.local_nnz);
         ogl_matrix_dims d2{};

@@ -119,19 +119,19 @@ def test_unsorted_rows_take_32_bit_columns():
 
 
 def test_one_long_row_per_chunk_is_spilled():
-    # tridiagonal matrix + a 200-wide row in every chunk: padding every row to 200 slots is out of the
-    # question; the chunk keeps 3 slots per row and the long row's tail (198 entries) goes to the spill list
+    # tridiagonal matrix + a 100-wide row in every chunk: padding every row to 100 slots is out of the
+    # question; the chunk keeps 3 slots per row and the long row's tail (98 entries) goes to the spill list
     n = 8192
     rows = []
     for r in range(n):
         c = {max(r - 1, 0), r, min(r + 1, n - 1)}
         if r % CHUNK == 7:
-            c |= set(range(r, min(n, r + 200)))
+            c |= set(range(r, min(n, r + 100)))
         rows.append(np.array(sorted(c)))
     rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
     cols = np.concatenate(rows).astype(np.int32)
     ok, read, spilled = capi.host_sell_spilled(rp, cols)
-    assert ok and read == 3 * n and spilled == (n // CHUNK) * 198      # 201 entries, 3 stay in the planes
+    assert ok and read == 3 * n and spilled == (n // CHUNK) * 98      # 101 entries, 3 stay in the planes
     assert capi.host_sell_check(rp, cols)[1] == 3 * n          # allocated = 3 planes per chunk
 
 
@@ -154,8 +154,7 @@ def test_a_few_long_rows_among_many_are_spilled_not_padded():
 
 def test_alternating_short_and_long_rows_are_too_much_padding():
     # rows of 1 and 9 entries alternate: no cap helps (half of the rows are long), the padding to 9 slots
-    # costs more than CSR's indices -> the layout does not qualify (the CSR-stream kernel runs; with
-    # `renumber` the rows of a chunk would be sorted by length instead)
+    # costs more than CSR's indices -> the layout does not qualify (the CSR-stream kernel runs)
     n = 4096
     rows = [np.array([r]) if r % 2 else np.unique(np.clip(r + np.arange(-4, 5), 0, n - 1)) for r in range(n)]
     rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)

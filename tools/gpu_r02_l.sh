@@ -14,5 +14,5 @@ for f in sorted(glob.glob("gpurun_out/r02l_*.json")):
         print(f, "unreadable", e); continue
     r=d["roofline"]; c=d["config"]
     print("%-30s %7.1f it/s layout=%-4s renumbered=%-5s sorted=%-5s spilled=%8d spmv %6.1f us frac %.3f moved_frac %.3f nnz %d" % (
-        f.split("/")[-1][5:-5], d["value"], r["layout"], c["renumbered"], c["rows_sorted_by_length"], c["spilled_entries"], 1e3*r["avg_kernel_ms"], r["frac"], r["moved_frac"], c["nnz_per_gpu"]))
+        f.split("/")[-1][5:-5], d["value"], r["layout"], c["renumbered"], c.get("rows_sorted_by_length"), c["spilled_entries"], 1e3*r["avg_kernel_ms"], r["frac"], r["moved_frac"], c["nnz_per_gpu"]))
 PY
