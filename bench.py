@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--asym", action="store_true", help="non-symmetric coefficients (momentum-like)")
     ap.add_argument("--format", default="Csr", choices=["Csr", "Ell"],
                     help="matrixFormat (Csr = the headline; Ell = configs[4]'s comparison)")
+    ap.add_argument("--force-compress", action="store_true",
+                    help="compressIndices force: the compressed layout without the one-off timing against the "
+                         "CSR-stream kernel that decides for irregular patterns")
     ap.add_argument("--no-compress", action="store_true",
                     help="compressIndices false: SpMV on the plain CSR arrays (CSR-stream kernel)")
     ap.add_argument("--shuffle", type=int, default=0,
@@ -182,7 +185,7 @@ def main():
                               eval_frequency=1, adapt_min_iter=0,
                               matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
                               export_res=0, profile_kernels=0 if args.no_profile else args.profile_stride,
-                              compress_indices=0 if args.no_compress else 1,
+                              compress_indices=0 if args.no_compress else (2 if args.force_compress else 1),
                               renumber={"off": 0, "on": 1, "auto": 2}[args.renumber])
 
     def all_ok(ok):
@@ -492,6 +495,10 @@ def main():
                                                                 or args.long_rows) else " (proxy of an unstructured mesh)"),
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
+            "rows_sorted_by_length": prop_or("rowsSortedByLength", 0.0) == 1.0,
+            # irregular patterns: both SpMV kernels timed once per pattern at set_matrix, the faster one runs
+            "layout_tuned_us": ({"csr": prop_or("spmvTunedCsrUs", None), "sell": prop_or("spmvTunedSellUs", None)}
+                                if prop_or("spmvTunedCsrUs", None) is not None else None),
             "spilled_entries": prop_or("sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
                                          "in_use": s.get_property("gatherSectorRatio")},

@@ -93,8 +93,10 @@ typedef struct ogl_config {
                                    (bench.py roofline leg)                                         */
     int32_t compress_indices;   /* 1; Coo/Csr formats: run the SpMV on the index-compressed chunked
                                    ELL copy of the matrix when the pattern qualifies (same bits in
-                                   y; 8.1-9 instead of 12 bytes per entry). NOT a reference keyword:
-                                   "compressIndices"                                               */
+                                   y; 8.1-10 instead of 12 bytes per entry).  0 off; 1 on -- for an
+                                   irregular pattern (unstructured mesh) both kernels are timed once
+                                   per pattern and the faster one runs; 2 on without that measurement.
+                                   NOT a reference keyword: "compressIndices" (false | true | force) */
     int32_t renumber;           /* 2; 0 off, 1 on, 2 auto.  The device matrix, b and x live in a
                                    bandwidth-reducing (reverse Cuthill-McKee) numbering of the cells,
                                    computed once per sparsity pattern -- what `renumberMesh` does for

@@ -74,12 +74,14 @@ enum SellMode : int { SELL_MODE_PATTERN = 0, SELL_MODE_OFFSET8 = 1, SELL_MODE_DE
 struct SellChunk {  // 32 bytes of 32/64-bit words: the whole header arrives by scalar loads (a 16-bit
                     // member would cost a vector load and a full memory round trip in the prologue)
     int64_t val_off;      // first value of the chunk (doubles); planes of CHUNK_ROWS, width() of them
-    int64_t code_off;     // first code byte of the chunk
+    int64_t code_off;     // first code byte of the chunk (the row lengths sit at code_off - SELL_LEN_BYTES)
     int32_t dict_off;     // first table entry of the chunk (delta mode: the base of the first codes)
     uint32_t mode_len;    // SellMode | table ints << 16 (pattern mode: patterns x width; offset mode:
                           // <= SELL_MAX_DICT)
     // slots each wavefront (SELL_WAVE_ROWS rows) runs to = its own longest row; the planes beyond,
-    // up to the chunk's longest row, are allocated but never read
+    // up to the chunk's longest row, are allocated but never read.  Within a wavefront every lane loads
+    // up to the longer of ITS two rows only (lengths: SELL_LEN_BYTES in front of the codes; not in
+    // pattern mode, where the rows of a chunk are (nearly) equally long)
     uint32_t w01, w23;    // wavefront 0 | wavefront 1 << 16,  wavefront 2 | wavefront 3 << 16
     OGL_HD int mode() const { return (int)(mode_len & 0xffffu); }
     OGL_HD int dict_len() const { return (int)(mode_len >> 16); }
@@ -113,8 +115,23 @@ constexpr int SELL_MAX_DELTA16 = 65534;                // 0xFFFF marks a padding
 constexpr int SELL_MAX_DICT = 255;        // offset mode: code 255 marks a padding slot
 constexpr int SELL_TABLE_INTS = 2048;     // LDS table of the SpMV kernel (8 KB)
 constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of a pattern
+constexpr int SPMV_TUNE_MIN_ROWS = 65536;     // smaller systems: launch-bound, the compressed layout stays
 constexpr int RENUMBER_AUTO_MIN_ROWS = 16384;  // config renumber = auto: smaller systems keep their numbering
-constexpr double SELL_MAX_PADDING = 1.15;  // (value slots READ + 4 x spilled) / nnz above which the
+// Padding is laid out but not read: every lane stops loading at the longer of its two rows (the row
+// lengths of the chunk, one byte each, sit in front of its codes -- SELL_LEN_BYTES), so a padded slot
+// costs HBM traffic only where it shares a 128-byte line (SELL_LINE_ROWS rows of a plane) with a slot in
+// use, plus the instruction issue of the wavefront that runs to its longest row.  With `renumber` the
+// rows of a wavefront are put longest first (host_matrix.cpp, choose_numbering), which keeps the lines in
+// use dense; the gather does not change (a wavefront still works on the same SELL_WAVE_ROWS rows).
+constexpr int SELL_LEN_BYTES = CHUNK_ROWS;  // row lengths in the planes, bytes, in front of the chunk's codes
+constexpr int SELL_MAX_WIDTH = 255;         // (so that a length fits a byte; longer rows spill)
+constexpr int SELL_LINE_ROWS = 16;          // rows of a plane in one 128-byte line
+constexpr double SELL_SORT_MAX_SLOT_RATIO = 0.55;  // slot-major gather sectors per entry above which the rows
+                                                 // are not sorted for the compressed layout (measured: a
+                                                 // Voronoi mesh, 0.66, is faster on CSR-stream; mixed row
+                                                 // lengths on a hex mesh, 0.44, on the compressed layout)
+constexpr double SELL_ISSUE_COST = 0.1;     // a slot a wavefront steps over without loading, in units of a slot read
+constexpr double SELL_MAX_PADDING = 1.15;  // (value slots in lines READ + 4 x spilled) / nnz above which the
                                            // CSR-stream kernel is at least as fast (12 B per entry, no padding)
 constexpr double SELL_SPILL_COST = 4.0;     // cost of one spilled entry in units of one plane slot read
 constexpr double SELL_MAX_ALLOC = 4.0;     // value slots ALLOCATED / nnz (planes no wavefront reads)

@@ -515,6 +515,43 @@ double gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const og
     return entries ? (double)sectors / (double)entries : 0.0;
 }
 
+// The same for the compressed layout's kernel, whose gather is slot-major: one instruction fetches the
+// s-th entry of the 64 even (or odd) rows of a wavefront's SELL_WAVE_ROWS rows.  0.25 on a hex mesh in
+// natural order (the s-th neighbours of consecutive rows are consecutive cells), towards 1 where the s-th
+// neighbours of neighbouring rows have nothing to do with each other (polyhedral meshes: there the
+// CSR-stream kernel's row-major gather touches fewer lines, gather_sector_ratio above).
+double slot_gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                                const ogl_label *new_id, const ogl_label *old_of)
+{
+    if (n_rows <= 0 || row_ptrs[n_rows] == 0) return 0.0;
+    const int64_t n_waves = (n_rows + SELL_WAVE_ROWS - 1) / SELL_WAVE_ROWS;
+    const int64_t n_samples = std::min<int64_t>(1024, n_waves);
+    const double step = (double)n_waves / (double)n_samples;
+    std::vector<ogl_label> sect;
+    sect.reserve(WAVE);
+    int64_t entries = 0, sectors = 0;
+    for (int64_t smp = 0; smp < n_samples; ++smp) {
+        const ogl_label k0 = (ogl_label)((int64_t)((double)smp * step) * SELL_WAVE_ROWS);
+        const ogl_label k1 = (ogl_label)std::min<int64_t>(n_rows, (int64_t)k0 + SELL_WAVE_ROWS);
+        for (int which = 0; which < ROWS_PER_THREAD; ++which)
+            for (ogl_label s = 0;; ++s) {
+                sect.clear();
+                for (ogl_label k = k0 + which; k < k1; k += ROWS_PER_THREAD) {
+                    const ogl_label r = old_of ? old_of[k] : k;
+                    if (row_ptrs[r] + s < row_ptrs[r + 1]) {
+                        const ogl_label c = cols[row_ptrs[r] + s];
+                        sect.push_back((new_id ? new_id[c] : c) >> 3);
+                    }
+                }
+                if (sect.empty()) break;
+                std::sort(sect.begin(), sect.end());
+                sectors += std::unique(sect.begin(), sect.end()) - sect.begin();
+                entries += (int64_t)sect.size();
+            }
+    }
+    return entries ? (double)sectors / (double)entries : 0.0;
+}
+
 void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
 {
     const ogl_label N = p.n_rows;
@@ -579,16 +616,30 @@ void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
 }
 
 // Slots a chunk's rows get in the value planes (its "cap"), chosen from the row lengths alone: the cap
-// that minimises  slots read (every wavefront to the longest of its rows, capped) + SELL_SPILL_COST x
-// entries spilled beyond the cap.  Equal to the longest row when lengths are uniform.  lens[n], n <=
-// CHUNK_ROWS, in the order the rows take in the chunk.
-static int32_t sell_chunk_cap_lens(const int32_t *lens, int n, double *cost_out)
+// that minimises  slots in the 128-byte lines the kernel reads (a lane loads up to the longer of its two
+// rows; a line of SELL_LINE_ROWS rows is fetched when one of them is that long) + SELL_ISSUE_COST x slots
+// the wavefronts step over (each runs to its own longest row) + SELL_SPILL_COST x entries spilled beyond
+// the cap.  Equal to the longest row when lengths are uniform.  lens[n], n <= CHUNK_ROWS, in the order
+// the rows take in the chunk.  touched_out: the first term at the chosen cap.
+static int32_t sell_chunk_cap_lens(const int32_t *lens, int n, bool allow_spill, double *cost_out,
+                                   int64_t *touched_out)
 {
-    int32_t hist_max = 0, wave_max[SELL_WAVES] = {}, wave_rows[SELL_WAVES] = {};
+    constexpr int N_LINES = CHUNK_ROWS / SELL_LINE_ROWS;
+    int32_t hist_max = 0, wave_max[SELL_WAVES] = {}, line_max[N_LINES] = {};
     for (int i = 0; i < n; ++i) {
         hist_max = std::max(hist_max, lens[i]);
         wave_max[i / SELL_WAVE_ROWS] = std::max(wave_max[i / SELL_WAVE_ROWS], lens[i]);
-        ++wave_rows[i / SELL_WAVE_ROWS];
+        line_max[i / SELL_LINE_ROWS] = std::max(line_max[i / SELL_LINE_ROWS], lens[i]);
+    }
+    auto touched_of = [&](int32_t w) {
+        int64_t t = 0;
+        for (int l = 0; l < N_LINES; ++l) t += (int64_t)std::min(line_max[l], w) * SELL_LINE_ROWS;
+        return t;
+    };
+    if (!allow_spill) {  // (the caller refuses rows beyond SELL_MAX_WIDTH)
+        if (touched_out) *touched_out = touched_of(hist_max);
+        if (cost_out) *cost_out = (double)touched_of(hist_max);
+        return hist_max;
     }
     std::vector<int64_t> longer((size_t)hist_max + 2, 0);  // longer[w] = sum max(0, len - w)
     std::vector<int32_t> cnt((size_t)hist_max + 2, 0);
@@ -599,14 +650,15 @@ static int32_t sell_chunk_cap_lens(const int32_t *lens, int n, double *cost_out)
         rows_longer += cnt[(size_t)w];
     }
     auto cost_of = [&](int32_t w) {
-        double read = 0;
-        for (int wv = 0; wv < SELL_WAVES; ++wv) read += (double)std::min(wave_max[wv], w) * wave_rows[wv];
-        return read + SELL_SPILL_COST * (double)longer[(size_t)w];
+        double issue = 0;
+        for (int wv = 0; wv < SELL_WAVES; ++wv) issue += (double)std::min(wave_max[wv], w) * SELL_WAVE_ROWS;
+        return (double)touched_of(w) + SELL_ISSUE_COST * issue + SELL_SPILL_COST * (double)longer[(size_t)w];
     };
-    const double full = hist_max ? cost_of(hist_max) : 0.0;
-    int32_t best_w = hist_max;
+    const int32_t w_top = std::min<int32_t>(hist_max, SELL_MAX_WIDTH);  // a length must fit a byte
+    const double full = hist_max ? cost_of(w_top) : 0.0;
+    int32_t best_w = w_top;
     double best = full;
-    for (int32_t w = hist_max - 1; w >= 1; --w) {
+    for (int32_t w = w_top - 1; w >= 1; --w) {
         const double cost = cost_of(w);
         if (cost < best) {
             best = cost;
@@ -614,20 +666,43 @@ static int32_t sell_chunk_cap_lens(const int32_t *lens, int n, double *cost_out)
         }
     }
     // spilling is for heavy tails (a few long rows among many): a saving below 10 % is not worth the
-    // second pass, the chunk keeps all its entries in the planes
+    // extra phase, the chunk keeps all its entries in the planes
     if (best > 0.9 * full) {
         best = full;
-        best_w = hist_max;
+        best_w = w_top;
     }
     if (cost_out) *cost_out = best;
+    if (touched_out) *touched_out = touched_of(best_w);
     return best_w;
 }
 
-static int32_t sell_chunk_cap(const ogl_label *row_ptrs, ogl_label r0, ogl_label r1)
+static int32_t sell_chunk_cap(const ogl_label *row_ptrs, ogl_label r0, ogl_label r1, bool allow_spill,
+                              int64_t *touched_out)
 {
     int32_t lens[CHUNK_ROWS];
     for (ogl_label r = r0; r < r1; ++r) lens[r - r0] = row_ptrs[r + 1] - row_ptrs[r];
-    return sell_chunk_cap_lens(lens, (int)(r1 - r0), nullptr);
+    return sell_chunk_cap_lens(lens, (int)(r1 - r0), allow_spill, nullptr, touched_out);
+}
+
+// Cost of the compressed layout per stored entry (sell_chunk_cap_lens, summed over the chunks) when the
+// rows are taken in the order order[0], order[1], ... (order == nullptr: the pattern's own).  1 = no
+// padding read, nothing spilled, every wavefront's rows equally long.
+static double sell_cost_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *order)
+{
+    if (n_rows <= 0 || row_ptrs[n_rows] == 0) return 1.0;
+    double total = 0;
+    int32_t lens[CHUNK_ROWS];
+    for (ogl_label k0 = 0; k0 < n_rows; k0 += CHUNK_ROWS) {
+        const int n = (int)std::min<int64_t>(CHUNK_ROWS, (int64_t)n_rows - k0);
+        for (int i = 0; i < n; ++i) {
+            const ogl_label r = order ? order[k0 + i] : k0 + i;
+            lens[i] = row_ptrs[r + 1] - row_ptrs[r];
+        }
+        double cost = 0;
+        (void)sell_chunk_cap_lens(lens, n, true, &cost, nullptr);
+        total += cost;
+    }
+    return total / (double)row_ptrs[n_rows];
 }
 
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
@@ -677,6 +752,36 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
             rep.ratio_used = r;
         }
     }
+    // ---- step 2 (compressed layout only): inside every wavefront's SELL_WAVE_ROWS rows, longest rows
+    // first.  The lanes of the SpMV stop loading at the end of their own rows, so with the long rows of a
+    // wavefront next to each other the 128-byte lines it reads hold (almost) no padding.  The x gather is
+    // untouched -- a wavefront still works on the same SELL_WAVE_ROWS rows (sorting over a whole chunk
+    // was tried: it scatters the gather, profiles/r02_unstructured_proxy.txt).  Matters for meshes with
+    // mixed cell types (polyhedral, hex-dominant); a no-op on hex meshes.
+    if (try_sell) {
+        const ogl_label *base = old_of.empty() ? nullptr : old_of.data();
+        const double before = sell_cost_ratio(N, p.row_ptrs.data(), base);
+        // ... and only where the compressed layout's slot-major gather has a chance against the
+        // CSR-stream kernel's row-major one (a polyhedral mesh stays in plain RCM order, which is what
+        // the CSR-stream kernel wants: consecutive rows = neighbouring cells)
+        if (before > 1.15)  // (1 + SELL_ISSUE_COST = rows of equal length everywhere)
+            rep.slot_ratio = slot_gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(),
+                                                      new_id.empty() ? nullptr : new_id.data(), base);
+        if (before > 1.15 && rep.slot_ratio <= SELL_SORT_MAX_SLOT_RATIO) {
+            std::vector<ogl_label> order((size_t)N);
+            for (ogl_label k = 0; k < N; ++k) order[(size_t)k] = base ? base[k] : k;
+            auto len = [&](ogl_label r) { return p.row_ptrs[r + 1] - p.row_ptrs[r]; };
+            for (ogl_label k0 = 0; k0 < N; k0 += SELL_WAVE_ROWS)
+                std::stable_sort(order.begin() + k0, order.begin() + std::min<int64_t>(N, (int64_t)k0 + SELL_WAVE_ROWS),
+                                 [&](ogl_label a, ogl_label b) { return len(a) > len(b); });
+            const double after = sell_cost_ratio(N, p.row_ptrs.data(), order.data());
+            if (after <= 0.95 * before) {
+                new_id.assign((size_t)N, 0);
+                for (ogl_label k = 0; k < N; ++k) new_id[(size_t)order[(size_t)k]] = k;
+                rep.sorted_by_length = true;
+            }
+        }
+    }
     if (new_id.empty()) {  // the caller's numbering stays
         if (have_natural) hand_over(natural, rep.sell_natural);
         return OGL_OK;
@@ -719,7 +824,10 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         // few long rows: split / polyhedral cells of a hex-dominant mesh) are "spilled" into a short
         // row-sorted list that the chunk's workgroup adds after the planes, continuing every row's sum
         // in stored order -- so one long row does not make 127 others read padding.
-        const int32_t cap = allow_spill ? sell_chunk_cap(row_ptrs, r0, r1) : INT32_MAX;
+        int64_t touched = 0;
+        const int32_t cap = sell_chunk_cap(row_ptrs, r0, r1, allow_spill, &touched);
+        if (cap > SELL_MAX_WIDTH) return false;  // (only without the spill: a length must fit a byte)
+        out.read_slots += touched;
         auto row_end = [&](ogl_label r) { return std::min(row_ptrs[r + 1], row_ptrs[r] + cap); };
         int32_t width = 0, wave_w[SELL_WAVES];
         for (int wv = 0; wv < SELL_WAVES; ++wv) {  // what each wavefront has to run to
@@ -727,7 +835,6 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             for (ogl_label r = r0 + wv * SELL_WAVE_ROWS; r < std::min<int64_t>(r1, (int64_t)r0 + (wv + 1) * SELL_WAVE_ROWS); ++r)
                 ww = std::max(ww, row_end(r) - row_ptrs[r]);
             wave_w[wv] = ww;
-            out.read_slots += (int64_t)ww * SELL_WAVE_ROWS;
             width = std::max(width, ww);
         }
         out.spill_chunk_ptr.push_back((int32_t)out.spill_rows.size());
@@ -740,7 +847,6 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
                     out.spill_map.push_back(k);
                 }
             }
-        if (width > 65535) return false;  // (a row that long fails the padding rules anyway)
         // (a) row patterns: one byte per row.  Known patterns are found through a small hash table
         // (an irregular chunk would otherwise compare every row with up to 256 patterns before giving up)
         bool pat_mode = width > 0;
@@ -831,6 +937,7 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         // (d) otherwise plain 32-bit columns (-1 = padding): always possible
         SellChunk &h = out.chunks[(size_t)c];
         h.val_off = val_len;
+        if (!pat_mode) code_len += SELL_LEN_BYTES;  // the row lengths, one byte each, in front of the codes
         h.code_off = code_len;
         h.dict_off = (int32_t)out.dict.size();
         if (pat_mode) {
@@ -882,10 +989,12 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             pid_pos += CHUNK_ROWS;
         }
         const int32_t *d0 = (d16_mode || c32_mode) ? nullptr : out.dict.data() + h.dict_off;
+        if (!pat_mode) std::fill_n(out.codes.begin() + (h.code_off - SELL_LEN_BYTES), SELL_LEN_BYTES, (uint8_t)0);
         for (ogl_label r = r0; r < r1; ++r) {
             const int32_t lr = r - r0, t = lr / ROWS_PER_THREAD, which = lr % ROWS_PER_THREAD;
             uint8_t *code = out.codes.data() + h.code_off + (int64_t)t * code_stride;
             const ogl_label k_end = std::min(row_ptrs[r + 1], row_ptrs[r] + h.width());  // (the rest is spilled)
+            if (!pat_mode) out.codes[(size_t)(h.code_off - SELL_LEN_BYTES + lr)] = (uint8_t)(k_end - row_ptrs[r]);
             for (ogl_label k = row_ptrs[r], s = 0; k < k_end; ++k, ++s) {
                 out.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS + lr)] = k;
                 if (pat_mode) continue;
@@ -1130,11 +1239,22 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
                 // the planes hold the first width() entries of a row; the rest is in the spill list
                 const ogl_label k_end = row < n_rows ? std::min(row_ptrs[row + 1], row_ptrs[row] + width) : 0;
                 int64_t run = row + h.dict_off;  // delta16: running column
+                // the lane loads up to the longer of its two rows (lengths in front of the codes)
+                int lane_len = width;
+                if (!pat_mode) {
+                    const uint8_t *lens = L.codes.data() + h.code_off - SELL_LEN_BYTES + t * ROWS_PER_THREAD;
+                    if (lens[which] != k_end - k)
+                        return fail(OGL_ERR_STATE, "row %ld: length byte %d, %d entries in the planes", (long)row,
+                                    (int)lens[which], (int)(k_end - k));
+                    lane_len = std::max<int>(lens[0], lens[1]);
+                }
                 for (int s = 0; s < width; ++s) {
                     const int32_t m = L.map[(size_t)(h.val_off + (int64_t)s * CHUNK_ROWS +
                                                      t * ROWS_PER_THREAD + which)];
                     int64_t col = -1;  // decoded column, -1 = padding
-                    if (d16_mode) {
+                    if (s >= lane_len) {
+                        // never loaded
+                    } else if (d16_mode) {
                         uint16_t v;
                         std::memcpy(&v, L.codes.data() + h.code_off + ((int64_t)(s / SELL_D16_GROUP) * BLOCK + t) * 16 +
                                             ((s % SELL_D16_GROUP) * ROWS_PER_THREAD + which) * 2, 2);

@@ -76,7 +76,7 @@ struct SellLayout {
     std::vector<int32_t> map;    // value slot -> position in the CSR value array, -1 = padding
     int64_t n_slots = 0;         // padded value slots
     int64_t n_delta16 = 0, n_col32 = 0;  // chunks coded with 16-bit deltas / plain 32-bit columns
-    int64_t read_slots = 0;  // value slots the kernel reads: sum of SellChunk::wave_w x SELL_WAVE_ROWS
+    int64_t read_slots = 0;  // value slots in the 128-byte lines the kernel reads (lanes stop at their own rows' ends)
     // spill: the tails of the rows that are longer than their chunk's cap, row-sorted; the workgroup of the
     // chunk adds them after the planes, continuing every row's sum in stored order
     std::vector<int32_t> spill_rows, spill_ptrs, spill_cols, spill_map;  // map = position in the CSR values
@@ -100,20 +100,30 @@ void rcm_order(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *col
 // new_id == nullptr: the pattern's own numbering.
 double gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                            const ogl_label *new_id, const ogl_label *old_of);
+// The same per instruction of the compressed layout's kernel (slot-major: the s-th entry of the 64 even
+// or odd rows of a wavefront's 128 rows).  0.25 on a hex mesh in natural order.
+double slot_gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                                const ogl_label *new_id, const ogl_label *old_of);
 // Rewrites `p` (built by build_host_pattern in the caller's numbering) into the numbering new_id.
 // Rows keep their entries; within a row the entries are ordered by NEW column (stable).
 void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id);
 struct SellLayout;
 struct RenumberReport {
     bool applied = false;
+    bool sorted_by_length = false;  // rows of a wavefront reordered longest first (compressed layout)
     bool sell_natural = false, sell_used = false;  // compressed layout qualifies (only when tried)
     double ratio_natural = 0.0, ratio_used = 0.0;  // gather_sector_ratio before / after
+    double slot_ratio = 0.0;  // slot_gather_sector_ratio of the numbering at large (0: not needed)
 };
 // mode 0: keep the caller's numbering; 1: always RCM; 2 (default, "auto"): keep it when the
 // compressed layout qualifies with 1-byte codes throughout (structured mesh); otherwise RCM when the
-// gather coalesces badly (ratio > 0.25) and RCM cuts the sector ratio by >= 10 %.  (Sorting the rows of a
-// chunk by length to save padding was tried and dropped: it scatters the gather inside the chunk and was
-// never faster than the CSR-stream kernel on the same rows, profiles/r02_unstructured_proxy.txt.)
+// gather coalesces badly (ratio > 0.25) and RCM cuts the sector ratio by >= 10 %.  With the compressed
+// layout in play (try_sell), modes 1 and 2 then put the rows of every wavefront (SELL_WAVE_ROWS consecutive
+// rows) longest first when row lengths are mixed and the layout's slot-major gather is local enough to have
+// a chance (slot_gather_sector_ratio <= SELL_SORT_MAX_SLOT_RATIO): the lanes of the kernel stop loading at
+// the end of their own rows, so sorted rows leave (almost) no padding in the lines that are read.  No row
+// leaves its wavefront.  (Sorting over a whole chunk was tried and dropped: it scatters the gather,
+// profiles/r02_unstructured_proxy.txt.)
 // `sell_out` (may be null) receives the compressed layout of the numbering that was chosen when
 // one was built on the way (sell_built tells), so the caller does not derive it twice.
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,

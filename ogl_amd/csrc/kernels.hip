@@ -1024,6 +1024,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     // longest row) are never touched.  Wave-uniform, so the loops below do not diverge.
     const int ww = h.wave_width(__builtin_amdgcn_readfirstlane(t / WAVE)), width = h.width();
     constexpr int BATCH = 8;
+    // ... and every lane loads up to the longer of ITS two rows only (lengths: one byte per row in front
+    // of the codes; not in pattern mode).  Padding that shares no 128-byte line with a slot in use costs
+    // no memory traffic -- with the rows of a wavefront sorted by length that is nearly all of it.
+    int ml = ww;
+    if (h.mode() != SELL_MODE_PATTERN) {
+        const unsigned ll =
+            *reinterpret_cast<const unsigned short *>(codes + h.code_off - SELL_LEN_BYTES + t * ROWS_PER_THREAD);
+        ml = (int)max(ll & 0xffu, ll >> 8);
+    }
     if (h.mode() == SELL_MODE_DELTA16) {
         // delta mode: 16 bits per (row, slot), group-major 16-byte words of 4 slots x 2 rows; the
         // column of a slot is the running sum of the row's codes (first code relative to
@@ -1033,24 +1042,25 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
         int c0 = row + h.dict_off, c1 = row + 1 + h.dict_off;
         for (int s0 = 0; s0 < ww; s0 += BATCH) {
             const int g = s0 / SELL_D16_GROUP;
-            const uint4 wa = cw[(long)g * BLOCK];
-            uint4 wb;
-            wb.x = wb.y = wb.z = wb.w = 0xffffffffu;
-            if (s0 + SELL_D16_GROUP < ww) wb = cw[(long)(g + 1) * BLOCK];
+            uint4 wa, wb;
+            wa.x = wa.y = wa.z = wa.w = 0xffffffffu;
+            wb = wa;
+            if (s0 < ml) wa = cw[(long)g * BLOCK];
+            if (s0 + SELL_D16_GROUP < ml) wb = cw[(long)(g + 1) * BLOCK];
             const unsigned w8[BATCH] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
             double2 vv[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                const int sl = min(s0 + k, ww - 1);  // clamp: always a valid plane
-                vv[k] = *reinterpret_cast<const double2 *>(v + (long)sl * CHUNK_ROWS);
+                vv[k].x = vv[k].y = 0.0;
+                if (s0 + k < ml) vv[k] = *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             int a0[BATCH], a1[BATCH];
             bool ok0[BATCH], ok1[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 const unsigned d0 = w8[k] & 0xffffu, d1 = w8[k] >> 16;
-                ok0[k] = (s0 + k < ww) && d0 != 0xffffu;
-                ok1[k] = (s0 + k < ww) && d1 != 0xffffu;
+                ok0[k] = (s0 + k < ml) && d0 != 0xffffu;
+                ok1[k] = (s0 + k < ml) && d1 != 0xffffu;
                 if (ok0[k]) c0 += (int)d0;
                 if (ok1[k]) c1 += (int)d1;
                 a0[k] = c0;
@@ -1085,17 +1095,17 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
             for (int q = 0; q < 4; ++q) {
                 int4 w;
                 w.x = w.y = w.z = w.w = -1;
-                if (s0 + SELL_C32_GROUP * q < ww) w = cw[(long)(g + q) * BLOCK];
+                if (s0 + SELL_C32_GROUP * q < ml) w = cw[(long)(g + q) * BLOCK];
                 a0[2 * q] = w.x;
                 a1[2 * q] = w.y;
-                a0[2 * q + 1] = (s0 + 2 * q + 1 < ww) ? w.z : -1;
-                a1[2 * q + 1] = (s0 + 2 * q + 1 < ww) ? w.w : -1;
+                a0[2 * q + 1] = (s0 + 2 * q + 1 < ml) ? w.z : -1;
+                a1[2 * q + 1] = (s0 + 2 * q + 1 < ml) ? w.w : -1;
             }
             double2 vv[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                const int sl = min(s0 + k, ww - 1);  // clamp: always a valid plane
-                vv[k] = *reinterpret_cast<const double2 *>(v + (long)sl * CHUNK_ROWS);
+                vv[k].x = vv[k].y = 0.0;
+                if (s0 + k < ml) vv[k] = *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
 #pragma unroll
@@ -1152,13 +1162,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
         // offset mode: one byte per (row, slot) -> entry of the chunk's offset dictionary
         const uint8_t *c = codes + h.code_off + (long)t * h.code_stride();
         for (int s0 = 0; s0 < ww; s0 += BATCH) {
-            const uint4 cw = *reinterpret_cast<const uint4 *>(c + 2 * s0);
+            uint4 cw;
+            cw.x = cw.y = cw.z = cw.w = 0xffffffffu;
+            if (s0 < ml) cw = *reinterpret_cast<const uint4 *>(c + 2 * s0);
             const unsigned w4[4] = {cw.x, cw.y, cw.z, cw.w};
             double2 vv[BATCH];
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
-                const int s = min(s0 + k, ww - 1);  // clamp: always a valid plane
-                vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
+                vv[k].x = vv[k].y = 0.0;
+                if (s0 + k < ml) vv[k] = *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
             bool ok0[BATCH], ok1[BATCH];
@@ -1167,8 +1179,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 const unsigned pair = (w4[k / 2] >> (16 * (k & 1))) & 0xffffu;
                 const unsigned c0 = pair & 0xffu, c1 = pair >> 8;
                 // padding slots carry code 255; rows past n_rows only have padding slots
-                ok0[k] = (s0 + k < ww) && c0 != 255u;
-                ok1[k] = (s0 + k < ww) && c1 != 255u;
+                ok0[k] = (s0 + k < ml) && c0 != 255u;
+                ok1[k] = (s0 + k < ml) && c1 != 255u;
                 x0[k] = ok0[k] ? x[row + stab[c0]] : 0.0;
                 x1[k] = ok1[k] ? x[row + 1 + stab[c1]] : 0.0;
             }

@@ -497,6 +497,8 @@ int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
     props["sellSpilledEntries"] = (double)n_spill;
     sell_slots = L.n_slots;
     sell_state = 1;
+    sell_irregular = L.n_delta16 + L.n_col32 > 0;
+    sell_tuned = 0;
     // bytes one SpMV reads of this layout (bench.py's moved-bytes model): the value planes and codes
     // up to every wavefront's own width (planes beyond it are allocated, not read), headers, tables
     const double read_frac = L.n_slots ? (double)L.read_slots / (double)L.n_slots : 1.0;
@@ -549,6 +551,66 @@ int ogl_solver::download_rows(double *dst, const double *src)
     if (!pat.renumbered()) return reg->stager.d2h(dst, src, bytes, reg->stream);
     launch_permute_gather(reg->stream, pat.n_rows, d_new_id.p, src, d_perm_tmp.p);
     return reg->stager.d2h(dst, d_perm_tmp.p, bytes, reg->stream);
+}
+
+namespace {
+struct EventPair {  // destroyed on every return path
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~EventPair()
+    {
+        for (auto &x : e)
+            if (x) (void)hipEventDestroy(x);
+    }
+    hipEvent_t &operator[](int i) { return e[i]; }
+};
+}  // namespace
+
+// Which kernel runs the in-loop SpMV of a pattern with irregular chunks: measured, once per pattern.  Both
+// read the same matrix and give the same bits (y and the fused dot partials), so this is a speed choice
+// only and ranks are free to differ.  Work vectors p (input, zeroed: the time does not depend on the
+// values) and q (output) are free between solves.
+int ogl_solver::tune_spmv_layout()
+{
+    hipStream_t st = reg->stream;
+    EventPair ev;
+    OGL_HIP_CHECK(hipEventCreate(&ev[0]));
+    OGL_HIP_CHECK(hipEventCreate(&ev[1]));
+    OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, ((size_t)pat.n_rows + 2) * sizeof(double), st));
+    SpmvDots dots;
+    dots.with = d_p.p;
+    dots.part = d_part0.p;
+    constexpr int WARM = 2, TIMED = 5;
+    float best[2] = {1e30f, 1e30f};  // [0] CSR-stream, [1] compressed
+    for (int round = 0; round < WARM + TIMED; ++round)
+        for (int which = 0; which < 2; ++which) {
+            OGL_HIP_CHECK(hipEventRecord(ev[0], st));
+            if (which)
+                launch_spmv_sell(st, sell(), SPMV_PLAIN, d_p.p, nullptr, d_q.p, dots, nullptr);
+            else
+                launch_spmv(st, csr(), SPMV_PLAIN, d_p.p, nullptr, d_q.p, dots, nullptr);
+            OGL_HIP_CHECK(hipEventRecord(ev[1], st));
+            OGL_HIP_CHECK(hipEventSynchronize(ev[1]));
+            float ms = 0;
+            OGL_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            if (round >= WARM) best[which] = std::min(best[which], ms);
+        }
+    OGL_HIP_CHECK(hipGetLastError());
+    sell_tuned = best[1] <= best[0] ? 1 : -1;
+    props["spmvTunedCsrUs"] = 1e3 * best[0];
+    props["spmvTunedSellUs"] = 1e3 * best[1];
+    if (sell_tuned < 0) {  // the compressed copy is of no use for this pattern: no refreshes, no memory
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        for (auto *b : {&d_sell_dict, &d_sell_map, &d_spill_rows, &d_spill_ptrs, &d_spill_cols, &d_spill_map,
+                        &d_spill_chunks})
+            b->release();
+        d_sell_chunks.release();
+        d_sell_codes.release();
+        d_sell_vals.release();
+        d_spill_vals.release();
+        n_spill = n_spill_rows = 0;
+        sell_state = -1;
+    }
+    return OGL_OK;
 }
 
 int ogl_solver::ensure_vectors()
@@ -681,6 +743,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep));
         pat_renumber_mode = cfg.renumber;
         pat_try_sell = try_sell;
+        props["rowsSortedByLength"] = rep.sorted_by_length ? 1.0 : 0.0;
+        props["gatherSlotSectorRatio"] = rep.slot_ratio;
         props["renumbered"] = rep.applied ? 1.0 : 0.0;
         props["gatherSectorRatioNatural"] = rep.ratio_natural;
         props["gatherSectorRatio"] = rep.ratio_used;
@@ -793,6 +857,9 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             if (n_spill) launch_gather_coeffs(st, n_spill, d_spill_map.p, d_vals.p, d_spill_vals.p);
             sell_values_stale = false;
         }
+        if (sell_state == 1 && sell_tuned == 0 && sell_irregular && cfg.compress_indices == 1 &&
+            pat.n_rows >= SPMV_TUNE_MIN_ROWS)
+            OGL_TRY(tune_spmv_layout());
     }
     // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
     props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : (use_sell() ? 2.0 : 0.0);
@@ -1183,15 +1250,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         OGL_HIP_CHECK(hipEventCreate(&e));
         prof_ev.push_back(e);
     }
-    struct EventPair {  // destroyed on every return path
-        hipEvent_t e[2] = {nullptr, nullptr};
-        ~EventPair()
-        {
-            for (auto &x : e)
-                if (x) (void)hipEventDestroy(x);
-        }
-        hipEvent_t &operator[](int i) { return e[i]; }
-    } ev_chk;
+    EventPair ev_chk;
     OGL_HIP_CHECK(hipEventCreate(&ev_chk[0]));
     OGL_HIP_CHECK(hipEventCreate(&ev_chk[1]));
 

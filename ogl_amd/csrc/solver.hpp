@@ -215,6 +215,15 @@ struct ogl_solver {
     ogl::DevBuf<double> d_spill_vals;
     int32_t n_spill_rows = 0, n_spill = 0;   // (d_spill_chunks holds the per-chunk ranges of d_spill_rows)
     bool sell_values_stale = true;
+    // Patterns with irregular chunks (16-bit delta / 32-bit column codes: unstructured meshes) are timed on
+    // both kernels once per pattern (tune_spmv_layout): the compressed layout moves fewer bytes, but its
+    // slot-major gather -- one entry of 64 different rows per instruction -- only pays where neighbouring
+    // rows have neighbouring columns; on a polyhedral mesh the CSR-stream kernel's row-major gather wins.
+    // sell_tuned: 0 = not measured, 1 = compressed layout is faster (or cfg.compress_indices == 2: forced),
+    // -1 = the CSR-stream kernel is.  The results are bit-identical either way.
+    bool sell_irregular = false;
+    int sell_tuned = 0;
+    int tune_spmv_layout();
     // `pre` != nullptr: the layout choose_numbering already derived for this pattern
     // (`pre_qualifies` tells whether it is usable)
     int build_sell(ogl::SellLayout *pre = nullptr, bool pre_qualifies = false);
@@ -250,7 +259,7 @@ struct ogl_solver {
     bool use_sell() const
     {
         return cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices && sell_state == 1 &&
-               !sell_values_stale;
+               !sell_values_stale && sell_tuned >= 0;
     }
     ogl::DevEll ell() const;
     // halo part

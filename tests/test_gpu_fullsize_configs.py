@@ -58,7 +58,10 @@ def test_config2_unstructured_2m_cells(reg):
     box = synthetic.poisson_case(128)
     case = synthetic.renumber_case(box, 65536)
     s = reg.solver("p", cfg()).set_matrix(case)
-    assert s.renumbering() is not None and s.get_property("spmvLayout") == 2.0
+    assert s.renumbering() is not None
+    # an irregular pattern of this size: both kernels were timed once, the faster one runs
+    t_csr, t_sell = s.get_property("spmvTunedCsrUs"), s.get_property("spmvTunedSellUs")
+    assert s.get_property("spmvLayout") == (2.0 if t_sell <= t_csr else 0.0)
     assert s.get_property("gatherSectorRatioNatural") > 0.5 > 0.2 > s.get_property("gatherSectorRatio")
     delta = 1e-3 * (1.0 + (case.global_index % 7) / 7.0)
     np.testing.assert_allclose(s.spmv(np.ones(case.n_cells)), delta, rtol=0, atol=4e-15)

@@ -191,11 +191,13 @@ def test_export_is_written_in_the_callers_numbering(reg, tmp_path):
     assert files[0]["rhs_b_"] == files[1]["rhs_b_"]
 
 
-def test_mixed_row_lengths_run_on_the_csr_stream_kernel_in_the_rcm_numbering(reg, oracle, chunk_rows):
-    """Row lengths 2..15 (a stand-in for mixed cell types): the padding disqualifies the compressed layout in
-    any numbering that keeps the gather local, so `renumber` is RCM only and the CSR-stream kernel runs;
-    everything stays bit-identical to the oracle on the permuted system."""
-    case = synthetic.random_global_case(20000, 4, 300, symmetric=True, seed=2)
+def test_mixed_row_lengths_run_on_the_compressed_layout_after_the_length_sort(reg, oracle, chunk_rows):
+    """Rows of 1..7 entries (a hex mesh that lost 30 % of its faces; a stand-in for mixed cell types): in the
+    caller's order the 128-byte lines of the planes mix long and short rows and the padding disqualifies the
+    compressed layout (CSR-stream kernel); with `renumber` the rows of every wavefront go longest first, the
+    lanes stop loading at the end of their own rows, and everything stays bit-identical to the oracle on the
+    permuted system."""
+    case = synthetic.drop_faces_case(synthetic.poisson_case(28), 0.3)
     rng = np.random.default_rng(SEED)
     x = rng.uniform(-1, 1, case.n_cells)
     s0 = reg.solver("rn_mixed_off", cfg(renumber=capi.RENUMBER_OFF)).set_matrix(case)
@@ -203,9 +205,12 @@ def test_mixed_row_lengths_run_on_the_csr_stream_kernel_in_the_rcm_numbering(reg
     for mode in (capi.RENUMBER_ON, capi.RENUMBER_AUTO):
         s = reg.solver(f"rn_mixed_{mode}", cfg(renumber=mode, preconditioner=capi.PRECOND_BJ, max_iter=30)).set_matrix(case)
         new_id = s.renumbering()
-        assert new_id is not None and s.get_property("spmvLayout") == 0.0
-        assert s.get_property("gatherSectorRatio") < 0.5 * s.get_property("gatherSectorRatioNatural")
+        assert new_id is not None and s.get_property("spmvLayout") == 2.0
+        assert s.get_property("rowsSortedByLength") == 1.0
+        assert s.get_property("sellReadSlots") < 1.15 * (case.nnz + 4096) < s.get_property("sellAllocatedSlots")
         A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+        lens = np.diff(rp)
+        assert all(np.all(np.diff(lens[c:c + 128]) <= 0) for c in range(0, case.n_cells, 128))
         np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, to_new(x, new_id))[new_id])
         np.testing.assert_allclose(s.spmv(x), s0.spmv(x), rtol=1e-13, atol=1e-13)
         b = synthetic.apply_case(case, x)

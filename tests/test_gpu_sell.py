@@ -107,7 +107,9 @@ def test_far_couplings_take_32_bit_columns_in_their_chunk(reg, oracle):
     f = len(pairs)
     case = synthetic.LduCase(n, pairs[:, 0].copy(), pairs[:, 1].copy(), rng.uniform(20, 30, n),
                              rng.uniform(-1, 1, f), rng.uniform(-1, 1, f))
-    s = reg.solver("sell_far", cfg(1, renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    # (compress_indices 2: without the one-off timing against the CSR-stream kernel that decides for
+    # irregular patterns of this size)
+    s = reg.solver("sell_far", cfg(2, renumber=capi.RENUMBER_OFF)).set_matrix(case)
     assert s.get_property("spmvLayout") == LAYOUT_SELL
     rp, cols, vals = oracle_csr(oracle, case)
     ok, d16, c32 = capi.host_sell_modes(rp, cols)
@@ -253,3 +255,42 @@ def test_offset_mode_when_a_chunk_has_too_many_row_patterns(reg, oracle):
     assert s.get_property("spmvLayout") == LAYOUT_SELL
     x = rng.uniform(-1, 1, n)
     np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+def test_irregular_pattern_is_timed_on_both_kernels_once(reg, oracle):
+    """A hex mesh in a shuffled numbering, above the tuning size: after RCM the compressed layout qualifies
+    with 16-bit deltas, but whether its slot-major gather beats the CSR-stream kernel's row-major one is
+    measured once per pattern.  Whichever runs, the bits are the oracle's; coefficient updates keep working
+    on the layout that was chosen; `force` skips the measurement."""
+    from helpers import oracle_matrix_renumbered, to_new
+    case = synthetic.renumber_case(synthetic.poisson_case(64), 65536)   # (some chunks need 16-bit deltas)
+    rng = np.random.default_rng(11)
+    case.upper[:] = rng.uniform(-1, -0.5, case.upper.size)
+    x = rng.uniform(-1, 1, case.n_cells)
+    s = reg.solver("sell_tuned", cfg(1)).set_matrix(case)
+    t_csr, t_sell = s.get_property("spmvTunedCsrUs"), s.get_property("spmvTunedSellUs")
+    assert t_csr > 0 and t_sell > 0
+    assert s.get_property("spmvLayout") == (LAYOUT_SELL if t_sell <= t_csr else LAYOUT_CSR)
+    forced = reg.solver("sell_forced", cfg(2)).set_matrix(case)
+    assert forced.get_property("spmvLayout") == LAYOUT_SELL
+    new_id = s.renumbering()
+    assert new_id is not None and np.array_equal(new_id, forced.renumbering())
+    for round_ in range(2):
+        A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+        ref = oracle.spmv(rp, cols, vals, to_new(x, new_id))[new_id]
+        np.testing.assert_array_equal(s.spmv(x), ref)
+        np.testing.assert_array_equal(forced.spmv(x), ref)
+        # next time step: new coefficients, same pattern -> no new measurement, same layout
+        case.upper[:] = rng.uniform(-1, -0.5, case.upper.size)
+        case.diag[:] += 0.25
+        s.set_matrix(case)
+        forced.set_matrix(case)
+        assert s.get_property("spmvTunedCsrUs") == t_csr and s.get_property("spmvTunedSellUs") == t_sell
+    # a polyhedral mesh: not even tried (plain RCM order, CSR-stream kernel), same bits
+    vor = synthetic.voronoi_case(70000)
+    sv = reg.solver("sell_voronoi", cfg(1)).set_matrix(vor)
+    assert sv.get_property("spmvLayout") == LAYOUT_CSR and sv.get_property("rowsSortedByLength") == 0.0
+    nid = sv.renumbering()
+    xv = rng.uniform(-1, 1, vor.n_cells)
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, vor, nid)
+    np.testing.assert_array_equal(sv.spmv(xv), oracle.spmv(rp, cols, vals, to_new(xv, nid))[nid])

@@ -154,24 +154,52 @@ def test_fingerprint_sees_every_face():
     assert capi.host_addressing_fingerprint(c2) != h2
 
 
-def test_mixed_row_lengths_keep_the_locality_numbering():
-    """Mixed cell types (row lengths 2..15 here): padding a wavefront's rows to its longest row makes the
-    compressed SpMV read ~1.6x the entries, so the layout does not qualify and the CSR-stream kernel runs.
-    The rows are NOT sorted by length to make it qualify (that scatters the gather inside a chunk and was
-    never faster, profiles/r02_unstructured_proxy.txt): `renumber` is RCM and nothing else."""
-    case = synthetic.random_global_case(20000, 4, 300, symmetric=True, seed=2)
+def test_rows_of_a_wavefront_are_put_longest_first_when_lengths_are_mixed():
+    """Mixed cell types (a hex mesh that lost 30 % of its faces: rows of 1..7 entries): the lanes of the
+    compressed SpMV stop loading at the end of their own rows, so padding costs traffic only where it shares
+    a 128-byte line with a slot in use.  With `renumber` the rows of every wavefront (128 consecutive rows)
+    go longest first: the lines in use are dense, the layout qualifies, and no row leaves its wavefront (the
+    gather is as local as it was)."""
+    case = synthetic.drop_faces_case(synthetic.poisson_case(28), 0.3)
     d0, loc0, _, _ = capi.host_pattern(case)
     rp0 = rowptr_of(loc0[0], d0.n_rows)
-    assert capi.host_sell_read_slots(rp0, loc0[1])[0] is False
+    assert capi.host_sell_read_slots(rp0, loc0[1])[0] is False       # as given: lines of mixed lengths
     rcm = capi.host_rcm(rp0, loc0[1])
-    for compress in (1, 0):
-        d, loc, _, _, (ren, new_id) = capi.host_pattern_renumbered(case, capi.RENUMBER_ON, compress_indices=compress)
-        assert ren
-        np.testing.assert_array_equal(new_id, rcm)
-        assert capi.host_sell_read_slots(rowptr_of(loc[0], d.n_rows), loc[1])[0] is False
-    # a hex mesh: the numbering is the plain RCM one, and the layout qualifies in it
+    for mode in (capi.RENUMBER_ON, capi.RENUMBER_AUTO):
+        d, loc, _, _, (ren, new_id) = capi.host_pattern_renumbered(case, mode)
+        assert ren and sorted(new_id.tolist()) == list(range(case.n_cells))
+        # every row stays in the wavefront the numbering at large (RCM, or the caller's when `auto` keeps
+        # it) put it in
+        _, _, _, _, (ren0, base) = capi.host_pattern_renumbered(case, mode, compress_indices=0)
+        base = base if ren0 else np.arange(case.n_cells)
+        if mode == capi.RENUMBER_ON:
+            np.testing.assert_array_equal(base, rcm)
+        np.testing.assert_array_equal(new_id // 128, base // 128)
+        rp = rowptr_of(loc[0], d.n_rows)
+        ok, allocated, read = capi.host_sell_read_slots(rp, loc[1])
+        assert ok and read <= 1.15 * d.local_nnz + 8 * 512 < allocated
+        lens = np.diff(rp)
+        for c in range(0, d.n_rows, 128):                            # longest first inside every wavefront
+            assert np.all(np.diff(lens[c:c + 128]) <= 0)
+    # a hex mesh has nothing to gain: the numbering is the plain RCM one
     box = synthetic.renumber_case(synthetic.poisson_case(28), 4096)
     d, loc, _, _, (ren, new_id) = capi.host_pattern_renumbered(box, capi.RENUMBER_ON)
     d1, loc1, _, _ = capi.host_pattern(box)
     np.testing.assert_array_equal(new_id, capi.host_rcm(rowptr_of(loc1[0], d1.n_rows), loc1[1]))
-    assert capi.host_sell_read_slots(rowptr_of(loc[0], d.n_rows), loc[1])[0] is True
+    # without the compressed layout in play nothing is sorted
+    d, loc, _, _, (ren, new_id) = capi.host_pattern_renumbered(case, capi.RENUMBER_ON, compress_indices=0)
+    np.testing.assert_array_equal(new_id, rcm)
+
+
+def test_rows_are_not_sorted_where_the_slot_major_gather_is_not_local():
+    """Mixed row lengths again, but neighbours picked at random within +-300 cells (and a Voronoi mesh): the
+    s-th neighbours of the rows of a wavefront have nothing to do with each other, the compressed layout's
+    slot-major gather loses against the CSR-stream kernel's row-major one -- the rows stay in plain RCM
+    order (consecutive rows = neighbouring cells, what the CSR-stream kernel wants)."""
+    for case in (synthetic.random_global_case(20000, 4, 300, symmetric=True, seed=2), synthetic.voronoi_case(20000)):
+        d0, loc0, _, _ = capi.host_pattern(case)
+        rcm = capi.host_rcm(rowptr_of(loc0[0], d0.n_rows), loc0[1])
+        d, loc, _, _, (ren, new_id) = capi.host_pattern_renumbered(case, capi.RENUMBER_ON)
+        assert ren
+        np.testing.assert_array_equal(new_id, rcm)
+        assert capi.host_sell_read_slots(rowptr_of(loc[0], d.n_rows), loc[1])[0] is False

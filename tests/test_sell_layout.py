@@ -60,7 +60,8 @@ def test_many_row_patterns_fall_back_to_offset_codes():
     ok, slots, dict_entries, code_bytes = capi.host_sell_check(rp, cols)
     widths = [max(len(c) for c in rows[i * CHUNK:(i + 1) * CHUNK]) for i in range(2)]
     assert ok and slots == CHUNK * sum(widths)
-    assert code_bytes == 256 * sum((2 * w + 15) // 16 * 16 for w in widths)
+    # per chunk: 512 row-length bytes in front of the codes, then 2 x width code bytes per thread
+    assert code_bytes == sum(512 + 256 * ((2 * w + 15) // 16 * 16) for w in widths)
     assert dict_entries <= 2 * 41
 
 
@@ -83,7 +84,8 @@ def test_unstructured_pattern_takes_16_bit_deltas():
     assert ok and dict_entries == 0
     widths = [max(len(c) for c in rows[i * CHUNK:(i + 1) * CHUNK]) for i in range(n // CHUNK)]
     assert slots == CHUNK * sum(widths)
-    assert code_bytes == sum(256 * 16 * ((w + 3) // 4) for w in widths)     # 4 slots x 2 rows per word
+    # 512 row-length bytes per chunk, then words of 4 slots x 2 rows
+    assert code_bytes == sum(512 + 256 * 16 * ((w + 3) // 4) for w in widths)
     assert capi.host_sell_modes(rp, cols) == (True, n // CHUNK, 0)
 
 
@@ -177,3 +179,27 @@ def test_wide_banded_rows_qualify():
 
 def test_empty_pattern():
     assert capi.host_sell_check(np.zeros(1, np.int32), np.zeros(0, np.int32)) == (False, 0, 0, 0)
+
+
+def test_padding_costs_only_the_lines_it_shares_with_entries():
+    # rows of 7 entries, except 16 rows per chunk with 12.  When the long rows sit next to each other (one
+    # 128-byte line of every plane) the lanes of the other rows stop loading after 7 slots: slots 7..11 cost
+    # 16 rows each, nothing is spilled.  Spread one per line, every line would be read to 12 slots -- the
+    # tails go to the spill list instead.
+    n = 4 * CHUNK
+
+    def pattern(is_long):
+        rows = [np.unique(np.clip(r + np.arange(-(k // 2), k - k // 2) * 3, 0, n - 1))
+                for r in range(n) for k in [12 if is_long(r) else 7]]
+        rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+        return rp, np.concatenate(rows).astype(np.int32), np.diff(rp)
+
+    rp, cols, lens = pattern(lambda r: r % CHUNK < 16)
+    ok, read, spilled = capi.host_sell_spilled(rp, cols)
+    assert ok and spilled == 0
+    assert read == sum(16 * lens[c:c + 16].max() + sum(16 * lens[l:l + 16].max() for l in range(c + 16, c + CHUNK, 16))
+                       for c in range(0, n, CHUNK))
+    assert read < 1.03 * rp[-1]
+    rp, cols, lens = pattern(lambda r: 32 * CHUNK // 512 <= r < n - 32 and r % 16 == 0)
+    ok, read, spilled = capi.host_sell_spilled(rp, cols)
+    assert ok and spilled == int(np.maximum(lens - 7, 0).sum()) and read <= 7 * n
