@@ -27,10 +27,18 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 constexpr int BLOCK = 256, N_WAVES = 4, CHUNK_ROWS = 512, RPT = 2;
 
+template <int G = 4>
 __device__ __forceinline__ int xcd_chunk(int block)
 {
+    if (G == 0) return block;
     const int slot = block / 8, xcd = block % 8;
-    return (slot / 4) * 32 + xcd * 4 + slot % 4;
+    return (slot / G) * (8 * G) + xcd * G + slot % G;
+}
+template <bool NT, class T>
+__device__ __forceinline__ T ldg(const T *p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
 }
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -54,7 +62,9 @@ __device__ __forceinline__ double block_sum(double v, double *slot)
 // SKIP: wave-uniform skip of the load groups that lie entirely beyond the chunk's last entry
 // ABL:  0 = full kernel, 1 = no gather (x := column as double; wrong result on purpose),
 //       2 = no LDS / row phase (per-thread sum of its products; wrong result on purpose)
-template <int TILE, int COLS, bool SKIP, int ABL, int MINW>
+// NT: non-temporal loads of values and columns; RB: LDS reads of the row phase issued RB at a time (the
+// adds stay in order); XG: consecutive chunks per XCD (0 = chunk = block)
+template <int TILE, int COLS, bool SKIP, int ABL, int MINW, bool NT = false, int RB = 1, int XG = 4>
 __global__ __launch_bounds__(BLOCK, MINW) void k_spmv(int n_rows, int n_chunks, const int *__restrict__ row_ptrs,
                                                       const int *__restrict__ cols,
                                                       const unsigned short *__restrict__ cols16,
@@ -64,7 +74,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_spmv(int n_rows, int n_chunks, 
 {
     __shared__ __attribute__((aligned(16))) double prod[TILE];
     __shared__ double slot[N_WAVES];
-    const int chunk = xcd_chunk(blockIdx.x);
+    const int chunk = xcd_chunk<XG>(blockIdx.x);
     if (chunk >= n_chunks) return;
     const int tid = threadIdx.x;
     const int r0 = chunk * CHUNK_ROWS;
@@ -86,17 +96,17 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_spmv(int n_rows, int n_chunks, 
             if (SKIP && t0 + g * BLOCK * 4 >= nz1) break;
             const int e = t0 + (g * BLOCK + tid) * 4;
             const int ec = e < nz1 ? e : t0;
-            va[g] = *reinterpret_cast<const d2 *>(vals + ec);
-            vb[g] = *reinterpret_cast<const d2 *>(vals + ec + 2);
+            va[g] = ldg<NT>(reinterpret_cast<const d2 *>(vals + ec));
+            vb[g] = ldg<NT>(reinterpret_cast<const d2 *>(vals + ec + 2));
             if (COLS == 1) {
-                const us4 c = *reinterpret_cast<const us4 *>(cols16 + ec);
+                const us4 c = ldg<NT>(reinterpret_cast<const us4 *>(cols16 + ec));
                 // (the up to 3 entries before nz0 carry the previous chunk's codes: keep them in range)
                 cc[g].x = min(base + c.x, n_rows - 1);
                 cc[g].y = min(base + c.y, n_rows - 1);
                 cc[g].z = min(base + c.z, n_rows - 1);
                 cc[g].w = min(base + c.w, n_rows - 1);
             } else {
-                cc[g] = *reinterpret_cast<const i4 *>(cols + ec);
+                cc[g] = ldg<NT>(reinterpret_cast<const i4 *>(cols + ec));
             }
         }
 #pragma unroll
@@ -127,7 +137,18 @@ __global__ __launch_bounds__(BLOCK, MINW) void k_spmv(int n_rows, int n_chunks, 
 #pragma unroll
             for (int j = 0; j < RPT; ++j) {
                 const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
-                for (int k = kb; k < ke; ++k) acc[j] += prod[k - t0];
+                if (RB == 1) {
+                    for (int k = kb; k < ke; ++k) acc[j] += prod[k - t0];
+                } else {
+                    for (int k = kb; k < ke; k += RB) {
+                        double pv[RB];
+#pragma unroll
+                        for (int i = 0; i < RB; ++i) pv[i] = prod[min(k + i, ke - 1) - t0];
+#pragma unroll
+                        for (int i = 0; i < RB; ++i)
+                            if (k + i < ke) acc[j] += pv[i];
+                    }
+                }
             }
             __syncthreads();
         }
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_wave(int n_rows, int n_chunks, c
 {
     __shared__ __attribute__((aligned(16))) double prod[N_WAVES][WTILE];
     __shared__ double slot[N_WAVES];
-    const int chunk = xcd_chunk(blockIdx.x);
+    const int chunk = xcd_chunk<4>(blockIdx.x);
     if (chunk >= n_chunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r0 = chunk * CHUNK_ROWS;
@@ -351,6 +372,13 @@ int main(int argc, char **argv)
                    hipLaunchKernelGGL((k_spmv<TILE, COLS, SKIP, ABL, MINW>), dim3(D.grid), dim3(BLOCK), 0, 0, D.n,    \
                                       D.nc, D.rp, D.cols, D.cols16, D.base, D.vals, x, D.y, D.part);                 \
                })
+#define RUNX(TILE, NT, RB, XG)                                                                                      \
+    timeit("tile" #TILE " nt" #NT " rowbatch" #RB " xcdgroup" #XG, D, yref, reps, true, [&](const double *x) {       \
+        const int q = XG ? 8 * XG : 1;                                                                               \
+        hipLaunchKernelGGL((k_spmv<TILE, 0, true, 0, 1, NT, RB, XG>), dim3((D.nc + q - 1) / q * q), dim3(BLOCK), 0,  \
+                           0, D.n, D.nc,                                                                             \
+                           D.rp, D.cols, D.cols16, D.base, D.vals, x, D.y, D.part);                                  \
+    })
 #define RUNW(WTILE, COLS)                                                                                            \
     if (COLS == 0 || D.has16)                                                                                        \
         timeit("per-wave tile" #WTILE " cols" #COLS, D, yref, reps, true, [&](const double *x) {                     \
@@ -359,19 +387,22 @@ int main(int argc, char **argv)
         })
     for (int pass = 0; pass < 2; ++pass) {
         RUN(4096, 0, false, 0, 1);  // the product kernel
-        RUN(4096, 0, true, 0, 1);
         RUN(2048, 0, true, 0, 1);
-        RUN(1024, 0, true, 0, 1);
-        RUN(8192, 0, true, 0, 1);
+        RUNX(4096, false, 4, 4);
+        RUNX(2048, false, 4, 4);
+        RUNX(2048, false, 2, 4);
+        RUNX(2048, false, 8, 4);
+        RUNX(2048, true, 1, 4);
+        RUNX(2048, true, 4, 4);
+        RUNX(2048, false, 4, 0);
+        RUNX(2048, false, 4, 1);
+        RUNX(2048, false, 4, 2);
+        RUNX(2048, false, 4, 8);
+        RUNX(2048, false, 4, 16);
         RUN(4096, 1, true, 0, 1);
         RUN(2048, 1, true, 0, 1);
-        RUNW(512, 0);
-        RUNW(1024, 0);
-        RUNW(2048, 0);
-        RUNW(1024, 1);
         RUN(4096, 0, true, 1, 1);
         RUN(4096, 0, true, 2, 1);
-        RUN(2048, 0, true, 0, 2);
     }
     return 0;
 }
