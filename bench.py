@@ -74,6 +74,13 @@ def parse():
                     help="instead of the box: the Voronoi cells of this many random points (a polyhedral mesh, "
                          "15.5 faces per cell on average, random numbering); single rank only; scipy Delaunay "
                          "takes about a minute per million points")
+    ap.add_argument("--octree", type=float, default=0.0,
+                    help="instead of the plain box: an octree (snappyHexMesh-like, hex-dominant) mesh -- the cells "
+                         "of the n^3 box within this many cells of a sphere are split 2x2x2, their unsplit "
+                         "neighbours get rows of 10..16 entries; single rank only")
+    ap.add_argument("--octree-append", action="store_true",
+                    help="with --octree: children 1..7 of a split cell are numbered at the end of the cell list "
+                         "(what splitting in place leaves behind) instead of next to their parent")
     ap.add_argument("--rcm", action="store_true",
                     help="after --shuffle: renumber the CASE with reverse Cuthill-McKee (scipy), as "
                          "renumberMesh would, before the library sees it")
@@ -160,6 +167,9 @@ def main():
     if args.voronoi:
         assert world == 1, "--voronoi is a single-rank option"
         case = synthetic.voronoi_case(args.voronoi)
+    if args.octree:
+        assert world == 1 and not args.voronoi and not args.asym, "--octree is a single-rank, symmetric option"
+        case = synthetic.octree_case(n, args.octree, args.octree_append)
     if args.drop_faces:
         assert world == 1, "--drop-faces is a single-rank option"
         case = synthetic.drop_faces_case(case, args.drop_faces)
@@ -479,7 +489,10 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": (f"Voronoi mesh of {args.voronoi} random points (polyhedral cells, random numbering) lduMatrix"
-                         if args.voronoi else f"{n}^3-per-GPU 7-pt Poisson lduMatrix") +
+                         if args.voronoi else
+                         f"octree mesh: {n}^3 hexahedra, those within {args.octree} cells of a sphere split 2x2x2"
+                         f"{' (children appended to the cell list)' if args.octree_append else ''} lduMatrix"
+                         if args.octree else f"{n}^3-per-GPU 7-pt Poisson lduMatrix") +
                         f"{' (non-symmetric)' if args.asym else ''}"
                         f"{f' ({args.drop_faces:.0%} of the faces removed at random)' if args.drop_faces else ''}"
                         f"{f' ({args.long_rows:.0%} of the cells with 5 extra couplings)' if args.long_rows else ''}"
@@ -492,7 +505,7 @@ def main():
                            "ell": "fp64/int32 ELL copy of the persistent device CSR"}[layout]
                         + (", device copy renumbered by the library (RCM)" if renumbered else "")
                         + (" (BASELINE.json configs[1])" if not (args.voronoi or args.shuffle or args.drop_faces
-                                                                or args.long_rows) else " (proxy of an unstructured mesh)"),
+                                                                or args.long_rows or args.octree) else " (proxy of an unstructured mesh)"),
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
             "rows_sorted_by_length": prop_or("rowsSortedByLength", 0.0) == 1.0,

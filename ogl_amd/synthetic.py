@@ -289,6 +289,75 @@ def voronoi_case(n_points: int, seed: int = 20241016) -> LduCase:
     return LduCase(n_points, lo, up, diag, np.full(lo.size, -1.0), None, [], gi, n_points)
 
 
+def octree_case(n: int, band: float = 1.5, append_children: bool = False) -> LduCase:
+    """A hex-dominant mesh as snappyHexMesh / an octree mesher makes it: an n^3 box of hexahedra in which
+    every cell within `band` cells of a sphere (radius n/3, centred) is split into 2x2x2 children.  An
+    unsplit cell next to a split one shares FOUR faces with it on that side, so the rows of the matrix have
+    7 entries in the bulk and 10, 13 or 16 along the two surfaces of the refined shell.  Numbering: cell by
+    cell in the box's x-fastest order, the 8 children of a split cell consecutively (append_children: child
+    0 keeps the parent's place and the other seven go to the end of the list, which is what cell splitting
+    in place leaves behind).  upper = -1, diag = #faces + delta.  Single-rank cases only."""
+    ii, jj, kk = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")   # [i, j, k], i = x
+    c = (n - 1) / 2.0
+    dist = np.sqrt((ii - c) ** 2 + (jj - c) ** 2 + (kk - c) ** 2)
+    split = np.abs(dist - n / 3.0) <= band                                             # [x, y, z]
+    flat = lambda a: np.transpose(a, (2, 1, 0)).reshape(-1)                            # x-fastest order
+    sp = flat(split)
+    ncoarse = n ** 3
+    if append_children:
+        first = np.arange(ncoarse, dtype=np.int64)                 # parent's place = child 0 / the unsplit cell
+        rest = ncoarse + 7 * (np.cumsum(sp) - sp).astype(np.int64)  # children 1..7 of a split cell
+        n_cells = ncoarse + 7 * int(sp.sum())
+
+        def child(cells, q):                                       # q = a + 2 b + 4 c
+            return np.where(q == 0, first[cells], rest[cells] + q - 1)
+    else:
+        first = np.cumsum(np.where(sp, 8, 1)) - np.where(sp, 8, 1)
+        first = first.astype(np.int64)
+        n_cells = int(first[-1] + (8 if sp[-1] else 1))
+
+        def child(cells, q):
+            return first[cells] + q
+    cid = np.arange(ncoarse, dtype=np.int64).reshape(n, n, n)      # [z, y, x]
+    pairs = []
+    strides = (1, n, n * n)
+    for d in range(3):                                             # faces between box neighbours along axis d
+        sl_lo = [slice(None)] * 3
+        sl_hi = [slice(None)] * 3
+        sl_lo[2 - d] = slice(0, n - 1)
+        sl_hi[2 - d] = slice(1, n)
+        a = cid[tuple(sl_lo)].reshape(-1)
+        b = cid[tuple(sl_hi)].reshape(-1)
+        sa, sb = sp[a], sp[b]
+        o1, o2 = [x for x in range(3) if x != d]                   # the two axes of the shared face
+        both = ~sa & ~sb
+        pairs.append((first[a[both]], first[b[both]]))
+        for u in (0, 1):
+            for v in (0, 1):
+                q_hi = (1 << d) | (u << o1) | (v << o2)            # child of the lower cell on its + side
+                q_lo = (u << o1) | (v << o2)                       # child of the upper cell on its - side
+                m = sa & sb
+                pairs.append((child(a[m], q_hi), child(b[m], q_lo)))
+                m = sa & ~sb
+                pairs.append((child(a[m], q_hi), first[b[m]]))
+                m = ~sa & sb
+                pairs.append((first[a[m]], child(b[m], q_lo)))
+    cells = np.flatnonzero(sp)
+    for d in range(3):                                             # the 12 faces inside a split cell
+        for q in range(8):
+            if not q & (1 << d):
+                pairs.append((child(cells, q), child(cells, q | (1 << d))))
+    lo = np.concatenate([np.minimum(p, q) for p, q in pairs])
+    up = np.concatenate([np.maximum(p, q) for p, q in pairs])
+    order = np.lexsort((up, lo))
+    lo, up = lo[order], up[order]
+    n_faces = np.bincount(lo, minlength=n_cells) + np.bincount(up, minlength=n_cells)
+    gi = np.arange(n_cells, dtype=np.int64)
+    diag = n_faces.astype(np.float64) + _delta(gi)
+    return LduCase(n_cells, lo.astype(np.int32), up.astype(np.int32), diag, np.full(lo.size, -1.0), None, [],
+                   gi, n_cells)
+
+
 def rcm_case(case: LduCase) -> LduCase:
     """What OpenFOAM's renumberMesh does: reverse Cuthill-McKee ordering of the cell graph (scipy)."""
     import scipy.sparse as sp

@@ -294,3 +294,27 @@ def test_irregular_pattern_is_timed_on_both_kernels_once(reg, oracle):
     xv = rng.uniform(-1, 1, vor.n_cells)
     A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, vor, nid)
     np.testing.assert_array_equal(sv.spmv(xv), oracle.spmv(rp, cols, vals, to_new(xv, nid))[nid])
+
+
+@pytest.mark.parametrize("append", [False, True])
+def test_octree_mesh_same_bits_as_the_oracle(reg, oracle, append):
+    """A hex-dominant (octree) mesh: rows of 7 entries and, along the refined shell, 10 / 13 / 16.  Lanes stop
+    at their rows' ends, long tails spill; SpMV and whole CG / BiCGStab solves are the oracle's bit for bit."""
+    case = synthetic.octree_case(28, 1.5, append)
+    rng = np.random.default_rng(5)
+    case.upper[:] = rng.uniform(-1.0, -0.5, case.upper.size)
+    s = reg.solver(f"octree{int(append)}", cfg(1, renumber=capi.RENUMBER_OFF)).set_matrix(case)
+    assert s.get_property("spmvLayout") == LAYOUT_SELL
+    rp, cols, vals = oracle_csr(oracle, case)
+    x = rng.uniform(-1, 1, case.n_cells)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+    b = oracle.spmv(rp, cols, vals, x)
+    A, _ = oracle_matrix(oracle, case)
+    for solver, fn, kw in ((capi.SOLVER_CG, oracle.cg, {}), (capi.SOLVER_BICGSTAB, oracle.bicgstab, {})):
+        sv = reg.solver(f"octree{int(append)}_{solver}", cfg(1, solver=solver, renumber=capi.RENUMBER_OFF, max_iter=40)).set_matrix(case)
+        xs, perf = sv.solve(b, np.zeros_like(b))
+        with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+            ref = fn(A, b, np.zeros_like(b), oracle.jacobi_generate_scalar(rp, cols, vals), tolerance=1e-11,
+                     rel_tol=0.0, max_iter=40, **kw)
+        np.testing.assert_array_equal(sv.history(), ref.history)
+        np.testing.assert_array_equal(xs, ref.x)
