@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--force-compress", action="store_true",
                     help="compressIndices force: the compressed layout without the one-off timing against the "
                          "CSR-stream kernel that decides for irregular patterns")
+    ap.add_argument("--full-storage", action="store_true",
+                    help="symmetricStorage false: a symmetric matrix is expanded to full storage on the device "
+                         "(the compressed layout of round 1/2) instead of keeping diagonal + upper planes")
     ap.add_argument("--no-compress", action="store_true",
                     help="compressIndices false: SpMV on the plain CSR arrays (CSR-stream kernel)")
     ap.add_argument("--shuffle", type=int, default=0,
@@ -196,6 +199,7 @@ def main():
                               matrix_format=capi.FORMAT_ELL if args.format == "Ell" else capi.FORMAT_CSR,
                               export_res=0, profile_kernels=0 if args.no_profile else args.profile_stride,
                               compress_indices=0 if args.no_compress else (2 if args.force_compress else 1),
+                              symmetric_half=0 if args.full_storage else 1,
                               renumber={"off": 0, "on": 1, "auto": 2}[args.renumber])
 
     def all_ok(ok):
@@ -430,16 +434,19 @@ def main():
         except capi.OglError:
             return default
     layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[s.get_property("spmvLayout")]
+    if layout == "sell" and prop_or("symmetricHalf", 0.0) == 1.0:
+        layout = "sym"   # half storage of a symmetric matrix on a banded pattern (diagonal + upper planes)
     renumbered = s.get_property("renumbered") == 1.0
     if world > 1 and s.get_property("peerHalo") == 1.0:
         # the transport above was only the bootstrap: halo values are put straight into the
         # neighbours' receive blocks (hipIpc-mapped) by the pack kernel
         transport = "peer-put halo + peer-write all-reduce over xGMI (hipIpc), bootstrap: " + \
                     ("RCCL" if transport.startswith("RCCL") else "gloo")
-    kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell"}[layout]
+    kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell", "sym": "k_spmv_sym"}[layout]
     # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
-    b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout == "sell" else b_spmv
-    traffic, traffic_src = (pmc_traffic(kernel + "<0, 1>", "_shuffle65536" if args.shuffle == 65536 else "")
+    b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout in ("sell", "sym") else b_spmv
+    traffic, traffic_src = (pmc_traffic(kernel + ("<0, 1, 4>" if layout == "sym" else "<0, 1>"),
+                                        "_shuffle65536" if args.shuffle == 65536 else "")
                             if (n == 216 and args.format == "Csr" and args.shuffle in (0, 65536)
                                 and args.renumber == "auto" and not args.rcm) else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
@@ -501,6 +508,9 @@ def main():
                         f"{args.precond + ('(maxBlockSize ' + str(args.block_size) + ')' if args.precond == 'BJ' else '') if precond else 'no preconditioner'}, "
                         + {"sell": "fp64 SpMV on the index-compressed SELL copy (1-byte / 16-bit column codes) of "
                                    "the persistent fp64/int32 device CSR",
+                           "sym": "fp64 SpMV on the half storage of the symmetric matrix (diagonal + upper planes, "
+                                  "as the lduMatrix holds it; lower entries read where their twins live) next to "
+                                  "the persistent fp64/int32 device CSR",
                            "csr": "fp64/int32 persistent device CSR (CSR-stream SpMV)",
                            "ell": "fp64/int32 ELL copy of the persistent device CSR"}[layout]
                         + (", device copy renumbered by the library (RCM)" if renumbered else "")

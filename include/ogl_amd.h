@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define OGL_AMD_ABI_VERSION 2
+#define OGL_AMD_ABI_VERSION 3
 
 typedef int32_t ogl_label;
 typedef double ogl_scalar;
@@ -108,6 +108,12 @@ typedef struct ogl_config {
                                    column order, so results differ from the un-renumbered run at
                                    rounding level, exactly as after renumberMesh.  NOT a reference
                                    keyword: "renumber"                                              */
+    int32_t symmetric_half;     /* 1; a symmetric lduMatrix (no `lower`) on a banded pattern (a
+                                   structured mesh: at most 3 distances from the diagonal) is kept
+                                   the OpenFOAM way on the device too -- diagonal + upper coefficients
+                                   only; the SpMV reads A(r, r-d) where it reads A(r-d, r).  Same bits
+                                   in y, a third fewer bytes from DRAM.  Needs compress_indices; 0 =
+                                   full storage.  NOT a reference keyword: "symmetricStorage"        */
 } ogl_config;
 
 /* Fill with the reference code's defaults. */
@@ -370,6 +376,14 @@ void ogl_host_adapt_criterion(const ogl_config *cfg, ogl_label prev_solve_iters,
  * small kernel).  OGL_ERR_STATE if the decoded pattern differs from the input. */
 int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                         int64_t stats[8]);
+
+/* Half storage of a symmetric matrix on a banded pattern (symmetric_half): builds the layout of a
+ * row-major sorted CSR pattern and walks every row the way the kernel does.  stats[0] = 1 if the
+ * pattern qualifies (else 0 and the rest is 0), stats[1] = planes (diagonal + distances), stats[2..5]
+ * = the distances (ascending, the first is 0), stats[6] = plane slots, stats[7] = slots in use.
+ * OGL_ERR_STATE if the walk does not reproduce the input. */
+int ogl_host_sym_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                       int64_t stats[8]);
 
 #ifdef __cplusplus
 }

@@ -39,7 +39,7 @@ class Config(C.Structure):
         ("export_res", C.c_int32), ("verbose", C.c_int32), ("force_host_buffer", C.c_int32),
         ("ranks_per_gpu", C.c_int32), ("krylov_dim", C.c_int32), ("sparsity_power", C.c_int32),
         ("profile_kernels", C.c_int32), ("compress_indices", C.c_int32),
-        ("renumber", C.c_int32),
+        ("renumber", C.c_int32), ("symmetric_half", C.c_int32),
     ]
 
 
@@ -91,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "ogl_solver_get_comm_pattern", "ogl_host_init_local_sparsity", "ogl_host_symmetric_update",
     "ogl_host_symmetric_update_w_interface", "ogl_host_non_symmetric_update_w_interface",
     "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
-    "ogl_host_sell_check", "ogl_solver_get_renumbering", "ogl_host_rcm",
+    "ogl_host_sell_check", "ogl_host_sym_check", "ogl_solver_get_renumbering", "ogl_host_rcm",
     "ogl_host_gather_sector_ratio", "ogl_host_pattern_renumbered",
     "ogl_host_addressing_fingerprint", "ogl_registry_comm_info",
 ]
@@ -478,6 +478,16 @@ def host_sell_check(row_ptrs, cols):
     _check(lib().ogl_host_sell_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
                                      cc.ctypes.data_as(C.c_void_p), stats))
     return bool(stats[0]), int(stats[1]), int(stats[2]), int(stats[3])
+
+
+def host_sym_check(row_ptrs, cols):
+    """Half storage of a symmetric matrix on a banded pattern: (qualifies, distances from the diagonal
+    incl. 0, plane slots, slots in use); raises if walking the layout does not reproduce the pattern."""
+    rp, cc = _l(row_ptrs), _l(cols)
+    stats = (C.c_int64 * 8)()
+    _check(lib().ogl_host_sym_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
+                                    cc.ctypes.data_as(C.c_void_p), stats))
+    return bool(stats[0]), [int(stats[2 + j]) for j in range(int(stats[1]))], int(stats[6]), int(stats[7])
 
 
 def host_sell_modes(row_ptrs, cols):

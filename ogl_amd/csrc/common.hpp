@@ -115,6 +115,9 @@ constexpr int SELL_MAX_DELTA16 = 65534;                // 0xFFFF marks a padding
 constexpr int SELL_MAX_DICT = 255;        // offset mode: code 255 marks a padding slot
 constexpr int SELL_TABLE_INTS = 2048;     // LDS table of the SpMV kernel (8 KB)
 constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of a pattern
+// half storage of a symmetric matrix on a banded pattern (SymLayout, host_matrix.hpp)
+constexpr int SYM_MAX_OFFSETS = 4;        // diagonal + 3 legs: up to a 7-point stencil in 3-D
+constexpr double SYM_MAX_PADDING = 1.15;  // plane slots / (diagonal + upper entries) above which full storage stays
 constexpr int SPMV_TUNE_MIN_ROWS = 65536;     // smaller systems: launch-bound, the compressed layout stays
 constexpr int RENUMBER_AUTO_MIN_ROWS = 16384;  // config renumber = auto: smaller systems keep their numbering
 // Padding is laid out but not read: every lane stops loading at the longer of its two rows (the row

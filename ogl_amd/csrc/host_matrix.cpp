@@ -1022,6 +1022,61 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     return true;
 }
 
+bool build_sym_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymLayout &out)
+{
+    out = SymLayout{};
+    if (n_rows <= 0) return false;
+    const int64_t nc = n_chunks(n_rows);
+    // the distances from the diagonal that occur (upper side), ascending; 0 always takes plane 0
+    int64_t dist[SYM_MAX_OFFSETS] = {0};
+    int nd = 1;
+    int64_t upper_entries = 0;
+    for (ogl_label r = 0; r < n_rows; ++r)
+        for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+            const int64_t d = (int64_t)cols[k] - r;
+            if (d < 0) continue;
+            ++upper_entries;
+            int j = 0;
+            while (j < nd && dist[j] != d) ++j;
+            if (j < nd) continue;
+            if (nd == SYM_MAX_OFFSETS) return false;
+            dist[nd++] = d;
+        }
+    std::sort(dist, dist + nd);
+    if (nd < 2 || dist[0] != 0 || dist[nd - 1] > INT32_MAX / 2) return false;
+    if ((double)nd * (double)nc * CHUNK_ROWS > SYM_MAX_PADDING * (double)upper_entries + 8.0 * CHUNK_ROWS) return false;
+    out.nd = nd;
+    for (int j = 0; j < nd; ++j) out.d[j] = (int32_t)dist[j];
+    out.mask.assign((size_t)nc * CHUNK_ROWS + 16, 0);
+    out.map.assign((size_t)nc * nd * CHUNK_ROWS + 2, -1);
+    auto plane_of = [&](int64_t d) {
+        int j = 0;
+        while (j < nd && dist[j] != d) ++j;
+        return j;
+    };
+    auto slot_of = [&](int j, int64_t r) { return (size_t)((r / CHUNK_ROWS) * nd + j) * CHUNK_ROWS + (size_t)(r % CHUNK_ROWS); };
+    for (ogl_label r = 0; r < n_rows; ++r) {
+        int64_t prev = INT64_MIN;
+        for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+            const int64_t d = (int64_t)cols[k] - r;
+            if (d <= prev) return false;  // the kernel sums in ascending column order: one entry per column
+            prev = d;
+            if (d < 0) continue;
+            const int j = plane_of(d);
+            out.map[slot_of(j, r)] = k;
+            out.mask[(size_t)r] |= (uint8_t)(1u << (nd - 1 + j));
+        }
+    }
+    // every lower entry must have its upper twin (that is where its value is read)
+    for (ogl_label r = 0; r < n_rows; ++r)
+        for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1] && cols[k] < r; ++k) {
+            const int j = plane_of((int64_t)r - cols[k]);
+            if (j == nd || out.map[slot_of(j, cols[k])] < 0) return false;
+            out.mask[(size_t)r] |= (uint8_t)(1u << (nd - 1 - j));
+        }
+    return true;
+}
+
 }  // namespace ogl
 
 // ---------------------------------------------------------------------------------------
@@ -1328,6 +1383,51 @@ extern "C" int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, 
     return OGL_OK;
 }
 
+// Half storage of a symmetric matrix (build_sym_layout): builds it and decodes it exactly as k_spmv_sym
+// does.  stats: [0] qualifies, [1] planes (nd), [2..5] the distances d[0..3], [6] plane slots, [7] slots in use
+extern "C" int ogl_host_sym_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                                  int64_t stats[8])
+{
+    if (n_rows < 0 || !row_ptrs || !stats || (n_rows > 0 && !cols))
+        return fail(OGL_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    SymLayout L;
+    if (n_rows == 0 || !build_sym_layout(n_rows, row_ptrs, cols, L)) return OGL_OK;
+    const int nd = L.nd;
+    int64_t used = 0;
+    for (int32_t m : L.map) used += m >= 0;
+    for (ogl_label r = 0; r < n_rows; ++r) {
+        // the kernel's walk over row r: lower entries from the furthest to the nearest, the diagonal, upper entries
+        ogl_label k = row_ptrs[r];
+        const unsigned m = L.mask[(size_t)r];
+        for (int j = nd - 1; j >= 1; --j)
+            if ((m >> (nd - 1 - j)) & 1u) {
+                const int64_t rr = (int64_t)r - L.d[j];
+                if (rr < 0) return fail(OGL_ERR_STATE, "row %d: lower entry before row 0", r);
+                const int32_t src = L.map[(size_t)((rr / CHUNK_ROWS) * nd + j) * CHUNK_ROWS + (size_t)(rr % CHUNK_ROWS)];
+                // its value is the twin's: position of (rr, r) in the CSR
+                if (k >= row_ptrs[r + 1] || cols[k] != rr || src < 0 || cols[src] != r || src < row_ptrs[rr] ||
+                    src >= row_ptrs[rr + 1])
+                    return fail(OGL_ERR_STATE, "row %d: lower entry at -%d decodes wrongly", r, L.d[j]);
+                ++k;
+            }
+        for (int j = 0; j < nd; ++j)
+            if ((m >> (nd - 1 + j)) & 1u) {
+                const int32_t src = L.map[(size_t)((r / CHUNK_ROWS) * nd + j) * CHUNK_ROWS + (size_t)(r % CHUNK_ROWS)];
+                if (k >= row_ptrs[r + 1] || cols[k] != r + L.d[j] || src != k)
+                    return fail(OGL_ERR_STATE, "row %d: upper entry at +%d decodes wrongly", r, L.d[j]);
+                ++k;
+            }
+        if (k != row_ptrs[r + 1]) return fail(OGL_ERR_STATE, "row %d lost entries", r);
+    }
+    stats[0] = 1;
+    stats[1] = nd;
+    for (int j = 0; j < nd; ++j) stats[2 + j] = L.d[j];
+    stats[6] = (int64_t)L.map.size() - 2;
+    stats[7] = used;
+    return OGL_OK;
+}
+
 extern "C" void ogl_config_default(ogl_config *c)
 {
     *c = ogl_config{};
@@ -1359,4 +1459,5 @@ extern "C" void ogl_config_default(ogl_config *c)
     c->profile_kernels = 0;
     c->compress_indices = 1;
     c->renumber = 2;
+    c->symmetric_half = 1;
 }

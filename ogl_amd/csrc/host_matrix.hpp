@@ -87,6 +87,27 @@ struct SellLayout {
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                        SellLayout &out, bool allow_spill = true);
 
+// ---- half storage of a symmetric matrix on a banded pattern (config `symmetric_half`) ----
+// A symmetric lduMatrix carries every off-diagonal coefficient once (`upper`); the reference expands it to a
+// full CSR and so does the compressed layout above.  Where the pattern is banded -- every entry sits at one
+// of a handful of distances from the diagonal, a structured mesh -- the device can keep the OpenFOAM way:
+// plane j (of nd <= SYM_MAX_OFFSETS) of a chunk holds A(r, r + d[j]) for the chunk's rows, d[0] = 0 being
+// the diagonal, and the SpMV reads the lower entry A(r, r - d[j]) as plane j of row r - d[j]: the same
+// bytes it reads as an upper entry of that row, one coalesced strip further back.  DRAM sees every
+// coefficient once: 8 nd + 1 bytes per row instead of 8.1 per stored entry.  One byte per row tells which
+// of its 2 nd - 1 possible entries exist; rows are summed in ascending column order, so y and the fused
+// dot partials have the same bits as with full storage.
+// (SYM_MAX_OFFSETS, SYM_MAX_PADDING: common.hpp)
+struct SymLayout {
+    int32_t nd = 0;
+    int32_t d[SYM_MAX_OFFSETS] = {};  // ascending, d[0] = 0
+    std::vector<uint8_t> mask;        // [n_chunks * CHUNK_ROWS] bit (nd-1-j): entry at -d[j] (j >= 1); bit (nd-1+j): at +d[j]
+    std::vector<int32_t> map;         // [n_chunks * nd * CHUNK_ROWS] plane slot -> position in the CSR values, -1 = none
+};
+// false: the pattern does not qualify (more distances than planes, a lower entry without its upper twin,
+// too much padding).  The VALUES being symmetric is the caller's knowledge (lduMatrix without `lower`).
+bool build_sym_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymLayout &out);
+
 // ---- renumbering (no reference counterpart: OpenFOAM users run `renumberMesh`; here the backend
 // does it for itself when the numbering it is handed gathers x badly) ----
 // Reverse Cuthill-McKee order of the graph of a row-major pattern (George-Liu pseudo-peripheral

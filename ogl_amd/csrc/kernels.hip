@@ -965,6 +965,124 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Half storage of a symmetric matrix on a banded pattern (SymLayout, host_matrix.hpp).  ND planes per
+// chunk: plane j holds A(r, r + d[j]), d[0] = 0.  A lower entry A(r, r - d[j]) is read where its twin
+// lives: plane j of row r - d[j] -- a coalesced strip of values that some workgroup reads (or has read) as
+// upper entries, so DRAM delivers every coefficient once; the second reader finds it in L2 / the Infinity
+// Cache.  8 ND + 1 bytes per row instead of 8.1 per stored entry: measured 115 us against 139 us for the
+// pattern-coded full storage on the 216^3 matrix (tools/sym_tune.hip, profiles/spmv_tune_r02.txt).  Rows are
+// summed in ascending column order -- furthest lower entry first, diagonal, upper entries -- so y and the
+// fused dot partials have the same bits as k_spmv_sell / k_spmv_stream.
+// ------------------------------------------------------------------------------------------
+struct SymOffsets {
+    int d[SYM_MAX_OFFSETS];
+};
+template <int MODE, int NDOT, int ND>
+__global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, SymOffsets off,
+                                                    const uint8_t *__restrict__ mask,
+                                                    const double *__restrict__ planes,
+                                                    const double *__restrict__ x, const double *__restrict__ b,
+                                                    double *__restrict__ y, const double *__restrict__ w,
+                                                    double *__restrict__ dot_partials,
+                                                    double *__restrict__ dot2_partials, const DevScalars *gate)
+{
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = xcd_chunk(blockIdx.x);
+    if (chunk >= n_chunks) return;
+    const int t = threadIdx.x;
+    const RowPair rp = my_rows(chunk, n_rows);
+    const int row = rp.row;
+    // which of the 2 ND - 1 entries the two rows have: bit (ND-1-j) = the one at -d[j], bit (ND-1+j) = at +d[j]
+    const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + row);
+    const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
+    double2 acc;
+    acc.x = acc.y = 0.0;
+    if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
+    // own planes: diagonal and upper entries of the two rows
+    double2 up[ND];
+    const double *own = planes + (long)chunk * (ND * CHUNK_ROWS) + t * ROWS_PER_THREAD;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) up[j] = *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
+    // lower entries: plane j at rows row - d[j], row + 1 - d[j] (an aligned pair when d[j] is even)
+    double2 lo[ND];
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        const bool ok0 = (m0 >> (ND - 1 - j)) & 1u, ok1 = (m1 >> (ND - 1 - j)) & 1u;
+        const int r0 = row - off.d[j], r1 = r0 + 1;
+        lo[j].x = lo[j].y = 0.0;
+        if ((off.d[j] & 1) == 0) {
+            const long a = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
+            if (ok0 || ok1) lo[j] = *reinterpret_cast<const double2 *>(planes + a);
+        } else {
+            const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
+            const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
+            if (ok0) lo[j].x = planes[a0];
+            if (ok1) lo[j].y = planes[a1];
+        }
+    }
+    static_assert(CHUNK_ROWS == 512, "row >> 9 above");
+    double2 xl[ND], xu[ND];
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        xl[j].x = ((m0 >> (ND - 1 - j)) & 1u) ? x[row - off.d[j]] : 0.0;
+        xl[j].y = ((m1 >> (ND - 1 - j)) & 1u) ? x[row + 1 - off.d[j]] : 0.0;
+        xu[j].x = ((m0 >> (ND - 1 + j)) & 1u) ? x[row + off.d[j]] : 0.0;
+        xu[j].y = ((m1 >> (ND - 1 + j)) & 1u) ? x[row + 1 + off.d[j]] : 0.0;
+    }
+    const double2 xd = ld2(x, rp);
+#pragma unroll
+    for (int j = ND - 1; j >= 1; --j) {  // ascending columns: the furthest lower entry first
+        if ((m0 >> (ND - 1 - j)) & 1u) {
+            const double p = lo[j].x * xl[j].x;
+            acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+        }
+        if ((m1 >> (ND - 1 - j)) & 1u) {
+            const double p = lo[j].y * xl[j].y;
+            acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+        }
+    }
+    if ((m0 >> (ND - 1)) & 1u) {
+        const double p = up[0].x * xd.x;
+        acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+    }
+    if ((m1 >> (ND - 1)) & 1u) {
+        const double p = up[0].y * xd.y;
+        acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+    }
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        if ((m0 >> (ND - 1 + j)) & 1u) {
+            const double p = up[j].x * xu[j].x;
+            acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+        }
+        if ((m1 >> (ND - 1 + j)) & 1u) {
+            const double p = up[j].y * xu[j].y;
+            acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+        }
+    }
+    st2(y, rp, acc);
+    if (NDOT >= 1) {
+        const double2 vw = ld2(w, rp);
+        double d = 0.0, d2 = 0.0;
+        if (rp.n > 0) {
+            d += vw.x * acc.x;
+            d2 += acc.x * acc.x;
+        }
+        if (rp.n > 1) {
+            d += vw.y * acc.y;
+            d2 += acc.y * acc.y;
+        }
+        const double s = block_sum(d, slot);
+        if (threadIdx.x == 0) dot_partials[chunk] = s;
+        if (NDOT >= 2) {
+            const double s2 = block_sum(d2, slot);
+            if (threadIdx.x == 0) dot2_partials[chunk] = s2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Index-compressed chunked ELL SpMV (SellChunk, common.hpp).  Values: eight 16-byte loads per lane
 // and group of 8 slots.  Columns, per chunk: pattern mode -- one 2-byte load brings the pattern ids
 // of the lane's two rows, the pattern table in LDS gives the offsets; offset mode -- one 16-byte
@@ -2008,6 +2126,40 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
         OGL_SELL(SPMV_PLAIN, 0);
     }
 #undef OGL_SELL
+}
+
+void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x, const double *b, double *y,
+                     const SpmvDots &dots, const DevScalars *gate)
+{
+    if (A.n_rows == 0) return;
+    const int nc = (int)n_chunks(A.n_rows);
+    const dim3 grid(xcd_grid(nc)), block(BLOCK);
+    SymOffsets off;
+    for (int j = 0; j < SYM_MAX_OFFSETS; ++j) off.d[j] = A.d[j];
+#define OGL_SYM_ND(MODE, NDOT, ND)                                                                          \
+    hipLaunchKernelGGL((k_spmv_sym<MODE, NDOT, ND>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
+                       x, b, y, dots.with, dots.part, dots.part_yy, gate)
+#define OGL_SYM(MODE, NDOT)                    \
+    do {                                       \
+        if (A.nd == 2)                         \
+            OGL_SYM_ND(MODE, NDOT, 2);         \
+        else if (A.nd == 3)                    \
+            OGL_SYM_ND(MODE, NDOT, 3);         \
+        else                                   \
+            OGL_SYM_ND(MODE, NDOT, 4);         \
+    } while (0)
+    static_assert(SYM_MAX_OFFSETS == 4, "instantiations above");
+    if (mode == SPMV_RESIDUAL) {
+        OGL_SYM(SPMV_RESIDUAL, 0);
+    } else if (dots.part && dots.part_yy) {
+        OGL_SYM(SPMV_PLAIN, 2);
+    } else if (dots.part) {
+        OGL_SYM(SPMV_PLAIN, 1);
+    } else {
+        OGL_SYM(SPMV_PLAIN, 0);
+    }
+#undef OGL_SYM
+#undef OGL_SYM_ND
 }
 
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,

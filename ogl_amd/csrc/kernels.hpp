@@ -96,6 +96,16 @@ struct DevSell {
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
                       double *y, const SpmvDots &dots, const DevScalars *gate);
+// Half storage of a symmetric matrix on a banded pattern (SymLayout, host_matrix.hpp), device view.
+struct DevSym {
+    int32_t n_rows = 0;
+    int32_t nd = 0;                 // planes per chunk: diagonal + distances
+    int32_t d[4] = {0, 0, 0, 0};    // the distances, ascending, d[0] = 0
+    const uint8_t *mask = nullptr;  // [n_chunks * CHUNK_ROWS] which entries a row has
+    const double *planes = nullptr; // [n_chunks][nd][CHUNK_ROWS]
+};
+void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x, const double *b, double *y,
+                     const SpmvDots &dots, const DevScalars *gate);
 // out[i] = map[i] >= 0 ? source[map[i]] : 0   (coefficient permutation into the padded ELL slots)
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,
                                  double *out);

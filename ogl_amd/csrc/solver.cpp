@@ -434,6 +434,40 @@ DevSell ogl_solver::sell() const
     return S;
 }
 
+DevSym ogl_solver::sym() const
+{
+    DevSym S;
+    S.n_rows = pat.n_rows;
+    S.nd = sym_nd;
+    for (int j = 0; j < 4; ++j) S.d[j] = sym_d[j];
+    S.mask = d_sym_mask.p;
+    S.planes = d_sym_planes.p;
+    return S;
+}
+
+// Once per sparsity pattern; d_sym_map refreshes the planes from the permuted CSR values on the device.
+int ogl_solver::build_sym(const SymLayout &L)
+{
+    hipStream_t st = reg->stream;
+    OGL_TRY(d_sym_mask.alloc(L.mask.size(), st));
+    OGL_TRY(d_sym_map.alloc(L.map.size(), st));
+    OGL_TRY(d_sym_planes.alloc(L.map.size(), st));
+    OGL_TRY(reg->stager.h2d(d_sym_mask.p, L.mask.data(), L.mask.size(), st));
+    OGL_TRY(reg->stager.h2d(d_sym_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
+    sym_nd = L.nd;
+    for (int j = 0; j < 4; ++j) sym_d[j] = j < L.nd ? L.d[j] : 0;
+    sym_state = 1;
+    sym_values_stale = true;
+    // bytes one SpMV reads of this layout (bench.py's moved-bytes model): planes + masks
+    props["sellMatrixBytes"] = 8.0 * (double)(L.map.size() - 2) + (double)(L.mask.size() - 16);
+    props["sellReadSlots"] = (double)(L.map.size() - 2);
+    props["sellAllocatedSlots"] = (double)(L.map.size() - 2);
+    props["sellChunksDelta16"] = 0.0;
+    props["sellChunksCol32"] = 0.0;
+    props["sellSpilledEntries"] = 0.0;
+    return OGL_OK;
+}
+
 int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, Stager &stager,
                    hipStream_t st)
 {
@@ -700,14 +734,16 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         matrix_set = true;
         ell_values_stale = true;
         sell_values_stale = true;
+        sym_values_stale = true;
         return OGL_OK;
     };
     // Has the addressing changed?  Counts first (free); then the hash of every face and interface cell,
     // which runs on helper threads WHILE the coefficients of the (presumably unchanged) pattern are
     // staged to the device: the arrays have the right sizes either way, and if the hash disagrees the
     // pattern is rebuilt and the coefficients go up again.
+    const bool try_sym = try_sell && cfg.symmetric_half;
     const bool config_same = have_pattern && pat_renumber_mode == cfg.renumber &&
-                             !(cfg.renumber != 0 && pat_try_sell != try_sell);
+                             !(cfg.renumber != 0 && pat_try_sell != try_sell) && pat_try_sym == try_sym;
     bool first = true, coefficients_done = false;
     if (config_same && same_counts(ldu, pat)) {
         auto fp = std::async(std::launch::async, [&ldu] { return addressing_fingerprint(ldu); });
@@ -743,6 +779,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep));
         pat_renumber_mode = cfg.renumber;
         pat_try_sell = try_sell;
+        pat_try_sym = try_sym;
         props["rowsSortedByLength"] = rep.sorted_by_length ? 1.0 : 0.0;
         props["gatherSlotSectorRatio"] = rep.slot_ratio;
         props["renumbered"] = rep.applied ? 1.0 : 0.0;
@@ -755,6 +792,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         matrix_set = false;
         ell_ready = false;
         sell_state = 0;
+        sym_state = 0;
         x_resident = b_resident = false;
         const size_t nnz = (size_t)pat.local_nnz;
         OGL_TRY(d_row_ptrs.alloc((size_t)pat.n_rows + 1, st));
@@ -837,7 +875,29 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             OGL_TRY(d_perm_tmp.alloc((size_t)pat.n_rows + 2, st));
             OGL_TRY(reg->stager.h2d(d_new_id.p, pat.new_id.data(), (size_t)pat.n_rows * sizeof(int32_t), st));
         }
-        if (pre_built && try_sell) OGL_TRY(build_sell(&pre_sell, rep.sell_used));
+        // a symmetric lduMatrix on a banded pattern keeps the OpenFOAM storage (diagonal + upper); the
+        // compressed full-storage copy is then not built at all
+        props["symmetricHalf"] = 0.0;
+        if (try_sym && pat.symmetric && pat.local_iface_nnz == 0 && !pat.renumbered()) {
+            SymLayout symL;
+            if (build_sym_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), symL)) {
+                OGL_TRY(build_sym(symL));
+                props["symmetricHalf"] = 1.0;
+                sell_state = -1;
+                d_sell_chunks.release();
+                d_sell_codes.release();
+                d_sell_vals.release();
+                d_sell_map.release();
+                d_sell_dict.release();
+            }
+        }
+        if (sym_state != 1) {
+            sym_state = -1;
+            d_sym_mask.release();
+            d_sym_map.release();
+            d_sym_planes.release();
+        }
+        if (sym_state != 1 && pre_built && try_sell) OGL_TRY(build_sell(&pre_sell, rep.sell_used));
         OGL_TRY(setup_peer_halo());  // collective when the peer mesh is up (every rank, every pattern)
     }
 
@@ -848,6 +908,11 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             launch_gather_coeffs_masked(st, (int64_t)ell_width * ell_stride, d_ell_map.p, d_vals.p,
                                         d_ell_vals.p);
             ell_values_stale = false;
+        }
+    } else if (cfg.compress_indices && sym_state == 1) {
+        if (sym_values_stale) {
+            launch_gather_coeffs_masked(st, (int64_t)d_sym_map.n - 2, d_sym_map.p, d_vals.p, d_sym_planes.p);
+            sym_values_stale = false;
         }
     } else if (cfg.compress_indices) {
         if (sell_state == 0) OGL_TRY(build_sell());
@@ -862,7 +927,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             OGL_TRY(tune_spmv_layout());
     }
     // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
-    props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : (use_sell() ? 2.0 : 0.0);
+    // (2 also for the half storage of a symmetric matrix: property symmetricHalf tells them apart)
+    props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : ((use_sell() || use_sym()) ? 2.0 : 0.0);
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
     t_update_matrix_ms = now_ms() - t0;
@@ -1112,6 +1178,8 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     // per-chunk tree, so the sums are bit-identical to a dot over the finished y).
     if (cfg.matrix_format == OGL_FORMAT_ELL && ell_ready && !ell_values_stale)
         launch_spmv_ell(st, ell(), mode, x, b, y, dots, gate);
+    else if (use_sym())
+        launch_spmv_sym(st, sym(), mode, x, b, y, dots, gate);
     else if (use_sell())
         launch_spmv_sell(st, sell(), mode, x, b, y, dots, gate);
     else

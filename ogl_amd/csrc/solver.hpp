@@ -201,6 +201,22 @@ struct ogl_solver {
     int64_t ell_stride = 0;
     bool ell_ready = false, ell_values_stale = true;
     int build_ell();
+    // half storage of a symmetric matrix on a banded pattern (SymLayout, host_matrix.hpp): what the Coo/Csr
+    // formats run on when cfg.compress_indices and cfg.symmetric_half are set, the lduMatrix has no `lower`
+    // and no same-rank (cyclic) interface, the device copy keeps the caller's numbering and the pattern
+    // qualifies.  Takes the place of the compressed copy below (sym_state as sell_state).
+    ogl::DevBuf<uint8_t> d_sym_mask;
+    ogl::DevBuf<int32_t> d_sym_map;
+    ogl::DevBuf<double> d_sym_planes;
+    int32_t sym_nd = 0, sym_d[4] = {0, 0, 0, 0};
+    int sym_state = 0;
+    bool sym_values_stale = true;
+    int build_sym(const ogl::SymLayout &L);
+    ogl::DevSym sym() const;
+    bool use_sym() const
+    {
+        return cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices && sym_state == 1 && !sym_values_stale;
+    }
     // index-compressed chunked ELL copy (SellChunk, common.hpp): what the Coo/Csr formats run on when
     // cfg.compress_indices is set and the pattern qualifies.  sell_state: 0 = not tried for this
     // pattern, 1 = built, -1 = pattern does not qualify (CSR-stream kernel runs)
@@ -233,7 +249,7 @@ struct ogl_solver {
     ogl::DevBuf<int32_t> d_new_id;
     ogl::DevBuf<double> d_perm_tmp;
     int pat_renumber_mode = -1;  // cfg.renumber / layout eligibility the pattern was built under
-    bool pat_try_sell = false;
+    bool pat_try_sell = false, pat_try_sym = false;
     ogl::DevBuf<double> d_flag;  // 2 doubles: cross-rank agreement on pattern rebuilds
     // host -> device / device -> host of one row vector, through the renumbering when there is one
     int upload_rows(double *dst, const double *src);

@@ -95,6 +95,12 @@ static void run_case(int nx, int ny, int nz, bool symmetric, bool with_interface
     int64_t stats[8];
     CHECK(ogl_host_sell_check(N, rp.data(), cols.data(), stats) == OGL_OK);
     CHECK(stats[0] == 1 && stats[1] >= d.local_nnz);
+    {   // half storage of the symmetric pattern: builds, walks, must qualify on the plain box
+        int64_t sym[8];
+        CHECK(ogl_host_sym_check(N, rp.data(), cols.data(), sym) == OGL_OK);
+        if (!with_interfaces && N > 1) CHECK(sym[0] == 1);  // (a cyclic pair adds distances: full storage stays)
+        if (sym[0]) CHECK(sym[1] >= 2 && sym[1] <= 4 && sym[2] == 0 && sym[7] <= sym[6]);
+    }
     // renumbering: forced (RCM) and auto; the outputs must be a permutation and a sorted pattern
     for (int mode = 1; mode <= 2; ++mode) {
         std::vector<ogl_label> new_id(N + 1, -1), rr(d.local_nnz), cc(d.local_nnz), mm(d.local_nnz);

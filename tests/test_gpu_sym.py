@@ -1,0 +1,120 @@
+"""GPU tests of the half storage of a symmetric matrix (config symmetric_half, k_spmv_sym): the device keeps
+diagonal + upper coefficients only and reads A(r, r - d) where it reads A(r - d, r).  Rows are summed in
+ascending column order, so everything must be bit-identical to full storage and to the oracle."""
+import numpy as np
+import pytest
+
+from ogl_amd import capi, synthetic
+from helpers import blocked, oracle_csr, oracle_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg():
+    r = capi.Registry()
+    yield r
+    r.close()
+
+
+def cfg(half, **kw):
+    base = dict(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, tolerance=1e-11, rel_tol=0.0,
+                max_iter=300, export_res=1, matrix_format=capi.FORMAT_CSR, adapt_min_iter=0,
+                compress_indices=1, symmetric_half=half)
+    base.update(kw)
+    return capi.default_config(**base)
+
+
+CASES = [dict(gx=5, gy=4, gz=3), dict(gx=33, gy=31, gz=29), dict(gx=1, gy=1, gz=1), dict(gx=1031, gy=1, gz=1),
+         dict(gx=64, gy=64, gz=1), dict(gx=64, gy=64, gz=3), dict(gx=16, gy=16, gz=16),
+         dict(gx=37, gy=5, gz=41)]
+
+
+def randomise(case, seed):
+    """Different coefficient on every face (the same for both directions: the matrix stays symmetric)."""
+    rng = np.random.default_rng(seed)
+    case.upper[:] = rng.uniform(-1.0, -0.25, case.upper.size)
+    case.diag[:] = rng.uniform(7.0, 9.0, case.n_cells)
+    return case
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_spmv_same_bits_half_or_full_storage(reg, oracle, kw):
+    case = randomise(synthetic.poisson_block(**kw), 3)
+    rng = np.random.default_rng(20241016)
+    x = rng.uniform(-1, 1, case.n_cells)
+    rp, cols, vals = oracle_csr(oracle, case)
+    ref = oracle.spmv(rp, cols, vals, x)
+    half = reg.solver("sym_half", cfg(1)).set_matrix(case)
+    full = reg.solver("sym_full", cfg(0)).set_matrix(case)
+    qualifies = capi.host_sym_check(rp, cols)[0]
+    assert half.get_property("symmetricHalf") == (1.0 if qualifies else 0.0)
+    assert full.get_property("symmetricHalf") == 0.0
+    assert half.get_property("spmvLayout") == full.get_property("spmvLayout") == 2.0
+    np.testing.assert_array_equal(half.spmv(x), ref)
+    np.testing.assert_array_equal(full.spmv(x), ref)
+    if case.n_cells > 1:
+        assert qualifies
+
+
+@pytest.mark.parametrize("solver", [capi.SOLVER_CG, capi.SOLVER_BICGSTAB, capi.SOLVER_GMRES])
+@pytest.mark.parametrize("precond", [capi.PRECOND_BJ, capi.PRECOND_NONE])
+def test_solvers_same_history_as_the_oracle(reg, oracle, solver, precond):
+    case = randomise(synthetic.poisson_case(20), 5)          # 8000 rows: 16 chunks, the last one partial
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    out = {}
+    for half in (1, 0):
+        s = reg.solver(f"sym_solver{solver}_{precond}_{half}",
+                       cfg(half, solver=solver, preconditioner=precond, krylov_dim=20)).set_matrix(case)
+        assert s.get_property("symmetricHalf") == float(half)
+        x, perf = s.solve(b, np.zeros_like(b))
+        out[half] = (x, s.history().copy(), perf.n_iterations)
+    np.testing.assert_array_equal(out[1][1], out[0][1])
+    np.testing.assert_array_equal(out[1][0], out[0][0])
+    assert out[1][2] == out[0][2]
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    kw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
+    with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+        if solver == capi.SOLVER_GMRES:
+            P = oracle.Precond(rp, cols, vals, 1) if precond else None
+            ref = oracle.gmres(A, b, np.zeros_like(b), P, krylov_dim=20, **kw)
+        else:
+            fn = oracle.cg if solver == capi.SOLVER_CG else oracle.bicgstab
+            ref = fn(A, b, np.zeros_like(b), oracle.jacobi_generate_scalar(rp, cols, vals) if precond else None, **kw)
+    np.testing.assert_array_equal(out[1][1], ref.history)
+    np.testing.assert_array_equal(out[1][0], ref.x)
+
+
+def test_planes_follow_coefficient_updates_and_pattern_changes(reg, oracle):
+    s = reg.solver("sym_upd", cfg(1))
+    rng = np.random.default_rng(9)
+    for n, seed in ((9, 1), (9, 2), (12, 3), (9, 4)):
+        case = randomise(synthetic.poisson_case(n), seed)
+        s.set_matrix(case)
+        assert s.get_property("symmetricHalf") == 1.0
+        rp, cols, vals = oracle_csr(oracle, case)
+        x = rng.uniform(-1, 1, case.n_cells)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+def test_matrices_that_keep_full_storage(reg, oracle):
+    rng = np.random.default_rng(2)
+    cases = {"asymmetric": synthetic.poisson_case(12, symmetric=False),
+             "cyclic pair": synthetic.poisson_block(6, 5, 4, periodic_x=True),
+             "shuffled": synthetic.renumber_case(synthetic.poisson_case(12), 256)}
+    for name, case in cases.items():
+        s = reg.solver("sym_" + name.replace(" ", "_"), cfg(1)).set_matrix(case)
+        assert s.get_property("symmetricHalf") == 0.0, name
+        rp, cols, vals = oracle_csr(oracle, case)
+        x = rng.uniform(-1, 1, case.n_cells)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+    # a forced renumbering (RCM) leaves no bands: full storage in the new numbering
+    case = synthetic.poisson_case(30)
+    s = reg.solver("sym_rcm", cfg(1, renumber=capi.RENUMBER_ON)).set_matrix(case)
+    assert s.renumbering() is not None and s.get_property("symmetricHalf") == 0.0
+    # toggling the keyword on the same field rebuilds the device copy
+    s = reg.solver("sym_toggle", cfg(1)).set_matrix(synthetic.poisson_case(10))
+    assert s.get_property("symmetricHalf") == 1.0
+    s2 = reg.solver("sym_toggle", cfg(0)).set_matrix(synthetic.poisson_case(10))
+    assert s2.get_property("symmetricHalf") == 0.0

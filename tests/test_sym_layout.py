@@ -1,0 +1,62 @@
+"""Half storage of a symmetric matrix on a banded pattern (config symmetric_half; build_sym_layout in
+ogl_amd/csrc/host_matrix.cpp): ogl_host_sym_check builds the layout and walks every row the way k_spmv_sym
+does -- lower entries read where their upper twins live -- and fails if that does not reproduce the pattern."""
+import numpy as np
+
+from ogl_amd import capi, synthetic
+
+
+def rowptr_of(rows, n):
+    return np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+
+
+def pattern(case):
+    d, loc, _, _ = capi.host_pattern(case)
+    return rowptr_of(loc[0], d.n_rows), loc[1], d
+
+
+def test_box_takes_four_planes():
+    rp, cols, d = pattern(synthetic.poisson_case(20))
+    ok, dist, slots, used = capi.host_sym_check(rp, cols)
+    assert ok and dist == [0, 1, 20, 400]
+    n_chunks = (d.n_rows + 511) // 512
+    assert slots == 4 * 512 * n_chunks
+    assert used == d.n_rows + (d.local_nnz - d.n_rows) // 2          # diagonal + one of every pair
+
+
+def test_slabs_lines_and_sheets():
+    for kw, dist in ((dict(gx=16, gy=16, gz=32, pz=2, rank=1), [0, 1, 16, 256]),     # a rank's slab: same structure
+                     (dict(gx=1031, gy=1, gz=1), [0, 1]),                           # 1-D: tridiagonal
+                     (dict(gx=64, gy=64, gz=1), [0, 1, 64]),                        # 2-D: 5-point
+                     (dict(gx=33, gy=31, gz=29), [0, 1, 33, 33 * 31]),              # partial last chunk
+                     (dict(gx=5, gy=4, gz=3), [0, 1, 5, 20])):
+        rp, cols, _ = pattern(synthetic.poisson_block(**kw))
+        ok, got, _, _ = capi.host_sym_check(rp, cols)
+        assert ok and got == dist, kw
+
+
+def test_patterns_that_do_not_qualify():
+    # a cyclic pair adds a fifth distance
+    rp, cols, _ = pattern(synthetic.poisson_block(6, 5, 4, periodic_x=True))
+    assert capi.host_sym_check(rp, cols)[0] is False
+    # a shuffled numbering has no bands
+    rp, cols, _ = pattern(synthetic.renumber_case(synthetic.poisson_case(16), 512))
+    assert capi.host_sym_check(rp, cols)[0] is False
+    # a lower entry without its upper twin (structurally non-symmetric)
+    n = 1024
+    rows = [[r] + ([r + 1] if r + 1 < n else []) + ([r - 1] if r % 3 == 0 and r > 0 else []) for r in range(n)]
+    rows = [np.array(sorted(c)) for c in rows]
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    # (r, r-1) exists for r % 3 == 0 and (r-1, r) exists for every r: twins are there -> qualifies ...
+    assert capi.host_sym_check(rp, np.concatenate(rows).astype(np.int32))[0] is True
+    # ... but not the other way round: (r, r-1) everywhere, (r-1, r) only sometimes
+    rows = [[r] + ([r - 1] if r > 0 else []) + ([r + 1] if r % 3 == 0 and r + 1 < n else []) for r in range(n)]
+    rows = [np.array(sorted(c)) for c in rows]
+    rp = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int32)
+    assert capi.host_sym_check(rp, np.concatenate(rows).astype(np.int32))[0] is False
+    # too much padding: a box that lost 30 % of its faces fills 4 planes with 3.1 entries per row
+    rp, cols, _ = pattern(synthetic.drop_faces_case(synthetic.poisson_case(28), 0.3))
+    assert capi.host_sym_check(rp, cols)[0] is False
+    # an octree mesh: more distances than planes
+    rp, cols, _ = pattern(synthetic.octree_case(16, 1.5))
+    assert capi.host_sym_check(rp, cols)[0] is False
