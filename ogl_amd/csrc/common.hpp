@@ -18,6 +18,7 @@ int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)))
 // Geometry of the deterministic reduction tree and of the CSR-stream SpMV (kernels.hip).
 // One workgroup = BLOCK threads = one chunk of CHUNK_ROWS consecutive rows; thread t owns the
 // ROWS_PER_THREAD consecutive rows starting at chunk_start + t * ROWS_PER_THREAD.
+constexpr int N_XCD = 8;  // MI355X: 8 XCDs, workgroup b is observed on XCD b % 8 (speed only)
 constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
 constexpr int CHUNK_ROWS = 512;

@@ -1022,6 +1022,23 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     return true;
 }
 
+void band_block_order(ogl_label n_rows, int64_t band, std::vector<int32_t> &order)
+{
+    order.clear();
+    if (band < (int64_t)N_XCD * CHUNK_ROWS || band * 4 > n_rows) return;
+    const int64_t nc = n_chunks(n_rows);
+    std::vector<std::vector<int32_t>> lists(N_XCD);
+    for (int64_t c = 0; c < nc; ++c) {
+        const int64_t ph = (c * CHUNK_ROWS) % band;  // position of the chunk's first row in its band period
+        lists[(size_t)std::min<int64_t>(N_XCD - 1, ph * N_XCD / band)].push_back((int32_t)c);
+    }
+    size_t longest = 0;
+    for (auto &l : lists) longest = std::max(longest, l.size());
+    order.assign(longest * N_XCD, -1);
+    for (int x = 0; x < N_XCD; ++x)
+        for (size_t i = 0; i < lists[(size_t)x].size(); ++i) order[i * N_XCD + (size_t)x] = lists[(size_t)x][i];
+}
+
 bool build_sym_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymLayout &out)
 {
     out = SymLayout{};

@@ -107,6 +107,13 @@ struct SymLayout {
 // false: the pattern does not qualify (more distances than planes, a lower entry without its upper twin,
 // too much padding).  The VALUES being symmetric is the caller's knowledge (lduMatrix without `lower`).
 bool build_sym_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymLayout &out);
+// Order of the SpMV's workgroups for a pattern whose furthest leg couples row r with r +- band: workgroup b
+// works on chunk order[b] (-1: none).  Workgroups go to the XCDs round robin (b % N_XCD); the order gives XCD
+// k the chunks whose first row lies in the k-th eighth of its band period, ascending -- so the chunk of row
+// r and the chunks of r +- band share an XCD, hence an L2: the x strips and (half storage) the value planes
+// that two of them read are fetched over the fabric once.  Empty when the band is too short to give every
+// XCD a chunk per period or too long to recur.
+void band_block_order(ogl_label n_rows, int64_t band, std::vector<int32_t> &order);
 
 // ---- renumbering (no reference counterpart: OpenFOAM users run `renumberMesh`; here the backend
 // does it for itself when the numbering it is handed gathers x badly) ----

@@ -22,7 +22,6 @@ namespace ogl {
 namespace {
 
 constexpr int N_WAVES = BLOCK / WAVE;
-constexpr int N_XCD = 8;  // MI355X: 8 XCDs, block b is observed on XCD b % 8 (speed only)
 
 // ------------------------------------------------------------------------------------------
 // reduction tree
@@ -984,12 +983,14 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
                                                     const double *__restrict__ x, const double *__restrict__ b,
                                                     double *__restrict__ y, const double *__restrict__ w,
                                                     double *__restrict__ dot_partials,
-                                                    double *__restrict__ dot2_partials, const DevScalars *gate)
+                                                    double *__restrict__ dot2_partials, const DevScalars *gate,
+                                                    const int *__restrict__ block_order)
 {
     __shared__ double slot[N_WAVES];
     if (gate && gate->stop) return;
-    const int chunk = xcd_chunk(blockIdx.x);
-    if (chunk >= n_chunks) return;
+    // banded patterns: the host's order puts the chunks of rows r and r +- d[ND-1] on one XCD (band_block_order)
+    const int chunk = block_order ? block_order[blockIdx.x] : xcd_chunk(blockIdx.x);
+    if (chunk < 0 || chunk >= n_chunks) return;
     const int t = threadIdx.x;
     const RowPair rp = my_rows(chunk, n_rows);
     const int row = rp.row;
@@ -1004,22 +1005,18 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
     const double *own = planes + (long)chunk * (ND * CHUNK_ROWS) + t * ROWS_PER_THREAD;
 #pragma unroll
     for (int j = 0; j < ND; ++j) up[j] = *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
-    // lower entries: plane j at rows row - d[j], row + 1 - d[j] (an aligned pair when d[j] is even)
+    // lower entries: plane j at rows row - d[j], row + 1 - d[j]
     double2 lo[ND];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
         const bool ok0 = (m0 >> (ND - 1 - j)) & 1u, ok1 = (m1 >> (ND - 1 - j)) & 1u;
         const int r0 = row - off.d[j], r1 = r0 + 1;
-        lo[j].x = lo[j].y = 0.0;
-        if ((off.d[j] & 1) == 0) {
-            const long a = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
-            if (ok0 || ok1) lo[j] = *reinterpret_cast<const double2 *>(planes + a);
-        } else {
-            const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
-            const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
-            if (ok0) lo[j].x = planes[a0];
-            if (ok1) lo[j].y = planes[a1];
-        }
+        // (two 8-byte loads, also where the pair is aligned: one 16-byte load per pair measured slower,
+        // tools/sym_tune.hip var2)
+        const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
+        const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
+        lo[j].x = ok0 ? planes[a0] : 0.0;
+        lo[j].y = ok1 ? planes[a1] : 0.0;
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
     double2 xl[ND], xu[ND];
@@ -2133,12 +2130,12 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
-    const dim3 grid(xcd_grid(nc)), block(BLOCK);
+    const dim3 grid(A.block_order ? A.n_blocks : xcd_grid(nc)), block(BLOCK);
     SymOffsets off;
     for (int j = 0; j < SYM_MAX_OFFSETS; ++j) off.d[j] = A.d[j];
 #define OGL_SYM_ND(MODE, NDOT, ND)                                                                          \
     hipLaunchKernelGGL((k_spmv_sym<MODE, NDOT, ND>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
-                       x, b, y, dots.with, dots.part, dots.part_yy, gate)
+                       x, b, y, dots.with, dots.part, dots.part_yy, gate, A.block_order)
 #define OGL_SYM(MODE, NDOT)                    \
     do {                                       \
         if (A.nd == 2)                         \

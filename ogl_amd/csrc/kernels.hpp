@@ -103,6 +103,9 @@ struct DevSym {
     int32_t d[4] = {0, 0, 0, 0};    // the distances, ascending, d[0] = 0
     const uint8_t *mask = nullptr;  // [n_chunks * CHUNK_ROWS] which entries a row has
     const double *planes = nullptr; // [n_chunks][nd][CHUNK_ROWS]
+    // workgroup b takes chunk block_order[b] (-1: none), n_blocks workgroups (band_block_order); nullptr: default map
+    const int32_t *block_order = nullptr;
+    int32_t n_blocks = 0;
 };
 void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x, const double *b, double *y,
                      const SpmvDots &dots, const DevScalars *gate);

@@ -442,6 +442,10 @@ DevSym ogl_solver::sym() const
     for (int j = 0; j < 4; ++j) S.d[j] = sym_d[j];
     S.mask = d_sym_mask.p;
     S.planes = d_sym_planes.p;
+    if (d_sym_order.n && !band_order_off) {
+        S.block_order = d_sym_order.p;
+        S.n_blocks = (int32_t)d_sym_order.n;
+    }
     return S;
 }
 
@@ -456,6 +460,13 @@ int ogl_solver::build_sym(const SymLayout &L)
     OGL_TRY(reg->stager.h2d(d_sym_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
     sym_nd = L.nd;
     for (int j = 0; j < 4; ++j) sym_d[j] = j < L.nd ? L.d[j] : 0;
+    std::vector<int32_t> order;
+    band_block_order(pat.n_rows, L.d[L.nd - 1], order);
+    d_sym_order.release();
+    if (!order.empty()) {
+        OGL_TRY(d_sym_order.alloc(order.size(), st));
+        OGL_TRY(reg->stager.h2d(d_sym_order.p, order.data(), order.size() * sizeof(int32_t), st));
+    }
     sym_state = 1;
     sym_values_stale = true;
     // bytes one SpMV reads of this layout (bench.py's moved-bytes model): planes + masks

@@ -206,7 +206,8 @@ struct ogl_solver {
     // and no same-rank (cyclic) interface, the device copy keeps the caller's numbering and the pattern
     // qualifies.  Takes the place of the compressed copy below (sym_state as sell_state).
     ogl::DevBuf<uint8_t> d_sym_mask;
-    ogl::DevBuf<int32_t> d_sym_map;
+    ogl::DevBuf<int32_t> d_sym_map, d_sym_order;  // (order: band_block_order, may be empty)
+    bool band_order_off = std::getenv("OGL_NO_BAND_ORDER") != nullptr;  // (A/B switch for measurements)
     ogl::DevBuf<double> d_sym_planes;
     int32_t sym_nd = 0, sym_d[4] = {0, 0, 0, 0};
     int sym_state = 0;

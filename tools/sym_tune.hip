@@ -138,7 +138,7 @@ constexpr int ND = 4;
 struct SymArgs {
     int d[ND];
 };
-template <int XCD>
+template <int XCD, int VAR>
 __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs S, const uint8_t *__restrict__ mask,
                                                const double *__restrict__ planes, const double *__restrict__ x,
                                                double *__restrict__ y, double *__restrict__ part)
@@ -164,20 +164,44 @@ __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs
         const bool ok0 = (m0 >> (ND - 1 - j)) & 1u, ok1 = (m1 >> (ND - 1 - j)) & 1u;
         const long a0 = (long)(r0 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r0 & (CHUNK - 1));
         const long a1 = (long)(r1 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r1 & (CHUNK - 1));
-        lo0[j] = ok0 ? planes[a0] : 0.0;
-        lo1[j] = ok1 ? planes[a1] : 0.0;
+        if (VAR >= 2 && (S.d[j] & 1) == 0) {
+            double2 pl = make_double2(0.0, 0.0);
+            if (ok0 || ok1) pl = *reinterpret_cast<const double2 *>(planes + a0);
+            lo0[j] = pl.x;
+            lo1[j] = pl.y;
+        } else if (VAR >= 2 && S.d[j] == 1) {
+            lo0[j] = ok0 ? planes[a0] : 0.0;  // plane 1 of row - 1 (the previous lane's second row)
+            lo1[j] = up[j].x;                 // plane 1 of row = this lane's own upper entry
+        } else {
+            lo0[j] = ok0 ? planes[a0] : 0.0;
+            lo1[j] = ok1 ? planes[a1] : 0.0;
+        }
     }
     double xl0[ND], xl1[ND], xu0[ND], xu1[ND];
-#pragma unroll
-    for (int j = 1; j < ND; ++j) {
-        xl0[j] = ((m0 >> (ND - 1 - j)) & 1u) ? x[row - S.d[j]] : 0.0;
-        xl1[j] = ((m1 >> (ND - 1 - j)) & 1u) ? x[row + 1 - S.d[j]] : 0.0;
-        xu0[j] = ((m0 >> (ND - 1 + j)) & 1u) ? x[row + S.d[j]] : 0.0;
-        xu1[j] = ((m1 >> (ND - 1 + j)) & 1u) ? x[row + 1 + S.d[j]] : 0.0;
-    }
     double xd0 = 0.0, xd1 = 0.0;
     if (nv > 0) xd0 = x[row];
     if (nv > 1) xd1 = x[row + 1];
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        const bool l0 = (m0 >> (ND - 1 - j)) & 1u, l1 = (m1 >> (ND - 1 - j)) & 1u;
+        const bool u0 = (m0 >> (ND - 1 + j)) & 1u, u1 = (m1 >> (ND - 1 + j)) & 1u;
+        if (VAR >= 1 && (S.d[j] & 1) == 0) {  // even distance: the two rows' x values are an aligned pair
+            double2 pl = make_double2(0.0, 0.0), pu = make_double2(0.0, 0.0);
+            if (l0 || l1) pl = *reinterpret_cast<const double2 *>(x + row - S.d[j]);
+            if (u0 || u1) pu = *reinterpret_cast<const double2 *>(x + row + S.d[j]);
+            xl0[j] = pl.x; xl1[j] = pl.y; xu0[j] = pu.x; xu1[j] = pu.y;
+        } else if (VAR >= 1 && S.d[j] == 1) {  // the neighbours of a pair are the pair itself + one on each side
+            xl0[j] = l0 ? x[row - 1] : 0.0;
+            xl1[j] = xd0;
+            xu0[j] = xd1;
+            xu1[j] = u1 ? x[row + 2] : 0.0;
+        } else {
+            xl0[j] = l0 ? x[row - S.d[j]] : 0.0;
+            xl1[j] = l1 ? x[row + 1 - S.d[j]] : 0.0;
+            xu0[j] = u0 ? x[row + S.d[j]] : 0.0;
+            xu1[j] = u1 ? x[row + 1 + S.d[j]] : 0.0;
+        }
+    }
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
     for (int j = ND - 1; j >= 1; --j) {  // ascending columns: the furthest lower entry first
@@ -374,18 +398,17 @@ int main(int argc, char **argv)
                                        d_ptab, d_pcodes, d_svals, x, d_y, d_part, (const int *)nullptr);
                 },
                 d_x0, d_x1, d_y, yref, reps, moved_full);
-        time_it("half storage (symmetric), xcd-grouped", A,
-                [&](const double *x) {
-                    hipLaunchKernelGGL((k_sym<1>), dim3(xcd_grid(nc)), dim3(BLOCK), 0, 0, A.n, nc, S, d_mask, d_planes, x,
-                                       d_y, d_part);
-                },
-                d_x0, d_x1, d_y, yref, reps, moved_half);
-        time_it("half storage (symmetric), chunk = block", A,
-                [&](const double *x) {
-                    hipLaunchKernelGGL((k_sym<0>), dim3(nc), dim3(BLOCK), 0, 0, A.n, nc, S, d_mask, d_planes, x, d_y,
-                                       d_part);
-                },
-                d_x0, d_x1, d_y, yref, reps, moved_half);
+#define RUNSYM(XCD, VAR)                                                                                          \
+        time_it("half storage, xcd" #XCD " var" #VAR, A,                                                          \
+                [&](const double *x) {                                                                            \
+                    hipLaunchKernelGGL((k_sym<XCD, VAR>), dim3(XCD ? xcd_grid(nc) : nc), dim3(BLOCK), 0, 0, A.n, nc, S, \
+                                       d_mask, d_planes, x, d_y, d_part);                                         \
+                },                                                                                                \
+                d_x0, d_x1, d_y, yref, reps, moved_half)
+        RUNSYM(1, 0);
+        RUNSYM(1, 1);
+        RUNSYM(1, 2);
+        RUNSYM(0, 2);
     }
     return 0;
 }
