@@ -446,7 +446,8 @@ def main():
     # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
     b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout in ("sell", "sym") else b_spmv
     traffic, traffic_src = (pmc_traffic(kernel + ("<0, 1, 4>" if layout == "sym" else "<0, 1>"),
-                                        "_shuffle65536" if args.shuffle == 65536 else "")
+                                        "_shuffle65536" if args.shuffle == 65536 else
+                                        ("_fullstorage" if args.full_storage else ""))
                             if (n == 216 and args.format == "Csr" and args.shuffle in (0, 65536)
                                 and args.renumber == "auto" and not args.rcm) else (None, None))
     b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N

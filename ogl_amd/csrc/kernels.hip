@@ -976,7 +976,12 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, in
 struct SymOffsets {
     int d[SYM_MAX_OFFSETS];
 };
-template <int MODE, int NDOT, int ND>
+// FAST: d[1] == 1 and every further distance even (a box with an even line length) -- known at compile
+// time, so the kernel stays straight-line code (a run-time test of the parity splits the loads into basic
+// blocks that wait for each other: 130 us instead of 113, tools/sym_tune.hip var1/var2).  Then the two rows
+// of a lane are an aligned pair in every strip: x and the lower values of the even distances come as one
+// 16-byte load per pair, the d = 1 neighbours from the diagonal pair and the lane's own plane-1 value.
+template <int MODE, int NDOT, int ND, bool FAST>
 __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, SymOffsets off,
                                                     const uint8_t *__restrict__ mask,
                                                     const double *__restrict__ planes,
@@ -1005,29 +1010,48 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
     const double *own = planes + (long)chunk * (ND * CHUNK_ROWS) + t * ROWS_PER_THREAD;
 #pragma unroll
     for (int j = 0; j < ND; ++j) up[j] = *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
+    const double2 xd = ld2(x, rp);
     // lower entries: plane j at rows row - d[j], row + 1 - d[j]
     double2 lo[ND];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
         const bool ok0 = (m0 >> (ND - 1 - j)) & 1u, ok1 = (m1 >> (ND - 1 - j)) & 1u;
         const int r0 = row - off.d[j], r1 = r0 + 1;
-        // (two 8-byte loads, also where the pair is aligned: one 16-byte load per pair measured slower,
-        // tools/sym_tune.hip var2)
         const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
         const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
-        lo[j].x = ok0 ? planes[a0] : 0.0;
-        lo[j].y = ok1 ? planes[a1] : 0.0;
+        lo[j].x = lo[j].y = 0.0;
+        if (FAST && j >= 2) {  // even distance: rows r0, r0 + 1 are an aligned pair of one chunk's plane
+            if (ok0 || ok1) lo[j] = *reinterpret_cast<const double2 *>(planes + a0);
+        } else if (FAST) {     // d = 1: A(row + 1, row) is this lane's own upper entry of row
+            if (ok0) lo[j].x = planes[a0];
+            lo[j].y = up[1].x;
+        } else {
+            if (ok0) lo[j].x = planes[a0];
+            if (ok1) lo[j].y = planes[a1];
+        }
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
     double2 xl[ND], xu[ND];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
-        xl[j].x = ((m0 >> (ND - 1 - j)) & 1u) ? x[row - off.d[j]] : 0.0;
-        xl[j].y = ((m1 >> (ND - 1 - j)) & 1u) ? x[row + 1 - off.d[j]] : 0.0;
-        xu[j].x = ((m0 >> (ND - 1 + j)) & 1u) ? x[row + off.d[j]] : 0.0;
-        xu[j].y = ((m1 >> (ND - 1 + j)) & 1u) ? x[row + 1 + off.d[j]] : 0.0;
+        const bool l0 = (m0 >> (ND - 1 - j)) & 1u, l1 = (m1 >> (ND - 1 - j)) & 1u;
+        const bool u0 = (m0 >> (ND - 1 + j)) & 1u, u1 = (m1 >> (ND - 1 + j)) & 1u;
+        xl[j].x = xl[j].y = xu[j].x = xu[j].y = 0.0;
+        if (FAST && j >= 2) {
+            if (l0 || l1) xl[j] = *reinterpret_cast<const double2 *>(x + row - off.d[j]);
+            if (u0 || u1) xu[j] = *reinterpret_cast<const double2 *>(x + row + off.d[j]);
+        } else if (FAST) {     // the neighbours of a pair at distance 1: the pair itself + one on each side
+            if (l0) xl[j].x = x[row - 1];
+            xl[j].y = xd.x;
+            xu[j].x = xd.y;
+            if (u1) xu[j].y = x[row + 2];
+        } else {
+            if (l0) xl[j].x = x[row - off.d[j]];
+            if (l1) xl[j].y = x[row + 1 - off.d[j]];
+            if (u0) xu[j].x = x[row + off.d[j]];
+            if (u1) xu[j].y = x[row + 1 + off.d[j]];
+        }
     }
-    const double2 xd = ld2(x, rp);
 #pragma unroll
     for (int j = ND - 1; j >= 1; --j) {  // ascending columns: the furthest lower entry first
         if ((m0 >> (ND - 1 - j)) & 1u) {
@@ -2133,9 +2157,19 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
     const dim3 grid(A.block_order ? A.n_blocks : xcd_grid(nc)), block(BLOCK);
     SymOffsets off;
     for (int j = 0; j < SYM_MAX_OFFSETS; ++j) off.d[j] = A.d[j];
-#define OGL_SYM_ND(MODE, NDOT, ND)                                                                          \
-    hipLaunchKernelGGL((k_spmv_sym<MODE, NDOT, ND>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
+    // d[1] == 1 and the further distances even: the straight-line pair-load instantiation
+    bool fast = A.nd >= 2 && A.d[1] == 1;
+    for (int j = 2; j < A.nd; ++j) fast = fast && (A.d[j] % 2 == 0);
+#define OGL_SYM_K(MODE, NDOT, ND, FAST)                                                                           \
+    hipLaunchKernelGGL((k_spmv_sym<MODE, NDOT, ND, FAST>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
                        x, b, y, dots.with, dots.part, dots.part_yy, gate, A.block_order)
+#define OGL_SYM_ND(MODE, NDOT, ND)            \
+    do {                                      \
+        if (fast)                             \
+            OGL_SYM_K(MODE, NDOT, ND, true);  \
+        else                                  \
+            OGL_SYM_K(MODE, NDOT, ND, false); \
+    } while (0)
 #define OGL_SYM(MODE, NDOT)                    \
     do {                                       \
         if (A.nd == 2)                         \
@@ -2157,6 +2191,7 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
     }
 #undef OGL_SYM
 #undef OGL_SYM_ND
+#undef OGL_SYM_K
 }
 
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,

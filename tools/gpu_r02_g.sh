@@ -8,6 +8,7 @@ python bench.py --steps 3 --warmup 1 --cpu-iters 0 --shuffle $W > gpurun_out/r02
 done
 python bench.py --steps 3 --warmup 1 --cpu-iters 0 --shuffle 65536 --renumber off > gpurun_out/r02g_shuffle_65536_off.json 2> /dev/null
 python bench.py --steps 3 --warmup 1 --cpu-iters 0 --no-compress > gpurun_out/r02g_nocompress.json 2> /dev/null
+python bench.py --steps 3 --warmup 1 --cpu-iters 0 --full-storage > gpurun_out/r02g_fullstorage.json 2> /dev/null
 python - <<'PY'
 import json,glob
 for f in sorted(glob.glob("gpurun_out/r02g_*.json")):

@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
@@ -25,7 +26,9 @@ def main():
     for (k, c), v in vals.items():
         mx = max(v)
         real = [x for x in v if x > 0.05 * mx] if mx > 0 else v
-        short = k.split("namespace)::")[-1].split("(")[0]
+        # "void ogl::(anonymous namespace)::k_name<0, 1>(int, ogl::(anonymous namespace)::Type, ...)" -> "k_name<0, 1>"
+        m = re.search(r"namespace\)::(k_\w+(?:<[^>]*>)?)\(", k)
+        short = m.group(1) if m else k.split("(")[0].split("::")[-1]
         res[short][c] = {"mean": sum(real) / len(real), "dispatches": len(real),
                          "dropped_noop_dispatches": len(v) - len(real)}
     with open(out, "w") as fh:

@@ -164,12 +164,14 @@ __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs
         const bool ok0 = (m0 >> (ND - 1 - j)) & 1u, ok1 = (m1 >> (ND - 1 - j)) & 1u;
         const long a0 = (long)(r0 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r0 & (CHUNK - 1));
         const long a1 = (long)(r1 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r1 & (CHUNK - 1));
-        if (VAR >= 2 && (S.d[j] & 1) == 0) {
+        const bool even_j = VAR >= 3 ? (j >= 2) : ((S.d[j] & 1) == 0);
+        const bool one_j = VAR >= 3 ? (j == 1) : (S.d[j] == 1);
+        if ((VAR == 2 || VAR == 4) && even_j) {
             double2 pl = make_double2(0.0, 0.0);
             if (ok0 || ok1) pl = *reinterpret_cast<const double2 *>(planes + a0);
             lo0[j] = pl.x;
             lo1[j] = pl.y;
-        } else if (VAR >= 2 && S.d[j] == 1) {
+        } else if ((VAR == 2 || VAR == 4) && one_j) {
             lo0[j] = ok0 ? planes[a0] : 0.0;  // plane 1 of row - 1 (the previous lane's second row)
             lo1[j] = up[j].x;                 // plane 1 of row = this lane's own upper entry
         } else {
@@ -185,12 +187,14 @@ __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs
     for (int j = 1; j < ND; ++j) {
         const bool l0 = (m0 >> (ND - 1 - j)) & 1u, l1 = (m1 >> (ND - 1 - j)) & 1u;
         const bool u0 = (m0 >> (ND - 1 + j)) & 1u, u1 = (m1 >> (ND - 1 + j)) & 1u;
-        if (VAR >= 1 && (S.d[j] & 1) == 0) {  // even distance: the two rows' x values are an aligned pair
+        const bool even_j = VAR >= 3 ? (j >= 2) : ((S.d[j] & 1) == 0);  // VAR 3+: known at compile time (d = 1, even, even)
+        const bool one_j = VAR >= 3 ? (j == 1) : (S.d[j] == 1);
+        if (VAR >= 1 && even_j) {  // even distance: the two rows' x values are an aligned pair
             double2 pl = make_double2(0.0, 0.0), pu = make_double2(0.0, 0.0);
             if (l0 || l1) pl = *reinterpret_cast<const double2 *>(x + row - S.d[j]);
             if (u0 || u1) pu = *reinterpret_cast<const double2 *>(x + row + S.d[j]);
             xl0[j] = pl.x; xl1[j] = pl.y; xu0[j] = pu.x; xu1[j] = pu.y;
-        } else if (VAR >= 1 && S.d[j] == 1) {  // the neighbours of a pair are the pair itself + one on each side
+        } else if (VAR >= 1 && one_j) {  // the neighbours of a pair are the pair itself + one on each side
             xl0[j] = l0 ? x[row - 1] : 0.0;
             xl1[j] = xd0;
             xu0[j] = xd1;
@@ -408,7 +412,8 @@ int main(int argc, char **argv)
         RUNSYM(1, 0);
         RUNSYM(1, 1);
         RUNSYM(1, 2);
-        RUNSYM(0, 2);
+        RUNSYM(1, 3);
+        RUNSYM(1, 4);
     }
     return 0;
 }
