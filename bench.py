@@ -445,7 +445,7 @@ def main():
     kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell", "sym": "k_spmv_sym"}[layout]
     # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
     b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout in ("sell", "sym") else b_spmv
-    traffic, traffic_src = (pmc_traffic(kernel + ("<0, 1, 4>" if layout == "sym" else "<0, 1>"),
+    traffic, traffic_src = (pmc_traffic(kernel + ("<0, 1, 4, true>" if layout == "sym" else "<0, 1>"),
                                         "_shuffle65536" if args.shuffle == 65536 else
                                         ("_fullstorage" if args.full_storage else ""))
                             if (n == 216 and args.format == "Csr" and args.shuffle in (0, 65536)
