@@ -161,17 +161,18 @@ __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
         const int r0 = row - S.d[j], r1 = r0 + 1;
-        const bool ok0 = (m0 >> (ND - 1 - j)) & 1u, ok1 = (m1 >> (ND - 1 - j)) & 1u;
+        // VAR 5: the loads do not wait for the mask (which only gates the arithmetic): predicates from the row index
+        const bool ok0 = VAR >= 5 ? (r0 >= 0) : ((m0 >> (ND - 1 - j)) & 1u), ok1 = VAR >= 5 ? (r1 >= 0) : ((m1 >> (ND - 1 - j)) & 1u);
         const long a0 = (long)(r0 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r0 & (CHUNK - 1));
         const long a1 = (long)(r1 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r1 & (CHUNK - 1));
         const bool even_j = VAR >= 3 ? (j >= 2) : ((S.d[j] & 1) == 0);
         const bool one_j = VAR >= 3 ? (j == 1) : (S.d[j] == 1);
-        if ((VAR == 2 || VAR == 4) && even_j) {
+        if ((VAR == 2 || VAR >= 4) && even_j) {
             double2 pl = make_double2(0.0, 0.0);
             if (ok0 || ok1) pl = *reinterpret_cast<const double2 *>(planes + a0);
             lo0[j] = pl.x;
             lo1[j] = pl.y;
-        } else if ((VAR == 2 || VAR == 4) && one_j) {
+        } else if ((VAR == 2 || VAR >= 4) && one_j) {
             lo0[j] = ok0 ? planes[a0] : 0.0;  // plane 1 of row - 1 (the previous lane's second row)
             lo1[j] = up[j].x;                 // plane 1 of row = this lane's own upper entry
         } else {
@@ -185,8 +186,8 @@ __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs
     if (nv > 1) xd1 = x[row + 1];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
-        const bool l0 = (m0 >> (ND - 1 - j)) & 1u, l1 = (m1 >> (ND - 1 - j)) & 1u;
-        const bool u0 = (m0 >> (ND - 1 + j)) & 1u, u1 = (m1 >> (ND - 1 + j)) & 1u;
+        const bool l0 = VAR >= 5 ? (row - S.d[j] >= 0) : ((m0 >> (ND - 1 - j)) & 1u), l1 = VAR >= 5 ? (row + 1 - S.d[j] >= 0) : ((m1 >> (ND - 1 - j)) & 1u);
+        const bool u0 = VAR >= 5 ? (row + S.d[j] < n_rows) : ((m0 >> (ND - 1 + j)) & 1u), u1 = VAR >= 5 ? (row + 1 + S.d[j] < n_rows) : ((m1 >> (ND - 1 + j)) & 1u);
         const bool even_j = VAR >= 3 ? (j >= 2) : ((S.d[j] & 1) == 0);  // VAR 3+: known at compile time (d = 1, even, even)
         const bool one_j = VAR >= 3 ? (j == 1) : (S.d[j] == 1);
         if (VAR >= 1 && even_j) {  // even distance: the two rows' x values are an aligned pair
@@ -414,6 +415,7 @@ int main(int argc, char **argv)
         RUNSYM(1, 2);
         RUNSYM(1, 3);
         RUNSYM(1, 4);
+        RUNSYM(1, 5);
     }
     return 0;
 }
