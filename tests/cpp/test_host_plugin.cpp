@@ -183,6 +183,14 @@ TEST(cpu_config_defaults_and_keywords)
     dictionary f;
     f.add("solver", "GKOCG");
     EXPECT_TRUE(fatal_message([&] { read_ogl_config(f, "GKOCG"); }).find("preconditioner") != std::string::npos);
+    // this build's own keywords and their defaults
+    EXPECT_TRUE(c.compress_indices == 1 && c.renumber == 2 && c.symmetric_half == 1 && c.krylov_dim == 0);
+    dictionary g = cg_dict();
+    g.add("compressIndices", "force").add("renumber", "off").add("symmetricStorage", "false").add("krylovDim", 30);
+    ogl_config c3 = read_ogl_config(g, "GKOCG");
+    EXPECT_TRUE(c3.compress_indices == 2 && c3.renumber == 0 && c3.symmetric_half == 0 && c3.krylov_dim == 30);
+    g.add("compressIndices", "sometimes");
+    EXPECT_TRUE(fatal_message([&] { read_ogl_config(g, "GKOCG"); }).find("compressIndices") != std::string::npos);
 }
 
 TEST(cpu_runtime_selection_tables)
