@@ -251,6 +251,61 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_wave(int n_rows, int n_chunks, c
     if (tid == 0) dot_partials[chunk] = s;
 }
 
+// Row-group SpMV: LPR consecutive lanes work on the consecutive entries of ONE row (64 / LPR rows per wavefront
+// and step), values and columns read straight from the CSR arrays (coalesced within the row, no padding), the
+// row sum formed strictly left to right by passing the running sum from lane to lane -- no LDS staging of the
+// products, no workgroup barrier in the main loop.  The gather of one instruction covers all entries of 64 / LPR
+// neighbouring rows (row-major locality, as in the CSR-stream kernel).  y goes through LDS once per chunk for the
+// fused dot's canonical tree.
+template <int LPR>
+__global__ __launch_bounds__(BLOCK) void k_spmv_rg(int n_rows, int n_chunks, const int *__restrict__ row_ptrs,
+                                                   const int *__restrict__ cols, const double *__restrict__ vals,
+                                                   const double *__restrict__ x, double *__restrict__ y,
+                                                   double *__restrict__ dot_partials)
+{
+    __shared__ double ys[CHUNK_ROWS];
+    __shared__ double slot[N_WAVES];
+    const int chunk = xcd_chunk<4>(blockIdx.x);
+    if (chunk >= n_chunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int G = 64 / LPR;  // rows per wavefront and step
+    const int g = lane / LPR, l = lane % LPR;
+    const int r0 = chunk * CHUNK_ROWS, r1 = min(r0 + CHUNK_ROWS, n_rows);
+    const int w0 = r0 + wv * 128, w1 = min(w0 + 128, r1);
+    for (int base = w0; base < w1; base += G) {
+        const int row = base + g;
+        const bool valid = row < w1;
+        const int k0 = valid ? row_ptrs[row] : 0, k1 = valid ? row_ptrs[row + 1] : 0;
+        double carry = 0.0;
+        for (int k = k0; __any(k < k1); k += LPR) {
+            const int e = k + l;
+            const bool has = e < k1;
+            double p = 0.0;
+            if (has) p = vals[e] * x[cols[e]];
+            // running sum, strictly left to right: lane i takes lane i-1's sum and adds its own product
+            double s = l == 0 ? (has ? carry + p : carry) : 0.0;
+#pragma unroll
+            for (int i = 1; i < LPR; ++i) {
+                const double t = __shfl_up(s, 1, LPR);
+                if (l == i) s = has ? t + p : t;
+            }
+            carry = __shfl(s, LPR - 1, LPR);
+        }
+        if (valid && l == 0) {
+            y[row] = carry;
+            ys[row - r0] = carry;
+        }
+    }
+    __syncthreads();
+    const int row = r0 + tid * RPT;
+    double d = 0.0;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j)
+        if (row + j < r1) d += x[row + j] * ys[tid * RPT + j];
+    const double sm = block_sum(d, slot);
+    if (tid == 0) dot_partials[chunk] = sm;
+}
+
 struct Dev {
     int n, nnz, nc, grid;
     int *rp, *cols, *base;
@@ -385,7 +440,15 @@ int main(int argc, char **argv)
             hipLaunchKernelGGL((k_spmv_wave<WTILE, COLS>), dim3(D.grid), dim3(BLOCK), 0, 0, D.n, D.nc, D.rp, D.cols, \
                                D.cols16, D.base, D.vals, x, D.y, D.part);                                            \
         })
+#define RUNRG(LPR)                                                                                                   \
+    timeit("row groups, " #LPR " lanes per row", D, yref, reps, true, [&](const double *x) {                          \
+        hipLaunchKernelGGL((k_spmv_rg<LPR>), dim3(D.grid), dim3(BLOCK), 0, 0, D.n, D.nc, D.rp, D.cols, D.vals, x, D.y, \
+                           D.part);                                                                                  \
+    })
     for (int pass = 0; pass < 2; ++pass) {
+        RUNRG(16);
+        RUNRG(8);
+        RUNRG(32);
         RUN(4096, 0, false, 0, 1);  // the product kernel
         RUN(2048, 0, true, 0, 1);
         RUNX(4096, false, 4, 4);
