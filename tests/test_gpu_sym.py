@@ -118,3 +118,28 @@ def test_matrices_that_keep_full_storage(reg, oracle):
     assert s.get_property("symmetricHalf") == 1.0
     s2 = reg.solver("sym_toggle", cfg(0)).set_matrix(synthetic.poisson_case(10))
     assert s2.get_property("symmetricHalf") == 0.0
+
+
+def test_random_boxes_same_bits_as_the_oracle(reg, oracle):
+    """Boxes of random shape (even and odd line lengths -> both instantiations of the kernel, 1-D / 2-D / 3-D,
+    partial last chunks) with random symmetric coefficients: SpMV, residual SpMV (first CG residual) and a
+    short CG history against the oracle."""
+    rng = np.random.default_rng(20241016)
+    shapes = [(int(rng.integers(1, 70)), int(rng.integers(1, 40)), int(rng.integers(1, 30))) for _ in range(24)]
+    shapes += [(64, 32, 16), (2, 2, 2), (128, 1, 1), (1, 96, 1), (1, 1, 77), (66, 1, 34)]
+    for i, (gx, gy, gz) in enumerate(shapes):
+        case = randomise(synthetic.poisson_block(gx=gx, gy=gy, gz=gz), 100 + i)
+        rp, cols, vals = oracle_csr(oracle, case)
+        s = reg.solver("sym_rand", cfg(1, max_iter=12)).set_matrix(case)
+        qualifies = capi.host_sym_check(rp, cols)[0]
+        assert s.get_property("symmetricHalf") == (1.0 if qualifies else 0.0), (gx, gy, gz)
+        x = rng.uniform(-1, 1, case.n_cells)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x), err_msg=str((gx, gy, gz)))
+        b = rng.uniform(-1, 1, case.n_cells)
+        xs, perf = s.solve(b, x.copy())
+        A, _ = oracle_matrix(oracle, case)
+        with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+            ref = oracle.cg(A, b, x.copy(), oracle.jacobi_generate_scalar(rp, cols, vals), tolerance=1e-11, rel_tol=0.0,
+                            max_iter=12)
+        np.testing.assert_array_equal(s.history(), ref.history, err_msg=str((gx, gy, gz)))
+        np.testing.assert_array_equal(xs, ref.x, err_msg=str((gx, gy, gz)))
