@@ -134,6 +134,7 @@ __global__ __launch_bounds__(BLOCK) void k_sell_pid(int n_rows, int n_chunks, co
 // (or will be) read as upper entries anyway -- DRAM sees every value once.  One byte per row says which of
 // the 2 ND - 1 entries exist (bit ND-1-j... see below); rows are summed in ascending column order, so y has
 // the same bits as with full storage.
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));  // a pair at an 8-byte aligned address
 constexpr int ND = 4;
 struct SymArgs {
     int d[ND];
@@ -162,12 +163,18 @@ __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs
     for (int j = 1; j < ND; ++j) {
         const int r0 = row - S.d[j], r1 = r0 + 1;
         // VAR 5: the loads do not wait for the mask (which only gates the arithmetic): predicates from the row index
-        const bool ok0 = VAR >= 5 ? (r0 >= 0) : ((m0 >> (ND - 1 - j)) & 1u), ok1 = VAR >= 5 ? (r1 >= 0) : ((m1 >> (ND - 1 - j)) & 1u);
+        const bool ok0 = VAR == 5 ? (r0 >= 0) : ((m0 >> (ND - 1 - j)) & 1u), ok1 = VAR == 5 ? (r1 >= 0) : ((m1 >> (ND - 1 - j)) & 1u);
         const long a0 = (long)(r0 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r0 & (CHUNK - 1));
         const long a1 = (long)(r1 >> 9) * (ND * CHUNK) + (long)j * CHUNK + (r1 & (CHUNK - 1));
         const bool even_j = VAR >= 3 ? (j >= 2) : ((S.d[j] & 1) == 0);
         const bool one_j = VAR >= 3 ? (j == 1) : (S.d[j] == 1);
-        if ((VAR == 2 || VAR >= 4) && even_j) {
+        if (VAR == 6 && j == 1) {
+            lo0[j] = ok0 ? planes[a0] : 0.0;
+            lo1[j] = up[j].x;
+        } else if (VAR == 6) {
+            lo0[j] = ok0 ? planes[a0] : 0.0;
+            lo1[j] = ok1 ? planes[a1] : 0.0;
+        } else if ((VAR == 2 || VAR >= 4) && even_j) {
             double2 pl = make_double2(0.0, 0.0);
             if (ok0 || ok1) pl = *reinterpret_cast<const double2 *>(planes + a0);
             lo0[j] = pl.x;
@@ -186,11 +193,22 @@ __global__ __launch_bounds__(BLOCK) void k_sym(int n_rows, int n_chunks, SymArgs
     if (nv > 1) xd1 = x[row + 1];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
-        const bool l0 = VAR >= 5 ? (row - S.d[j] >= 0) : ((m0 >> (ND - 1 - j)) & 1u), l1 = VAR >= 5 ? (row + 1 - S.d[j] >= 0) : ((m1 >> (ND - 1 - j)) & 1u);
-        const bool u0 = VAR >= 5 ? (row + S.d[j] < n_rows) : ((m0 >> (ND - 1 + j)) & 1u), u1 = VAR >= 5 ? (row + 1 + S.d[j] < n_rows) : ((m1 >> (ND - 1 + j)) & 1u);
+        const bool l0 = VAR == 5 ? (row - S.d[j] >= 0) : ((m0 >> (ND - 1 - j)) & 1u), l1 = VAR == 5 ? (row + 1 - S.d[j] >= 0) : ((m1 >> (ND - 1 - j)) & 1u);
+        const bool u0 = VAR == 5 ? (row + S.d[j] < n_rows) : ((m0 >> (ND - 1 + j)) & 1u), u1 = VAR == 5 ? (row + 1 + S.d[j] < n_rows) : ((m1 >> (ND - 1 + j)) & 1u);
         const bool even_j = VAR >= 3 ? (j >= 2) : ((S.d[j] & 1) == 0);  // VAR 3+: known at compile time (d = 1, even, even)
         const bool one_j = VAR >= 3 ? (j == 1) : (S.d[j] == 1);
-        if (VAR >= 1 && even_j) {  // even distance: the two rows' x values are an aligned pair
+        if (VAR == 6 && j >= 2) {  // any parity: the pair as one 16-byte load from an 8-byte aligned address
+            // (NOT RUN: with an odd distance the pair of row = d - 1 starts at x[-1]; needs a scalar fallback there)
+            d2u pl = {0.0, 0.0}, pu = {0.0, 0.0};
+            if (l0 || l1) pl = *reinterpret_cast<const d2u *>(x + row - S.d[j]);
+            if (u0 || u1) pu = *reinterpret_cast<const d2u *>(x + row + S.d[j]);
+            xl0[j] = pl.x; xl1[j] = pl.y; xu0[j] = pu.x; xu1[j] = pu.y;
+        } else if (VAR == 6) {
+            xl0[j] = l0 ? x[row - 1] : 0.0;
+            xl1[j] = xd0;
+            xu0[j] = xd1;
+            xu1[j] = u1 ? x[row + 2] : 0.0;
+        } else if (VAR >= 1 && even_j) {  // even distance: the two rows' x values are an aligned pair
             double2 pl = make_double2(0.0, 0.0), pu = make_double2(0.0, 0.0);
             if (l0 || l1) pl = *reinterpret_cast<const double2 *>(x + row - S.d[j]);
             if (u0 || u1) pu = *reinterpret_cast<const double2 *>(x + row + S.d[j]);
@@ -411,6 +429,7 @@ int main(int argc, char **argv)
                 },                                                                                                \
                 d_x0, d_x1, d_y, yref, reps, moved_half)
         RUNSYM(1, 0);
+        if (n & 1) continue;  // (the variants below assume even distances)
         RUNSYM(1, 1);
         RUNSYM(1, 2);
         RUNSYM(1, 3);
