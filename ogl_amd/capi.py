@@ -266,10 +266,14 @@ class Solver:
         _check(lib().ogl_solver_set_matrix(self._h, C.byref(self._ldu.view)))
         return self
 
-    def solve(self, source, psi):
-        """Returns (psi_out, Perf).  psi is the initial guess (honoured per updateInitGuess)."""
+    def solve(self, source, psi, inplace=False):
+        """Returns (psi_out, Perf).  psi is the initial guess (honoured per updateInitGuess).  inplace: psi
+        (a contiguous float64 array) is overwritten with the solution, as the C ABI does -- no copy on the
+        Python side (bench.py's PCIe-inclusive timing)."""
         b = _s(source)
-        x = np.array(psi, dtype=np.float64, copy=True)
+        if inplace:
+            assert isinstance(psi, np.ndarray) and psi.dtype == np.float64 and psi.flags.c_contiguous
+        x = psi if inplace else np.array(psi, dtype=np.float64, copy=True)
         perf = Perf()
         _check(lib().ogl_solver_solve(self._h, _ps(b), _ps(x), C.byref(perf)))
         return x, perf
