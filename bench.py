@@ -553,6 +553,15 @@ def main():
             "moved_frac": b_moved / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "moved_frac_of_measured_copy_peak": b_moved / (spmv_ms * 1e-3) / 1e9 / HBM_COPY_GBPS,
             "avg_kernel_ms": spmv_ms, "timing": spmv_src,
+            "note": ("achieved / frac count SURVEY.md 8(d)'s CSR bytes of the matrix per launch (the unit of work); "
+                     "the kernel itself moves moved_model_bytes_per_launch -- "
+                     + {"sym": "diagonal + upper coefficients only: the matrix is symmetric and every lower entry is "
+                               "read where its upper twin lives (same bits in y); --full-storage runs the expanded "
+                               "matrix (frac 0.88-0.92, profiles/r02_bench_n216_fullstorage.json)",
+                        "sell": "an index-compressed copy of the CSR arrays",
+                        "ell": "slot-major planes of the CSR arrays",
+                        "csr": "the CSR arrays themselves"}[layout]
+                     + "; a frac above 1 means the layout moves fewer bytes than CSR, not that HBM ran above its peak"),
         },
         "cg_iteration": {
             "algorithmic_bytes": b_cg, "ms": 1e3 * elapsed / max(1, iters),
