@@ -143,3 +143,20 @@ def test_random_boxes_same_bits_as_the_oracle(reg, oracle):
                             max_iter=12)
         np.testing.assert_array_equal(s.history(), ref.history, err_msg=str((gx, gy, gz)))
         np.testing.assert_array_equal(xs, ref.x, err_msg=str((gx, gy, gz)))
+
+
+def test_field_switching_between_symmetric_and_asymmetric_matrices(reg, oracle):
+    """The same field handed a symmetric, then an asymmetric, then again a symmetric matrix on the same
+    addressing: the half storage must come and go with the `lower` pointer."""
+    s = reg.solver("sym_switch", cfg(1))
+    rng = np.random.default_rng(31)
+    for symmetric, expect in ((True, 1.0), (False, 0.0), (True, 1.0), (True, 1.0), (False, 0.0)):
+        case = synthetic.poisson_case(14, symmetric=symmetric)
+        case.upper[:] = rng.uniform(-1.0, -0.25, case.upper.size)
+        if not symmetric:
+            case.lower[:] = rng.uniform(-1.0, -0.25, case.lower.size)
+        s.set_matrix(case)
+        assert s.get_property("symmetricHalf") == expect
+        rp, cols, vals = oracle_csr(oracle, case)
+        x = rng.uniform(-1, 1, case.n_cells)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
