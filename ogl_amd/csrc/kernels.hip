@@ -794,13 +794,13 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2(int n, double *__restrict__ 
     double2 vr = ld2(r, rp);
     if (beta != 0.0) {
         const double t = rho / beta;
-        double2 vx = ld2(x, rp);
-        const double2 vp = ld2(p, rp), vq = ld2(q, rp);
+        double2 vx = ld2_stream(x, rp);  // x: once per turn; q: last use of the turn
+        const double2 vp = ld2(p, rp), vq = ld2_stream(q, rp);
         vx.x += t * vp.x;
         vx.y += t * vp.y;
         vr.x -= t * vq.x;
         vr.y -= t * vq.y;
-        st2(x, rp, vx);
+        st2_stream(x, rp, vx);
         st2(r, rp, vr);
     }
     double2 vz = vr;
@@ -1563,15 +1563,16 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_step3(int n, double *__restrict_
     const double alpha = s->alpha, omega = s->omega;
     const int chunk = blockIdx.x;
     const RowPair rp = my_rows(chunk, n);
-    double2 vx = ld2(x, rp);
-    const double2 vy = ld2(y, rp), vz = ld2(z, rp), vs = ld2(sv, rp), vt = ld2(t, rp),
-                  vrr = ld2(rr, rp);
+    // x, y, z, s, t, rr: touched here for the last (x, rr: only) time of the turn -> streamed past the caches
+    double2 vx = ld2_stream(x, rp);
+    const double2 vy = ld2_stream(y, rp), vz = ld2_stream(z, rp), vs = ld2_stream(sv, rp), vt = ld2_stream(t, rp),
+                  vrr = ld2_stream(rr, rp);
     vx.x += alpha * vy.x + omega * vz.x;
     vx.y += alpha * vy.y + omega * vz.y;
     double2 vr;
     vr.x = vs.x - omega * vt.x;
     vr.y = vs.y - omega * vt.y;
-    st2(x, rp, vx);
+    st2_stream(x, rp, vx);
     st2(r, rp, vr);
     double d = 0.0, a = 0.0;
     if (rp.n > 0) {
