@@ -589,6 +589,16 @@ __device__ __forceinline__ double2 ld2_stream(const double *__restrict__ p, cons
     }
     return v;
 }
+// a pair of values of a matrix plane that is read exactly once per launch
+__device__ __forceinline__ double2 ld_pair_stream(const double *__restrict__ p)
+{
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+    double2 v;
+    v.x = t.x;
+    v.y = t.y;
+    return v;
+}
 __device__ __forceinline__ void st2_stream(double *__restrict__ p, const RowPair &r, double2 v)
 {
     typedef double d2v __attribute__((ext_vector_type(2)));
@@ -1219,7 +1229,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 vv[k].x = vv[k].y = 0.0;
-                if (s0 + k < ml) vv[k] = *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
+                if (s0 + k < ml) vv[k] = ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             int a0[BATCH], a1[BATCH];
             bool ok0[BATCH], ok1[BATCH];
@@ -1272,7 +1282,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 vv[k].x = vv[k].y = 0.0;
-                if (s0 + k < ml) vv[k] = *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
+                if (s0 + k < ml) vv[k] = ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
 #pragma unroll
@@ -1303,7 +1313,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 const int s = min(s0 + k, ww - 1);  // clamp: always a valid plane
-                vv[k] = *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
+                vv[k] = ld_pair_stream(v + (long)s * CHUNK_ROWS);
                 d0[k] = (s0 + k < ww) ? stab[p0 + s] : SELL_PAD_OFFSET;
                 d1[k] = (s0 + k < ww) ? stab[p1 + s] : SELL_PAD_OFFSET;
             }
@@ -1337,7 +1347,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 vv[k].x = vv[k].y = 0.0;
-                if (s0 + k < ml) vv[k] = *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
+                if (s0 + k < ml) vv[k] = ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
             bool ok0[BATCH], ok1[BATCH];
