@@ -150,29 +150,31 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     for (int j = 0; j < ROWS_PER_THREAD; ++j)
         acc[j] = (MODE == SPMV_RESIDUAL && row + j < r1) ? b[row + j] : 0.0;
 
-    constexpr int GROUPS = SPMV_TILE / (BLOCK * 4);
+    // Two consecutive entries per lane and load (16 B of values, 8 B of columns): every load instruction of a
+    // wavefront covers whole, disjoint cache lines, so values and columns -- read exactly once per launch -- can
+    // be streamed past the caches (non-temporal), which then hold the vectors.  (With four entries per lane as
+    // two 16-byte loads the two instructions share their lines and a non-temporal hint fetches them twice:
+    // 208 us instead of 186, profiles/spmv_tune_r02.txt.)
+    constexpr int GROUPS = SPMV_TILE / (BLOCK * 2);
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    typedef int i2v __attribute__((ext_vector_type(2)));
     for (int t0 = nz0 & ~3; t0 < nz1; t0 += SPMV_TILE) {
-        double2 va[GROUPS], vb[GROUPS];
-        int4 cc[GROUPS];
+        d2v va[GROUPS];
+        i2v cc[GROUPS];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            const int e = t0 + (g * BLOCK + tid) * 4;
+            const int e = t0 + (g * BLOCK + tid) * 2;
             const int ec = e < nz1 ? e : t0;  // clamp: stay inside the (padded) arrays
-            va[g] = *reinterpret_cast<const double2 *>(vals + ec);
-            vb[g] = *reinterpret_cast<const double2 *>(vals + ec + 2);
-            cc[g] = *reinterpret_cast<const int4 *>(cols + ec);
+            va[g] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vals + ec));
+            cc[g] = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(cols + ec));
         }
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
-            const double x0 = x[cc[g].x], x1 = x[cc[g].y], x2 = x[cc[g].z], x3 = x[cc[g].w];
-            double2 p0, p1;
+            const double x0 = x[cc[g].x], x1 = x[cc[g].y];
+            double2 p0;
             p0.x = va[g].x * x0;
             p0.y = va[g].y * x1;
-            p1.x = vb[g].x * x2;
-            p1.y = vb[g].y * x3;
-            const int le = (g * BLOCK + tid) * 4;
-            *reinterpret_cast<double2 *>(prod + le) = p0;
-            *reinterpret_cast<double2 *>(prod + le + 2) = p1;
+            *reinterpret_cast<double2 *>(prod + (g * BLOCK + tid) * 2) = p0;
         }
         __syncthreads();
         const int t1 = t0 + SPMV_TILE;
