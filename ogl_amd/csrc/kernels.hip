@@ -1224,8 +1224,22 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
             uint4 wa, wb;
             wa.x = wa.y = wa.z = wa.w = 0xffffffffu;
             wb = wa;
-            if (s0 < ml) wa = cw[(long)g * BLOCK];
-            if (s0 + SELL_D16_GROUP < ml) wb = cw[(long)(g + 1) * BLOCK];
+            // (code words: read once per launch, whole lines per instruction -> streamed like the values)
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            if (s0 < ml) {
+                const u4v tw = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(cw + (long)g * BLOCK));
+                wa.x = tw.x;
+                wa.y = tw.y;
+                wa.z = tw.z;
+                wa.w = tw.w;
+            }
+            if (s0 + SELL_D16_GROUP < ml) {
+                const u4v tw = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(cw + (long)(g + 1) * BLOCK));
+                wb.x = tw.x;
+                wb.y = tw.y;
+                wb.z = tw.z;
+                wb.w = tw.w;
+            }
             const unsigned w8[BATCH] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
             double2 vv[BATCH];
 #pragma unroll
@@ -1274,7 +1288,14 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
             for (int q = 0; q < 4; ++q) {
                 int4 w;
                 w.x = w.y = w.z = w.w = -1;
-                if (s0 + SELL_C32_GROUP * q < ml) w = cw[(long)(g + q) * BLOCK];
+                if (s0 + SELL_C32_GROUP * q < ml) {
+                    typedef int i4v __attribute__((ext_vector_type(4)));
+                    const i4v tw = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(cw + (long)(g + q) * BLOCK));
+                    w.x = tw.x;
+                    w.y = tw.y;
+                    w.z = tw.z;
+                    w.w = tw.w;
+                }
                 a0[2 * q] = w.x;
                 a1[2 * q] = w.y;
                 a0[2 * q + 1] = (s0 + 2 * q + 1 < ml) ? w.z : -1;
