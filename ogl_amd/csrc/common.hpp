@@ -119,6 +119,10 @@ constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of 
 // half storage of a symmetric matrix on a banded pattern (SymLayout, host_matrix.hpp)
 constexpr int SYM_MAX_OFFSETS = 4;        // diagonal + 3 legs: up to a 7-point stencil in 3-D
 constexpr double SYM_MAX_PADDING = 1.15;  // plane slots / (diagonal + upper entries) above which full storage stays
+// Matrix data that is read once per launch is streamed past the caches when matrix + the turn's five vectors do
+// not fit the 256 MB Infinity Cache (measured: +3-4 % turn rate at 6-10 M rows; at 2 M rows / 1 M polyhedral
+// cells, where everything fits, the hint costs 5-12 %: profiles/spmv_tune_r02.txt section 9)
+constexpr double STREAM_MATRIX_ABOVE_BYTES = 288e6;
 constexpr int SPMV_TUNE_MIN_ROWS = 65536;     // smaller systems: launch-bound, the compressed layout stays
 constexpr int RENUMBER_AUTO_MIN_ROWS = 16384;  // config renumber = auto: smaller systems keep their numbering
 // Padding is laid out but not read: every lane stops loading at the longer of its two rows (the row

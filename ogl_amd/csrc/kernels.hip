@@ -122,7 +122,10 @@ inline int xcd_grid(int n_chunks)
 // ------------------------------------------------------------------------------------------
 // NDOT = 1: partials of sum_i w_i*y_i (w = x for CG's p.q, w = rr or s for BiCGStab);
 // NDOT = 2: additionally partials of sum_i y_i*y_i (BiCGStab's t.t).
-template <int MODE, int NDOT>
+// STREAM: the matrix is larger than the Infinity Cache -- values and columns are streamed past the caches
+// (non-temporal), which then hold the vectors; a matrix that fits keeps the default policy and is served from
+// the cache turn after turn.
+template <int MODE, int NDOT, bool STREAM>
 __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ b,
@@ -165,8 +168,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
         for (int g = 0; g < GROUPS; ++g) {
             const int e = t0 + (g * BLOCK + tid) * 2;
             const int ec = e < nz1 ? e : t0;  // clamp: stay inside the (padded) arrays
-            va[g] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vals + ec));
-            cc[g] = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(cols + ec));
+            if (STREAM) {
+                va[g] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vals + ec));
+                cc[g] = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(cols + ec));
+            } else {
+                va[g] = *reinterpret_cast<const d2v *>(vals + ec);
+                cc[g] = *reinterpret_cast<const i2v *>(cols + ec);
+            }
         }
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
@@ -1152,7 +1160,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
 // for the CSR-stream kernel on the 216^3 matrix (profiles/spmv_tune_r01.txt).  Same per-row order
 // as k_spmv_stream.
 // ------------------------------------------------------------------------------------------
-template <int MODE, int NDOT>
+// STREAM: as in k_spmv_stream -- value planes and 16 / 32-bit code words of a matrix larger than the Infinity
+// Cache are streamed past the caches.
+template <int MODE, int NDOT, bool STREAM>
 __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const SellChunk *__restrict__ chunks,
                                                      const int *__restrict__ dict,
@@ -1227,14 +1237,16 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
             // (code words: read once per launch, whole lines per instruction -> streamed like the values)
             typedef unsigned u4v __attribute__((ext_vector_type(4)));
             if (s0 < ml) {
-                const u4v tw = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(cw + (long)g * BLOCK));
+                const u4v tw = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const u4v *>(cw + (long)g * BLOCK))
+                                      : *reinterpret_cast<const u4v *>(cw + (long)g * BLOCK);
                 wa.x = tw.x;
                 wa.y = tw.y;
                 wa.z = tw.z;
                 wa.w = tw.w;
             }
             if (s0 + SELL_D16_GROUP < ml) {
-                const u4v tw = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(cw + (long)(g + 1) * BLOCK));
+                const u4v tw = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const u4v *>(cw + (long)(g + 1) * BLOCK))
+                                      : *reinterpret_cast<const u4v *>(cw + (long)(g + 1) * BLOCK);
                 wb.x = tw.x;
                 wb.y = tw.y;
                 wb.z = tw.z;
@@ -1245,7 +1257,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 vv[k].x = vv[k].y = 0.0;
-                if (s0 + k < ml) vv[k] = ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS);
+                if (s0 + k < ml) vv[k] = STREAM ? ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS) : *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             int a0[BATCH], a1[BATCH];
             bool ok0[BATCH], ok1[BATCH];
@@ -1290,7 +1302,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                 w.x = w.y = w.z = w.w = -1;
                 if (s0 + SELL_C32_GROUP * q < ml) {
                     typedef int i4v __attribute__((ext_vector_type(4)));
-                    const i4v tw = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(cw + (long)(g + q) * BLOCK));
+                    const i4v tw = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const i4v *>(cw + (long)(g + q) * BLOCK))
+                                          : *reinterpret_cast<const i4v *>(cw + (long)(g + q) * BLOCK);
                     w.x = tw.x;
                     w.y = tw.y;
                     w.z = tw.z;
@@ -1305,7 +1318,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 vv[k].x = vv[k].y = 0.0;
-                if (s0 + k < ml) vv[k] = ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS);
+                if (s0 + k < ml) vv[k] = STREAM ? ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS) : *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
 #pragma unroll
@@ -1336,7 +1349,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 const int s = min(s0 + k, ww - 1);  // clamp: always a valid plane
-                vv[k] = ld_pair_stream(v + (long)s * CHUNK_ROWS);
+                vv[k] = STREAM ? ld_pair_stream(v + (long)s * CHUNK_ROWS) : *reinterpret_cast<const double2 *>(v + (long)s * CHUNK_ROWS);
                 d0[k] = (s0 + k < ww) ? stab[p0 + s] : SELL_PAD_OFFSET;
                 d1[k] = (s0 + k < ww) ? stab[p1 + s] : SELL_PAD_OFFSET;
             }
@@ -1370,7 +1383,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) {
                 vv[k].x = vv[k].y = 0.0;
-                if (s0 + k < ml) vv[k] = ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS);
+                if (s0 + k < ml) vv[k] = STREAM ? ld_pair_stream(v + (long)(s0 + k) * CHUNK_ROWS) : *reinterpret_cast<const double2 *>(v + (long)(s0 + k) * CHUNK_ROWS);
             }
             double x0[BATCH], x1[BATCH];
             bool ok0[BATCH], ok1[BATCH];
@@ -2153,9 +2166,16 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
-#define OGL_SPMV(MODE, NDOT)                                                                       \
-    hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
+#define OGL_SPMV_K(MODE, NDOT, STREAM)                                                                     \
+    hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
                        A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+#define OGL_SPMV(MODE, NDOT)               \
+    do {                                   \
+        if (A.stream)                      \
+            OGL_SPMV_K(MODE, NDOT, true);  \
+        else                               \
+            OGL_SPMV_K(MODE, NDOT, false); \
+    } while (0)
     if (mode == SPMV_RESIDUAL) {
         OGL_SPMV(SPMV_RESIDUAL, 0);
     } else if (dots.part && dots.part_yy) {
@@ -2166,6 +2186,7 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
         OGL_SPMV(SPMV_PLAIN, 0);
     }
 #undef OGL_SPMV
+#undef OGL_SPMV_K
 }
 
 void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,
@@ -2195,10 +2216,17 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
-#define OGL_SELL(MODE, NDOT)                                                                     \
-    hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
-                       A.dict, A.codes, A.vals, A.spill_chunk_ptr, A.spill_rows, A.spill_ptrs,  \
+#define OGL_SELL_K(MODE, NDOT, STREAM)                                                                   \
+    hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
+                       A.dict, A.codes, A.vals, A.spill_chunk_ptr, A.spill_rows, A.spill_ptrs,          \
                        A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+#define OGL_SELL(MODE, NDOT)               \
+    do {                                   \
+        if (A.stream)                      \
+            OGL_SELL_K(MODE, NDOT, true);  \
+        else                               \
+            OGL_SELL_K(MODE, NDOT, false); \
+    } while (0)
     if (mode == SPMV_RESIDUAL) {
         OGL_SELL(SPMV_RESIDUAL, 0);
     } else if (dots.part && dots.part_yy) {
@@ -2209,6 +2237,7 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
         OGL_SELL(SPMV_PLAIN, 0);
     }
 #undef OGL_SELL
+#undef OGL_SELL_K
 }
 
 void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x, const double *b, double *y,

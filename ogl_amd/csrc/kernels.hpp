@@ -42,6 +42,9 @@ struct DevCsr {
     const int32_t *row_ptrs = nullptr;  // [n_rows + 1]
     const int32_t *cols = nullptr;      // [nnz + NNZ_PAD]
     const double *vals = nullptr;       // [nnz + NNZ_PAD]
+    // the matrix does not fit the Infinity Cache next to the solver's vectors: its values and columns are
+    // streamed past the caches (non-temporal loads); a matrix that fits stays cached from turn to turn
+    bool stream = false;
 };
 
 // Rows that own non-local entries, for "y += A_non_local * recv" (distributed::Matrix::apply).
@@ -93,6 +96,7 @@ struct DevSell {
     // spill_ptrs = their entry ranges in spill_cols / spill_vals
     const int32_t *spill_chunk_ptr = nullptr, *spill_rows = nullptr, *spill_ptrs = nullptr, *spill_cols = nullptr;
     const double *spill_vals = nullptr;
+    bool stream = false;  // as DevCsr::stream, for the value planes and the 16 / 32-bit code words
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
                       double *y, const SpmvDots &dots, const DevScalars *gate);

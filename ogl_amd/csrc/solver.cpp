@@ -374,6 +374,7 @@ DevCsr ogl_solver::csr() const
     A.row_ptrs = d_row_ptrs.p;
     A.cols = d_cols.p;
     A.vals = d_vals.p;
+    A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
     return A;
 }
 
@@ -424,6 +425,7 @@ DevSell ogl_solver::sell() const
     S.dict = d_sell_dict.p;
     S.codes = d_sell_codes.p;
     S.vals = d_sell_vals.p;
+    S.stream = sell_bytes + 40.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
     if (n_spill) {
         S.spill_chunk_ptr = d_spill_chunks.p;
         S.spill_rows = d_spill_rows.p;
@@ -550,6 +552,7 @@ int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
     props["sellMatrixBytes"] = 8.0 * (double)L.read_slots + read_frac * (double)(L.codes.size() - 16) +
                                (double)(L.chunks.size() * sizeof(SellChunk)) + 4.0 * (double)L.dict.size() +
                                16.0 * (double)L.spill_cols.size();  // spilled entries: value + column + their share of row data
+    sell_bytes = props["sellMatrixBytes"];
     props["sellReadSlots"] = (double)L.read_slots;
     props["sellAllocatedSlots"] = (double)L.n_slots;
     props["sellChunksDelta16"] = (double)L.n_delta16;

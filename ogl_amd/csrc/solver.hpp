@@ -99,6 +99,7 @@ struct SellDev {
         S.dict = dict.p;
         S.codes = codes.p;
         S.vals = vals.p;
+        S.stream = 9.0 * (double)slots + 40.0 * (double)n_rows > ogl::STREAM_MATRIX_ABOVE_BYTES;
         return S;
     }
 };
@@ -226,6 +227,7 @@ struct ogl_solver {
     ogl::DevBuf<uint8_t> d_sell_codes;
     ogl::DevBuf<double> d_sell_vals;
     int64_t sell_slots = 0;
+    double sell_bytes = 0.0;  // bytes one SpMV reads of the compressed copy (decides the cache policy of its loads)
     int sell_state = 0;
     // spill of the compressed copy: tails of the rows longer than their chunk's cap (SellLayout)
     ogl::DevBuf<int32_t> d_spill_rows, d_spill_ptrs, d_spill_cols, d_spill_map, d_spill_chunks;
