@@ -1525,17 +1525,19 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_step1(int n, double *__restrict_
     if (s->stop) return;
     const double rho = s->rho, prev = s->prev_rho, alpha = s->alpha, omega = s->omega;
     const RowPair rp = my_rows(blockIdx.x, n);
-    const double2 vr = ld2(r, rp);
+    // r, p, v, inv_diag: a whole SpMV passes before any of them is touched again -> streamed past the caches;
+    // y is gathered by the SpMV that follows and stays cached
+    const double2 vr = ld2_stream(r, rp);
     double2 vp = vr;
     if (prev * omega != 0.0) {
         const double tmp = rho / prev * alpha / omega;
-        const double2 po = ld2(p, rp), vv = ld2(v, rp);
+        const double2 po = ld2_stream(p, rp), vv = ld2_stream(v, rp);
         vp.x = vr.x + tmp * (po.x - omega * vv.x);
         vp.y = vr.y + tmp * (po.y - omega * vv.y);
     }
-    st2(p, rp, vp);
+    if (inv_diag) st2_stream(p, rp, vp); else st2(p, rp, vp);  // (without a preconditioner p itself is the SpMV's input)
     if (inv_diag) {
-        const double2 vi = ld2(inv_diag, rp);
+        const double2 vi = ld2_stream(inv_diag, rp);
         double2 vy;
         vy.x = vp.x * vi.x;
         vy.y = vp.y * vi.y;
@@ -1558,15 +1560,15 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_step2(int n, const double *__res
     const double alpha = s->alpha, beta = s->beta;
     const int chunk = blockIdx.x;
     const RowPair rp = my_rows(chunk, n);
-    double2 vs = ld2(r, rp);
+    double2 vs = ld2_stream(r, rp);  // (as in step_1: r, v and inv_diag are not touched again before an SpMV has passed)
     if (beta != 0.0) {
-        const double2 vv = ld2(v, rp);
+        const double2 vv = ld2_stream(v, rp);
         vs.x = vs.x - alpha * vv.x;
         vs.y = vs.y - alpha * vv.y;
     }
-    st2(sv, rp, vs);
+    st2(sv, rp, vs);  // (s is read by the SpMV that follows, for the fused t.s: stays cached)
     if (inv_diag) {
-        const double2 vi = ld2(inv_diag, rp);
+        const double2 vi = ld2_stream(inv_diag, rp);
         double2 vz;
         vz.x = vs.x * vi.x;
         vz.y = vs.y * vi.y;
