@@ -939,7 +939,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__
 // 2t, 2t+1 and adds the slots in order (= stored column order; padding slots are skipped), so the
 // result and the fused dot partials are bit-identical to the CSR kernel's.
 // ------------------------------------------------------------------------------------------
-template <int MODE, int NDOT>
+template <int MODE, int NDOT, bool STREAM>
 __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, int width, long stride,
                                                     const int *__restrict__ cols,
                                                     const double *__restrict__ vals,
@@ -968,9 +968,24 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, in
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             const int i = min(i0 + k, width - 1);  // clamp: always a valid plane
-            v[k] = *reinterpret_cast<const double2 *>(vals + (long)i * stride + r);
-            c[k] = *reinterpret_cast<const int2 *>(cols + (long)i * stride + r);
-            if (i0 + k >= width) c[k].x = c[k].y = -1;
+            if (STREAM) {  // planes larger than the Infinity Cache: read once, streamed past the caches
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                typedef int i2v __attribute__((ext_vector_type(2)));
+                v[k].x = v[k].y = 0.0;
+                c[k].x = c[k].y = -1;
+                if (i0 + k < width) {  // (no second, clamped read of the last plane: it would be fetched again)
+                    const d2v tv = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vals + (long)i * stride + r));
+                    const i2v tc = __builtin_nontemporal_load(reinterpret_cast<const i2v *>(cols + (long)i * stride + r));
+                    v[k].x = tv.x;
+                    v[k].y = tv.y;
+                    c[k].x = tc.x;
+                    c[k].y = tc.y;
+                }
+            } else {
+                v[k] = *reinterpret_cast<const double2 *>(vals + (long)i * stride + r);
+                c[k] = *reinterpret_cast<const int2 *>(cols + (long)i * stride + r);
+                if (i0 + k >= width) c[k].x = c[k].y = -1;
+            }
         }
         double xv0[BATCH], xv1[BATCH];
 #pragma unroll
@@ -2197,9 +2212,16 @@ void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x,
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
-#define OGL_ELL(MODE, NDOT)                                                                      \
-    hipLaunchKernelGGL((k_spmv_ell<MODE, NDOT>), grid, block, 0, st, A.n_rows, nc, A.width,      \
+#define OGL_ELL_K(MODE, NDOT, STREAM)                                                                   \
+    hipLaunchKernelGGL((k_spmv_ell<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.width,      \
                        (long)A.stride, A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+#define OGL_ELL(MODE, NDOT)               \
+    do {                                  \
+        if (A.stream)                     \
+            OGL_ELL_K(MODE, NDOT, true);  \
+        else                              \
+            OGL_ELL_K(MODE, NDOT, false); \
+    } while (0)
     if (mode == SPMV_RESIDUAL) {
         OGL_ELL(SPMV_RESIDUAL, 0);
     } else if (dots.part && dots.part_yy) {
@@ -2210,6 +2232,7 @@ void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x,
         OGL_ELL(SPMV_PLAIN, 0);
     }
 #undef OGL_ELL
+#undef OGL_ELL_K
 }
 
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,

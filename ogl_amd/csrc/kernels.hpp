@@ -81,6 +81,7 @@ struct DevEll {
     int64_t stride = 0;
     const int32_t *cols = nullptr;  // [width * stride]
     const double *vals = nullptr;   // [width * stride]
+    bool stream = false;            // as DevCsr::stream
 };
 void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,
                      double *y, const SpmvDots &dots, const DevScalars *gate);

@@ -386,6 +386,7 @@ DevEll ogl_solver::ell() const
     E.stride = ell_stride;
     E.cols = d_ell_cols.p;
     E.vals = d_ell_vals.p;
+    E.stream = 12.0 * (double)ell_width * (double)ell_stride + 40.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
     return E;
 }
 
