@@ -1044,7 +1044,10 @@ struct SymOffsets {
 // blocks that wait for each other: 130 us instead of 113, tools/sym_tune.hip var1/var2).  Then the two rows
 // of a lane are an aligned pair in every strip: x and the lower values of the even distances come as one
 // 16-byte load per pair, the d = 1 neighbours from the diagonal pair and the lane's own plane-1 value.
-template <int MODE, int NDOT, int ND, bool FAST>
+// STREAM (planes + vectors larger than the Infinity Cache): the planes that are read exactly once per launch are
+// streamed past the caches -- the diagonal always, and with FAST also plane 1, whose second reader (the d = 1
+// lower entry of the next row) is the neighbouring lane: a lane shuffle instead of a load.
+template <int MODE, int NDOT, int ND, bool FAST, bool STREAM>
 __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, SymOffsets off,
                                                     const uint8_t *__restrict__ mask,
                                                     const double *__restrict__ planes,
@@ -1072,7 +1075,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
     double2 up[ND];
     const double *own = planes + (long)chunk * (ND * CHUNK_ROWS) + t * ROWS_PER_THREAD;
 #pragma unroll
-    for (int j = 0; j < ND; ++j) up[j] = *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
+    for (int j = 0; j < ND; ++j)
+        up[j] = (STREAM && (j == 0 || (FAST && j == 1))) ? ld_pair_stream(own + (long)j * CHUNK_ROWS)
+                                                         : *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
     const double2 xd = ld2(x, rp);
     // lower entries: plane j at rows row - d[j], row + 1 - d[j]
     double2 lo[ND];
@@ -1086,7 +1091,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
         if (FAST && j >= 2) {  // even distance: rows r0, r0 + 1 are an aligned pair of one chunk's plane
             if (ok0 || ok1) lo[j] = *reinterpret_cast<const double2 *>(planes + a0);
         } else if (FAST) {     // d = 1: A(row + 1, row) is this lane's own upper entry of row
-            if (ok0) lo[j].x = planes[a0];
+            if (STREAM) {      // A(row, row - 1) is the previous lane's second plane-1 value (lane 0: from memory)
+                const double prev = __shfl_up(up[1].y, 1, WAVE);
+                lo[j].x = prev;
+                if ((t & (WAVE - 1)) == 0 && ok0) lo[j].x = planes[a0];
+            } else if (ok0) {
+                lo[j].x = planes[a0];
+            }
             lo[j].y = up[1].x;
         } else {
             if (ok0) lo[j].x = planes[a0];
@@ -2276,15 +2287,19 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
     // d[1] == 1 and the further distances even: the straight-line pair-load instantiation
     bool fast = A.nd >= 2 && A.d[1] == 1;
     for (int j = 2; j < A.nd; ++j) fast = fast && (A.d[j] % 2 == 0);
-#define OGL_SYM_K(MODE, NDOT, ND, FAST)                                                                           \
-    hipLaunchKernelGGL((k_spmv_sym<MODE, NDOT, ND, FAST>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
+#define OGL_SYM_K(MODE, NDOT, ND, FAST, STREAM)                                                                          \
+    hipLaunchKernelGGL((k_spmv_sym<MODE, NDOT, ND, FAST, STREAM>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
                        x, b, y, dots.with, dots.part, dots.part_yy, gate, A.block_order)
-#define OGL_SYM_ND(MODE, NDOT, ND)            \
-    do {                                      \
-        if (fast)                             \
-            OGL_SYM_K(MODE, NDOT, ND, true);  \
-        else                                  \
-            OGL_SYM_K(MODE, NDOT, ND, false); \
+#define OGL_SYM_ND(MODE, NDOT, ND)                   \
+    do {                                             \
+        if (fast && A.stream)                        \
+            OGL_SYM_K(MODE, NDOT, ND, true, true);   \
+        else if (fast)                               \
+            OGL_SYM_K(MODE, NDOT, ND, true, false);  \
+        else if (A.stream)                           \
+            OGL_SYM_K(MODE, NDOT, ND, false, true);  \
+        else                                         \
+            OGL_SYM_K(MODE, NDOT, ND, false, false); \
     } while (0)
 #define OGL_SYM(MODE, NDOT)                    \
     do {                                       \

@@ -108,6 +108,7 @@ struct DevSym {
     int32_t d[4] = {0, 0, 0, 0};    // the distances, ascending, d[0] = 0
     const uint8_t *mask = nullptr;  // [n_chunks * CHUNK_ROWS] which entries a row has
     const double *planes = nullptr; // [n_chunks][nd][CHUNK_ROWS]
+    bool stream = false;            // as DevCsr::stream, for the planes that are read once per launch
     // workgroup b takes chunk block_order[b] (-1: none), n_blocks workgroups (band_block_order); nullptr: default map
     const int32_t *block_order = nullptr;
     int32_t n_blocks = 0;

@@ -445,6 +445,7 @@ DevSym ogl_solver::sym() const
     for (int j = 0; j < 4; ++j) S.d[j] = sym_d[j];
     S.mask = d_sym_mask.p;
     S.planes = d_sym_planes.p;
+    S.stream = 8.0 * (double)d_sym_planes.n + 41.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
     if (d_sym_order.n && !band_order_off) {
         S.block_order = d_sym_order.p;
         S.n_blocks = (int32_t)d_sym_order.n;
