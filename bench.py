@@ -121,7 +121,9 @@ def pmc_traffic(kernel, variant=""):
         d = json.load(fh)
     # template spellings over the rounds: <0, true> (r01), <0, 1> (r02), <0, 1, true|false> (STREAM flag)
     k = (d.get(kernel) or d.get(kernel.replace("<0, 1>", "<0, 1, true>")) or d.get(kernel.replace("<0, 1>", "<0, 1, false>"))
-         or d.get(kernel.replace("<0, 1>", "<0, true>")))
+         or d.get(kernel.replace("<0, 1>", "<0, true>"))
+         or d.get(kernel.replace("<0, 1, 4, true>", "<0, 1, 4, true, true>"))
+         or d.get(kernel.replace("<0, 1, 4, true>", "<0, 1, 4, true, false>")))
     if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         return None, None
     total = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
