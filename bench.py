@@ -10,13 +10,18 @@ matrix, b and x already resident in HBM.
   value     = CG iterations per second; at N GPUs the global box is 216 x 216 x (216 N), cut into
               N z-slabs (weak scaling: 10M rows per GPU, halo exchange + scalar all-reduces over
               RCCL), and value counts 10M-row block iterations: N * iterations / time.
-  roofline  = the in-loop SpMV of matrixFormat Csr: algorithmic bytes 12 nnz + 20 N + 4 (SURVEY.md
-              §8d) over the kernel's mean duration, measured with HIP events on the solver's stream
-              inside the timed steps (profile_kernels=1), against 8 TB/s.  By default the kernel
-              runs on the index-compressed copy of the matrix (compressIndices: 1-byte column codes,
-              9 instead of 12 bytes per entry), so it MOVES fewer bytes than the CSR figure:
-              `moved_model` / `moved_frac` give the bytes of that layout over the same time.
-              --no-compress measures the plain CSR-stream kernel.
+  roofline  = the in-loop SpMV: the bytes the kernel has to move for the layout it runs on (matrix data of
+              that layout + x read once + y written; for the plain CSR-stream kernel that is SURVEY.md
+              §8d's 12 nnz + 20 N + 4) over the kernel's mean duration, measured with HIP events on the
+              solver's stream inside the timed steps (profile_kernels), against 8 TB/s: `achieved`, `frac`
+              (always <= 1).  The default layouts move fewer bytes than a CSR would (half storage of a
+              symmetric matrix; index-compressed copy): the rate on SURVEY §8d's CSR bytes over the same
+              time is reported apart as `csr_equivalent_achieved` / `csr_equivalent_frac` (may exceed 1: it
+              is a unit-of-work rate, not a bandwidth).
+  roofline_general = the same measurement for the general layouts on the same system, after the headline
+              and outside its timed region: --full-storage (k_spmv_sell, pattern codes), --no-compress
+              (k_spmv_stream, the kernel north_star describes), --shuffle 65536 (irregular numbering: the
+              library renumbers itself, k_spmv_sell with 16-bit delta codes or k_spmv_stream).
   cpu_baseline = the oracle (sequential restatement, 1 core, "port") on the same matrix for a
               bounded number of iterations; plus its OpenMP variant as `cpu_baseline_omp`.
 
@@ -101,33 +106,44 @@ def parse():
     ap.add_argument("--no-selfcheck", dest="selfcheck", action="store_false",
                     help="N > 1: skip the cross-rank self-check that runs before anything is timed")
     ap.add_argument("--selfcheck-edge", type=int, default=64, help="box edge per rank of the self-check")
+    ap.add_argument("--no-general-legs", dest="general_legs", action="store_false",
+                    help="skip the roofline_general legs (full storage, CSR-stream, shuffled cells) that follow the "
+                         "headline measurement of the default run")
+    ap.add_argument("--general-steps", type=int, default=5, help="timed steps of each roofline_general leg")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not event-time the in-loop SpMV (roofline then comes from a "
                          "separate back-to-back SpMV loop)")
     return ap.parse_args()
 
 
+def kernels_sha16():
+    import hashlib
+    with open(os.path.join(ROOT, "ogl_amd", "csrc", "kernels.hip"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
 def pmc_traffic(kernel, variant=""):
-    """HBM-side bytes per launch of `kernel` from the committed PMC passes of this same command
-    (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs).  Units and the
-    gfx950 correction per MI355X_MICROARCH.md "HBM": counters are KiB, FETCH_SIZE reads half the
-    bytes of a wide coalesced stream (calibrated here on k_cg_step1: 2 x 118,111 KiB = 241.9 MB
-    measured vs 24 N = 241.9 MB algorithmic)."""
+    """HBM-side bytes per launch of exactly the instantiation `kernel` (what the library says it launched)
+    from the committed PMC passes of this same command (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 --pmc runs).  Units and the gfx950 correction per MI355X_MICROARCH.md "HBM":
+    counters are KiB, FETCH_SIZE reads half the bytes of a wide coalesced stream (calibrated here on
+    k_cg_step1: 2 x 118,111 KiB = 241.9 MB measured vs 24 N = 241.9 MB algorithmic).  The summary records
+    the hash of kernels.hip it was collected with; a summary of other kernels yields None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{variant}_summary.json")))
     if not files:
-        return None, None
+        return None, "no committed PMC summary for this command"
     with open(files[-1]) as fh:
         d = json.load(fh)
-    # template spellings over the rounds: <0, true> (r01), <0, 1> (r02), <0, 1, true|false> (STREAM flag)
-    k = (d.get(kernel) or d.get(kernel.replace("<0, 1>", "<0, 1, true>")) or d.get(kernel.replace("<0, 1>", "<0, 1, false>"))
-         or d.get(kernel.replace("<0, 1>", "<0, true>"))
-         or d.get(kernel.replace("<0, 1, 4, true>", "<0, 1, 4, true, true>"))
-         or d.get(kernel.replace("<0, 1, 4, true>", "<0, 1, 4, true, false>")))
+    rel = os.path.relpath(files[-1], ROOT)
+    meta = d.get("_meta", {})
+    if meta.get("kernels_sha16") != kernels_sha16():
+        return None, f"{rel} was collected with other kernels (kernels.hip {meta.get('kernels_sha16')}): stale"
+    k = d.get(kernel)
     if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
-        return None, None
+        return None, f"{rel} holds no counters for {kernel}"
     total = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
-    return total, os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE) KiB, separate passes"
+    return total, rel + " (2*FETCH_SIZE + WRITE_SIZE) KiB, separate passes, head " + str(meta.get("head"))
 
 
 def main():
@@ -419,10 +435,49 @@ def main():
     assert all(p.n_iterations == expect for p in perfs), [p.n_iterations for p in perfs]
     value = world * iters / elapsed
 
-    # ---- roofline of the dominant kernel: the in-loop CSR SpMV -------------------------------
-    b_spmv = 12 * nnz + 20 * N + 4            # CSR: values + columns + row pointers + x + y
-    if args.format == "Ell":                  # 7 slots/row -> 84 N + 16 N
-        b_spmv = (12 * 7 + 16) * N
+    # ---- roofline of the dominant kernel: the in-loop SpMV -----------------------------------
+    def prop_or(sv, name, default):
+        try:
+            return sv.get_property(name)
+        except capi.OglError:
+            return default
+
+    def spmv_roofline(sv, n_rows, n_nnz, spmv_ms, timing, pmc_variant):
+        """roofline object of the in-loop SpMV of solver `sv`: `achieved` / `frac` on the bytes the layout in
+        use has to move (matrix data + x read once + y written), the CSR-equivalent rate apart."""
+        b_csr = 12 * n_nnz + 20 * n_rows + 4            # SURVEY.md §8d: values + columns + row pointers + x + y
+        if args.format == "Ell":                        # SURVEY.md §8d: 7 slots/row -> 84 N + 16 N
+            b_csr = (12 * 7 + 16) * n_rows
+        layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[sv.get_property("spmvLayout")]
+        if layout == "sell" and prop_or(sv, "symmetricHalf", 0.0) == 1.0:
+            layout = "sym"   # half storage of a symmetric matrix on a banded pattern (diagonal + upper planes)
+        stream = "true" if prop_or(sv, "spmvStream", 0.0) == 1.0 else "false"
+        kernel = {"csr": f"k_spmv_stream<0, 1, {stream}>", "ell": f"k_spmv_ell<0, 1, {stream}>",
+                  "sell": f"k_spmv_sell<0, 1, {stream}>",
+                  "sym": f"k_spmv_sym<0, 1, {int(prop_or(sv, 'spmvSymPlanes', 0))}, "
+                         f"{'true' if prop_or(sv, 'spmvSymFast', 0.0) == 1.0 else 'false'}, {stream}>"}[layout]
+        # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
+        b_moved = (sv.get_property("sellMatrixBytes") + 16 * n_rows) if layout in ("sell", "sym") else b_csr
+        traffic, traffic_src = pmc_traffic(kernel, pmc_variant) if pmc_variant is not None else (None, None)
+        moved = b_moved / (spmv_ms * 1e-3) / 1e9
+        return layout, b_moved, b_csr, {
+            "kernel": kernel, "layout": layout, "bound": "hbm",
+            "achieved": moved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": moved / HBM_PEAK_GBPS,
+            "bytes_per_launch": b_moved,
+            "frac_of_measured_copy_peak": moved / HBM_COPY_GBPS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            # the PMC passes are separate rocprofv3 runs of this same command (tools/gpu_pmc.sh); the number is
+            # read from the committed summary of exactly this kernel instantiation, not collected by this process
+            "traffic_measured_in_this_run": False,
+            "traffic_over_model": None if traffic is None else traffic / b_moved,
+            # the same time priced in SURVEY.md 8(d)'s CSR bytes (the unit of work `matrixFormat Csr` names):
+            # a rate of work, not a bandwidth -- above 1 when the layout moves fewer bytes than a CSR
+            "csr_equivalent_bytes_per_launch": b_csr,
+            "csr_equivalent_achieved": b_csr / (spmv_ms * 1e-3) / 1e9,
+            "csr_equivalent_frac": b_csr / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "avg_kernel_ms": spmv_ms, "timing": timing,
+        }
+
     if args.no_profile:
         spmv_ms = s.time_spmv(100)
         spmv_src = "100 back-to-back launches, HIP events"
@@ -431,35 +486,30 @@ def main():
         spmv_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in perfs) / max(1, launches)
         spmv_src = (f"{launches} in-loop launches of the timed steps (every "
                     f"{args.profile_stride}th turn), HIP event pairs")
-    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9
-    def prop_or(name, default):
-        try:
-            return s.get_property(name)
-        except capi.OglError:
-            return default
-    layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[s.get_property("spmvLayout")]
-    if layout == "sell" and prop_or("symmetricHalf", 0.0) == 1.0:
-        layout = "sym"   # half storage of a symmetric matrix on a banded pattern (diagonal + upper planes)
+    plain_box = not (args.voronoi or args.octree or args.drop_faces or args.long_rows or args.asym)
+    pmc_variant = None
+    if n == 216 and args.format == "Csr" and plain_box and args.renumber == "auto" and not args.rcm \
+            and args.shuffle in (0, 65536):
+        pmc_variant = ("_shuffle65536" if args.shuffle else "_fullstorage" if args.full_storage else
+                       "_nocompress" if args.no_compress else "")
+    layout, b_moved, b_spmv, roofline = spmv_roofline(s, N, nnz, spmv_ms, spmv_src, pmc_variant)
     renumbered = s.get_property("renumbered") == 1.0
     if world > 1 and s.get_property("peerHalo") == 1.0:
         # the transport above was only the bootstrap: halo values are put straight into the
         # neighbours' receive blocks (hipIpc-mapped) by the pack kernel
         transport = "peer-put halo + peer-write all-reduce over xGMI (hipIpc), bootstrap: " + \
                     ("RCCL" if transport.startswith("RCCL") else "gloo")
-    kernel = {"csr": "k_spmv_stream", "ell": "k_spmv_ell", "sell": "k_spmv_sell", "sym": "k_spmv_sym"}[layout]
-    # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
-    b_moved = (s.get_property("sellMatrixBytes") + 16 * N) if layout in ("sell", "sym") else b_spmv
-    traffic, traffic_src = (pmc_traffic(kernel + ("<0, 1, 4, true>" if layout == "sym" else "<0, 1>"),
-                                        "_shuffle65536" if args.shuffle == 65536 else
-                                        ("_fullstorage" if args.full_storage else ""))
-                            if (n == 216 and args.format == "Csr" and args.shuffle in (0, 65536)
-                                and args.renumber == "auto" and not args.rcm) else (None, None))
-    b_cg = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N
+    # one CG turn: the SpMV + the vector passes of the fused kernels (x update deferred into step_1x: p is
+    # read once per turn): 80 N with scalar Jacobi, 64 N without; SURVEY.md §8d's model has 88 N / 72 N
+    cg_headline = (args.solver == "GKOCG" and precond in (capi.PRECOND_BJ, capi.PRECOND_NONE)
+                   and args.block_size == 1)
+    b_cg = b_moved + (80 if precond == capi.PRECOND_BJ else 64) * N if cg_headline else None
+    b_cg_csr = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N if cg_headline else None
 
-    def turn_model():
-        """Algorithmic bytes of ONE solver turn: the SpMV(s) at the CSR figure + every vector pass the
-        Ginkgo step order needs when neighbouring element-wise steps are fused (what the kernels here
-        do), each vector counted once per read or write.  GKOCG: SURVEY.md §8d.  Others: DESIGN.md §4."""
+    def turn_model(b_mat):
+        """Bytes of ONE solver turn: the SpMV(s) priced at `b_mat` + every vector pass the Ginkgo step order
+        needs when neighbouring element-wise steps are fused (what the kernels here do), each vector counted
+        once per read or write.  GKOCG: SURVEY.md §8d.  Others: DESIGN.md §4."""
         k, m = args.block_size, args.krylov_dim
         nnz_w = (nnz + N) // 2 if args.precond == "ISAI" else nnz          # tril(A) resp. pattern of A
         if args.precond == "none":
@@ -474,19 +524,18 @@ def main():
         if args.solver == "GKOCG":
             # fused: step_1 24 N (+ deferred x update 16 N) , step_2 24 N + partials; materialised z: +16 N
             vec = 72 * N if not materialised else (24 + 48 + 0) * N
-            return b_spmv + vec + (apply_b if apply_b != 8 * N else 16 * N), "B_spmv + vector passes + M^-1"
+            return b_mat + vec + (apply_b if apply_b != 8 * N else 16 * N), "B_spmv + vector passes + M^-1"
         if args.solver == "GKOBiCGStab":
             vec = (24 + 24 + 64) * N + (2 * 16 * N if apply_b == 8 * N else 0)   # step_1/2/3 (+ y, z written)
-            return 2 * b_spmv + vec + 2 * (apply_b if materialised else 0), "2 B_spmv + step_1/2/3 + 2 M^-1"
+            return 2 * b_mat + vec + 2 * (apply_b if materialised else 0), "2 B_spmv + step_1/2/3 + 2 M^-1"
         # GKOGMRES(m): column `it` of a cycle costs it + 1 modified Gram-Schmidt links of 32 N (w read and
         # written, v_k-1 and v_k read), the closing link 24 N, the scaling 16 N; per cycle once: update of
         # x (8 m N + 24 N), the residual SpMV and the restart (24 N)
-        per_col = b_spmv + (apply_b + 16 * N if not materialised else apply_b) + 32 * N * (m + 1) / 2 + 40 * N
-        per_cycle = b_spmv + (8 * m + 48) * N + (apply_b if materialised else 8 * N)
+        per_col = b_mat + (apply_b + 16 * N if not materialised else apply_b) + 32 * N * (m + 1) / 2 + 40 * N
+        per_cycle = b_mat + (8 * m + 48) * N + (apply_b if materialised else 8 * N)
         return per_col + per_cycle / m, "B_spmv + M^-1 + (m+1)/2 MGS links of 32 N + cycle overhead / m"
-    b_turn, b_turn_what = turn_model()
-    if args.solver != "GKOCG" or precond not in (capi.PRECOND_BJ, capi.PRECOND_NONE) or args.block_size != 1:
-        b_cg = None              # the per-iteration byte model of SURVEY.md §8d is for CG only
+    b_turn, b_turn_what = turn_model(b_moved)
+    b_turn_csr, _ = turn_model(b_spmv)
     # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
     # (host arrays prepared outside the timed region: the C ABI borrows the caller's arrays, it allocates nothing)
     ldu_arrays = capi.LduArrays(case)
@@ -495,6 +544,53 @@ def main():
     s.set_matrix(ldu_arrays)
     _, p_e2e = s.solve(b, psi_io, inplace=True)
     t_e2e = time.perf_counter() - t0
+
+    # ---- the general layouts on the same system (N = 1, the plain benchmark box only), outside the timed
+    # region: full storage (pattern-coded compressed copy), plain CSR-stream, cells shuffled (irregular
+    # numbering: the library renumbers its device copy itself) -- each a short run of its own solver
+    general = None
+    if world == 1 and args.general_legs and plain_box and not args.shuffle and args.format == "Csr" \
+            and not (args.full_storage or args.no_compress or args.force_compress) and cg_headline \
+            and not args.no_profile:
+        general = []
+        legs = [("full_storage", dict(symmetric_half=0), None, "_fullstorage"),
+                ("no_compress", dict(compress_indices=0), None, "_nocompress"),
+                ("shuffle65536", dict(), 65536, "_shuffle65536")]
+        for name, over, shuffle, variant in legs:
+            leg_case, leg_b = case, b
+            if shuffle:
+                leg_case = synthetic.renumber_case(case, shuffle)
+                leg_b, _ = synthetic.rhs_for_x_star(leg_case)
+            d = {f: getattr(cfg, f) for f, _ in cfg._fields_}
+            d.update(over)
+            leg_cfg = type(cfg)(**d)
+            sv = reg.solver("p_" + name, leg_cfg)
+            t0 = time.perf_counter()
+            sv.set_matrix(leg_case)
+            t_first = time.perf_counter() - t0
+            sv.upload_rhs(leg_b)
+            sv.upload_solution(None)
+            sv.apply_resident()                                    # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            lp = []
+            for _ in range(args.general_steps):
+                sv.upload_solution(None)
+                lp.append(sv.apply_resident())
+            torch.cuda.synchronize()
+            t_leg = time.perf_counter() - t0
+            ln = sum(p.spmv_launches for p in lp)
+            l_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in lp) / max(1, ln)
+            _, _, _, r = spmv_roofline(sv, leg_case.n_cells, leg_case.nnz, l_ms,
+                                       f"{ln} in-loop launches, HIP event pairs",
+                                       variant if (n == 216 and args.renumber == "auto") else None)
+            r.update({"leg": name, "steps": args.general_steps,
+                      "cg_iters_per_sec": sum(p.n_iterations - 1 for p in lp) / t_leg,
+                      "first_set_matrix_s": t_first,
+                      "renumbered": sv.get_property("renumbered") == 1.0,
+                      "moved_frac": r["frac"]})
+            general.append(r)
+            del sv
 
     out = {
         "metric": "cg_iters_per_sec", "value": value, "unit": "iter/s",
@@ -526,11 +622,11 @@ def main():
                                                                 or args.long_rows or args.octree) else " (proxy of an unstructured mesh)"),
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
-            "rows_sorted_by_length": prop_or("rowsSortedByLength", 0.0) == 1.0,
+            "rows_sorted_by_length": prop_or(s, "rowsSortedByLength", 0.0) == 1.0,
             # irregular patterns: both SpMV kernels timed once per pattern at set_matrix, the faster one runs
-            "layout_tuned_us": ({"csr": prop_or("spmvTunedCsrUs", None), "sell": prop_or("spmvTunedSellUs", None)}
-                                if prop_or("spmvTunedCsrUs", None) is not None else None),
-            "spilled_entries": prop_or("sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
+            "layout_tuned_us": ({"csr": prop_or(s, "spmvTunedCsrUs", None), "sell": prop_or(s, "spmvTunedSellUs", None)}
+                                if prop_or(s, "spmvTunedCsrUs", None) is not None else None),
+            "spilled_entries": prop_or(s, "sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
                                          "in_use": s.get_property("gatherSectorRatio")},
             "parallelism": f"rows sharded into {world} z-slab(s), {transport}"
@@ -540,42 +636,34 @@ def main():
                           "peer_mesh": bool(comm_info.peer_mesh), "stepped_down_from": tried},
             "selfcheck": selfcheck_report,
         },
-        "roofline": {
-            "kernel": kernel + "<PLAIN, fused p.q>", "layout": layout,
-            "bound": "hbm",
-            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_source": traffic_src,
-            # the PMC passes are separate rocprofv3 runs of this same command (tools/gpu_pmc.sh);
-            # the number is read from the committed summary, not collected by this process
-            "traffic_measured_in_this_run": False,
-            "algorithmic_bytes_per_launch": b_spmv,
-            # what the layout in use really has to move, over the same time: the honest distance
-            # to the memory system's ceiling (6.29 TB/s measured copy, 8 TB/s spec)
-            "moved_model_bytes_per_launch": b_moved,
-            "moved_model": b_moved / (spmv_ms * 1e-3) / 1e9,
-            "moved_frac": b_moved / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "moved_frac_of_measured_copy_peak": b_moved / (spmv_ms * 1e-3) / 1e9 / HBM_COPY_GBPS,
-            "avg_kernel_ms": spmv_ms, "timing": spmv_src,
-            "note": ("achieved / frac count SURVEY.md 8(d)'s CSR bytes of the matrix per launch (the unit of work); "
-                     "the kernel itself moves moved_model_bytes_per_launch -- "
-                     + {"sym": "diagonal + upper coefficients only: the matrix is symmetric and every lower entry is "
-                               "read where its upper twin lives (same bits in y); --full-storage runs the expanded "
-                               "matrix (frac 0.88-0.92, profiles/r02_bench_n216_fullstorage.json)",
-                        "sell": "an index-compressed copy of the CSR arrays",
-                        "ell": "slot-major planes of the CSR arrays",
-                        "csr": "the CSR arrays themselves"}[layout]
-                     + "; a frac above 1 means the layout moves fewer bytes than CSR, not that HBM ran above its peak"),
-        },
+        "roofline": dict(roofline, note=(
+            "achieved / frac: the bytes the kernel has to move for the layout it runs on (bytes_per_launch: matrix "
+            "data of that layout + x read once + y written; layout model, checked against the PMC traffic) over "
+            "avg_kernel_ms -- "
+            + {"sym": "diagonal + upper coefficients only: the matrix is symmetric and every lower entry is read "
+                      "where its upper twin lives (same bits in y)",
+               "sell": "an index-compressed copy of the CSR arrays",
+               "ell": "slot-major planes of the CSR arrays",
+               "csr": "the CSR arrays themselves (= SURVEY.md 8(d)'s figure)"}[layout]
+            + "; csr_equivalent_*: the same time priced in SURVEY.md 8(d)'s CSR bytes, a rate of work that exceeds "
+              "the bandwidth when the layout moves fewer bytes than a CSR would")),
+        "roofline_general": general,
         "cg_iteration": {
-            "algorithmic_bytes": b_cg, "ms": 1e3 * elapsed / max(1, iters),
+            "bytes": b_cg, "ms": 1e3 * elapsed / max(1, iters),
             "achieved_GBps": None if b_cg is None else b_cg * iters / elapsed / 1e9,
             "frac_of_peak": None if b_cg is None else b_cg * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
+            "model": "bytes the kernels of one turn move: SpMV layout bytes + 16 N + 80 N (scalar Jacobi; 64 N without)",
+            "csr_equivalent_bytes": b_cg_csr,
+            "csr_equivalent_frac_of_peak": None if b_cg_csr is None else
+                                           b_cg_csr * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
         },
         "solver_turn": {
-            "algorithmic_bytes": b_turn, "model": b_turn_what, "ms": 1e3 * elapsed / max(1, iters),
+            "bytes": b_turn, "model": b_turn_what + " (SpMV priced at the bytes its layout moves)",
+            "ms": 1e3 * elapsed / max(1, iters),
             "achieved_GBps": b_turn * iters / elapsed / 1e9,
             "frac_of_peak": b_turn * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
+            "csr_equivalent_bytes": b_turn_csr,
+            "csr_equivalent_frac_of_peak": b_turn_csr * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
         },
         "boundary": {
             "first_set_matrix_s": t_first_matrix, "refresh_set_matrix_s": t_refresh_matrix,

@@ -366,6 +366,18 @@ double ogl_solver::prop(const std::string &key, double dflt) const
     return it == props.end() ? dflt : it->second;
 }
 
+// Size above which matrix data is streamed past the caches (STREAM instantiations, common.hpp).  The
+// property `streamAboveBytes` / the environment variable OGL_STREAM_ABOVE_BYTES override the built-in
+// threshold: 0 forces the STREAM kernels onto small systems, which is how the parity tests reach them.
+double ogl_solver::stream_above_bytes() const
+{
+    static const double env_default = [] {
+        const char *e = std::getenv("OGL_STREAM_ABOVE_BYTES");
+        return e ? atof(e) : STREAM_MATRIX_ABOVE_BYTES;
+    }();
+    return prop("streamAboveBytes", env_default);
+}
+
 DevCsr ogl_solver::csr() const
 {
     DevCsr A;
@@ -374,7 +386,7 @@ DevCsr ogl_solver::csr() const
     A.row_ptrs = d_row_ptrs.p;
     A.cols = d_cols.p;
     A.vals = d_vals.p;
-    A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
+    A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows > stream_above_bytes();
     return A;
 }
 
@@ -386,7 +398,7 @@ DevEll ogl_solver::ell() const
     E.stride = ell_stride;
     E.cols = d_ell_cols.p;
     E.vals = d_ell_vals.p;
-    E.stream = 12.0 * (double)ell_width * (double)ell_stride + 40.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
+    E.stream = 12.0 * (double)ell_width * (double)ell_stride + 40.0 * (double)pat.n_rows > stream_above_bytes();
     return E;
 }
 
@@ -426,7 +438,7 @@ DevSell ogl_solver::sell() const
     S.dict = d_sell_dict.p;
     S.codes = d_sell_codes.p;
     S.vals = d_sell_vals.p;
-    S.stream = sell_bytes + 40.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
+    S.stream = sell_bytes + 40.0 * (double)pat.n_rows > stream_above_bytes();
     if (n_spill) {
         S.spill_chunk_ptr = d_spill_chunks.p;
         S.spill_rows = d_spill_rows.p;
@@ -445,7 +457,7 @@ DevSym ogl_solver::sym() const
     for (int j = 0; j < 4; ++j) S.d[j] = sym_d[j];
     S.mask = d_sym_mask.p;
     S.planes = d_sym_planes.p;
-    S.stream = 8.0 * (double)d_sym_planes.n + 41.0 * (double)pat.n_rows > STREAM_MATRIX_ABOVE_BYTES;
+    S.stream = 8.0 * (double)d_sym_planes.n + 41.0 * (double)pat.n_rows > stream_above_bytes();
     if (d_sym_order.n && !band_order_off) {
         S.block_order = d_sym_order.p;
         S.n_blocks = (int32_t)d_sym_order.n;
@@ -761,6 +773,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     const bool config_same = have_pattern && pat_renumber_mode == cfg.renumber &&
                              !(cfg.renumber != 0 && pat_try_sell != try_sell) && pat_try_sym == try_sym;
     bool first = true, coefficients_done = false;
+    int upload_rc = OGL_OK;  // (a failed speculative upload is reported after the ranks have agreed below)
     if (config_same && same_counts(ldu, pat)) {
         auto fp = std::async(std::launch::async, [&ldu] { return addressing_fingerprint(ldu); });
         int rc = OGL_OK;
@@ -769,8 +782,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             coefficients_done = rc == OGL_OK;
         }
         first = fp.get() != pat.fingerprint;  // (joined before any return)
-        if (rc != OGL_OK) return rc;
-        if (first) coefficients_done = false;
+        upload_rc = rc;
     }
     if (reg->comm->multi()) {
         // a rebuild is collective once the peer mesh is up (setup_peer_halo): every rank rebuilds
@@ -784,6 +796,10 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         OGL_HIP_CHECK(hipStreamSynchronize(st));
         first = any != 0.0;
     }
+    if (upload_rc != OGL_OK) return upload_rc;
+    // a rebuild -- this rank's own or one another rank asked for -- re-creates the value arrays: whatever was
+    // uploaded speculatively above is gone
+    if (first) coefficients_done = false;
     if (first) {  // :79-87
         HostPattern np;
         OGL_TRY(build_host_pattern(ldu, np));
@@ -945,6 +961,24 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
     // (2 also for the half storage of a symmetric matrix: property symmetricHalf tells them apart)
     props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : ((use_sell() || use_sym()) ? 2.0 : 0.0);
+    {   // ... and which instantiation of its kernel (what a profiler lists; bench.py looks up exactly that one)
+        bool stream = false, fast = false;
+        if (cfg.matrix_format == OGL_FORMAT_ELL) {
+            stream = ell().stream;
+        } else if (use_sym()) {
+            const DevSym S = sym();
+            stream = S.stream;
+            fast = S.nd >= 2 && S.d[1] == 1;
+            for (int j = 2; j < S.nd; ++j) fast = fast && (S.d[j] % 2 == 0);
+            props["spmvSymPlanes"] = (double)S.nd;
+        } else if (use_sell()) {
+            stream = sell().stream;
+        } else {
+            stream = csr().stream;
+        }
+        props["spmvStream"] = stream ? 1.0 : 0.0;
+        props["spmvSymFast"] = fast ? 1.0 : 0.0;
+    }
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
     t_update_matrix_ms = now_ms() - t0;

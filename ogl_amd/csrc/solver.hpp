@@ -337,4 +337,5 @@ struct ogl_solver {
     ogl::DevCsr csr() const;
     ogl::DevHalo halo() const;
     double prop(const std::string &key, double dflt) const;
+    double stream_above_bytes() const;
 };

@@ -86,44 +86,8 @@ def gather_global(case, x):
     return allreduce(out)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", required=True)
-    ap.add_argument("--shape", default="8,8,8")
-    ap.add_argument("--procs", default="1,1,2")
-    ap.add_argument("--precond", type=int, default=1)
-    ap.add_argument("--asym", type=int, default=0)
-    ap.add_argument("--gmres", type=int, default=0)
-    ap.add_argument("--renumber", type=int, default=0,
-                    help="1: the library renumbers every rank's device copy (config renumber = on); the "
-                         "oracle then solves each rank's system permuted by the numbering the library reports")
-    ap.add_argument("--random", type=int, default=-1,
-                    help="seed: random irregular global system cut into contiguous row blocks of random "
-                         "sizes (instead of the structured box of --shape/--procs)")
-    args = ap.parse_args()
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    if args.random >= 0:
-        rng = np.random.default_rng(args.random)
-        n_glob = int(rng.integers(600, 2500))
-        glob = synthetic.random_global_case(n_glob, int(rng.integers(1, 5)), int(rng.choice([4, 60, 900])),
-                                            symmetric=not args.asym, seed=args.random)
-        cuts = np.sort(rng.choice(np.arange(1, n_glob), world - 1, replace=False)) if world > 1 else []
-        bounds = [0, *[int(c) for c in cuts], n_glob]
-        case = synthetic.partition_rows(glob, bounds, rank)
-    else:
-        gx, gy, gz = map(int, args.shape.split(","))
-        px, py, pz = map(int, args.procs.split(","))
-        assert px * py * pz == world
-        kw = dict(symmetric=not args.asym)
-        if args.asym:
-            kw.update(off_upper=-0.9, off_lower=-1.1)
-        case = synthetic.poisson_block(gx, gy, gz, px, py, pz, rank, **kw)
-        glob = synthetic.poisson_block(gx, gy, gz, **kw)
-    xs_g = synthetic.x_star(glob.global_index, glob.global_n)
-    b_g = synthetic.apply_case(glob, xs_g)
+def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
     b = b_g[case.global_index]
-    skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
 
     A, (rp, cols, vals), nl, comm = oracle_dist_matrix(
         case, allreduce_rank_order if args.mode == "gpu-peer" else allreduce)
@@ -171,8 +135,10 @@ def main():
     else:
         n_dev = torch.cuda.device_count()
         dev = rank % max(1, n_dev)
-        reg = capi.Registry(device_id=dev)
-        if args.mode in ("gpu-host", "gpu-peer"):
+        reg = state.get("reg") or capi.Registry(device_id=dev)
+        if "reg" in state:
+            pass                                   # second round: same registry, same transport, same field
+        elif args.mode in ("gpu-host", "gpu-peer"):
             ex = make_exchange(None)
             reg.set_host_comm(rank, world, allreduce, lambda nb, ct, s: ex(nb, ct, s))
             if args.mode == "gpu-peer":
@@ -192,6 +158,7 @@ def main():
             tolerance=1e-11, rel_tol=0.0, max_iter=300, export_res=1, adapt_min_iter=0,
             matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode != "gpu-rccl"),
             renumber=capi.RENUMBER_ON if args.renumber else capi.RENUMBER_OFF)
+        state["reg"] = reg
         s = reg.solver("p", cfg).set_matrix(case)
         new_id = s.renumbering()
         assert (new_id is not None) == bool(args.renumber and case.n_cells >= 2)
@@ -240,7 +207,58 @@ def main():
             np.testing.assert_allclose(hist[:m], ref.history[:m], rtol=1e-10)
             np.testing.assert_allclose(x, ref.x, atol=1e-9, rtol=0)
         np.testing.assert_allclose(gather_global(case, x), xs_g, atol=1e-8, rtol=0)
-        reg.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", required=True)
+    ap.add_argument("--shape", default="8,8,8")
+    ap.add_argument("--procs", default="1,1,2")
+    ap.add_argument("--precond", type=int, default=1)
+    ap.add_argument("--asym", type=int, default=0)
+    ap.add_argument("--gmres", type=int, default=0)
+    ap.add_argument("--renumber", type=int, default=0,
+                    help="1: the library renumbers every rank's device copy (config renumber = on); the "
+                         "oracle then solves each rank's system permuted by the numbering the library reports")
+    ap.add_argument("--relabel", type=int, default=0,
+                    help="1 (gpu modes): after the first solve the LAST rank alone renames its cells (same "
+                         "counts, new addressing) and every rank calls set_matrix + solve again: the rebuild "
+                         "one rank asks for is collective, the others must re-upload their coefficients too")
+    ap.add_argument("--random", type=int, default=-1,
+                    help="seed: random irregular global system cut into contiguous row blocks of random "
+                         "sizes (instead of the structured box of --shape/--procs)")
+    args = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.random >= 0:
+        rng = np.random.default_rng(args.random)
+        n_glob = int(rng.integers(600, 2500))
+        glob = synthetic.random_global_case(n_glob, int(rng.integers(1, 5)), int(rng.choice([4, 60, 900])),
+                                            symmetric=not args.asym, seed=args.random)
+        cuts = np.sort(rng.choice(np.arange(1, n_glob), world - 1, replace=False)) if world > 1 else []
+        bounds = [0, *[int(c) for c in cuts], n_glob]
+        case = synthetic.partition_rows(glob, bounds, rank)
+    else:
+        gx, gy, gz = map(int, args.shape.split(","))
+        px, py, pz = map(int, args.procs.split(","))
+        assert px * py * pz == world
+        kw = dict(symmetric=not args.asym)
+        if args.asym:
+            kw.update(off_upper=-0.9, off_lower=-1.1)
+        case = synthetic.poisson_block(gx, gy, gz, px, py, pz, rank, **kw)
+        glob = synthetic.poisson_block(gx, gy, gz, **kw)
+    xs_g = synthetic.x_star(glob.global_index, glob.global_n)
+    b_g = synthetic.apply_case(glob, xs_g)
+    skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
+    cases = [case]
+    if args.relabel:
+        assert args.mode != "oracle"
+        cases.append(synthetic.renumber_case(case, case.n_cells, seed=7) if rank == world - 1 else case)
+    state = {}
+    for round_no, case in enumerate(cases):
+        run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no)
+    if "reg" in state:
+        state["reg"].close()
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: {args.mode} ok")

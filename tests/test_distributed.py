@@ -178,3 +178,12 @@ def test_gpu_peer_mesh_soak():
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-6000:]
     assert p.stdout.count("solves ok") == 3, p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["gpu-host", "gpu-peer"])
+def test_gpu_rebuild_forced_by_one_rank(mode):
+    # only the last rank's addressing changes between two solves: the rebuild is agreed by all ranks, and
+    # the ranks whose own addressing is unchanged must upload their coefficients again
+    run_ranks(2, "--mode", mode, "--shape", "10,10,12", "--procs", "1,1,2", "--relabel", "1")
+    run_ranks(3, "--mode", mode, "--random", "14", "--relabel", "1")

@@ -1,0 +1,98 @@
+"""GPU parity on the unstructured proxies of bench.py at sizes where every mechanism is in play (>= 50 k rows;
+Voronoi >= 100 k cells): the library's own renumbering (RCM, rows of a wavefront sorted by length), 16-bit delta /
+32-bit column codes, lane-level row ends, the spill list, the one-off timing that picks the SpMV kernel of an
+irregular pattern.  Whatever layout and numbering the library ends up with, the SpMV and a 12-turn GKOCG + BJ
+history must be bit-identical to the oracle run on the system permuted by the numbering the library REPORTS
+(an explicit input of the oracle), in the device's reduction tree.  """
+import numpy as np
+import pytest
+
+from ogl_amd import capi, synthetic
+from helpers import blocked, oracle_csr, oracle_matrix_renumbered, to_new
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg():
+    r = capi.Registry()
+    yield r
+    r.close()
+
+
+_cache = {}
+
+
+def proxy(name):
+    if name not in _cache:
+        _cache[name] = {
+            "octree": lambda: synthetic.octree_case(40, 1.5),
+            "octree_append": lambda: synthetic.octree_case(40, 4.0, True),
+            "long_rows": lambda: synthetic.long_rows_case(synthetic.poisson_case(40), 0.03, 40),
+            "long_rows_shuffled": lambda: synthetic.renumber_case(
+                synthetic.long_rows_case(synthetic.poisson_case(40), 0.03, 40), 4096),
+            "drop_faces": lambda: synthetic.drop_faces_case(synthetic.poisson_case(40), 0.3),
+            "drop_faces_shuffled": lambda: synthetic.renumber_case(
+                synthetic.drop_faces_case(synthetic.poisson_case(40), 0.3), 4096),
+            "shuffled": lambda: synthetic.renumber_case(synthetic.poisson_case(44), 65536),
+            "voronoi": lambda: synthetic.voronoi_case(110000),
+        }[name]()
+    return _cache[name]
+
+
+PROXIES = ["octree", "octree_append", "long_rows", "long_rows_shuffled", "drop_faces", "drop_faces_shuffled",
+           "shuffled", "voronoi"]
+# compressIndices: 1 = the default policy (irregular patterns: both kernels timed once, the faster runs),
+# 2 = force the compressed layout when it qualifies, 0 = plain CSR-stream
+MODES = {"auto": 1, "force": 2, "csr": 0}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+@pytest.mark.parametrize("name", PROXIES)
+def test_spmv_and_cg_history_bit_identical_to_the_oracle(reg, oracle, name, mode):
+    case = proxy(name)
+    assert case.n_cells >= 50000
+    cfg = capi.default_config(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, tolerance=0.0, rel_tol=0.0,
+                              max_iter=12, export_res=1, matrix_format=capi.FORMAT_CSR, adapt_min_iter=0,
+                              compress_indices=MODES[mode], renumber=capi.RENUMBER_AUTO)
+    s = reg.solver(f"proxy_{name}_{mode}", cfg).set_matrix(case)
+    new_id = s.renumbering()
+    if new_id is None:
+        new_id = np.arange(case.n_cells)
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    d_rp, d_cols, _, d_vals = s.local_matrix()
+    np.testing.assert_array_equal(d_rp, rp)
+    np.testing.assert_array_equal(d_cols, cols)
+    np.testing.assert_array_equal(d_vals, vals)
+    rng = np.random.default_rng(20241016)
+    x = rng.uniform(-1, 1, case.n_cells)
+    np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, to_new(x, new_id))[new_id])
+    b = rng.uniform(-1, 1, case.n_cells)
+    xs, perf = s.solve(b, x.copy())
+    with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+        ref = oracle.cg(A, to_new(b, new_id), to_new(x, new_id), oracle.jacobi_generate_scalar(rp, cols, vals),
+                        tolerance=0.0, rel_tol=0.0, max_iter=12)
+    assert perf.n_iterations == ref.n_iterations == 13
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(xs, ref.x[new_id])
+    # the same operator as the un-renumbered reference matrix, at rounding level
+    o_rp, o_cols, o_vals = oracle_csr(oracle, case)
+    np.testing.assert_allclose(s.spmv(x), oracle.spmv(o_rp, o_cols, o_vals, x), rtol=1e-12, atol=1e-12)
+
+
+def test_the_mechanisms_are_really_in_play(reg):
+    """The cases above are only worth their time if they reach the code they are meant for."""
+    got = {}
+    for name in PROXIES:
+        case = proxy(name)
+        cfg = capi.default_config(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, matrix_format=capi.FORMAT_CSR,
+                                  compress_indices=2, renumber=capi.RENUMBER_AUTO)
+        s = reg.solver(f"proxy_{name}_force", cfg).set_matrix(case)
+        got[name] = {k: s.get_property(k) for k in ("renumbered", "rowsSortedByLength", "sellSpilledEntries",
+                                                    "sellChunksDelta16", "sellChunksCol32", "spmvLayout")}
+    assert got["voronoi"]["renumbered"] == 1.0 and got["shuffled"]["renumbered"] == 1.0
+    assert got["shuffled"]["sellChunksDelta16"] > 0 and got["shuffled"]["spmvLayout"] == 2.0
+    assert got["long_rows"]["sellSpilledEntries"] > 0 or got["long_rows_shuffled"]["sellSpilledEntries"] > 0
+    assert got["octree"]["spmvLayout"] == 2.0
+    assert any(g["rowsSortedByLength"] == 1.0 for g in got.values()), got
+    assert got["voronoi"]["spmvLayout"] == 0.0 or got["voronoi"]["sellChunksDelta16"] + got["voronoi"]["sellChunksCol32"] > 0

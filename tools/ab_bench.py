@@ -20,7 +20,7 @@ runner = ("import sys, runpy; sys.path.insert(0, %r); from ogl_amd import capi; 
 libs = [("in-tree", os.path.join(ROOT, "ogl_amd", "lib", "libogl_amd.so")), (os.path.basename(other), other)]
 for r in range(rounds):
     for name, lib in libs:
-        p = subprocess.run([sys.executable, "-c", runner, lib, "--steps", "3", "--warmup", "1", "--cpu-iters", "0", *flags],
+        p = subprocess.run([sys.executable, "-c", runner, lib, "--steps", "3", "--warmup", "1", "--cpu-iters", "0", "--no-general-legs", *flags],
                            cwd=ROOT, capture_output=True, text=True)
         try:
             d = json.loads(p.stdout.strip().splitlines()[-1])

@@ -5,17 +5,17 @@ TAG=${1:-r02}
 mkdir -p gpurun_out
 OUT=gpurun_out/${TAG}_configs.txt
 echo "# tools/gpu_bench_configs.sh on one MI355X (bench.py --steps 3 --warmup 2, HBM-resident, fixed turn count)" > $OUT
-echo "# turn = one solver iteration (BiCGStab: two SpMVs); spmv = in-loop SpMV (HIP event pairs); frac = turn byte model / time / 8 TB/s" >> $OUT
+echo "# turn = one solver iteration (BiCGStab: two SpMVs); spmv = in-loop SpMV (HIP event pairs); frac = bytes the turn's kernels move (SpMV at its layout's bytes) / time / 8 TB/s; csr-eq = the same with the SpMV priced at SURVEY 8(d)'s CSR bytes" >> $OUT
 run() {
   T=$1; shift
-  python bench.py --steps 3 --warmup 2 --cpu-iters 0 "$@" > gpurun_out/cfg_$T.json 2> gpurun_out/cfg_$T.err || { echo "$T FAILED" | tee -a $OUT; tail -3 gpurun_out/cfg_$T.err; return; }
+  python bench.py --steps 3 --warmup 2 --cpu-iters 0 --no-general-legs "$@" > gpurun_out/cfg_$T.json 2> gpurun_out/cfg_$T.err || { echo "$T FAILED" | tee -a $OUT; tail -3 gpurun_out/cfg_$T.err; return; }
   python - "$T" <<'PY' | tee -a $OUT
 import json,sys
 d=json.load(open(f"gpurun_out/cfg_{sys.argv[1]}.json"))
 r=d["roofline"]; t=d["solver_turn"]
-print("%-18s turns/s=%8.1f  ms/turn=%.4f  spmv_us=%6.1f (frac %.3f, %s)  turn bytes=%.3f GB -> %.0f GB/s = %.3f of 8 TB/s | %s" % (
-    sys.argv[1], d["value"], t["ms"], 1e3*r["avg_kernel_ms"], r["frac"], r["layout"], t["algorithmic_bytes"]/1e9,
-    t["achieved_GBps"], t["frac_of_peak"], d["config"]["workload"][:96]))
+print("%-18s turns/s=%8.1f  ms/turn=%.4f  spmv_us=%6.1f (frac %.3f, csr-eq %.3f, %s)  turn bytes=%.3f GB -> %.0f GB/s = %.3f of 8 TB/s (csr-eq %.3f) | %s" % (
+    sys.argv[1], d["value"], t["ms"], 1e3*r["avg_kernel_ms"], r["frac"], r["csr_equivalent_frac"], r["layout"], t["bytes"]/1e9,
+    t["achieved_GBps"], t["frac_of_peak"], t["csr_equivalent_frac_of_peak"], d["config"]["workload"][:96]))
 PY
 }
 run cg_bj_216        --iters 100

@@ -31,9 +31,20 @@ def main():
         short = m.group(1) if m else k.split("(")[0].split("::")[-1]
         res[short][c] = {"mean": sum(real) / len(real), "dispatches": len(real),
                          "dropped_noop_dispatches": len(v) - len(real)}
+    # which kernels these counters belong to: bench.py refuses a summary collected with other kernels
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import hashlib
+    with open(os.path.join(root, "ogl_amd", "csrc", "kernels.hip"), "rb") as fh:
+        sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+    head = None
+    for d in dirs:  # the bench line of the profiled run carries nothing about git: the pass script exports it
+        head = head or os.environ.get("OGL_GIT_HEAD")
+    res["_meta"] = {"kernels_sha16": sha, "head": head, "passes": [os.path.basename(d) for d in dirs]}
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
     for k in sorted(res):
+        if k == "_meta":
+            continue
         print(k, {c: round(x["mean"], 1) for c, x in res[k].items()})
 
 
