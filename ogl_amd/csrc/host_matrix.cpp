@@ -2,7 +2,9 @@
 #include "host_matrix.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -705,9 +707,25 @@ static double sell_cost_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const
     return total / (double)row_ptrs[n_rows];
 }
 
+namespace {
+// OGL_TIME_SETUP=1: the phases of the first set_matrix of a pattern on stderr (development aid)
+struct PhaseTimer {
+    bool on = std::getenv("OGL_TIME_SETUP") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ogl setup] %-34s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
+
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
                      RenumberReport &rep)
 {
+    PhaseTimer tm;
     rep = RenumberReport{};
     if (sell_built) *sell_built = false;
     if (mode < 0 || mode > 2) return fail(OGL_ERR_INVALID, "renumber %d outside {0 off, 1 on, 2 auto}", mode);
@@ -733,6 +751,7 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
         // gather locality and by the padding they make the kernel read.
         rep.sell_natural = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), natural);
         have_natural = true;
+        tm.lap("sell layout, caller's numbering");
         if (rep.sell_natural && natural.n_delta16 + natural.n_col32 == 0) {
             hand_over(natural, true);
             return OGL_OK;
@@ -743,6 +762,7 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
     if (mode == 1 || rep.ratio_natural > 0.25) {
         std::vector<ogl_label> cand, cand_old((size_t)N);
         rcm_order(N, p.row_ptrs.data(), p.cols.data(), cand);
+        tm.lap("rcm_order");
         for (ogl_label c = 0; c < N; ++c) cand_old[(size_t)cand[(size_t)c]] = c;
         const double r = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), cand.data(),
                                              cand_old.data());
@@ -752,6 +772,7 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
             rep.ratio_used = r;
         }
     }
+    tm.lap("gather ratio of the candidate");
     // ---- step 2 (compressed layout only): inside every wavefront's SELL_WAVE_ROWS rows, longest rows
     // first.  The lanes of the SpMV stop loading at the end of their own rows, so with the long rows of a
     // wavefront next to each other the 128-byte lines it reads hold (almost) no padding.  The x gather is
@@ -786,12 +807,15 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
         if (have_natural) hand_over(natural, rep.sell_natural);
         return OGL_OK;
     }
+    tm.lap("row-length sort policy");
     renumber_pattern(p, std::move(new_id));
+    tm.lap("renumber_pattern");
     rep.applied = true;
     rep.ratio_used = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
     if (try_sell && sell_out && sell_built) {
         SellLayout L;
         const bool ok = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), L);
+        tm.lap("sell layout, new numbering");
         hand_over(L, ok);
     }
     return OGL_OK;
