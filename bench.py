@@ -106,6 +106,9 @@ def parse():
     ap.add_argument("--no-selfcheck", dest="selfcheck", action="store_false",
                     help="N > 1: skip the cross-rank self-check that runs before anything is timed")
     ap.add_argument("--selfcheck-edge", type=int, default=64, help="box edge per rank of the self-check")
+    ap.add_argument("--prop", action="append", default=[], metavar="KEY=VALUE",
+                    help="set a solver property before set_matrix (development switches: xcdGroup, streamAboveBytes, "
+                         "deviceSetup, ...); repeatable")
     ap.add_argument("--no-general-legs", dest="general_legs", action="store_false",
                     help="skip the roofline_general legs (full storage, CSR-stream, shuffled cells) that follow the "
                          "headline measurement of the default run")
@@ -349,6 +352,9 @@ def main():
         """The benchmark's own system on a connected registry: matrix and b resident, warm-up done."""
         s = reg.solver("p", cfg)
         s.set_property("hipGraph", 1.0 if args.graph == "on" else 0.0)
+        for kv in args.prop:
+            k, v = kv.split("=", 1)
+            s.set_property(k, float(v))
         t0 = time.perf_counter()
         s.set_matrix(case)                       # pattern + H2D + device permutation (not timed below)
         t_first = time.perf_counter() - t0

@@ -201,6 +201,7 @@ extern "C" int ogl_solver_export_system(ogl_solver *s, const char *directory)
     if (!s || !directory) return fail(OGL_ERR_INVALID, "NULL argument");
     if (!s->matrix_set) return fail(OGL_ERR_STATE, "no matrix yet");
     OGL_HIP_CHECK(hipSetDevice(s->reg->device));
+    OGL_TRY(s->download_local_pattern(s->pat));
     const HostPattern &p = s->pat;
     const std::string base = std::string(directory) + "/" + s->field;
     std::vector<double> vals((size_t)p.local_nnz), nl((size_t)p.non_local_nnz), b((size_t)p.n_rows);

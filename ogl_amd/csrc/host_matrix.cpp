@@ -212,7 +212,7 @@ bool same_shape(const ogl_ldu_view &ldu, const HostPattern &p)
     return same_counts(ldu, p) && addressing_fingerprint(ldu) == p.fingerprint;
 }
 
-int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
+int build_host_pattern_meta(const ogl_ldu_view &ldu, HostPattern &p, bool check_faces)
 {
     if (ldu.n_cells < 0 || ldu.n_faces < 0 || ldu.n_interfaces < 0)
         return fail(OGL_ERR_INVALID, "negative size in ldu view");
@@ -221,10 +221,11 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
         return fail(OGL_ERR_INVALID, "face addressing / upper is NULL");
     if (ldu.n_interfaces > 0 && !ldu.interfaces) return fail(OGL_ERR_INVALID, "interfaces is NULL");
     const ogl_label N = ldu.n_cells, F = ldu.n_faces;
-    for (ogl_label f = 0; f < F; ++f)
-        if (ldu.lower_addr[f] < 0 || ldu.lower_addr[f] >= N || ldu.upper_addr[f] < 0 ||
-            ldu.upper_addr[f] >= N)
-            return fail(OGL_ERR_INVALID, "face %d addresses a cell outside [0,%d)", f, N);
+    if (check_faces)  // (the device build checks the faces while it counts them)
+        for (ogl_label f = 0; f < F; ++f)
+            if (ldu.lower_addr[f] < 0 || ldu.lower_addr[f] >= N || ldu.upper_addr[f] < 0 ||
+                ldu.upper_addr[f] >= N)
+                return fail(OGL_ERR_INVALID, "face %d addresses a cell outside [0,%d)", f, N);
 
     p = HostPattern{};
     p.n_rows = N;
@@ -260,57 +261,7 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
     p.local_iface_nnz = (ogl_label)loc;
     p.non_local_nnz = (ogl_label)nl;
     p.local_nnz = (ogl_label)total;
-
-    // ---- local pattern (init_local_sparsity_pattern, HostMatrix.C:468-589) ----
-    p.rows.resize(total);
-    p.cols.resize(total);
-    p.ldu_mapping.resize(total);
-    init_local_sparsity(N, F, p.symmetric, ldu.upper_addr, ldu.lower_addr, p.rows.data(),
-                        p.cols.data(), p.ldu_mapping.data());
-    if (loc) {
-        // collect_local_interface_indices (:385-410): (interface_idx, row, col) of every cyclic
-        // face; the column is the face cell of the neighbour patch (:324-327)
-        std::vector<std::tuple<ogl_label, ogl_label, ogl_label>> ifc;  // (row, col, idx)
-        ifc.reserve(loc);
-        ogl_label ctr = 0;
-        for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
-            const ogl_interface &itf = ldu.interfaces[i];
-            if (itf.kind != OGL_IFACE_CYCLIC) continue;
-            const ogl_label *nbr = ldu.interfaces[itf.neighb_patch].face_cells;
-            for (ogl_label f = 0; f < itf.size; ++f) ifc.emplace_back(itf.face_cells[f], nbr[f], ctr++);
-        }
-        std::stable_sort(ifc.begin(), ifc.end(), [](const auto &a, const auto &b) {  // :510-515
-            return std::tie(std::get<0>(a), std::get<1>(a)) < std::tie(std::get<0>(b), std::get<1>(b));
-        });
-        const int64_t base_nnz = (int64_t)N + 2 * (int64_t)F;
-        const ogl_label iface_base = p.diag_start() + N;  // after_neighbours + nrows_  (:574)
-        std::vector<ogl_label> r2(total), c2(total), m2(total);
-        int64_t cur = 0, tot = 0;
-        for (const auto &[r, c, idx] : ifc) {  // :539-576
-            while (cur < base_nnz && (p.rows[cur] < r || (p.rows[cur] == r && p.cols[cur] <= c))) {
-                r2[tot] = p.rows[cur];
-                c2[tot] = p.cols[cur];
-                m2[tot] = p.ldu_mapping[cur];
-                ++cur;
-                ++tot;
-            }
-            r2[tot] = r;
-            c2[tot] = c;
-            m2[tot] = iface_base + idx;
-            ++tot;
-        }
-        for (; cur < base_nnz; ++cur, ++tot) {  // :580-585
-            r2[tot] = p.rows[cur];
-            c2[tot] = p.cols[cur];
-            m2[tot] = p.ldu_mapping[cur];
-        }
-        p.rows.swap(r2);
-        p.cols.swap(c2);
-        p.ldu_mapping.swap(m2);
-    }
-    p.row_ptrs.assign((size_t)N + 1, 0);
-    for (int64_t e = 0; e < total; ++e) ++p.row_ptrs[p.rows[e] + 1];
-    for (ogl_label r = 0; r < N; ++r) p.row_ptrs[r + 1] += p.row_ptrs[r];
+    p.local_on_host = false;
 
     // ---- non-local pattern (HostMatrix.C:412-466) ----
     // row = faceCell, col = ldu_mapping = running index over processor-interface faces in
@@ -356,6 +307,81 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
             p.send_idxs.insert(p.send_idxs.end(), cells.begin(), cells.end());
         }
     }
+    return OGL_OK;
+}
+
+// collect_local_interface_indices (HostMatrix.C:385-410): (row, col) of every same-rank (cyclic) interface
+// face in interface order; the column is the face cell of the neighbour patch (:324-327)
+void local_interface_entries(const ogl_ldu_view &ldu, std::vector<ogl_label> &rows, std::vector<ogl_label> &cols)
+{
+    rows.clear();
+    cols.clear();
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+        const ogl_interface &itf = ldu.interfaces[i];
+        if (itf.kind != OGL_IFACE_CYCLIC) continue;
+        const ogl_label *nbr = ldu.interfaces[itf.neighb_patch].face_cells;
+        for (ogl_label f = 0; f < itf.size; ++f) {
+            rows.push_back(itf.face_cells[f]);
+            cols.push_back(nbr[f]);
+        }
+    }
+}
+
+// ---- local pattern (init_local_sparsity_pattern, HostMatrix.C:468-589) on the host ----
+void build_local_pattern(const ogl_ldu_view &ldu, HostPattern &p)
+{
+    const ogl_label N = p.n_rows, F = p.upper_nnz;
+    const int64_t total = p.local_nnz, loc = p.local_iface_nnz;
+    p.rows.resize(total);
+    p.cols.resize(total);
+    p.ldu_mapping.resize(total);
+    init_local_sparsity(N, F, p.symmetric, ldu.upper_addr, ldu.lower_addr, p.rows.data(),
+                        p.cols.data(), p.ldu_mapping.data());
+    if (loc) {
+        std::vector<ogl_label> ir, ic;
+        local_interface_entries(ldu, ir, ic);
+        std::vector<std::tuple<ogl_label, ogl_label, ogl_label>> ifc;  // (row, col, idx)
+        ifc.reserve(loc);
+        for (ogl_label k = 0; k < (ogl_label)ir.size(); ++k) ifc.emplace_back(ir[(size_t)k], ic[(size_t)k], k);
+        std::stable_sort(ifc.begin(), ifc.end(), [](const auto &a, const auto &b) {  // :510-515
+            return std::tie(std::get<0>(a), std::get<1>(a)) < std::tie(std::get<0>(b), std::get<1>(b));
+        });
+        const int64_t base_nnz = (int64_t)N + 2 * (int64_t)F;
+        const ogl_label iface_base = p.diag_start() + N;  // after_neighbours + nrows_  (:574)
+        std::vector<ogl_label> r2(total), c2(total), m2(total);
+        int64_t cur = 0, tot = 0;
+        for (const auto &[r, c, idx] : ifc) {  // :539-576
+            while (cur < base_nnz && (p.rows[cur] < r || (p.rows[cur] == r && p.cols[cur] <= c))) {
+                r2[tot] = p.rows[cur];
+                c2[tot] = p.cols[cur];
+                m2[tot] = p.ldu_mapping[cur];
+                ++cur;
+                ++tot;
+            }
+            r2[tot] = r;
+            c2[tot] = c;
+            m2[tot] = iface_base + idx;
+            ++tot;
+        }
+        for (; cur < base_nnz; ++cur, ++tot) {  // :580-585
+            r2[tot] = p.rows[cur];
+            c2[tot] = p.cols[cur];
+            m2[tot] = p.ldu_mapping[cur];
+        }
+        p.rows.swap(r2);
+        p.cols.swap(c2);
+        p.ldu_mapping.swap(m2);
+    }
+    p.row_ptrs.assign((size_t)N + 1, 0);
+    for (int64_t e = 0; e < total; ++e) ++p.row_ptrs[p.rows[e] + 1];
+    for (ogl_label r = 0; r < N; ++r) p.row_ptrs[r + 1] += p.row_ptrs[r];
+    p.local_on_host = true;
+}
+
+int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
+{
+    if (int rc = build_host_pattern_meta(ldu, p, /*check_faces*/ true)) return rc;
+    build_local_pattern(ldu, p);
     p.fingerprint = addressing_fingerprint(ldu);
     return OGL_OK;
 }

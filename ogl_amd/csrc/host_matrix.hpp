@@ -21,6 +21,9 @@ struct HostPattern {
     // "<field>_local_{rows,cols,ldu_map}"
     std::vector<ogl_label> rows, cols, ldu_mapping;
     std::vector<ogl_label> row_ptrs;  // CSR view of `rows` (Csr::read of the sorted triplets)
+    // false: the four arrays above were built on the device (setup_kernels.hip) and exist only there; the
+    // solver downloads cols / ldu_mapping / row_ptrs (never `rows`) when a host consumer asks for them
+    bool local_on_host = true;
 
     // "<field>_non_local_{rows,cols,ldu_map}"
     ogl_label non_local_nnz = 0;  // HostMatrix.C:55
@@ -52,6 +55,13 @@ void init_local_sparsity(ogl_label nrows, ogl_label upper_nnz, bool is_symmetric
 
 // Validates the view and fills `p`.  Returns OGL_OK or a negative status (message set).
 int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p);
+// The same in two halves, for the device set-up path: everything that is small (validation, counts, non-local
+// pattern, communication pattern; no fingerprint) ...
+int build_host_pattern_meta(const ogl_ldu_view &ldu, HostPattern &p, bool check_faces);
+// ... and the local pattern arrays (rows, cols, ldu_mapping, row_ptrs) on the host
+void build_local_pattern(const ogl_ldu_view &ldu, HostPattern &p);
+// (row, col) of every same-rank interface face in interface order (HostMatrix.C:385-410)
+void local_interface_entries(const ogl_ldu_view &ldu, std::vector<ogl_label> &rows, std::vector<ogl_label> &cols);
 
 // Cheap identity check used to decide whether a cached pattern still matches a new view
 // ("For now we assume columns and rows to be constant", HostMatrix.H:33).

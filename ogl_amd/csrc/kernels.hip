@@ -101,16 +101,19 @@ __device__ __forceinline__ void reduce_partials(const double *const (&part)[2], 
 //   * groups of 4 consecutive chunks per XCD, all XCDs advancing on ONE front -> 190 us
 // so neighbouring rows (the +-1 / +-nx stencil legs) share an L2 while HBM still sees a single
 // streaming front.  Purely a speed choice: results do not depend on placement.
+// On an irregular pattern (unstructured mesh in RCM order) the group is a launch parameter: with slabs of
+// tens of thousands of rows per XCD the window of x a slab gathers from is fetched into ONE L2 instead of
+// all eight (DevCsr::xcd_group, profiles/r03_xcd_group.txt).
 constexpr int XCD_GROUP = 4;
-__device__ __forceinline__ int xcd_chunk(int block)
+__device__ __forceinline__ int xcd_chunk(int block, int group = XCD_GROUP)
 {
     const int slot = block / N_XCD, xcd = block % N_XCD;
-    return (slot / XCD_GROUP) * (N_XCD * XCD_GROUP) + xcd * XCD_GROUP + slot % XCD_GROUP;
+    return (slot / group) * (N_XCD * group) + xcd * group + slot % group;
 }
-inline int xcd_grid(int n_chunks)
+inline int xcd_grid(int n_chunks, int group = XCD_GROUP)
 {
-    constexpr int Q = N_XCD * XCD_GROUP;
-    return ((n_chunks + Q - 1) / Q) * Q;
+    const int q = N_XCD * group;
+    return ((n_chunks + q - 1) / q) * q;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -130,12 +133,12 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ b,
     double *__restrict__ y, const double *__restrict__ w, double *__restrict__ dot_partials,
-    double *__restrict__ dot2_partials, const DevScalars *gate)
+    double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup)
 {
     __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
     __shared__ double slot[N_WAVES];
     if (gate && gate->stop) return;
-    const int chunk = xcd_chunk(blockIdx.x);
+    const int chunk = xcd_chunk(blockIdx.x, xgroup);
     if (chunk >= n_chunks) return;
     const int tid = threadIdx.x;
     const int r0 = chunk * CHUNK_ROWS;
@@ -1205,12 +1208,12 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const double *__restrict__ w,
                                                      double *__restrict__ dot_partials,
                                                      double *__restrict__ dot2_partials,
-                                                     const DevScalars *gate)
+                                                     const DevScalars *gate, int xgroup)
 {
     __shared__ double slot[N_WAVES];
     __shared__ int stab[SELL_TABLE_INTS];
     if (gate && gate->stop) return;
-    const int chunk = xcd_chunk(blockIdx.x);
+    const int chunk = xcd_chunk(blockIdx.x, xgroup);
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
@@ -2193,10 +2196,11 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
-    const dim3 grid(xcd_grid(nc)), block(BLOCK);
+    const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
+    const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
 #define OGL_SPMV_K(MODE, NDOT, STREAM)                                                                     \
     hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
-                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg)
 #define OGL_SPMV(MODE, NDOT)               \
     do {                                   \
         if (A.stream)                      \
@@ -2251,11 +2255,12 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
-    const dim3 grid(xcd_grid(nc)), block(BLOCK);
+    const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
+    const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
 #define OGL_SELL_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
                        A.dict, A.codes, A.vals, A.spill_chunk_ptr, A.spill_rows, A.spill_ptrs,          \
-                       A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+                       A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg)
 #define OGL_SELL(MODE, NDOT)               \
     do {                                   \
         if (A.stream)                      \

@@ -45,6 +45,9 @@ struct DevCsr {
     // the matrix does not fit the Infinity Cache next to the solver's vectors: its values and columns are
     // streamed past the caches (non-temporal loads); a matrix that fits stays cached from turn to turn
     bool stream = false;
+    // consecutive chunks one XCD takes before the next XCD's group starts (0: the built-in 4).  Large groups
+    // (slabs of tens of thousands of rows) keep the x window of an irregular pattern in ONE L2
+    int32_t xcd_group = 0;
 };
 
 // Rows that own non-local entries, for "y += A_non_local * recv" (distributed::Matrix::apply).
@@ -98,6 +101,7 @@ struct DevSell {
     const int32_t *spill_chunk_ptr = nullptr, *spill_rows = nullptr, *spill_ptrs = nullptr, *spill_cols = nullptr;
     const double *spill_vals = nullptr;
     bool stream = false;  // as DevCsr::stream, for the value planes and the 16 / 32-bit code words
+    int32_t xcd_group = 0;  // as DevCsr::xcd_group
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
                       double *y, const SpmvDots &dots, const DevScalars *gate);

@@ -1,0 +1,273 @@
+// setup_kernels.hip -- see setup_kernels.hpp.  Integer work, HBM- and atomics-bound; nothing here is on the
+// per-turn path.  Determinism: atomics only decide where an entry waits inside its row before the row is
+// sorted by a key that is unique per entry, so every array comes out the same on every run.
+#include "setup_kernels.hpp"
+
+#include <algorithm>
+
+namespace ogl {
+
+namespace {
+
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+inline int blocks_for(int64_t n, int per_block = BLOCK) { return (int)((n + per_block - 1) / per_block); }
+
+// exclusive scan of one value per thread over the workgroup; returns the exclusive prefix, *total = block sum
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total)
+{
+    __shared__ int wave_sums[SCAN_BLOCK / WAVE];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int t = __shfl_up(inc, off, WAVE);
+        if (lane >= off) inc += t;
+    }
+    if (lane == WAVE - 1) wave_sums[wave] = inc;
+    __syncthreads();
+    int base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / WAVE; ++w) {
+        if (w < wave) base += wave_sums[w];
+        all += wave_sums[w];
+    }
+    __syncthreads();
+    *total = all;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tile_sums(const int32_t *__restrict__ in, int64_t n,
+                                                               int32_t *__restrict__ sums)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s += in[base + k];
+    int total;
+    (void)block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// one workgroup: sums[0..nb) -> exclusive prefixes in place, sums[nb] = total
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(int32_t *sums, int nb)
+{
+    int carry = 0;
+    for (int i0 = 0; i0 < nb; i0 += SCAN_BLOCK) {
+        const int i = i0 + threadIdx.x;
+        const int v = i < nb ? sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        if (i < nb) sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[nb] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const int32_t *in, int32_t *out, int64_t n,
+                                                           const int32_t *__restrict__ sums, int nb)
+{
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        s += v[k];
+    }
+    int total;
+    int run = block_exclusive_scan(s, &total) + sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
+}
+
+// ---- pattern build ----
+__global__ __launch_bounds__(BLOCK) void k_pat_count(PatternBuild b)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < b.n_rows) atomicAdd(&b.counts[i], 1);  // the diagonal
+    if (i < b.n_faces) {
+        const int lo = b.lower_addr[i], up = b.upper_addr[i];
+        if (lo < 0 || lo >= b.n_rows || up < 0 || up >= b.n_rows) {
+            b.flags[PAT_FLAG_OUT_OF_RANGE] = 1;
+        } else {
+            if (lo >= up) b.flags[PAT_FLAG_NONCONFORMING] = 1;
+            atomicAdd(&b.counts[lo], 1);
+            atomicAdd(&b.counts[up], 1);
+        }
+    }
+    if (i < b.n_iface) atomicAdd(&b.counts[b.if_rows[i]], 1);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pat_fill(PatternBuild b)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    int *fill = b.diag_pos;  // zeroed scratch until k_pat_sort writes the diagonal positions
+    const int after_neighbours = b.symmetric ? b.n_faces : 2 * b.n_faces;  // HostMatrixFreeFunctions.C:116
+    if (i < b.n_rows) {  // diagonal -> source slot after_neighbours + row (:179-182)
+        const int e = b.row_ptrs[i] + atomicAdd(&fill[i], 1);
+        b.cols[e] = i;
+        b.ldu_mapping[e] = after_neighbours + i;
+    }
+    if (i < b.n_faces) {
+        const int lo = b.lower_addr[i], up = b.upper_addr[i];
+        if (lo >= 0 && lo < b.n_rows && up >= 0 && up < b.n_rows) {
+            int e = b.row_ptrs[lo] + atomicAdd(&fill[lo], 1);  // upper-triangle entry lives in row lower[f] (:123-124,188)
+            b.cols[e] = up;
+            b.ldu_mapping[e] = i;
+            e = b.row_ptrs[up] + atomicAdd(&fill[up], 1);      // its transpose in row upper[f] (:139-140,164-165)
+            b.cols[e] = lo;
+            b.ldu_mapping[e] = b.symmetric ? i : b.n_faces + i;
+        }
+    }
+    if (i < b.n_iface) {  // same-rank interface entry -> source slot after_neighbours + nrows + idx (HostMatrix.C:574)
+        const int r = b.if_rows[i];
+        const int e = b.row_ptrs[r] + atomicAdd(&fill[r], 1);
+        b.cols[e] = b.if_cols[i];
+        b.ldu_mapping[e] = after_neighbours + b.n_rows + i;
+    }
+}
+
+// one thread per row: order the row by (column, source slot); rows are short (a cell's faces + 1)
+__global__ __launch_bounds__(BLOCK) void k_pat_sort(int32_t n_rows, const int32_t *__restrict__ row_ptrs,
+                                                    int32_t *cols, int32_t *perm, int32_t *diag_pos)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_rows) return;
+    const int k0 = row_ptrs[r], k1 = row_ptrs[r + 1];
+    for (int i = k0 + 1; i < k1; ++i) {
+        const int c = cols[i], p = perm[i];
+        int j = i;
+        while (j > k0 && (cols[j - 1] > c || (cols[j - 1] == c && perm[j - 1] > p))) {
+            cols[j] = cols[j - 1];
+            perm[j] = perm[j - 1];
+            --j;
+        }
+        cols[j] = c;
+        perm[j] = p;
+    }
+    int dp = -1;
+    for (int k = k0; k < k1; ++k)
+        if (cols[k] == r) {  // Csr::extract_diagonal takes the first (i, i) entry of a row
+            dp = k;
+            break;
+        }
+    diag_pos[r] = dp;
+}
+
+// ---- half storage ----
+__global__ __launch_bounds__(BLOCK) void k_sym_distances(int32_t n_rows, const int32_t *__restrict__ row_ptrs,
+                                                         const int32_t *__restrict__ cols, int32_t *table,
+                                                         int32_t *flags)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_rows) return;
+    int last = -1;  // the previous distance of this row that was looked up (rows repeat few distances)
+    int prev_col = -1;
+    for (int k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+        const int c = cols[k];
+        if (c <= prev_col) flags[SYM_FLAG_UNSORTED_ROW] = 1;  // the kernel sums in ascending column order: one entry per column
+        prev_col = c;
+        const int d = c - r;
+        if (d < 0 || d == last) continue;
+        last = d;
+        bool found = false;
+        for (int j = 0; j < SYM_TABLE && !found; ++j) {
+            int cur = __hip_atomic_load(&table[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == SYM_EMPTY) {  // claim the slot; a lost race leaves somebody else's distance in it
+                const int old = atomicCAS(&table[j], SYM_EMPTY, d);
+                cur = old == SYM_EMPTY ? d : old;
+            }
+            found = cur == d;
+        }
+        if (!found) flags[SYM_FLAG_TOO_MANY] = 1;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sym_fill(int32_t n_rows, const int32_t *__restrict__ row_ptrs,
+                                                    const int32_t *__restrict__ cols, SymDistances dist,
+                                                    uint8_t *__restrict__ mask, int32_t *__restrict__ map,
+                                                    int32_t *flags)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_rows) return;
+    const int nd = dist.nd;
+    unsigned m = 0;
+    for (int k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+        const int d = cols[k] - r;
+        const int a = d < 0 ? -d : d;
+        int j = 0;
+        while (j < nd && dist.d[j] != a) ++j;
+        if (j == nd) {  // a lower entry whose distance no upper entry has: no twin to read it from
+            flags[SYM_FLAG_TOO_MANY] = 1;
+            continue;
+        }
+        if (d >= 0) {  // plane j of this row holds the entry: slot -> position in the CSR values
+            map[((size_t)(r / CHUNK_ROWS) * nd + j) * CHUNK_ROWS + (size_t)(r % CHUNK_ROWS)] = k;
+            m |= 1u << (nd - 1 + j);
+        } else {       // read where its twin (r - a, r) lives: plane j of row r - a -- which must hold it
+            const int c = cols[k];
+            bool twin = false;
+            for (int kk = row_ptrs[c]; kk < row_ptrs[c + 1] && !twin; ++kk) twin = cols[kk] == r;
+            if (!twin) flags[SYM_FLAG_TOO_MANY] = 1;
+            m |= 1u << (nd - 1 - j);
+        }
+    }
+    mask[r] = (uint8_t)m;
+}
+
+}  // namespace
+
+size_t scan_tmp_len(int64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
+
+void launch_exclusive_scan(hipStream_t st, const int32_t *in, int32_t *out, int64_t n, int32_t *tmp)
+{
+    const int nb = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+    if (nb == 0) {
+        (void)hipMemsetAsync(out, 0, sizeof(int32_t), st);
+        return;
+    }
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, n, tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, tmp, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(SCAN_BLOCK), 0, st, in, out, n, tmp, nb);
+}
+
+void launch_build_pattern(hipStream_t st, const PatternBuild &b)
+{
+    if (b.n_rows == 0) {
+        (void)hipMemsetAsync(b.row_ptrs, 0, sizeof(int32_t), st);
+        return;
+    }
+    const int64_t items = std::max<int64_t>(std::max(b.n_rows, b.n_faces), b.n_iface);
+    (void)hipMemsetAsync(b.counts, 0, (size_t)b.n_rows * sizeof(int32_t), st);
+    (void)hipMemsetAsync(b.diag_pos, 0, (size_t)b.n_rows * sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_pat_count, dim3(blocks_for(items)), dim3(BLOCK), 0, st, b);
+    launch_exclusive_scan(st, b.counts, b.row_ptrs, b.n_rows, b.scan_tmp);
+    hipLaunchKernelGGL(k_pat_fill, dim3(blocks_for(items)), dim3(BLOCK), 0, st, b);
+    hipLaunchKernelGGL(k_pat_sort, dim3(blocks_for(b.n_rows)), dim3(BLOCK), 0, st, b.n_rows, b.row_ptrs, b.cols,
+                       b.ldu_mapping, b.diag_pos);
+}
+
+void launch_sym_distances(hipStream_t st, int32_t n_rows, const int32_t *row_ptrs, const int32_t *cols,
+                          int32_t *table, int32_t *flags)
+{
+    if (n_rows == 0) return;
+    hipLaunchKernelGGL(k_sym_distances, dim3(blocks_for(n_rows)), dim3(BLOCK), 0, st, n_rows, row_ptrs, cols, table,
+                       flags);
+}
+
+void launch_sym_fill(hipStream_t st, int32_t n_rows, const int32_t *row_ptrs, const int32_t *cols,
+                     SymDistances dist, uint8_t *mask, int32_t *map, int32_t *flags)
+{
+    if (n_rows == 0) return;
+    hipLaunchKernelGGL(k_sym_fill, dim3(blocks_for(n_rows)), dim3(BLOCK), 0, st, n_rows, row_ptrs, cols, dist, mask,
+                       map, flags);
+}
+
+}  // namespace ogl

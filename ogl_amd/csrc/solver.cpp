@@ -1,6 +1,8 @@
 // solver.cpp -- see solver.hpp.  Citations: reference tree (hpsim/OGL @ 2024-10-16).
 #include "solver.hpp"
 
+#include "setup_kernels.hpp"
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -378,6 +380,18 @@ double ogl_solver::stream_above_bytes() const
     return prop("streamAboveBytes", env_default);
 }
 
+// chunks per XCD group of the CSR-stream / compressed SpMV (DevCsr::xcd_group): property `xcdGroup`, else the
+// environment's OGL_XCD_GROUP, else what the pattern's set-up chose (0 = the kernels' built-in 4)
+int32_t ogl_solver::xcd_group() const
+{
+    static const int env_default = [] {
+        const char *e = std::getenv("OGL_XCD_GROUP");
+        return e ? atoi(e) : -1;
+    }();
+    const int v = (int)prop("xcdGroup", (double)env_default);
+    return v >= 0 ? v : pat_xcd_group;
+}
+
 DevCsr ogl_solver::csr() const
 {
     DevCsr A;
@@ -387,6 +401,7 @@ DevCsr ogl_solver::csr() const
     A.cols = d_cols.p;
     A.vals = d_vals.p;
     A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows > stream_above_bytes();
+    A.xcd_group = xcd_group();
     return A;
 }
 
@@ -408,6 +423,7 @@ DevEll ogl_solver::ell() const
 int ogl_solver::build_ell()
 {
     hipStream_t st = reg->stream;
+    OGL_TRY(download_local_pattern(pat));
     const int32_t N = pat.n_rows;
     int32_t width = 0;
     for (int32_t r = 0; r < N; ++r) width = std::max(width, pat.row_ptrs[r + 1] - pat.row_ptrs[r]);
@@ -439,6 +455,7 @@ DevSell ogl_solver::sell() const
     S.codes = d_sell_codes.p;
     S.vals = d_sell_vals.p;
     S.stream = sell_bytes + 40.0 * (double)pat.n_rows > stream_above_bytes();
+    S.xcd_group = xcd_group();
     if (n_spill) {
         S.spill_chunk_ptr = d_spill_chunks.p;
         S.spill_rows = d_spill_rows.p;
@@ -474,10 +491,17 @@ int ogl_solver::build_sym(const SymLayout &L)
     OGL_TRY(d_sym_planes.alloc(L.map.size(), st));
     OGL_TRY(reg->stager.h2d(d_sym_mask.p, L.mask.data(), L.mask.size(), st));
     OGL_TRY(reg->stager.h2d(d_sym_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
-    sym_nd = L.nd;
-    for (int j = 0; j < 4; ++j) sym_d[j] = j < L.nd ? L.d[j] : 0;
+    return finish_sym(L.nd, L.d);
+}
+
+// the part of the half-storage set-up that does not depend on where mask and map were built
+int ogl_solver::finish_sym(int nd, const int32_t *d)
+{
+    hipStream_t st = reg->stream;
+    sym_nd = nd;
+    for (int j = 0; j < 4; ++j) sym_d[j] = j < nd ? d[j] : 0;
     std::vector<int32_t> order;
-    band_block_order(pat.n_rows, L.d[L.nd - 1], order);
+    band_block_order(pat.n_rows, d[nd - 1], order);
     d_sym_order.release();
     if (!order.empty()) {
         OGL_TRY(d_sym_order.alloc(order.size(), st));
@@ -486,12 +510,139 @@ int ogl_solver::build_sym(const SymLayout &L)
     sym_state = 1;
     sym_values_stale = true;
     // bytes one SpMV reads of this layout (bench.py's moved-bytes model): planes + masks
-    props["sellMatrixBytes"] = 8.0 * (double)(L.map.size() - 2) + (double)(L.mask.size() - 16);
-    props["sellReadSlots"] = (double)(L.map.size() - 2);
-    props["sellAllocatedSlots"] = (double)(L.map.size() - 2);
+    props["sellMatrixBytes"] = 8.0 * (double)(d_sym_map.n - 2) + (double)(d_sym_mask.n - 16);
+    props["sellReadSlots"] = (double)(d_sym_map.n - 2);
+    props["sellAllocatedSlots"] = (double)(d_sym_map.n - 2);
     props["sellChunksDelta16"] = 0.0;
     props["sellChunksCol32"] = 0.0;
     props["sellSpilledEntries"] = 0.0;
+    return OGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Device set-up (setup_kernels.hip): the pattern of a field straight from the lduMatrix addressing, without
+// the host holding its 12 bytes per entry.  `np` carries the small parts (build_host_pattern_meta); the
+// arrays land in d_row_ptrs / d_cols / d_ldu_mapping / d_diag_pos (allocated by the caller).  *built stays
+// false when the addressing is not conforming (a face with owner >= neighbour): the host algorithm, which
+// follows the reference's segment order for such input, takes over.
+// ------------------------------------------------------------------------------------------
+int ogl_solver::build_pattern_on_device(const ogl_ldu_view &ldu, HostPattern &np, bool *built)
+{
+    *built = false;
+    hipStream_t st = reg->stream;
+    const int32_t N = np.n_rows, F = np.upper_nnz;
+    if (N == 0) return OGL_OK;
+    std::vector<ogl_label> ir, ic;
+    if (np.local_iface_nnz) local_interface_entries(ldu, ir, ic);
+    DevBuf<int32_t> addr, counts, tmp, flags, d_ir, d_ic;
+    OGL_TRY(addr.alloc(2 * (size_t)F + 2, st));
+    OGL_TRY(counts.alloc((size_t)N, st));
+    OGL_TRY(tmp.alloc(scan_tmp_len(N), st));
+    OGL_TRY(flags.alloc(PATTERN_FLAGS, st));
+    if (F) {
+        OGL_TRY(reg->stager.h2d(addr.p, ldu.lower_addr, (size_t)F * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(addr.p + F, ldu.upper_addr, (size_t)F * sizeof(int32_t), st));
+    }
+    if (!ir.empty()) {
+        OGL_TRY(d_ir.alloc(ir.size(), st));
+        OGL_TRY(d_ic.alloc(ic.size(), st));
+        OGL_TRY(reg->stager.h2d(d_ir.p, ir.data(), ir.size() * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_ic.p, ic.data(), ic.size() * sizeof(int32_t), st));
+    }
+    PatternBuild b;
+    b.n_rows = N;
+    b.n_faces = F;
+    b.n_iface = (int32_t)ir.size();
+    b.symmetric = np.symmetric ? 1 : 0;
+    b.lower_addr = addr.p;
+    b.upper_addr = addr.p + F;
+    b.if_rows = d_ir.p;
+    b.if_cols = d_ic.p;
+    b.row_ptrs = d_row_ptrs.p;
+    b.cols = d_cols.p;
+    b.ldu_mapping = d_ldu_mapping.p;
+    b.diag_pos = d_diag_pos.p;
+    b.counts = counts.p;
+    b.scan_tmp = tmp.p;
+    b.flags = flags.p;
+    launch_build_pattern(st, b);
+    int32_t hf[PATTERN_FLAGS] = {};
+    OGL_HIP_CHECK(hipMemcpyAsync(hf, flags.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    if (hf[PAT_FLAG_OUT_OF_RANGE]) return fail(OGL_ERR_INVALID, "a face addresses a cell outside [0,%d)", N);
+    if (hf[PAT_FLAG_NONCONFORMING]) return OGL_OK;
+    np.local_on_host = false;
+    *built = true;
+    return OGL_OK;
+}
+
+// cols / ldu_mapping / row_ptrs of a device-built pattern for the host code that wants them (numbering
+// policy, compressed layout, Ell, block-Jacobi blocks, ISAI pattern, export): once, on demand
+int ogl_solver::download_local_pattern(HostPattern &hp)
+{
+    if (hp.local_on_host) return OGL_OK;
+    hipStream_t st = reg->stream;
+    const size_t nnz = (size_t)hp.local_nnz;
+    hp.row_ptrs.resize((size_t)hp.n_rows + 1);
+    hp.cols.resize(nnz);
+    hp.ldu_mapping.resize(nnz);
+    hp.rows.clear();  // (row of entry k = the r with row_ptrs[r] <= k < row_ptrs[r + 1]; nobody here needs the array)
+    OGL_TRY(reg->stager.d2h(hp.row_ptrs.data(), d_row_ptrs.p, hp.row_ptrs.size() * sizeof(int32_t), st));
+    if (nnz) {
+        OGL_TRY(reg->stager.d2h(hp.cols.data(), d_cols.p, nnz * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.d2h(hp.ldu_mapping.data(), d_ldu_mapping.p, nnz * sizeof(int32_t), st));
+    }
+    hp.local_on_host = true;
+    return OGL_OK;
+}
+
+// Half storage from the device pattern (build_sym_layout's rules, host_matrix.cpp): the distances that occur,
+// then mask and map per row.  *done stays false when the pattern does not qualify.
+int ogl_solver::build_sym_on_device(const HostPattern &np, SymDistances *sd_out, bool *done)
+{
+    *done = false;
+    hipStream_t st = reg->stream;
+    const int32_t N = np.n_rows;
+    if (N <= 0) return OGL_OK;
+    DevBuf<int32_t> work;  // [table | flags]
+    OGL_TRY(work.alloc(SYM_TABLE + SYM_FLAGS, st));
+    int32_t init[SYM_TABLE + SYM_FLAGS];
+    for (int j = 0; j < SYM_TABLE; ++j) init[j] = SYM_EMPTY;
+    for (int j = 0; j < SYM_FLAGS; ++j) init[SYM_TABLE + j] = 0;
+    OGL_HIP_CHECK(hipMemcpyAsync(work.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    launch_sym_distances(st, N, d_row_ptrs.p, d_cols.p, work.p, work.p + SYM_TABLE);
+    int32_t got[SYM_TABLE + SYM_FLAGS];
+    OGL_HIP_CHECK(hipMemcpyAsync(got, work.p, sizeof(got), hipMemcpyDeviceToHost, st));
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    if (got[SYM_TABLE + SYM_FLAG_TOO_MANY] || got[SYM_TABLE + SYM_FLAG_UNSORTED_ROW]) return OGL_OK;
+    int32_t dist[SYM_TABLE];
+    int nd = 0;
+    for (int j = 0; j < SYM_TABLE; ++j)
+        if (got[j] != SYM_EMPTY) dist[nd++] = got[j];
+    std::sort(dist, dist + nd);
+    if (nd < 2 || nd > SYM_MAX_OFFSETS || dist[0] != 0 || dist[nd - 1] > INT32_MAX / 2) return OGL_OK;
+    const int64_t nc = n_chunks(N);
+    const double upper_entries = (double)N + (double)np.upper_nnz;  // diagonal + one entry per face
+    if ((double)nd * (double)nc * CHUNK_ROWS > SYM_MAX_PADDING * upper_entries + 8.0 * CHUNK_ROWS) return OGL_OK;
+    const size_t mask_len = (size_t)nc * CHUNK_ROWS + 16, map_len = (size_t)nc * nd * CHUNK_ROWS + 2;
+    OGL_TRY(d_sym_mask.alloc(mask_len, st));
+    OGL_TRY(d_sym_map.alloc(map_len, st));
+    OGL_TRY(d_sym_planes.alloc(map_len, st));
+    OGL_HIP_CHECK(hipMemsetAsync(d_sym_mask.p, 0, mask_len, st));
+    OGL_HIP_CHECK(hipMemsetAsync(d_sym_map.p, 0xFF, map_len * sizeof(int32_t), st));
+    SymDistances sd{};
+    sd.nd = nd;
+    for (int j = 0; j < nd; ++j) sd.d[j] = dist[j];
+    OGL_HIP_CHECK(hipMemsetAsync(work.p + SYM_TABLE, 0, SYM_FLAGS * sizeof(int32_t), st));
+    launch_sym_fill(st, N, d_row_ptrs.p, d_cols.p, sd, d_sym_mask.p, d_sym_map.p, work.p + SYM_TABLE);
+    OGL_HIP_CHECK(hipMemcpyAsync(got, work.p + SYM_TABLE, SYM_FLAGS * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    if (got[SYM_FLAG_TOO_MANY]) return OGL_OK;
+    *sd_out = sd;
+    *done = true;
     return OGL_OK;
 }
 
@@ -523,6 +674,7 @@ int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
     SellLayout own;
     SellLayout &L = pre ? *pre : own;
     n_spill = n_spill_rows = 0;
+    if (!pre) OGL_TRY(download_local_pattern(pat));
     const bool ok = pre ? pre_qualifies
                         : (pat.n_rows > 0 &&
                            build_sell_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), own));
@@ -720,6 +872,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             collect_interface_coeffs(ldu, true, iface.data());
         }
         if (cfg.reorder_on_host) {  // :608-633, scaling applied by the host update functions
+            OGL_TRY(download_local_pattern(pat));
             std::vector<double> sorted(nnz);
             if (pat.local_iface_nnz) {
                 if (pat.symmetric)
@@ -802,13 +955,52 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     if (first) coefficients_done = false;
     if (first) {  // :79-87
         HostPattern np;
-        OGL_TRY(build_host_pattern(ldu, np));
+        // Where the pattern is built: on the device from the face addressing (setup_kernels.hip), unless the
+        // environment / property says otherwise or the addressing is not conforming; host_matrix.cpp then
+        static const bool host_setup_env = std::getenv("OGL_HOST_SETUP") != nullptr;
+        const bool device_setup = !host_setup_env && prop("deviceSetup", 1.0) != 0.0;
+        OGL_TRY(build_host_pattern_meta(ldu, np, /*check_faces*/ !device_setup));
+        // (the hash of the addressing runs on helper threads next to everything below; joined before any return)
+        auto fp_new = std::async(std::launch::async, [&ldu] { return addressing_fingerprint(ldu); });
+        const size_t nnz = (size_t)np.local_nnz;
+        OGL_TRY(d_row_ptrs.alloc((size_t)np.n_rows + 1, st));
+        OGL_TRY(d_cols.alloc(nnz + NNZ_PAD, st));
+        OGL_TRY(d_vals.alloc(nnz + NNZ_PAD, st));
+        OGL_TRY(d_ldu_mapping.alloc(nnz + NNZ_PAD, st));
+        OGL_TRY(d_source.alloc((size_t)np.source_len() + NNZ_PAD, st));
+        OGL_TRY(d_diag_pos.alloc(std::max<size_t>(1, (size_t)np.n_rows), st));
+        bool built_on_device = false;
+        if (device_setup) OGL_TRY(build_pattern_on_device(ldu, np, &built_on_device));
+        if (!built_on_device) {
+            if (device_setup)  // (non-conforming addressing: the device pass has checked the face range already)
+                for (ogl_label f = 0; f < np.upper_nnz; ++f)
+                    if (ldu.lower_addr[f] < 0 || ldu.lower_addr[f] >= np.n_rows || ldu.upper_addr[f] < 0 ||
+                        ldu.upper_addr[f] >= np.n_rows)
+                        return fail(OGL_ERR_INVALID, "face %d addresses a cell outside [0,%d)", f, np.n_rows);
+            build_local_pattern(ldu, np);
+        }
+        props["deviceSetup"] = device_setup ? 1.0 : 0.0;
+        props["patternBuiltOnDevice"] = built_on_device ? 1.0 : 0.0;
+        // A symmetric lduMatrix without same-rank interfaces is tried on the half storage first (banded with
+        // at most SYM_MAX_OFFSETS - 1 distances = a structured mesh, whose numbering the policy below would
+        // keep anyway): everything stays on the device then
+        SymDistances sym_dist{};
+        bool sym_on_device = false, sym_tried = false;
+        if (built_on_device && try_sym && np.symmetric && np.local_iface_nnz == 0 && cfg.renumber != 1) {
+            sym_tried = true;
+            OGL_TRY(build_sym_on_device(np, &sym_dist, &sym_on_device));
+        }
         // numbering of the device copy (config `renumber`); the compressed layout the policy may
         // have derived on the way is kept for build_sell below
         SellLayout pre_sell;
         bool pre_built = false;
         RenumberReport rep;
-        OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep));
+        if (sym_on_device) {
+            rep.ratio_natural = rep.ratio_used = -1.0;  // (not measured: the pattern never came to the host)
+        } else {
+            OGL_TRY(download_local_pattern(np));
+            OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep));
+        }
         pat_renumber_mode = cfg.renumber;
         pat_try_sell = try_sell;
         pat_try_sym = try_sym;
@@ -817,6 +1009,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         props["renumbered"] = rep.applied ? 1.0 : 0.0;
         props["gatherSectorRatioNatural"] = rep.ratio_natural;
         props["gatherSectorRatio"] = rep.ratio_used;
+        np.fingerprint = fp_new.get();
         pat = std::move(np);
         have_pattern = true;
         static std::atomic<uint64_t> pattern_counter{0};  // registries may live on different threads
@@ -826,17 +1019,12 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         sell_state = 0;
         sym_state = 0;
         x_resident = b_resident = false;
-        const size_t nnz = (size_t)pat.local_nnz;
-        OGL_TRY(d_row_ptrs.alloc((size_t)pat.n_rows + 1, st));
-        OGL_TRY(d_cols.alloc(nnz + NNZ_PAD, st));
-        OGL_TRY(d_vals.alloc(nnz + NNZ_PAD, st));
-        OGL_TRY(d_ldu_mapping.alloc(nnz + NNZ_PAD, st));
-        OGL_TRY(d_source.alloc((size_t)pat.source_len() + NNZ_PAD, st));
-        OGL_TRY(reg->stager.h2d(d_row_ptrs.p, pat.row_ptrs.data(),
-                                pat.row_ptrs.size() * sizeof(int32_t), st));
-        OGL_TRY(reg->stager.h2d(d_cols.p, pat.cols.data(), nnz * sizeof(int32_t), st));
-        OGL_TRY(reg->stager.h2d(d_ldu_mapping.p, pat.ldu_mapping.data(), nnz * sizeof(int32_t), st));
-        {  // Csr::extract_diagonal takes the first (i, i) entry of a row
+        if (!built_on_device || rep.applied) {  // the device does not hold the pattern (in this numbering) yet
+            OGL_TRY(reg->stager.h2d(d_row_ptrs.p, pat.row_ptrs.data(),
+                                    pat.row_ptrs.size() * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(d_cols.p, pat.cols.data(), nnz * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(d_ldu_mapping.p, pat.ldu_mapping.data(), nnz * sizeof(int32_t), st));
+            // Csr::extract_diagonal takes the first (i, i) entry of a row
             std::vector<int32_t> dpos((size_t)pat.n_rows, -1);
             for (int32_t r = 0; r < pat.n_rows; ++r)
                 for (int32_t k = pat.row_ptrs[r]; k < pat.row_ptrs[r + 1]; ++k)
@@ -844,8 +1032,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
                         dpos[(size_t)r] = k;
                         break;
                     }
-            OGL_TRY(d_diag_pos.alloc(std::max<size_t>(1, dpos.size()), st));
-            OGL_TRY(reg->stager.h2d(d_diag_pos.p, dpos.data(), dpos.size() * sizeof(int32_t), st));
+            if (!dpos.empty())
+                OGL_TRY(reg->stager.h2d(d_diag_pos.p, dpos.data(), dpos.size() * sizeof(int32_t), st));
         }
 
         // halo: rows owning non-local entries (row-sorted triplets -> one run per row)
@@ -910,18 +1098,25 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         // a symmetric lduMatrix on a banded pattern keeps the OpenFOAM storage (diagonal + upper); the
         // compressed full-storage copy is then not built at all
         props["symmetricHalf"] = 0.0;
-        if (try_sym && pat.symmetric && pat.local_iface_nnz == 0 && !pat.renumbered()) {
+        bool sym_ok = false;
+        if (sym_on_device) {
+            OGL_TRY(finish_sym(sym_dist.nd, sym_dist.d));
+            sym_ok = true;
+        } else if (!sym_tried && try_sym && pat.symmetric && pat.local_iface_nnz == 0 && !pat.renumbered()) {
             SymLayout symL;
             if (build_sym_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), symL)) {
                 OGL_TRY(build_sym(symL));
-                props["symmetricHalf"] = 1.0;
-                sell_state = -1;
-                d_sell_chunks.release();
-                d_sell_codes.release();
-                d_sell_vals.release();
-                d_sell_map.release();
-                d_sell_dict.release();
+                sym_ok = true;
             }
+        }
+        if (sym_ok) {
+            props["symmetricHalf"] = 1.0;
+            sell_state = -1;
+            d_sell_chunks.release();
+            d_sell_codes.release();
+            d_sell_vals.release();
+            d_sell_map.release();
+            d_sell_dict.release();
         }
         if (sym_state != 1) {
             sym_state = -1;
@@ -1008,6 +1203,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             P.struct_pat_id = 0;
             std::vector<int32_t> wrp, wc;
             ogl_label wide = -1;
+            OGL_TRY(download_local_pattern(pat));
             if (!isai_pattern(pat, spd, cfg.sparsity_power, MAX_ISAI_ROW, wrp, wc, wide))
                 return fail(OGL_ERR_UNSUPPORTED,
                             "ISAI sparsityPower %d: row %d of the approximate inverse has more than %d "
@@ -1077,6 +1273,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         if (!P.has_structure(pat_id, 2, cfg.max_block_size)) {
             P.struct_pat_id = 0;
             std::vector<int32_t> ptrs, row_block;
+            OGL_TRY(download_local_pattern(pat));
             find_jacobi_blocks(pat, cfg.max_block_size, ptrs, row_block);
             P.n_blocks = (int32_t)ptrs.size() - 1;
             P.uniform_blocks = true;

@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "host_matrix.hpp"
 #include "kernels.hpp"
+#include "setup_kernels.hpp"
 
 namespace ogl {
 
@@ -214,6 +215,11 @@ struct ogl_solver {
     int sym_state = 0;
     bool sym_values_stale = true;
     int build_sym(const ogl::SymLayout &L);
+    int finish_sym(int nd, const int32_t *d);
+    // device set-up (setup_kernels.hip)
+    int build_pattern_on_device(const ogl_ldu_view &ldu, ogl::HostPattern &np, bool *built);
+    int build_sym_on_device(const ogl::HostPattern &np, ogl::SymDistances *sd_out, bool *done);
+    int download_local_pattern(ogl::HostPattern &hp);
     ogl::DevSym sym() const;
     bool use_sym() const
     {
@@ -338,4 +344,6 @@ struct ogl_solver {
     ogl::DevHalo halo() const;
     double prop(const std::string &key, double dflt) const;
     double stream_above_bytes() const;
+    int32_t xcd_group() const;
+    int32_t pat_xcd_group = 0;  // chosen per pattern (0 = the built-in group of 4 chunks)
 };

@@ -34,6 +34,11 @@ variant() {
     oct4) echo "--octree 4";;             oct4append) echo "--octree 4 --octree-append";;
     vor1m) echo "--voronoi 1000000";;     vor3m) echo "--voronoi 3000000";;
     vor3moff) echo "--voronoi 3000000 --renumber off";;
+    vor3mg*) echo "--voronoi 3000000 --prop xcdGroup=${1#vor3mg}";;
+    vor1mg*) echo "--voronoi 1000000 --prop xcdGroup=${1#vor1mg}";;
+    shuffle65536g*) echo "--shuffle 65536 --prop xcdGroup=${1#shuffle65536g}";;
+    nocompressg*) echo "--no-compress --prop xcdGroup=${1#nocompressg}";;
+    hostsetup) echo "--prop deviceSetup=0";;
     vor3mnc) echo "--voronoi 3000000 --no-compress";;
     n32|n64|n100|n128) echo "--edge ${1#n} --iters 200";;
     *) echo "${1//+/ }";;
