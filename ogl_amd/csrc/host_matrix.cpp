@@ -16,6 +16,35 @@ namespace ogl {
 
 namespace {
 
+// threads for the once-per-pattern host work that splits over chunks / rows (OGL_SETUP_THREADS; default: the
+// hardware's, at most 16)
+int setup_threads()
+{
+    static const int n = [] {
+        const char *e = std::getenv("OGL_SETUP_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        return std::max(1, std::min(64, e ? atoi(e) : std::min(16, hw > 0 ? hw : 4)));
+    }();
+    return n;
+}
+
+// fn(begin, end) over [0, n) in contiguous parts, one per thread
+template <class F>
+void parallel_ranges(int64_t n, int64_t min_per_thread, F fn)
+{
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(setup_threads(), n / std::max<int64_t>(1, min_per_thread)));
+    if (nt <= 1) {
+        fn((int64_t)0, n);
+        return;
+    }
+    const int64_t part = (n + nt - 1) / nt;
+    std::vector<std::thread> helpers;
+    for (int t = 1; t < nt; ++t)
+        if ((int64_t)t * part < n) helpers.emplace_back(fn, (int64_t)t * part, std::min<int64_t>(n, (int64_t)(t + 1) * part));
+    fn((int64_t)0, std::min(part, n));
+    for (auto &h : helpers) h.join();
+}
+
 // Order one row segment by column; entries arrive in face order, so equal columns keep it.
 inline void sort_segment(ogl_label *cols, ogl_label *perm, ogl_label len)
 {
@@ -580,20 +609,21 @@ double slot_gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, con
     return entries ? (double)sectors / (double)entries : 0.0;
 }
 
-void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
+void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id, const NumberingHooks *hooks)
 {
     const ogl_label N = p.n_rows;
     const int64_t nnz = p.local_nnz;
     std::vector<ogl_label> old_of((size_t)N);
     for (ogl_label c = 0; c < N; ++c) old_of[(size_t)new_id[(size_t)c]] = c;
+    if (!(hooks && hooks->renumber_local && hooks->renumber_local(p, new_id))) {
     std::vector<ogl_label> rp((size_t)N + 1, 0);
     for (ogl_label k = 0; k < N; ++k) {
         const ogl_label r = old_of[(size_t)k];
         rp[(size_t)k + 1] = rp[(size_t)k] + (p.row_ptrs[r + 1] - p.row_ptrs[r]);
     }
     std::vector<ogl_label> rows((size_t)nnz), cols((size_t)nnz), map((size_t)nnz);
-    auto fill_rows = [&](ogl_label k0, ogl_label k1) {  // new rows [k0, k1): independent of each other
-        for (ogl_label k = k0; k < k1; ++k) {
+    auto fill_rows = [&](int64_t k0, int64_t k1) {  // new rows [k0, k1): independent of each other
+        for (ogl_label k = (ogl_label)k0; k < (ogl_label)k1; ++k) {
             const ogl_label r = old_of[(size_t)k];
             const ogl_label len = p.row_ptrs[r + 1] - p.row_ptrs[r];
             ogl_label *c = cols.data() + rp[(size_t)k], *m = map.data() + rp[(size_t)k];
@@ -605,21 +635,12 @@ void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id)
             sort_segment(c, m, len);  // stable: equal columns keep the reference's order
         }
     };
-    {
-        const char *e = std::getenv("OGL_STAGE_THREADS");
-        const int n_threads = N < (1 << 18) ? 1 : std::max(1, std::min(16, e ? atoi(e) : 4));
-        const ogl_label part = (N + n_threads - 1) / n_threads;
-        std::vector<std::thread> helpers;
-        for (int t = 1; t < n_threads; ++t)
-            if ((int64_t)t * part < N)
-                helpers.emplace_back(fill_rows, (ogl_label)(t * part), (ogl_label)std::min<int64_t>(N, (int64_t)(t + 1) * part));
-        fill_rows(0, std::min(part, N));
-        for (auto &h : helpers) h.join();
-    }
+    parallel_ranges(N, 1 << 16, fill_rows);
     p.rows.swap(rows);
     p.cols.swap(cols);
     p.ldu_mapping.swap(map);
     p.row_ptrs.swap(rp);
+    }
     // non-local part: rows renamed, row-sorted again (stable, so entries of one row keep their order)
     const size_t nl = (size_t)p.non_local_nnz;
     if (nl) {
@@ -749,7 +770,7 @@ struct PhaseTimer {
 }  // namespace
 
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
-                     RenumberReport &rep)
+                     RenumberReport &rep, const NumberingHooks *hooks)
 {
     PhaseTimer tm;
     rep = RenumberReport{};
@@ -775,19 +796,23 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
         // "structured" = the compressed layout qualifies with 1-byte codes in every chunk: kept as it
         // is.  Patterns that only fit the 16-bit delta / 32-bit column codes are judged by their
         // gather locality and by the padding they make the kernel read.
-        rep.sell_natural = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), natural);
-        have_natural = true;
-        tm.lap("sell layout, caller's numbering");
-        if (rep.sell_natural && natural.n_delta16 + natural.n_col32 == 0) {
-            hand_over(natural, true);
-            return OGL_OK;
+        // (a look at a few chunks first: one that needs 16 / 32-bit codes settles "not structured" without
+        //  laying out the whole matrix; none found -> the full layout decides, as it always did)
+        if (!sell_pattern_is_irregular_sampled(N, p.row_ptrs.data(), p.cols.data())) {
+            rep.sell_natural = build_sell_layout(N, p.row_ptrs.data(), p.cols.data(), natural);
+            have_natural = true;
+            tm.lap("sell layout, caller's numbering");
+            if (rep.sell_natural && natural.n_delta16 + natural.n_col32 == 0) {
+                hand_over(natural, true);
+                return OGL_OK;
+            }
         }
     }
     // ---- step 1: the order of the rows at large: the caller's, or reverse Cuthill-McKee
     std::vector<ogl_label> new_id, old_of;  // empty = the caller's numbering
     if (mode == 1 || rep.ratio_natural > 0.25) {
         std::vector<ogl_label> cand, cand_old((size_t)N);
-        rcm_order(N, p.row_ptrs.data(), p.cols.data(), cand);
+        if (!(hooks && hooks->rcm && hooks->rcm(p, cand))) rcm_order(N, p.row_ptrs.data(), p.cols.data(), cand);
         tm.lap("rcm_order");
         for (ogl_label c = 0; c < N; ++c) cand_old[(size_t)cand[(size_t)c]] = c;
         const double r = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), cand.data(),
@@ -834,7 +859,7 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
         return OGL_OK;
     }
     tm.lap("row-length sort policy");
-    renumber_pattern(p, std::move(new_id));
+    renumber_pattern(p, std::move(new_id), hooks);
     tm.lap("renumber_pattern");
     rep.applied = true;
     rep.ratio_used = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), nullptr, nullptr);
@@ -853,6 +878,168 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
 // and banded finite-volume meshes, where a chunk sees a handful of diagonals -- and the padding to
 // the chunk's longest row stays below SELL_MAX_PADDING x nnz.
 // ---------------------------------------------------------------------------------------
+namespace {
+
+// What one chunk of the compressed layout looks like, from its rows alone (pass 1 of build_sell_layout):
+// the chunks are independent of each other until their offsets into the common arrays are assigned.
+struct SellChunkPlan {
+    bool ok = true;             // false: a row longer than SELL_MAX_WIDTH without the spill
+    int mode = SELL_MODE_COL32;
+    int32_t wave_w[SELL_WAVES] = {0, 0, 0, 0};
+    int32_t width = 0, base = 0;
+    int64_t touched = 0;        // value slots in the 128-byte lines the kernel reads
+    std::vector<int32_t> table; // pattern mode: patterns x width offsets; offset mode: the dictionary
+    std::vector<uint8_t> pid;   // pattern mode: pattern id of each of the CHUNK_ROWS rows
+    std::vector<int32_t> spill_rows, spill_len;  // rows whose tails spill, entries spilled per row
+};
+
+void plan_sell_chunk(int64_t c, ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, bool allow_spill,
+                     SellChunkPlan &P)
+{
+    const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
+    const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+    // Cap of the chunk: the slots its rows get in the planes.  Entries beyond it (the tails of a
+    // few long rows: split / polyhedral cells of a hex-dominant mesh) are "spilled" into a short
+    // row-sorted list that the chunk's workgroup adds after the planes, continuing every row's sum
+    // in stored order -- so one long row does not make 127 others read padding.
+    const int32_t cap = sell_chunk_cap(row_ptrs, r0, r1, allow_spill, &P.touched);
+    if (cap > SELL_MAX_WIDTH) {  // (only without the spill: a length must fit a byte)
+        P.ok = false;
+        return;
+    }
+    auto row_end = [&](ogl_label r) { return std::min(row_ptrs[r + 1], row_ptrs[r] + cap); };
+    int32_t width = 0;
+    for (int wv = 0; wv < SELL_WAVES; ++wv) {  // what each wavefront has to run to
+        int32_t ww = 0;
+        for (ogl_label r = r0 + wv * SELL_WAVE_ROWS; r < std::min<int64_t>(r1, (int64_t)r0 + (wv + 1) * SELL_WAVE_ROWS); ++r)
+            ww = std::max(ww, row_end(r) - row_ptrs[r]);
+        P.wave_w[wv] = ww;
+        width = std::max(width, ww);
+    }
+    P.width = width;
+    for (ogl_label r = r0; r < r1; ++r)
+        if (row_end(r) < row_ptrs[r + 1]) {
+            P.spill_rows.push_back(r);
+            P.spill_len.push_back(row_ptrs[r + 1] - row_end(r));
+        }
+    // (a) row patterns: one byte per row.  Known patterns are found through a small hash table
+    // (an irregular chunk would otherwise compare every row with up to 256 patterns before giving up)
+    bool pat_mode = width > 0;
+    std::vector<int32_t> &pats = P.table;
+    std::vector<int32_t> pat;
+    P.pid.assign(CHUNK_ROWS, 0);
+    size_t last_pat = 0;
+    constexpr int PAT_HASH = 1024;  // > 2 x 256 patterns, power of two
+    int16_t pat_slot[PAT_HASH];
+    for (int i = 0; i < PAT_HASH; ++i) pat_slot[i] = -1;
+    for (ogl_label lr = 0; lr < CHUNK_ROWS && pat_mode; ++lr) {
+        const ogl_label r = r0 + lr;
+        pat.assign((size_t)width, SELL_PAD_OFFSET);
+        uint32_t hsh = 2166136261u;
+        if (r < r1)
+            for (ogl_label k = row_ptrs[r], s = 0; k < row_end(r); ++k, ++s) {
+                pat[(size_t)s] = cols[k] - r;
+                hsh = (hsh ^ (uint32_t)pat[(size_t)s]) * 16777619u;
+            }
+        const size_t n_pat = pats.size() / (size_t)width;
+        auto same = [&](size_t i) {
+            return std::equal(pat.begin(), pat.end(), pats.begin() + (std::ptrdiff_t)(i * width));
+        };
+        size_t id = n_pat;
+        if (n_pat && same(last_pat)) {
+            id = last_pat;
+        } else {
+            uint32_t slot = (hsh ^ (hsh >> 15)) & (PAT_HASH - 1);
+            while (pat_slot[slot] >= 0 && !same((size_t)pat_slot[slot])) slot = (slot + 1) & (PAT_HASH - 1);
+            if (pat_slot[slot] >= 0) {
+                id = (size_t)pat_slot[slot];
+            } else {
+                if (n_pat == 256 || (n_pat + 1) * (size_t)width > (size_t)SELL_TABLE_INTS) {
+                    pat_mode = false;
+                    break;
+                }
+                pat_slot[slot] = (int16_t)n_pat;
+                pats.insert(pats.end(), pat.begin(), pat.end());
+            }
+        }
+        last_pat = id;
+        P.pid[(size_t)lr] = (uint8_t)id;
+    }
+    if (pat_mode) {
+        P.mode = SELL_MODE_PATTERN;
+        return;
+    }
+    P.pid.clear();
+    // (b) otherwise offsets: one byte per (row, slot), when the chunk has <= 255 distinct ones
+    std::vector<int32_t> &ds = P.table;
+    ds.clear();
+    bool off8_mode = width > 0;
+    if (off8_mode) {
+        size_t last = 0;
+        for (ogl_label r = r0; r < r1 && off8_mode; ++r)
+            for (ogl_label k = row_ptrs[r]; k < row_end(r); ++k) {
+                const int32_t d = cols[k] - r;
+                if (!ds.empty()) {
+                    if (ds[last] == d) continue;
+                    size_t i = 0;
+                    while (i < ds.size() && ds[i] != d) ++i;
+                    if (i < ds.size()) {
+                        last = i;
+                        continue;
+                    }
+                }
+                if (ds.size() == (size_t)SELL_MAX_DICT) {
+                    off8_mode = false;
+                    break;
+                }
+                ds.push_back(d);
+                last = ds.size() - 1;
+            }
+        if (off8_mode) std::sort(ds.begin(), ds.end());
+    }
+    if (off8_mode) {
+        P.mode = SELL_MODE_OFFSET8;
+        return;
+    }
+    ds.clear();
+    // (c) otherwise 16-bit deltas along the row: first code = (first column - row) - base, then
+    // column[s] - column[s-1] (rows are stored in ascending column order); 0xFFFF = padding
+    bool d16_mode = width > 0;
+    if (d16_mode) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (ogl_label r = r0; r < r1 && d16_mode; ++r) {
+            if (row_ptrs[r] == row_end(r)) continue;
+            const int64_t first = (int64_t)cols[row_ptrs[r]] - r;
+            lo = std::min(lo, first);
+            hi = std::max(hi, first);
+            for (ogl_label k = row_ptrs[r] + 1; k < row_end(r); ++k) {
+                const int64_t d = (int64_t)cols[k] - cols[k - 1];
+                if (d < 0 || d > SELL_MAX_DELTA16) d16_mode = false;
+            }
+        }
+        if (lo == INT64_MAX) lo = hi = 0;
+        if (hi - lo > SELL_MAX_DELTA16) d16_mode = false;
+        P.base = (int32_t)lo;
+    }
+    // (d) otherwise plain 32-bit columns (-1 = padding): always possible (also what an empty chunk gets:
+    // nothing is ever read)
+    P.mode = d16_mode ? SELL_MODE_DELTA16 : SELL_MODE_COL32;
+}
+
+}  // namespace
+
+bool sell_pattern_is_irregular_sampled(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols)
+{
+    const int64_t nc = n_chunks(n_rows);
+    const int64_t n_samples = std::min<int64_t>(64, nc);
+    for (int64_t i = 0; i < n_samples; ++i) {
+        SellChunkPlan P;
+        plan_sell_chunk(i * nc / n_samples, n_rows, row_ptrs, cols, true, P);
+        if (P.ok && P.width > 0 && P.mode >= SELL_MODE_DELTA16) return true;
+    }
+    return false;
+}
+
 bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                        SellLayout &out, bool allow_spill)
 {
@@ -860,157 +1047,50 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     const int64_t nc = n_chunks(n_rows);
     const int64_t nnz = n_rows > 0 ? row_ptrs[n_rows] : 0;
     out.chunks.resize((size_t)nc);
-    std::vector<int32_t> ds;    // distinct offsets of the chunk
-    std::vector<int32_t> pats;  // distinct row patterns of the chunk, `width` offsets each
-    std::vector<int32_t> pat;
-    std::vector<uint8_t> pid(CHUNK_ROWS);
+    // pass 1: per chunk the width, the coding mode, the dictionary / pattern table (independent: in parallel)
+    std::vector<SellChunkPlan> plans((size_t)nc);
+    parallel_ranges(nc, 64, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) plan_sell_chunk(c, n_rows, row_ptrs, cols, allow_spill, plans[(size_t)c]);
+    });
+    // ... then their places in the common arrays, chunk after chunk
     int64_t val_len = 0, code_len = 0;
-    // pass 1: per chunk the width, the coding mode, the dictionary / pattern table and the offsets
-    std::vector<uint8_t> pid_all;  // pattern ids of the chunks in pattern mode, chunk after chunk
+    std::vector<int64_t> pid_off((size_t)nc, -1);
     for (int64_t c = 0; c < nc; ++c) {
-        const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
-        const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
-        // Cap of the chunk: the slots its rows get in the planes.  Entries beyond it (the tails of a
-        // few long rows: split / polyhedral cells of a hex-dominant mesh) are "spilled" into a short
-        // row-sorted list that the chunk's workgroup adds after the planes, continuing every row's sum
-        // in stored order -- so one long row does not make 127 others read padding.
-        int64_t touched = 0;
-        const int32_t cap = sell_chunk_cap(row_ptrs, r0, r1, allow_spill, &touched);
-        if (cap > SELL_MAX_WIDTH) return false;  // (only without the spill: a length must fit a byte)
-        out.read_slots += touched;
-        auto row_end = [&](ogl_label r) { return std::min(row_ptrs[r + 1], row_ptrs[r] + cap); };
-        int32_t width = 0, wave_w[SELL_WAVES];
-        for (int wv = 0; wv < SELL_WAVES; ++wv) {  // what each wavefront has to run to
-            int32_t ww = 0;
-            for (ogl_label r = r0 + wv * SELL_WAVE_ROWS; r < std::min<int64_t>(r1, (int64_t)r0 + (wv + 1) * SELL_WAVE_ROWS); ++r)
-                ww = std::max(ww, row_end(r) - row_ptrs[r]);
-            wave_w[wv] = ww;
-            width = std::max(width, ww);
-        }
+        const SellChunkPlan &P = plans[(size_t)c];
+        if (!P.ok) return false;
+        out.read_slots += P.touched;
         out.spill_chunk_ptr.push_back((int32_t)out.spill_rows.size());
-        for (ogl_label r = r0; r < r1; ++r)
-            if (row_end(r) < row_ptrs[r + 1]) {
-                out.spill_rows.push_back(r);
-                out.spill_ptrs.push_back((int32_t)out.spill_cols.size());
-                for (ogl_label k = row_end(r); k < row_ptrs[r + 1]; ++k) {
-                    out.spill_cols.push_back(cols[k]);
-                    out.spill_map.push_back(k);
-                }
+        for (size_t i = 0; i < P.spill_rows.size(); ++i) {
+            const ogl_label r = P.spill_rows[i];
+            out.spill_rows.push_back(r);
+            out.spill_ptrs.push_back((int32_t)out.spill_cols.size());
+            for (ogl_label k = row_ptrs[r + 1] - P.spill_len[i]; k < row_ptrs[r + 1]; ++k) {
+                out.spill_cols.push_back(cols[k]);
+                out.spill_map.push_back(k);
             }
-        // (a) row patterns: one byte per row.  Known patterns are found through a small hash table
-        // (an irregular chunk would otherwise compare every row with up to 256 patterns before giving up)
-        bool pat_mode = width > 0;
-        pats.clear();
-        size_t last_pat = 0;
-        constexpr int PAT_HASH = 1024;  // > 2 x 256 patterns, power of two
-        int16_t pat_slot[PAT_HASH];
-        for (int i = 0; i < PAT_HASH; ++i) pat_slot[i] = -1;
-        for (ogl_label lr = 0; lr < CHUNK_ROWS && pat_mode; ++lr) {
-            const ogl_label r = r0 + lr;
-            pat.assign((size_t)width, SELL_PAD_OFFSET);
-            uint32_t hsh = 2166136261u;
-            if (r < r1)
-                for (ogl_label k = row_ptrs[r], s = 0; k < row_end(r); ++k, ++s) {
-                    pat[(size_t)s] = cols[k] - r;
-                    hsh = (hsh ^ (uint32_t)pat[(size_t)s]) * 16777619u;
-                }
-            const size_t n_pat = pats.size() / (size_t)width;
-            auto same = [&](size_t i) {
-                return std::equal(pat.begin(), pat.end(), pats.begin() + (std::ptrdiff_t)(i * width));
-            };
-            size_t id = n_pat;
-            if (n_pat && same(last_pat)) {
-                id = last_pat;
-            } else {
-                uint32_t slot = (hsh ^ (hsh >> 15)) & (PAT_HASH - 1);
-                while (pat_slot[slot] >= 0 && !same((size_t)pat_slot[slot])) slot = (slot + 1) & (PAT_HASH - 1);
-                if (pat_slot[slot] >= 0) {
-                    id = (size_t)pat_slot[slot];
-                } else {
-                    if (n_pat == 256 || (n_pat + 1) * (size_t)width > (size_t)SELL_TABLE_INTS) {
-                        pat_mode = false;
-                        break;
-                    }
-                    pat_slot[slot] = (int16_t)n_pat;
-                    pats.insert(pats.end(), pat.begin(), pat.end());
-                }
-            }
-            last_pat = id;
-            pid[(size_t)lr] = (uint8_t)id;
         }
-        // (b) otherwise offsets: one byte per (row, slot), when the chunk has <= 255 distinct ones
-        ds.clear();
-        bool off8_mode = !pat_mode && width > 0;
-        if (off8_mode) {
-            size_t last = 0;
-            for (ogl_label r = r0; r < r1 && off8_mode; ++r)
-                for (ogl_label k = row_ptrs[r]; k < row_end(r); ++k) {
-                    const int32_t d = cols[k] - r;
-                    if (!ds.empty()) {
-                        if (ds[last] == d) continue;
-                        size_t i = 0;
-                        while (i < ds.size() && ds[i] != d) ++i;
-                        if (i < ds.size()) {
-                            last = i;
-                            continue;
-                        }
-                    }
-                    if (ds.size() == (size_t)SELL_MAX_DICT) {
-                        off8_mode = false;
-                        break;
-                    }
-                    ds.push_back(d);
-                    last = ds.size() - 1;
-                }
-            if (off8_mode) std::sort(ds.begin(), ds.end());
-        }
-        // (c) otherwise 16-bit deltas along the row: first code = (first column - row) - base, then
-        // column[s] - column[s-1] (rows are stored in ascending column order); 0xFFFF = padding
-        bool d16_mode = !pat_mode && !off8_mode && width > 0;
-        int32_t base = 0;
-        if (d16_mode) {
-            int64_t lo = INT64_MAX, hi = INT64_MIN;
-            for (ogl_label r = r0; r < r1 && d16_mode; ++r) {
-                if (row_ptrs[r] == row_end(r)) continue;
-                const int64_t first = (int64_t)cols[row_ptrs[r]] - r;
-                lo = std::min(lo, first);
-                hi = std::max(hi, first);
-                for (ogl_label k = row_ptrs[r] + 1; k < row_end(r); ++k) {
-                    const int64_t d = (int64_t)cols[k] - cols[k - 1];
-                    if (d < 0 || d > SELL_MAX_DELTA16) d16_mode = false;
-                }
-            }
-            if (lo == INT64_MAX) lo = hi = 0;
-            if (hi - lo > SELL_MAX_DELTA16) d16_mode = false;
-            base = (int32_t)lo;
-        }
-        // (d) otherwise plain 32-bit columns (-1 = padding): always possible
         SellChunk &h = out.chunks[(size_t)c];
         h.val_off = val_len;
-        if (!pat_mode) code_len += SELL_LEN_BYTES;  // the row lengths, one byte each, in front of the codes
+        if (P.mode != SELL_MODE_PATTERN) code_len += SELL_LEN_BYTES;  // the row lengths, one byte each, in front of the codes
         h.code_off = code_len;
         h.dict_off = (int32_t)out.dict.size();
-        if (pat_mode) {
-            h.set(SELL_MODE_PATTERN, (int)pats.size(), wave_w);
-            out.dict.insert(out.dict.end(), pats.begin(), pats.end());
-            pid_all.insert(pid_all.end(), pid.begin(), pid.end());
-        } else if (off8_mode) {
-            h.set(SELL_MODE_OFFSET8, (int)ds.size(), wave_w);
-            out.dict.insert(out.dict.end(), ds.begin(), ds.end());
-        } else if (d16_mode) {
+        if (P.mode == SELL_MODE_PATTERN || P.mode == SELL_MODE_OFFSET8) {
+            h.set(P.mode, (int)P.table.size(), P.wave_w);
+            out.dict.insert(out.dict.end(), P.table.begin(), P.table.end());
+        } else if (P.mode == SELL_MODE_DELTA16) {
             // group-major 16-byte words: word (g, t) holds SELL_D16_GROUP slots of thread t's two rows;
             // lane t of a wavefront reads consecutive words
-            h.set(SELL_MODE_DELTA16, 0, wave_w);
-            h.dict_off = base;
+            h.set(SELL_MODE_DELTA16, 0, P.wave_w);
+            h.dict_off = P.base;
             out.n_delta16 += 1;
         } else {
-            h.set(SELL_MODE_COL32, 0, wave_w);  // (also what an empty chunk gets: nothing is ever read)
+            h.set(SELL_MODE_COL32, 0, P.wave_w);
             h.dict_off = 0;
-            if (width > 0) out.n_col32 += 1;
+            if (P.width > 0) out.n_col32 += 1;
         }
         const int cs = h.code_stride();
         code_len += (int64_t)(cs > 0 ? cs : 16) * BLOCK;
-        val_len += (int64_t)width * CHUNK_ROWS;
+        val_len += (int64_t)P.width * CHUNK_ROWS;
         code_len = (code_len + 15) / 16 * 16;
         // padding that is READ (a wavefront runs to its own longest row) must stay below what CSR's
         // indices cost; padding that is only allocated (to the chunk's longest row) is bounded too
@@ -1024,20 +1104,17 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     out.spill_chunk_ptr.push_back((int32_t)out.spill_rows.size());
     out.codes.assign((size_t)code_len + 16, (uint8_t)255);
     out.map.assign((size_t)val_len + 2, -1);
-    // pass 2: codes and the value map
-    size_t pid_pos = 0;
-    for (int64_t c = 0; c < nc; ++c) {
+    // pass 2: codes and the value map (every chunk writes its own ranges: in parallel)
+    parallel_ranges(nc, 64, [&](int64_t c0, int64_t c1) {
+      for (int64_t c = c0; c < c1; ++c) {
         const SellChunk &h = out.chunks[(size_t)c];
         const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS);
         const ogl_label r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
         const bool d16_mode = h.mode() == SELL_MODE_DELTA16, c32_mode = h.mode() == SELL_MODE_COL32;
         const bool pat_mode = h.mode() == SELL_MODE_PATTERN;
         const int code_stride = h.code_stride();
-        if (pat_mode) {  // rows 2t, 2t+1 of thread t are adjacent bytes
-            std::copy(pid_all.begin() + (std::ptrdiff_t)pid_pos, pid_all.begin() + (std::ptrdiff_t)(pid_pos + CHUNK_ROWS),
-                      out.codes.begin() + h.code_off);
-            pid_pos += CHUNK_ROWS;
-        }
+        if (pat_mode)  // rows 2t, 2t+1 of thread t are adjacent bytes
+            std::copy(plans[(size_t)c].pid.begin(), plans[(size_t)c].pid.end(), out.codes.begin() + h.code_off);
         const int32_t *d0 = (d16_mode || c32_mode) ? nullptr : out.dict.data() + h.dict_off;
         if (!pat_mode) std::fill_n(out.codes.begin() + (h.code_off - SELL_LEN_BYTES), SELL_LEN_BYTES, (uint8_t)0);
         for (ogl_label r = r0; r < r1; ++r) {
@@ -1068,7 +1145,8 @@ bool build_sell_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
                 }
             }
         }
-    }
+      }
+    });
     return true;
 }
 

@@ -3,6 +3,7 @@
 // Re-implements what HostMatrixWrapper builds once per field (reference HostMatrix/HostMatrix.C,
 // HostMatrix/HostMatrixFreeFunctions.C).  Pure host code: no device, no oracle.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "common.hpp"
@@ -142,9 +143,20 @@ double gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const og
 // or odd rows of a wavefront's 128 rows).  0.25 on a hex mesh in natural order.
 double slot_gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                                 const ogl_label *new_id, const ogl_label *old_of);
+// The two heavy steps of the renumbering may be done elsewhere (the solver does them on the device,
+// setup_kernels.hip, with the same results): a hook that returns false leaves the step to the host code.
+struct NumberingHooks {
+    // reverse Cuthill-McKee order of p's graph: new_id[old] = new
+    std::function<bool(const HostPattern &p, std::vector<ogl_label> &new_id)> rcm;
+    // p.row_ptrs / p.cols / p.ldu_mapping rewritten into the numbering new_id (p.rows is left alone)
+    std::function<bool(HostPattern &p, const std::vector<ogl_label> &new_id)> renumber_local;
+};
 // Rewrites `p` (built by build_host_pattern in the caller's numbering) into the numbering new_id.
 // Rows keep their entries; within a row the entries are ordered by NEW column (stable).
-void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id);
+void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id, const NumberingHooks *hooks = nullptr);
+// true: one of a few chunks sampled over the matrix needs 16-bit delta / 32-bit column codes in the compressed
+// layout (an irregular pattern for sure); false: none of the sampled ones does
+bool sell_pattern_is_irregular_sampled(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols);
 struct SellLayout;
 struct RenumberReport {
     bool applied = false;
@@ -165,7 +177,7 @@ struct RenumberReport {
 // `sell_out` (may be null) receives the compressed layout of the numbering that was chosen when
 // one was built on the way (sell_built tells), so the caller does not derive it twice.
 int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_out, bool *sell_built,
-                     RenumberReport &rep);
+                     RenumberReport &rep, const NumberingHooks *hooks = nullptr);
 
 // Pattern of the ISAI approximate inverse W (keyword sparsityPower, Preconditioner.H:227): rows of
 // S^power in ascending column order, S = tril(A) (spd = ISAI) or A (general = GISAI).  Returns false

@@ -222,6 +222,167 @@ __global__ __launch_bounds__(BLOCK) void k_sym_fill(int32_t n_rows, const int32_
     mask[r] = (uint8_t)m;
 }
 
+// ---- reverse Cuthill-McKee, level-synchronous ----
+__global__ __launch_bounds__(BLOCK) void k_rcm_init(RcmWork w)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= w.n_rows) return;
+    w.lvl[i] = -1;
+    w.key[i] = RCM_NO_KEY;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rcm_find_seed(RcmWork w)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    // (one candidate per wavefront reaches the cell: the lowest untouched index of the wavefront)
+    unsigned long long mine = (i < w.n_rows && w.lvl[i] == -1) ? (unsigned long long)i : ~0ull;
+#pragma unroll
+    for (int off = WAVE / 2; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(mine, off, WAVE);
+        mine = o < mine ? o : mine;
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && mine != ~0ull) atomicMin(&w.cell[0], mine);
+}
+
+__global__ void k_rcm_start(RcmWork w, int32_t *list, int32_t pos, int32_t node, int32_t level)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    list[pos] = node;
+    w.lvl[node] = level;
+}
+
+// every untouched neighbour of a frontier node learns the earliest frontier position that reaches it
+__global__ __launch_bounds__(BLOCK) void k_rcm_mark(RcmWork w, const int32_t *__restrict__ list, int32_t begin,
+                                                    int32_t end)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (begin + i >= end) return;
+    const int p = list[begin + i];
+    for (int k = w.row_ptrs[p]; k < w.row_ptrs[p + 1]; ++k) {
+        const int c = w.cols[k];
+        if (w.lvl[c] == -1) atomicMin(&w.key[c], i);
+    }
+}
+
+// children of frontier position i = untouched neighbours whose key is i (a column twice in a row counts once:
+// rows are ordered by column, so repeats are adjacent)
+__global__ __launch_bounds__(BLOCK) void k_rcm_count(RcmWork w, const int32_t *__restrict__ list, int32_t begin,
+                                                     int32_t end)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (begin + i >= end) return;
+    const int p = list[begin + i];
+    int n = 0, prev = -1;
+    for (int k = w.row_ptrs[p]; k < w.row_ptrs[p + 1]; ++k) {
+        const int c = w.cols[k];
+        if (c != prev && w.lvl[c] == -1 && w.key[c] == i) ++n;
+        prev = c;
+    }
+    w.cnt[i] = n;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rcm_emit(RcmWork w, int32_t *list, int32_t begin, int32_t end,
+                                                    int32_t level, int by_degree)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (begin + i >= end) return;
+    const int p = list[begin + i];
+    int32_t *out = list + end + w.cnt[i];  // (cnt holds the exclusive offsets by now)
+    int n = 0, prev = -1;
+    for (int k = w.row_ptrs[p]; k < w.row_ptrs[p + 1]; ++k) {
+        const int c = w.cols[k];
+        if (c != prev && w.lvl[c] == -1 && w.key[c] == i) {
+            // insertion by (degree, index) resp. by index: the row arrives in ascending index order
+            int j = n;
+            if (by_degree) {
+                const int d = w.row_ptrs[c + 1] - w.row_ptrs[c];
+                while (j > 0) {
+                    const int o = out[j - 1];
+                    const int od = w.row_ptrs[o + 1] - w.row_ptrs[o];
+                    if (od > d || (od == d && o > c)) {
+                        out[j] = o;
+                        --j;
+                    } else {
+                        break;
+                    }
+                }
+            }
+            out[j] = c;
+            ++n;
+        }
+        prev = c;
+    }
+    for (int j = 0; j < n; ++j) w.lvl[out[j]] = level + 1;  // (only now: the tests above must see them untouched)
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rcm_far_node(RcmWork w, const int32_t *__restrict__ list, int32_t begin,
+                                                        int32_t end)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    unsigned long long mine = ~0ull;
+    if (begin + i < end) {
+        const int v = list[begin + i];
+        mine = ((unsigned long long)(unsigned)(w.row_ptrs[v + 1] - w.row_ptrs[v]) << 32) | (unsigned)i;
+    }
+#pragma unroll
+    for (int off = WAVE / 2; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(mine, off, WAVE);
+        mine = o < mine ? o : mine;
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && mine != ~0ull) atomicMin(&w.cell[1], mine);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rcm_reset(RcmWork w, const int32_t *__restrict__ list, int32_t count)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const int v = list[i];
+    w.lvl[v] = -1;
+    w.key[v] = RCM_NO_KEY;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_rcm_finish(RcmWork w, int32_t *new_id)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k < w.n_rows) new_id[w.order[w.n_rows - 1 - k]] = k;
+}
+
+// ---- pattern in a new numbering ----
+__global__ __launch_bounds__(BLOCK) void k_renumber_lens(RenumberWork w)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= w.n_rows) return;
+    const int k = w.new_id[r];
+    w.old_of[k] = r;
+    w.row_ptrs_out[k] = w.row_ptrs[r + 1] - w.row_ptrs[r];  // (lengths; scanned in place afterwards)
+}
+
+__global__ __launch_bounds__(BLOCK) void k_renumber_fill(RenumberWork w)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;  // new row
+    if (k >= w.n_rows) return;
+    const int r = w.old_of[k];
+    const int src = w.row_ptrs[r], len = w.row_ptrs[r + 1] - src, dst = w.row_ptrs_out[k];
+    int dp = -1;
+    for (int i = 0; i < len; ++i) {  // stable insertion by new column: equal columns keep the reference's order
+        const int c = w.new_id[w.cols[src + i]], m = w.map[src + i];
+        int j = i;
+        while (j > 0 && w.cols_out[dst + j - 1] > c) {
+            w.cols_out[dst + j] = w.cols_out[dst + j - 1];
+            w.map_out[dst + j] = w.map_out[dst + j - 1];
+            --j;
+        }
+        w.cols_out[dst + j] = c;
+        w.map_out[dst + j] = m;
+    }
+    for (int i = 0; i < len; ++i)
+        if (w.cols_out[dst + i] == k) {
+            dp = dst + i;
+            break;
+        }
+    w.diag_pos_out[k] = dp;
+}
+
 }  // namespace
 
 size_t scan_tmp_len(int64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
@@ -268,6 +429,62 @@ void launch_sym_fill(hipStream_t st, int32_t n_rows, const int32_t *row_ptrs, co
     if (n_rows == 0) return;
     hipLaunchKernelGGL(k_sym_fill, dim3(blocks_for(n_rows)), dim3(BLOCK), 0, st, n_rows, row_ptrs, cols, dist, mask,
                        map, flags);
+}
+
+void launch_rcm_init(hipStream_t st, const RcmWork &w)
+{
+    if (w.n_rows) hipLaunchKernelGGL(k_rcm_init, dim3(blocks_for(w.n_rows)), dim3(BLOCK), 0, st, w);
+}
+
+void launch_rcm_find_seed(hipStream_t st, const RcmWork &w)
+{
+    (void)hipMemsetAsync(w.cell, 0xFF, sizeof(unsigned long long), st);
+    if (w.n_rows) hipLaunchKernelGGL(k_rcm_find_seed, dim3(blocks_for(w.n_rows)), dim3(BLOCK), 0, st, w);
+}
+
+void launch_rcm_start(hipStream_t st, const RcmWork &w, int32_t *list, int32_t pos, int32_t node, int32_t level)
+{
+    hipLaunchKernelGGL(k_rcm_start, dim3(1), dim3(64), 0, st, w, list, pos, node, level);
+}
+
+void launch_rcm_level(hipStream_t st, const RcmWork &w, int32_t *list, int32_t begin, int32_t end, int32_t level,
+                      bool by_degree)
+{
+    const int m = end - begin;
+    if (m <= 0) return;
+    const dim3 grid(blocks_for(m)), block(BLOCK);
+    hipLaunchKernelGGL(k_rcm_mark, grid, block, 0, st, w, list, begin, end);
+    hipLaunchKernelGGL(k_rcm_count, grid, block, 0, st, w, list, begin, end);
+    launch_exclusive_scan(st, w.cnt, w.cnt, m, w.scan_tmp);
+    hipLaunchKernelGGL(k_rcm_emit, grid, block, 0, st, w, list, begin, end, level, by_degree ? 1 : 0);
+}
+
+void launch_rcm_far_node(hipStream_t st, const RcmWork &w, const int32_t *list, int32_t begin, int32_t end)
+{
+    (void)hipMemsetAsync(w.cell + 1, 0xFF, sizeof(unsigned long long), st);
+    if (end > begin)
+        hipLaunchKernelGGL(k_rcm_far_node, dim3(blocks_for(end - begin)), dim3(BLOCK), 0, st, w, list, begin, end);
+}
+
+void launch_rcm_reset(hipStream_t st, const RcmWork &w, const int32_t *list, int32_t count)
+{
+    if (count > 0) hipLaunchKernelGGL(k_rcm_reset, dim3(blocks_for(count)), dim3(BLOCK), 0, st, w, list, count);
+}
+
+void launch_rcm_finish(hipStream_t st, const RcmWork &w, int32_t *new_id)
+{
+    if (w.n_rows) hipLaunchKernelGGL(k_rcm_finish, dim3(blocks_for(w.n_rows)), dim3(BLOCK), 0, st, w, new_id);
+}
+
+void launch_renumber_pattern(hipStream_t st, const RenumberWork &w)
+{
+    if (w.n_rows == 0) {
+        (void)hipMemsetAsync(w.row_ptrs_out, 0, sizeof(int32_t), st);
+        return;
+    }
+    hipLaunchKernelGGL(k_renumber_lens, dim3(blocks_for(w.n_rows)), dim3(BLOCK), 0, st, w);
+    launch_exclusive_scan(st, w.row_ptrs_out, w.row_ptrs_out, w.n_rows, w.scan_tmp);
+    hipLaunchKernelGGL(k_renumber_fill, dim3(blocks_for(w.n_rows)), dim3(BLOCK), 0, st, w);
 }
 
 }  // namespace ogl

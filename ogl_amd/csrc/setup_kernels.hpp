@@ -55,3 +55,51 @@ void launch_sym_fill(hipStream_t st, int32_t n_rows, const int32_t *row_ptrs, co
                      SymDistances dist, uint8_t *mask, int32_t *map, int32_t *flags);
 
 }  // namespace ogl
+
+namespace ogl {
+
+// ---- reverse Cuthill-McKee on the device: the same order as rcm_order (host_matrix.cpp), level by level ----
+// State per node: lvl (-1 untouched, >= 0 level / placed), key (position of the earliest parent in the
+// current frontier).  One BFS level = mark (atomicMin of the parents' positions) -> count -> scan -> emit.
+struct RcmWork {
+    int32_t n_rows = 0;
+    const int32_t *row_ptrs = nullptr, *cols = nullptr;
+    int32_t *lvl = nullptr;      // [n_rows]
+    int32_t *key = nullptr;      // [n_rows]
+    int32_t *order = nullptr;    // [n_rows] Cuthill-McKee order, filled front to back
+    int32_t *scratch = nullptr;  // [n_rows] BFS order of the start-node sweep
+    int32_t *cnt = nullptr;      // [n_rows + 1] children per frontier node, then their offsets
+    int32_t *scan_tmp = nullptr; // [scan_tmp_len(n_rows)]
+    unsigned long long *cell = nullptr;  // [4] reduction cells (seed search, far-node search)
+};
+constexpr int32_t RCM_NO_KEY = INT32_MAX;
+// lvl = -1, key = RCM_NO_KEY for all nodes
+void launch_rcm_init(hipStream_t st, const RcmWork &w);
+// cell[0] = smallest index with lvl == -1 (or ~0 when none)
+void launch_rcm_find_seed(hipStream_t st, const RcmWork &w);
+// put `node` at list[pos] with lvl = level (single thread)
+void launch_rcm_start(hipStream_t st, const RcmWork &w, int32_t *list, int32_t pos, int32_t node, int32_t level);
+// one level: frontier = list[begin, end) (level `level`); children go to list[end, end + total), total -> cnt[end - begin]
+// by_degree: children of a parent ordered by (degree, index) (Cuthill-McKee); else by index (= stored order)
+void launch_rcm_level(hipStream_t st, const RcmWork &w, int32_t *list, int32_t begin, int32_t end, int32_t level,
+                      bool by_degree);
+// cell[1] = (degree << 32 | position) minimum over list[begin, end)
+void launch_rcm_far_node(hipStream_t st, const RcmWork &w, const int32_t *list, int32_t begin, int32_t end);
+// lvl = -1, key = none for the nodes of list[0, count) (undo a sweep)
+void launch_rcm_reset(hipStream_t st, const RcmWork &w, const int32_t *list, int32_t count);
+// new_id[order[n - 1 - k]] = k
+void launch_rcm_finish(hipStream_t st, const RcmWork &w, int32_t *new_id);
+
+// ---- the pattern in another numbering (renumber_pattern, host_matrix.cpp): row new_id[r] holds row r's
+// entries with columns renamed, ordered by new column (stable)
+struct RenumberWork {
+    int32_t n_rows = 0;
+    const int32_t *new_id = nullptr;                                  // [n_rows]
+    const int32_t *row_ptrs = nullptr, *cols = nullptr, *map = nullptr;   // the pattern as it is
+    int32_t *old_of = nullptr;                                        // [n_rows] out: inverse permutation
+    int32_t *row_ptrs_out = nullptr, *cols_out = nullptr, *map_out = nullptr, *diag_pos_out = nullptr;
+    int32_t *scan_tmp = nullptr;
+};
+void launch_renumber_pattern(hipStream_t st, const RenumberWork &w);
+
+}  // namespace ogl

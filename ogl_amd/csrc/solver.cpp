@@ -597,6 +597,140 @@ int ogl_solver::download_local_pattern(HostPattern &hp)
     return OGL_OK;
 }
 
+// Reverse Cuthill-McKee on the device, level by level (setup_kernels.hip): start node of every component by one
+// breadth-first sweep (the node of smallest degree in its last level), then Cuthill-McKee from it -- children of a
+// node by ascending (degree, index), a node belonging to the earliest parent of the level before.  The same
+// order as rcm_order (tests/test_gpu_device_setup.py).  A level costs four small launches and one 4-byte
+// read-back; graphs with very many components or levels (chains) are left to the host.
+int ogl_solver::rcm_on_device(const HostPattern &hp, std::vector<ogl_label> &new_id)
+{
+    new_id.clear();
+    hipStream_t st = reg->stream;
+    const int32_t N = hp.n_rows;
+    if (N < 2) return OGL_OK;
+    constexpr int MAX_COMPONENTS = 64, MAX_LEVELS = 60000;
+    DevBuf<int32_t> lvl, key, order, scratch, cnt, tmp, nid;
+    DevBuf<unsigned long long> cell;
+    OGL_TRY(lvl.alloc((size_t)N, st));
+    OGL_TRY(key.alloc((size_t)N, st));
+    OGL_TRY(order.alloc((size_t)N, st));
+    OGL_TRY(scratch.alloc((size_t)N, st));
+    OGL_TRY(cnt.alloc((size_t)N + 2, st));
+    OGL_TRY(tmp.alloc(scan_tmp_len(N), st));
+    OGL_TRY(nid.alloc((size_t)N, st));
+    OGL_TRY(cell.alloc(4, st));
+    RcmWork w;
+    w.n_rows = N;
+    w.row_ptrs = d_row_ptrs.p;
+    w.cols = d_cols.p;
+    w.lvl = lvl.p;
+    w.key = key.p;
+    w.order = order.p;
+    w.scratch = scratch.p;
+    w.cnt = cnt.p;
+    w.scan_tmp = tmp.p;
+    w.cell = cell.p;
+    launch_rcm_init(st, w);
+    int levels = 0;
+    // breadth-first levels from list[begin] (already placed at `begin`); returns the end of the list and the
+    // start of its last level
+    auto run_levels = [&](int32_t *list, int32_t begin, bool by_degree, int32_t *last_begin, int32_t *end_out) -> int {
+        int32_t b = begin, e = begin + 1, level = 0;
+        for (;;) {
+            launch_rcm_level(st, w, list, b, e, level, by_degree);
+            int32_t total = 0;
+            OGL_HIP_CHECK(hipMemcpyAsync(&total, cnt.p + (e - b), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            OGL_HIP_CHECK(hipStreamSynchronize(st));
+            if (total == 0) break;
+            b = e;
+            e += total;
+            ++level;
+            if (++levels > MAX_LEVELS) return 1;
+            // thin levels for thousands of levels on end (a chain, a very long duct): a launch-bound crawl
+            if (level > 2000 && (int64_t)(e - begin) < 64 * (int64_t)level) return 1;
+        }
+        *last_begin = b;
+        *end_out = e;
+        return OGL_OK;
+    };
+    int32_t filled = 0;
+    for (int comp = 0; filled < N; ++comp) {
+        if (comp >= MAX_COMPONENTS) return OGL_OK;  // (new_id stays empty: host)
+        launch_rcm_find_seed(st, w);
+        unsigned long long seed64 = 0;
+        OGL_HIP_CHECK(hipMemcpyAsync(&seed64, cell.p, sizeof(seed64), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        if (seed64 >= (unsigned long long)N) return fail(OGL_ERR_STATE, "device RCM lost %d nodes", N - filled);
+        const int32_t seed = (int32_t)seed64;
+        int32_t rp2[2] = {0, 0};
+        OGL_HIP_CHECK(hipMemcpy(rp2, d_row_ptrs.p + seed, sizeof(rp2), hipMemcpyDeviceToHost));
+        int32_t start = seed;
+        if (rp2[1] - rp2[0] > 1) {  // (isolated cells and chain ends are peripheral already)
+            int32_t last_begin = 0, end = 0;
+            launch_rcm_start(st, w, scratch.p, 0, seed, 0);
+            const int rc = run_levels(scratch.p, 0, /*by_degree*/ false, &last_begin, &end);
+            if (rc == 1) return OGL_OK;
+            if (rc != OGL_OK) return rc;
+            launch_rcm_far_node(st, w, scratch.p, last_begin, end);
+            unsigned long long far = 0;
+            OGL_HIP_CHECK(hipMemcpyAsync(&far, cell.p + 1, sizeof(far), hipMemcpyDeviceToHost, st));
+            OGL_HIP_CHECK(hipStreamSynchronize(st));
+            OGL_HIP_CHECK(hipMemcpy(&start, scratch.p + last_begin + (int32_t)(far & 0xffffffffu), sizeof(int32_t),
+                                    hipMemcpyDeviceToHost));
+            launch_rcm_reset(st, w, scratch.p, end);
+        }
+        int32_t last_begin = 0, end = 0;
+        launch_rcm_start(st, w, order.p, filled, start, 0);
+        const int rc = run_levels(order.p, filled, /*by_degree*/ true, &last_begin, &end);
+        if (rc == 1) return OGL_OK;
+        if (rc != OGL_OK) return rc;
+        filled = end;
+    }
+    launch_rcm_finish(st, w, nid.p);
+    new_id.resize((size_t)N);
+    OGL_TRY(reg->stager.d2h(new_id.data(), nid.p, (size_t)N * sizeof(int32_t), st));
+    OGL_HIP_CHECK(hipGetLastError());
+    props["rcmLevels"] = (double)levels;
+    return OGL_OK;
+}
+
+int ogl_solver::renumber_on_device(HostPattern &hp, const std::vector<ogl_label> &new_id)
+{
+    hipStream_t st = reg->stream;
+    const int32_t N = hp.n_rows;
+    const size_t nnz = (size_t)hp.local_nnz;
+    DevBuf<int32_t> nid, old_of, rp2, cols2, map2, dpos2, tmp;
+    OGL_TRY(nid.alloc((size_t)N, st));
+    OGL_TRY(old_of.alloc((size_t)N, st));
+    OGL_TRY(rp2.alloc((size_t)N + 1, st));
+    OGL_TRY(cols2.alloc(nnz + NNZ_PAD, st));
+    OGL_TRY(map2.alloc(nnz + NNZ_PAD, st));
+    OGL_TRY(dpos2.alloc(std::max<size_t>(1, (size_t)N), st));
+    OGL_TRY(tmp.alloc(scan_tmp_len(N), st));
+    OGL_TRY(reg->stager.h2d(nid.p, new_id.data(), (size_t)N * sizeof(int32_t), st));
+    RenumberWork w;
+    w.n_rows = N;
+    w.new_id = nid.p;
+    w.row_ptrs = d_row_ptrs.p;
+    w.cols = d_cols.p;
+    w.map = d_ldu_mapping.p;
+    w.old_of = old_of.p;
+    w.row_ptrs_out = rp2.p;
+    w.cols_out = cols2.p;
+    w.map_out = map2.p;
+    w.diag_pos_out = dpos2.p;
+    w.scan_tmp = tmp.p;
+    launch_renumber_pattern(st, w);
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    d_row_ptrs.swap(rp2);
+    d_cols.swap(cols2);
+    d_ldu_mapping.swap(map2);
+    d_diag_pos.swap(dpos2);
+    hp.local_on_host = false;  // the host arrays are in the old numbering: fetch the new ones
+    return download_local_pattern(hp);
+}
+
 // Half storage from the device pattern (build_sym_layout's rules, host_matrix.cpp): the distances that occur,
 // then mask and map per row.  *done stays false when the pattern does not qualify.
 int ogl_solver::build_sym_on_device(const HostPattern &np, SymDistances *sd_out, bool *done)
@@ -985,7 +1119,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         // at most SYM_MAX_OFFSETS - 1 distances = a structured mesh, whose numbering the policy below would
         // keep anyway): everything stays on the device then
         SymDistances sym_dist{};
-        bool sym_on_device = false, sym_tried = false;
+        bool sym_on_device = false, sym_tried = false, renumbered_on_device = false;
         if (built_on_device && try_sym && np.symmetric && np.local_iface_nnz == 0 && cfg.renumber != 1) {
             sym_tried = true;
             OGL_TRY(build_sym_on_device(np, &sym_dist, &sym_on_device));
@@ -999,7 +1133,17 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             rep.ratio_natural = rep.ratio_used = -1.0;  // (not measured: the pattern never came to the host)
         } else {
             OGL_TRY(download_local_pattern(np));
-            OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep));
+            // with the pattern on the device the two heavy steps of a renumbering run there (same results)
+            NumberingHooks hooks;
+            hooks.rcm = [&](const HostPattern &hp, std::vector<ogl_label> &nid) {
+                return rcm_on_device(hp, nid) == OGL_OK && !nid.empty();
+            };
+            hooks.renumber_local = [&](HostPattern &hp, const std::vector<ogl_label> &nid) {
+                renumbered_on_device = renumber_on_device(hp, nid) == OGL_OK;
+                return renumbered_on_device;
+            };
+            OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep,
+                                     built_on_device ? &hooks : nullptr));
         }
         pat_renumber_mode = cfg.renumber;
         pat_try_sell = try_sell;
@@ -1019,7 +1163,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         sell_state = 0;
         sym_state = 0;
         x_resident = b_resident = false;
-        if (!built_on_device || rep.applied) {  // the device does not hold the pattern (in this numbering) yet
+        props["renumberedOnDevice"] = renumbered_on_device ? 1.0 : 0.0;
+        if (!built_on_device || (rep.applied && !renumbered_on_device)) {  // the device does not hold the pattern (in this numbering) yet
             OGL_TRY(reg->stager.h2d(d_row_ptrs.p, pat.row_ptrs.data(),
                                     pat.row_ptrs.size() * sizeof(int32_t), st));
             OGL_TRY(reg->stager.h2d(d_cols.p, pat.cols.data(), nnz * sizeof(int32_t), st));

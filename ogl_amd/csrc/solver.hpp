@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <string>
@@ -45,6 +46,11 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+    }
+    void swap(DevBuf &o)
+    {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
     }
     // (re)allocate `count` elements, zero-filled
     int alloc(size_t count, hipStream_t st)
@@ -220,6 +226,11 @@ struct ogl_solver {
     int build_pattern_on_device(const ogl_ldu_view &ldu, ogl::HostPattern &np, bool *built);
     int build_sym_on_device(const ogl::HostPattern &np, ogl::SymDistances *sd_out, bool *done);
     int download_local_pattern(ogl::HostPattern &hp);
+    // reverse Cuthill-McKee of the device pattern (same order as rcm_order); new_id stays empty when the graph
+    // is not one for a level-synchronous search (very many components or levels): the host does it then
+    int rcm_on_device(const ogl::HostPattern &hp, std::vector<ogl_label> &new_id);
+    // device pattern rewritten into the numbering new_id (and downloaded into hp for the host-side layout code)
+    int renumber_on_device(ogl::HostPattern &hp, const std::vector<ogl_label> &new_id);
     ogl::DevSym sym() const;
     bool use_sym() const
     {

@@ -141,3 +141,49 @@ def test_pattern_rebuilds_follow_the_addressing(reg, oracle):
         rp, cols, vals = oracle_csr(oracle, case)
         x = rng.uniform(-1, 1, case.n_cells)
         np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+GRAPHS = [
+    ("shuffled", lambda: synthetic.renumber_case(synthetic.poisson_case(24), 4096)),
+    ("box", lambda: synthetic.poisson_block(33, 31, 29)),
+    ("periodic", lambda: synthetic.poisson_block(16, 15, 14, periodic_x=True)),
+    ("random", lambda: synthetic.random_global_case(3000, 3, 900, symmetric=False, seed=5)),
+    ("components", lambda: synthetic.drop_faces_case(synthetic.poisson_block(60, 4, 1), 0.45)),
+    ("voronoi", lambda: synthetic.voronoi_case(20000)),
+    ("long_rows", lambda: synthetic.renumber_case(synthetic.long_rows_case(synthetic.poisson_case(20), 0.05, 20), 512)),
+]
+
+
+@pytest.mark.parametrize("name,make", GRAPHS, ids=[g[0] for g in GRAPHS])
+def test_device_rcm_and_renumbering_equal_the_host_algorithms(reg, oracle, name, make):
+    """renumber on, compressed layout off: the numbering in use is the plain reverse Cuthill-McKee order.  Built
+    level by level on the device it must be the host's rcm_order (ogl_host_rcm) node for node, and the pattern
+    rewritten on the device the host's renumber_pattern."""
+    case = randomise(make(), 13)
+    rp, cols, vals = oracle_csr(oracle, case)
+    out = {}
+    for device in (1.0, 0.0):
+        s = reg.solver(f"ds_rcm_{name}_{int(device)}", cfg(renumber=capi.RENUMBER_ON, compress_indices=0))
+        s.set_property("deviceSetup", device)
+        s.set_matrix(case)
+        assert s.get_property("patternBuiltOnDevice") == device
+        assert s.get_property("renumberedOnDevice") == device
+        out[device] = (s.renumbering(), s.local_matrix())
+    np.testing.assert_array_equal(out[1.0][0], capi.host_rcm(rp, cols))
+    np.testing.assert_array_equal(out[1.0][0], out[0.0][0])
+    for a, b in zip(out[1.0][1], out[0.0][1]):
+        np.testing.assert_array_equal(a, b)
+    # and it is the oracle's matrix permuted by that numbering
+    p_rp, p_cols, p_vals, _ = oracle.permute_csr(rp, cols, vals, out[1.0][0])
+    np.testing.assert_array_equal(out[1.0][1][0], p_rp)
+    np.testing.assert_array_equal(out[1.0][1][1], p_cols)
+    np.testing.assert_array_equal(out[1.0][1][3], p_vals)
+
+
+def test_device_rcm_leaves_chains_to_the_host(reg):
+    """A graph with tens of thousands of breadth-first levels is no work for a level-synchronous search."""
+    case = synthetic.poisson_block(70000, 1, 1)
+    s = reg.solver("ds_chain", cfg(renumber=capi.RENUMBER_ON, compress_indices=0)).set_matrix(case)
+    rp, cols, _, _ = s.local_matrix()
+    assert s.renumbering() is not None
+    assert s.get_property("patternBuiltOnDevice") == 1.0

@@ -54,6 +54,8 @@ def test_stream_kernels_same_bits_as_the_oracle(reg, oracle, layout):
         case = randomise(synthetic.poisson_block(gx=gx, gy=gy, gz=gz), 40 + i)
         rp, cols, vals = oracle_csr(oracle, case)
         out = {}
+        x = rng.uniform(-1, 1, case.n_cells)
+        b = rng.uniform(-1, 1, case.n_cells)
         for forced in (1, 0):
             s = reg.solver(f"stream_{layout}_{forced}", cfg(**LAYOUTS[layout]))
             s.set_property("streamAboveBytes", 0.0 if forced else 1e18)
@@ -64,9 +66,7 @@ def test_stream_kernels_same_bits_as_the_oracle(reg, oracle, layout):
                 ds = sorted({d for d, on in ((1, gx > 1), (gx, gy > 1), (gx * gy, gz > 1)) if on})
                 fast = ds[0] == 1 and all(d % 2 == 0 for d in ds[1:])   # the pair-load instantiation
                 assert s.get_property("spmvSymFast") == float(fast), (gx, gy, gz)
-            x = rng.uniform(-1, 1, case.n_cells)
             np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x), err_msg=str((layout, gx, gy, gz)))
-            b = rng.uniform(-1, 1, case.n_cells)
             xs, perf = s.solve(b, x.copy())
             out[forced] = (xs, s.history().copy())
         A, _ = oracle_matrix(oracle, case)
