@@ -454,16 +454,18 @@ def main():
         b_csr = 12 * n_nnz + 20 * n_rows + 4            # values + columns + row pointers + x + y
         if args.format == "Ell":                        # 7 slots/row -> 84 N + 16 N
             b_csr = (12 * 7 + 16) * n_rows
-        layout = {0.0: "csr", 1.0: "ell", 2.0: "sell"}[sv.get_property("spmvLayout")]
+        layout = {0.0: "csr", 1.0: "ell", 2.0: "sell", 3.0: "csr21"}[sv.get_property("spmvLayout")]
         if layout == "sell" and prop_or(sv, "symmetricHalf", 0.0) == 1.0:
             layout = "sym"   # half storage of a symmetric matrix on a banded pattern (diagonal + upper planes)
         stream = "true" if prop_or(sv, "spmvStream", 0.0) == 1.0 else "false"
-        kernel = {"csr": f"k_spmv_stream<0, 1, {stream}>", "ell": f"k_spmv_ell<0, 1, {stream}>",
+        kernel = {"csr": f"k_spmv_stream<0, 1, {stream}>", "csr21": f"k_spmv_stream21<0, 1, {stream}>",
+                  "ell": f"k_spmv_ell<0, 1, {stream}>",
                   "sell": f"k_spmv_sell<0, 1, {stream}>",
                   "sym": f"k_spmv_sym<0, 1, {int(prop_or(sv, 'spmvSymPlanes', 0))}, "
                          f"{'true' if prop_or(sv, 'spmvSymFast', 0.0) == 1.0 else 'false'}, {stream}>"}[layout]
         # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
-        b_moved = (sv.get_property("sellMatrixBytes") + 16 * n_rows) if layout in ("sell", "sym") else b_csr
+        b_moved = ((sv.get_property("sellMatrixBytes") + 16 * n_rows) if layout in ("sell", "sym") else
+                   (sv.get_property("csr21MatrixBytes") + 16 * n_rows) if layout == "csr21" else b_csr)
         traffic, traffic_src = pmc_traffic(kernel, pmc_variant) if pmc_variant is not None else (None, None)
         moved = b_moved / (spmv_ms * 1e-3) / 1e9
         return layout, b_moved, b_csr, {
@@ -622,6 +624,8 @@ def main():
                                   "as the lduMatrix holds it; lower entries read where their twins live) next to "
                                   "the persistent fp64/int32 device CSR",
                            "csr": "fp64/int32 persistent device CSR (CSR-stream SpMV)",
+                           "csr21": "fp64 persistent device CSR values, columns as 21-bit offsets packed six to a "
+                                    "16-byte word (CSR-stream SpMV)",
                            "ell": "fp64/int32 ELL copy of the persistent device CSR"}[layout]
                         + (", device copy renumbered by the library (RCM)" if renumbered else "")
                         + (" (BASELINE.json configs[1])" if not (args.voronoi or args.shuffle or args.drop_faces
@@ -630,7 +634,8 @@ def main():
             "renumber": args.renumber, "renumbered": renumbered,
             "rows_sorted_by_length": prop_or(s, "rowsSortedByLength", 0.0) == 1.0,
             # irregular patterns: both SpMV kernels timed once per pattern at set_matrix, the faster one runs
-            "layout_tuned_us": ({"csr": prop_or(s, "spmvTunedCsrUs", None), "sell": prop_or(s, "spmvTunedSellUs", None)}
+            "layout_tuned_us": ({"csr": prop_or(s, "spmvTunedCsrUs", None), "sell": prop_or(s, "spmvTunedSellUs", None),
+                                 "csr21": prop_or(s, "spmvTunedCsr21Us", None)}
                                 if prop_or(s, "spmvTunedCsrUs", None) is not None else None),
             "spilled_entries": prop_or(s, "sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
@@ -650,6 +655,7 @@ def main():
                       "where its upper twin lives (same bits in y)",
                "sell": "an index-compressed copy of the CSR arrays",
                "ell": "slot-major planes of the CSR arrays",
+               "csr21": "the CSR values and row pointers with the columns packed to 21 bits",
                "csr": "the CSR arrays themselves (= SURVEY.md 8(d)'s figure)"}[layout]
             + "; csr_equivalent_*: the same time priced in SURVEY.md 8(d)'s CSR bytes, a rate of work that exceeds "
               "the bandwidth when the layout moves fewer bytes than a CSR would")),

@@ -25,6 +25,17 @@ constexpr int CHUNK_ROWS = 512;
 constexpr int ROWS_PER_THREAD = CHUNK_ROWS / BLOCK;
 // Non-zeros staged through LDS per pass of the SpMV (products, 8 B each).
 constexpr int SPMV_TILE = 4096;
+// CSR-stream with packed columns (DevCsr::codes21; irregular patterns whose rows are too long / too uneven for the
+// chunked ELL, e.g. polyhedral meshes): the values stay the plain CSR array, the columns of a chunk are kept as
+// 21-bit offsets from the chunk's smallest column, six to a 16-byte word, in the order the lanes of the kernel
+// consume them -- 10.67 instead of 12 bytes per entry.  Needs every chunk's columns within a window of 2^21.
+constexpr int STREAM21_TILE = 3072;                 // entries per pass: 256 lanes x 2 groups x 6 entries
+constexpr int STREAM21_GROUPS = STREAM21_TILE / (BLOCK * 6);
+constexpr int STREAM21_BITS = 21;
+struct Stream21Chunk {  // per chunk
+    int32_t base;       // smallest column of the chunk
+    int32_t word_off;   // first 16-byte code word of the chunk
+};
 // Vector loads read up to 3 entries past a tile end: value/column arrays carry this much padding.
 constexpr int NNZ_PAD = 8;
 

@@ -221,6 +221,110 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     }
 }
 
+// The same with the columns read from the packed stream (Stream21Chunk, common.hpp): one 16-byte word brings the
+// six columns a lane needs for a group -- entries (k * 512 + 2 * lane, + 1), k = 0..2, of the group's 1536 -- as
+// 21-bit offsets from the chunk's smallest column.  Values, row phase and sums as above: same bits.
+template <int MODE, int NDOT, bool STREAM>
+__global__ __launch_bounds__(BLOCK) void k_spmv_stream21(
+    int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const Stream21Chunk *__restrict__ chunks21,
+    const uint4 *__restrict__ codes, const double *__restrict__ vals, const double *__restrict__ x,
+    const double *__restrict__ b, double *__restrict__ y, const double *__restrict__ w,
+    double *__restrict__ dot_partials, double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup)
+{
+    __shared__ __attribute__((aligned(16))) double prod[STREAM21_TILE];
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = xcd_chunk(blockIdx.x, xgroup);
+    if (chunk >= n_chunks) return;
+    const int tid = threadIdx.x;
+    const int r0 = chunk * CHUNK_ROWS;
+    const int r1 = min(r0 + CHUNK_ROWS, n_rows);
+    const int nz0 = row_ptrs[r0];
+    const int nz1 = row_ptrs[r1];
+    const Stream21Chunk ck = chunks21[chunk];
+    const int row = r0 + tid * ROWS_PER_THREAD;
+    int rs[ROWS_PER_THREAD + 1];
+#pragma unroll
+    for (int j = 0; j <= ROWS_PER_THREAD; ++j) rs[j] = row_ptrs[min(row + j, r1)];
+    double acc[ROWS_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_THREAD; ++j)
+        acc[j] = (MODE == SPMV_RESIDUAL && row + j < r1) ? b[row + j] : 0.0;
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const uint4 *cw = codes + ck.word_off + tid;
+    constexpr unsigned long long M = (1ull << STREAM21_BITS) - 1;
+    int tile = 0;
+    for (int t0 = nz0 & ~3; t0 < nz1; t0 += STREAM21_TILE, ++tile) {
+        d2v va[STREAM21_GROUPS][3];
+        u4v cc[STREAM21_GROUPS];
+#pragma unroll
+        for (int g = 0; g < STREAM21_GROUPS; ++g) {
+            const u4v *cp = reinterpret_cast<const u4v *>(cw + (long)(tile * STREAM21_GROUPS + g) * BLOCK);
+            cc[g] = STREAM ? __builtin_nontemporal_load(cp) : *cp;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = t0 + ((g * 3 + k) * BLOCK + tid) * 2;
+                const int ec = e < nz1 ? e : t0;  // clamp: stay inside the (padded) array
+                va[g][k] = STREAM ? __builtin_nontemporal_load(reinterpret_cast<const d2v *>(vals + ec))
+                                  : *reinterpret_cast<const d2v *>(vals + ec);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < STREAM21_GROUPS; ++g) {
+            const unsigned long long lo = (unsigned long long)cc[g].x | ((unsigned long long)cc[g].y << 32);
+            const unsigned long long hi = (unsigned long long)cc[g].z | ((unsigned long long)cc[g].w << 32);
+            int c[6];
+            c[0] = ck.base + (int)(lo & M);
+            c[1] = ck.base + (int)((lo >> 21) & M);
+            c[2] = ck.base + (int)((lo >> 42) & M);
+            c[3] = ck.base + (int)(((lo >> 63) | (hi << 1)) & M);
+            c[4] = ck.base + (int)((hi >> 20) & M);
+            c[5] = ck.base + (int)((hi >> 41) & M);
+            double xv[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xv[i] = x[c[i]];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double2 p0;
+                p0.x = va[g][k].x * xv[2 * k];
+                p0.y = va[g][k].y * xv[2 * k + 1];
+                *reinterpret_cast<double2 *>(prod + ((g * 3 + k) * BLOCK + tid) * 2) = p0;
+            }
+        }
+        __syncthreads();
+        const int t1 = t0 + STREAM21_TILE;
+#pragma unroll
+        for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+            const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
+            for (int k = kb; k < ke; ++k) {
+                if (MODE == SPMV_RESIDUAL)
+                    acc[j] -= prod[k - t0];
+                else
+                    acc[j] += prod[k - t0];
+            }
+        }
+        __syncthreads();
+    }
+    double d = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+        if (row + j < r1) {
+            y[row + j] = acc[j];
+            if (NDOT >= 1) d += w[row + j] * acc[j];
+            if (NDOT >= 2) d2 += acc[j] * acc[j];
+        }
+    }
+    if (NDOT >= 1) {
+        const double s = block_sum(d, slot);
+        if (tid == 0) dot_partials[chunk] = s;
+    }
+    if (NDOT >= 2) {
+        const double s = block_sum(d2, slot);
+        if (tid == 0) dot2_partials[chunk] = s;
+    }
+}
+
 // y[row] (+/-)= A_non_local(row,:) * recv, continuing the accumulator the local kernel stored.
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_spmv_non_local(int n_boundary,
@@ -2201,12 +2305,19 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
 #define OGL_SPMV_K(MODE, NDOT, STREAM)                                                                     \
     hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
                        A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg)
-#define OGL_SPMV(MODE, NDOT)               \
-    do {                                   \
-        if (A.stream)                      \
-            OGL_SPMV_K(MODE, NDOT, true);  \
-        else                               \
-            OGL_SPMV_K(MODE, NDOT, false); \
+#define OGL_SPMV21_K(MODE, NDOT, STREAM)                                                                   \
+    hipLaunchKernelGGL((k_spmv_stream21<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs, \
+                       A.chunks21, A.codes21, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg)
+#define OGL_SPMV(MODE, NDOT)                 \
+    do {                                     \
+        if (A.codes21 && A.stream)           \
+            OGL_SPMV21_K(MODE, NDOT, true);  \
+        else if (A.codes21)                  \
+            OGL_SPMV21_K(MODE, NDOT, false); \
+        else if (A.stream)                   \
+            OGL_SPMV_K(MODE, NDOT, true);    \
+        else                                 \
+            OGL_SPMV_K(MODE, NDOT, false);   \
     } while (0)
     if (mode == SPMV_RESIDUAL) {
         OGL_SPMV(SPMV_RESIDUAL, 0);
@@ -2219,6 +2330,7 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
     }
 #undef OGL_SPMV
 #undef OGL_SPMV_K
+#undef OGL_SPMV21_K
 }
 
 void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,

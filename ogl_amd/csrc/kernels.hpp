@@ -48,6 +48,9 @@ struct DevCsr {
     // consecutive chunks one XCD takes before the next XCD's group starts (0: the built-in 4).  Large groups
     // (slabs of tens of thousands of rows) keep the x window of an irregular pattern in ONE L2
     int32_t xcd_group = 0;
+    // packed columns (Stream21Chunk, common.hpp): when set, the kernel reads these instead of `cols`
+    const Stream21Chunk *chunks21 = nullptr;
+    const uint4 *codes21 = nullptr;
 };
 
 // Rows that own non-local entries, for "y += A_non_local * recv" (distributed::Matrix::apply).

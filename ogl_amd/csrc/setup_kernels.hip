@@ -383,6 +383,73 @@ __global__ __launch_bounds__(BLOCK) void k_renumber_fill(RenumberWork w)
     w.diag_pos_out[k] = dp;
 }
 
+// ---- packed columns for the CSR-stream kernel ----
+__global__ __launch_bounds__(BLOCK) void k_s21_plan(Stream21Build b, int n_chunks_)
+{
+    __shared__ int smin[BLOCK / WAVE], smax[BLOCK / WAVE];
+    const int c = blockIdx.x;
+    if (c >= n_chunks_) return;
+    const int r0 = c * CHUNK_ROWS, r1 = min(r0 + CHUNK_ROWS, b.n_rows);
+    const int nz0 = b.row_ptrs[r0], nz1 = b.row_ptrs[r1];
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int e = nz0 + threadIdx.x; e < nz1; e += BLOCK) {
+        const int col = b.cols[e];
+        lo = min(lo, col);
+        hi = max(hi, col);
+    }
+#pragma unroll
+    for (int off = WAVE / 2; off >= 1; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, WAVE));
+        hi = max(hi, __shfl_xor(hi, off, WAVE));
+    }
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        smin[threadIdx.x / WAVE] = lo;
+        smax[threadIdx.x / WAVE] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLOCK / WAVE; ++w) {
+            lo = min(lo, smin[w]);
+            hi = max(hi, smax[w]);
+        }
+        if (nz1 == nz0) lo = hi = 0;
+        if ((long)hi - (long)lo >= (1L << STREAM21_BITS)) b.flags[0] = 1;
+        b.chunks[c].base = lo;
+        const int t0 = nz0 & ~3;
+        const int tiles = nz1 > nz0 ? (nz1 - t0 + STREAM21_TILE - 1) / STREAM21_TILE : 0;
+        b.words[c] = tiles * STREAM21_GROUPS * BLOCK;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_s21_fill(Stream21Build b, int n_chunks_, uint4 *__restrict__ codes)
+{
+    const int c = blockIdx.x;
+    if (c >= n_chunks_) return;
+    const int r0 = c * CHUNK_ROWS, r1 = min(r0 + CHUNK_ROWS, b.n_rows);
+    const int nz0 = b.row_ptrs[r0], nz1 = b.row_ptrs[r1];
+    const int base = b.chunks[c].base, word_off = b.words[c];
+    if (threadIdx.x == 0) b.chunks[c].word_off = word_off;
+    const int tid = threadIdx.x;
+    int tile = 0;
+    for (int t0 = nz0 & ~3; t0 < nz1; t0 += STREAM21_TILE, ++tile)
+        for (int g = 0; g < STREAM21_GROUPS; ++g) {
+            unsigned long long code[6];
+            for (int k = 0; k < 3; ++k)
+                for (int j = 0; j < 2; ++j) {
+                    const int e = t0 + ((g * 3 + k) * BLOCK + tid) * 2 + j;
+                    code[2 * k + j] = (e >= nz0 && e < nz1) ? (unsigned long long)(b.cols[e] - base) : 0ull;
+                }
+            const unsigned long long lo = code[0] | (code[1] << 21) | (code[2] << 42) | (code[3] << 63);
+            const unsigned long long hi = (code[3] >> 1) | (code[4] << 20) | (code[5] << 41);
+            uint4 w;
+            w.x = (unsigned)lo;
+            w.y = (unsigned)(lo >> 32);
+            w.z = (unsigned)hi;
+            w.w = (unsigned)(hi >> 32);
+            codes[(size_t)word_off + (size_t)(tile * STREAM21_GROUPS + g) * BLOCK + tid] = w;
+        }
+}
+
 }  // namespace
 
 size_t scan_tmp_len(int64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
@@ -485,6 +552,21 @@ void launch_renumber_pattern(hipStream_t st, const RenumberWork &w)
     hipLaunchKernelGGL(k_renumber_lens, dim3(blocks_for(w.n_rows)), dim3(BLOCK), 0, st, w);
     launch_exclusive_scan(st, w.row_ptrs_out, w.row_ptrs_out, w.n_rows, w.scan_tmp);
     hipLaunchKernelGGL(k_renumber_fill, dim3(blocks_for(w.n_rows)), dim3(BLOCK), 0, st, w);
+}
+
+void launch_stream21_plan(hipStream_t st, const Stream21Build &b)
+{
+    const int nc = (int)n_chunks(b.n_rows);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_s21_plan, dim3(nc), dim3(BLOCK), 0, st, b, nc);
+    launch_exclusive_scan(st, b.words, b.words, nc, b.scan_tmp);
+}
+
+void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes)
+{
+    const int nc = (int)n_chunks(b.n_rows);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_s21_fill, dim3(nc), dim3(BLOCK), 0, st, b, nc, codes);
 }
 
 }  // namespace ogl

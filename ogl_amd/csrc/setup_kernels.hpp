@@ -102,4 +102,17 @@ struct RenumberWork {
 };
 void launch_renumber_pattern(hipStream_t st, const RenumberWork &w);
 
+// ---- packed columns of the CSR-stream kernel (Stream21Chunk, common.hpp) ----
+struct Stream21Build {
+    int32_t n_rows = 0;
+    const int32_t *row_ptrs = nullptr, *cols = nullptr;
+    Stream21Chunk *chunks = nullptr;  // [n_chunks] out
+    int32_t *words = nullptr;         // [n_chunks + 1] scratch: code words per chunk, then their offsets; [n_chunks] = total
+    int32_t *scan_tmp = nullptr;      // [scan_tmp_len(n_chunks)]
+    int32_t *flags = nullptr;         // [1] zeroed by the caller; set when a chunk's columns span 2^21 or more
+};
+// per chunk: smallest column, code words needed; offsets by a scan (read words[n_chunks] and flags[0] afterwards)
+void launch_stream21_plan(hipStream_t st, const Stream21Build &b);
+void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes);
+
 }  // namespace ogl

@@ -402,7 +402,54 @@ DevCsr ogl_solver::csr() const
     A.vals = d_vals.p;
     A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows > stream_above_bytes();
     A.xcd_group = xcd_group();
+    if (s21_use && s21_state == 1) {
+        A.chunks21 = d_s21_chunks.p;
+        A.codes21 = d_s21_codes.p;
+    }
     return A;
+}
+
+// Packed columns for the CSR-stream kernel, from the device pattern (setup_kernels.hip).  The values stay the
+// CSR array: nothing to refresh per coefficient update.
+int ogl_solver::build_stream21()
+{
+    hipStream_t st = reg->stream;
+    s21_state = -1;
+    s21_use = false;
+    const int32_t N = pat.n_rows;
+    const size_t nc = (size_t)n_chunks(N);
+    if (N == 0) return OGL_OK;
+    DevBuf<int32_t> words, tmp, flags;
+    OGL_TRY(d_s21_chunks.alloc(nc, st));
+    OGL_TRY(words.alloc(nc + 1, st));
+    OGL_TRY(tmp.alloc(scan_tmp_len((int64_t)nc), st));
+    OGL_TRY(flags.alloc(1, st));
+    Stream21Build b;
+    b.n_rows = N;
+    b.row_ptrs = d_row_ptrs.p;
+    b.cols = d_cols.p;
+    b.chunks = d_s21_chunks.p;
+    b.words = words.p;
+    b.scan_tmp = tmp.p;
+    b.flags = flags.p;
+    launch_stream21_plan(st, b);
+    int32_t total = 0, flag = 0;
+    OGL_HIP_CHECK(hipMemcpyAsync(&total, words.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    OGL_HIP_CHECK(hipMemcpyAsync(&flag, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    if (flag || total < 0) {
+        d_s21_chunks.release();
+        return OGL_OK;
+    }
+    OGL_TRY(d_s21_codes.alloc((size_t)total + 1, st));
+    launch_stream21_fill(st, b, d_s21_codes.p);
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    OGL_HIP_CHECK(hipGetLastError());
+    s21_state = 1;
+    // bytes one SpMV reads of this layout: values + code words + row pointers + chunk headers
+    props["csr21MatrixBytes"] = 8.0 * (double)pat.local_nnz + 16.0 * (double)total + 4.0 * ((double)N + 1.0) + 8.0 * (double)nc;
+    return OGL_OK;
 }
 
 DevEll ogl_solver::ell() const
@@ -928,14 +975,19 @@ int ogl_solver::tune_spmv_layout()
     dots.with = d_p.p;
     dots.part = d_part0.p;
     constexpr int WARM = 2, TIMED = 5;
-    float best[2] = {1e30f, 1e30f};  // [0] CSR-stream, [1] compressed
+    // [0] CSR-stream, [1] compressed chunked ELL, [2] CSR-stream with packed columns
+    const bool have[3] = {true, sell_state == 1 && !sell_values_stale, s21_state == 1};
+    float best[3] = {1e30f, 1e30f, 1e30f};
     for (int round = 0; round < WARM + TIMED; ++round)
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 0; which < 3; ++which) {
+            if (!have[which]) continue;
             OGL_HIP_CHECK(hipEventRecord(ev[0], st));
-            if (which)
+            if (which == 1) {
                 launch_spmv_sell(st, sell(), SPMV_PLAIN, d_p.p, nullptr, d_q.p, dots, nullptr);
-            else
+            } else {
+                s21_use = which == 2;
                 launch_spmv(st, csr(), SPMV_PLAIN, d_p.p, nullptr, d_q.p, dots, nullptr);
+            }
             OGL_HIP_CHECK(hipEventRecord(ev[1], st));
             OGL_HIP_CHECK(hipEventSynchronize(ev[1]));
             float ms = 0;
@@ -943,11 +995,17 @@ int ogl_solver::tune_spmv_layout()
             if (round >= WARM) best[which] = std::min(best[which], ms);
         }
     OGL_HIP_CHECK(hipGetLastError());
-    sell_tuned = best[1] <= best[0] ? 1 : -1;
+    int winner = 0;
+    for (int which = 1; which < 3; ++which)
+        if (have[which] && best[which] <= best[winner]) winner = which;
+    layout_tuned = true;
+    sell_tuned = winner == 1 ? 1 : -1;
+    s21_use = winner == 2;
     props["spmvTunedCsrUs"] = 1e3 * best[0];
-    props["spmvTunedSellUs"] = 1e3 * best[1];
-    if (sell_tuned < 0) {  // the compressed copy is of no use for this pattern: no refreshes, no memory
-        OGL_HIP_CHECK(hipStreamSynchronize(st));
+    if (have[1]) props["spmvTunedSellUs"] = 1e3 * best[1];
+    if (have[2]) props["spmvTunedCsr21Us"] = 1e3 * best[2];
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    if (have[1] && sell_tuned < 0) {  // the compressed copy is of no use for this pattern: no refreshes, no memory
         for (auto *b : {&d_sell_dict, &d_sell_map, &d_spill_rows, &d_spill_ptrs, &d_spill_cols, &d_spill_map,
                         &d_spill_chunks})
             b->release();
@@ -957,6 +1015,11 @@ int ogl_solver::tune_spmv_layout()
         d_spill_vals.release();
         n_spill = n_spill_rows = 0;
         sell_state = -1;
+    }
+    if (have[2] && !s21_use) {
+        d_s21_chunks.release();
+        d_s21_codes.release();
+        s21_state = -1;
     }
     return OGL_OK;
 }
@@ -1162,6 +1225,11 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         ell_ready = false;
         sell_state = 0;
         sym_state = 0;
+        s21_state = 0;
+        s21_use = false;
+        layout_tuned = false;
+        d_s21_chunks.release();
+        d_s21_codes.release();
         x_resident = b_resident = false;
         props["renumberedOnDevice"] = renumbered_on_device ? 1.0 : 0.0;
         if (!built_on_device || (rep.applied && !renumbered_on_device)) {  // the device does not hold the pattern (in this numbering) yet
@@ -1294,13 +1362,22 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             if (n_spill) launch_gather_coeffs(st, n_spill, d_spill_map.p, d_vals.p, d_spill_vals.p);
             sell_values_stale = false;
         }
-        if (sell_state == 1 && sell_tuned == 0 && sell_irregular && cfg.compress_indices == 1 &&
-            pat.n_rows >= SPMV_TUNE_MIN_ROWS)
+        // irregular patterns (16 / 32-bit codes in the chunked ELL, or one that does not qualify for it at all: a
+        // polyhedral mesh) of a size where the SpMV is not launch-bound: the CSR-stream kernel gets its packed
+        // columns, and the candidates are timed once per pattern
+        const bool big = pat.n_rows >= SPMV_TUNE_MIN_ROWS;
+        const bool irregular_sell = sell_state == 1 && sell_irregular;
+        if (big && s21_state == 0 && (irregular_sell || sell_state == -1)) OGL_TRY(build_stream21());
+        if (big && cfg.compress_indices == 1 && !layout_tuned && (irregular_sell || s21_state == 1))
             OGL_TRY(tune_spmv_layout());
+        if (cfg.compress_indices == 2) s21_use = s21_state == 1 && sell_state != 1;  // force: no timing
     }
     // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
     // (2 also for the half storage of a symmetric matrix: property symmetricHalf tells them apart)
-    props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : ((use_sell() || use_sym()) ? 2.0 : 0.0);
+    // 3: CSR-stream with packed columns
+    const bool on_csr = cfg.matrix_format != OGL_FORMAT_ELL && !use_sell() && !use_sym();
+    if (!cfg.compress_indices) s21_use = false;
+    props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : (!on_csr ? 2.0 : (s21_use && s21_state == 1 ? 3.0 : 0.0));
     {   // ... and which instantiation of its kernel (what a profiler lists; bench.py looks up exactly that one)
         bool stream = false, fast = false;
         if (cfg.matrix_format == OGL_FORMAT_ELL) {
@@ -1940,7 +2017,8 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_row_ptrs.p, (uintptr_t)d_cols.p, (uintptr_t)d_vals.p,
             (uintptr_t)d_sell_chunks.p, (uintptr_t)d_sell_dict.p, (uintptr_t)d_sell_codes.p,
             (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
-            (uintptr_t)ell_width, (uintptr_t)ell_stride};
+            (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
+            (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
             cg_graph = nullptr;

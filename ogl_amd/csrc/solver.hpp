@@ -259,7 +259,16 @@ struct ogl_solver {
     // -1 = the CSR-stream kernel is.  The results are bit-identical either way.
     bool sell_irregular = false;
     int sell_tuned = 0;
+    bool layout_tuned = false;  // tune_spmv_layout has run for this pattern
     int tune_spmv_layout();
+    // packed columns for the CSR-stream kernel (Stream21Chunk, common.hpp): built for irregular patterns of
+    // >= SPMV_TUNE_MIN_ROWS rows when compress_indices is set; s21_use: the in-loop CSR-stream SpMV reads them
+    // (it won the one-off timing, or compress_indices = force and the chunked ELL does not qualify)
+    ogl::DevBuf<ogl::Stream21Chunk> d_s21_chunks;
+    ogl::DevBuf<uint4> d_s21_codes;
+    int s21_state = 0;  // 0 not tried for this pattern, 1 built, -1 a chunk's columns span 2^21 or more
+    bool s21_use = false;
+    int build_stream21();
     // `pre` != nullptr: the layout choose_numbering already derived for this pattern
     // (`pre_qualifies` tells whether it is usable)
     int build_sell(ogl::SellLayout *pre = nullptr, bool pre_qualifies = false);

@@ -100,3 +100,39 @@ def test_the_mechanisms_are_really_in_play(reg):
     assert got["long_rows"]["sellSpilledEntries"] > 0 or got["long_rows_shuffled"]["sellSpilledEntries"] > 0, got
     assert any(g["rowsSortedByLength"] == 1.0 for g in got.values()), got
     assert any(g["sellChunksDelta16"] + g["sellChunksCol32"] > 0 for g in got.values()), got
+
+
+def test_packed_columns_of_the_csr_stream_kernel(reg, oracle):
+    """A polyhedral mesh does not qualify for the chunked ELL; with compressIndices the CSR-stream kernel then reads
+    its columns as 21-bit offsets packed six to a word (k_spmv_stream21).  Plain, residual and two-dot (BiCGStab)
+    instantiations, with and without the cache-bypassing loads, against the oracle on the reported numbering."""
+    import copy
+    base = proxy("voronoi")
+    rng = np.random.default_rng(7)
+    for asym in (False, True):
+        case = copy.deepcopy(base)
+        case.upper[:] = rng.uniform(-1.0, -0.25, case.upper.size)
+        case.diag[:] = rng.uniform(20.0, 24.0, case.n_cells)
+        if asym:
+            case.lower = rng.uniform(-1.0, -0.25, case.upper.size)
+        for stream in (0.0, 1e18):
+            cfg = capi.default_config(solver=capi.SOLVER_BICGSTAB if asym else capi.SOLVER_CG,
+                                      preconditioner=capi.PRECOND_BJ, tolerance=0.0, rel_tol=0.0, max_iter=10,
+                                      export_res=1, matrix_format=capi.FORMAT_CSR, adapt_min_iter=0,
+                                      compress_indices=2, renumber=capi.RENUMBER_AUTO)
+            s = reg.solver(f"packed_{int(asym)}_{int(stream > 0)}", cfg)
+            s.set_property("streamAboveBytes", stream)
+            s.set_matrix(case)
+            assert s.get_property("spmvLayout") == 3.0
+            new_id = s.renumbering()
+            A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+            x = rng.uniform(-1, 1, case.n_cells)
+            np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, to_new(x, new_id))[new_id])
+            b = rng.uniform(-1, 1, case.n_cells)
+            xs, perf = s.solve(b, x.copy())
+            fn = oracle.bicgstab if asym else oracle.cg
+            with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+                ref = fn(A, to_new(b, new_id), to_new(x, new_id), oracle.jacobi_generate_scalar(rp, cols, vals),
+                         tolerance=0.0, rel_tol=0.0, max_iter=10)
+            np.testing.assert_array_equal(s.history(), ref.history)
+            np.testing.assert_array_equal(xs, ref.x[new_id])
