@@ -1040,6 +1040,175 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__
     }
 }
 
+__device__ void criterion_check(DevScalars *s, const DevCriterion &c, double norm, double *history);
+
+// ------------------------------------------------------------------------------------------
+// Small systems (a turn of a 64^3 case is 5 dependent launches of ~4.5 us for ~6 us of memory time): the two
+// single-workgroup finalisers of a GKOCG turn are folded into the kernels that consume their results.  Every
+// workgroup of step_1x / step_2r first reduces the (few hundred) per-chunk partials ITSELF -- with 256 threads
+// walking the 1024-thread tree of k_finalize, so the sums have the same bits -- and runs the scalar logic on its
+// own copy of the solver scalars; workgroup 0 stores the new scalars.  The scalars ping-pong between two slots
+// (a kernel reads `sin`, writes `sout`), so that no workgroup can see them half-way.  Turn = 3 launches:
+//   [check of the previous turn + pending x update + step_1]  ->  SpMV  ->  [beta + step_2r]
+// ------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void reduce_partials_as_finaliser(const double *__restrict__ p0,
+                                                             const double *__restrict__ p1, int m, double *lds,
+                                                             double (&out)[2])
+{
+    // virtual thread v = t + 256 j of the finaliser's 1024: partials v, v + 1024, ... in order; its wavefront
+    // (v / 64 = t / 64 + 4 j) is summed by the xor tree; then the 16 wavefront sums left to right
+    constexpr int VT = FIN_BLOCK / BLOCK;
+    const int t = threadIdx.x;
+    double s[2][VT];
+#pragma unroll
+    for (int j = 0; j < VT; ++j) {
+        s[0][j] = s[1][j] = 0.0;
+        for (int i = t + BLOCK * j; i < m; i += FIN_BLOCK) {
+            s[0][j] += p0[i];
+            if (K > 1) s[1][j] += p1[i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VT; ++j) {
+        s[0][j] = wave_sum(s[0][j]);
+        if (K > 1) s[1][j] = wave_sum(s[1][j]);
+    }
+    if ((t & (WAVE - 1)) == 0) {
+#pragma unroll
+        for (int j = 0; j < VT; ++j) {
+            lds[t / WAVE + N_WAVES * j] = s[0][j];
+            if (K > 1) lds[FIN_WAVES + t / WAVE + N_WAVES * j] = s[1][j];
+        }
+    }
+    __syncthreads();
+    double a = lds[0], b = K > 1 ? lds[FIN_WAVES] : 0.0;
+#pragma unroll
+    for (int w = 1; w < FIN_WAVES; ++w) {
+        a += lds[w];
+        if (K > 1) b += lds[FIN_WAVES + w];
+    }
+    out[0] = a;
+    out[1] = b;
+    __syncthreads();
+}
+static_assert(FIN_BLOCK % BLOCK == 0 && FIN_WAVES == N_WAVES * (FIN_BLOCK / BLOCK), "virtual finaliser threads");
+
+__global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restrict__ p, double *__restrict__ x,
+                                                         const double *__restrict__ r,
+                                                         const double *__restrict__ inv_diag,
+                                                         const DevScalars *sin, DevScalars *sout,
+                                                         const double *__restrict__ part_rho,
+                                                         const double *__restrict__ part_norm, int n_part,
+                                                         double *history, int first)
+{
+    __shared__ double red[2 * FIN_WAVES];
+    __shared__ double sh[4];
+    __shared__ int sh_stop;
+    if (sin->stop) {  // (the solve has ended: hand the scalars on, nothing else)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = *sin;
+        return;
+    }
+    double v[2];
+    reduce_partials_as_finaliser<2>(part_rho, part_norm, n_part, red, v);
+    if (threadIdx.x == 0) {
+        DevScalars L = *sin;
+        L.prev_rho = L.rho;  // swap(prev_rho, rho) of the previous turn
+        L.rho = v[0];
+        criterion_check(&L, L.crit, v[1], blockIdx.x == 0 ? history : nullptr);
+        L.x_pending = 0;
+        sh[0] = L.beta;
+        sh[1] = L.prev_rho;
+        sh[2] = L.rho;
+        sh_stop = L.stop;
+        if (blockIdx.x == 0) *sout = L;
+    }
+    __syncthreads();
+    const double beta = sh[0], prev = sh[1], rho = sh[2];
+    const int stop = sh_stop;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 vp = ld2(p, rp);
+    if (!first && beta != 0.0) {  // x += t_j p of the turn this check closed (same scalars, same bits as step_2)
+        const double t = prev / beta;
+        double2 vx = ld2_stream(x, rp);
+        vx.x += t * vp.x;
+        vx.y += t * vp.y;
+        st2_stream(x, rp, vx);
+    }
+    if (stop) return;
+    const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
+    double2 vz = ld2_stream(r, rp);
+    if (inv_diag) {
+        const double2 vi = ld2_stream(inv_diag, rp);
+        vz.x = vz.x * vi.x;
+        vz.y = vz.y * vi.y;
+    }
+    vp.x = vz.x + tmp * vp.x;
+    vp.y = vz.y + tmp * vp.y;
+    st2(p, rp, vp);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restrict__ r,
+                                                         const double *__restrict__ q,
+                                                         const double *__restrict__ inv_diag,
+                                                         double *__restrict__ part_rho,
+                                                         double *__restrict__ part_norm, const DevScalars *sin,
+                                                         DevScalars *sout, const double *__restrict__ part_beta,
+                                                         int n_part)
+{
+    __shared__ double red[2 * FIN_WAVES];
+    __shared__ double sh[2];
+    __shared__ double slot[N_WAVES];
+    if (sin->stop) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = *sin;
+        return;
+    }
+    double v[2];
+    reduce_partials_as_finaliser<1>(part_beta, nullptr, n_part, red, v);
+    if (threadIdx.x == 0) {
+        sh[0] = sin->rho;
+        sh[1] = v[0];
+        if (blockIdx.x == 0) {
+            DevScalars L = *sin;
+            L.beta = v[0];
+            *sout = L;
+        }
+    }
+    __syncthreads();
+    const double rho = sh[0], beta = sh[1];
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vr = ld2(r, rp);
+    if (beta != 0.0) {
+        const double t = rho / beta;
+        const double2 vq = ld2_stream(q, rp);  // q: last use of this turn
+        vr.x -= t * vq.x;
+        vr.y -= t * vq.y;
+        st2(r, rp, vr);
+    }
+    double2 vz = vr;
+    if (inv_diag) {
+        const double2 vi = ld2(inv_diag, rp);
+        vz.x = vr.x * vi.x;
+        vz.y = vr.y * vi.y;
+    }
+    double d = 0.0, a = 0.0;
+    if (rp.n > 0) {
+        d += vr.x * vz.x;
+        a += fabs(vr.x);
+    }
+    if (rp.n > 1) {
+        d += vr.y * vz.y;
+        a += fabs(vr.y);
+    }
+    const double s0 = block_sum(d, slot);
+    const double s1 = block_sum(a, slot);
+    if (threadIdx.x == 0) {
+        part_rho[chunk] = s0;
+        part_norm[chunk] = s1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // ELL SpMV (matrixFormat Ell).  Slot-major planes: every load is a 16-byte (values) / 8-byte
 // (columns) coalesced access over the chunk's rows, no LDS, no row pointers; a thread owns rows
@@ -2654,6 +2823,26 @@ void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, con
     if (nc == 0) return;
     hipLaunchKernelGGL(k_cg_step2r, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho,
                        part_norm, s);
+}
+
+void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
+                          const DevScalars *sin, DevScalars *sout, const double *part_rho,
+                          const double *part_norm, double *history, int first)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_cg_step1x_fin, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, sin, sout, part_rho,
+                       part_norm, nc, history, first);
+}
+
+void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
+                          double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
+                          const double *part_beta)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_cg_step2r_fin, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho, part_norm, sin,
+                       sout, part_beta, nc);
 }
 
 void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const double *p,

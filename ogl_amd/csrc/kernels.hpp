@@ -221,6 +221,19 @@ void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const dou
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                       double *part_rho, double *part_norm, const DevScalars *s);
 
+// Small systems: the same pair with the finalisers folded in (kernels.hip).  Every workgroup reduces the
+// per-chunk partials itself in the finaliser's order; the scalars are read from `sin` and written to `sout`.
+//   step_1x_fin: check on (part_rho, part_norm) of the previous step_2r (first: of the initial residual), the
+//                pending x update (not when `first`), then step_1
+//   step_2r_fin: beta from part_beta, then step_2r
+void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
+                          const DevScalars *sin, DevScalars *sout, const double *part_rho,
+                          const double *part_norm, double *history, int first);
+void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
+                          double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
+                          const double *part_beta);
+constexpr int FUSED_FIN_MAX_CHUNKS = 1024;  // up to 524,288 rows: one partial per virtual finaliser thread
+
 // --- BiCGStab steps ([UPSTREAM] bicgstab::step_1/2/3, finalize) ---
 void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,
                        const double *inv_diag, double *y, const DevScalars *s);

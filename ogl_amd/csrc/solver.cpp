@@ -1038,7 +1038,8 @@ int ogl_solver::ensure_vectors()
     OGL_TRY(d_w.alloc(n, st));
     OGL_TRY(d_part0.alloc(nc, st));
     OGL_TRY(d_part1.alloc(nc, st));
-    OGL_TRY(d_scal.alloc(1, st));
+    OGL_TRY(d_part2.alloc(nc, st));
+    OGL_TRY(d_scal.alloc(2, st));  // (two slots: the fused-finaliser kernels of small systems ping-pong between them)
     if (!h_scal) {
         OGL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 2 * sizeof(DevScalars), 0));
         for (auto &e : poll_ev) OGL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1739,6 +1740,12 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // block Jacobi (maxBlockSize > 1): z = M^-1 r is materialised by its own kernel; the scalar
     // case stays fused into the step kernels
     const bool generic = precond_data && precond_data->kind >= 2;  // block Jacobi, ISAI, GISAI
+    // small single-rank GKOCG systems: finalisers folded into the step kernels, 3 launches per turn (kernels.hip)
+    const bool fused = !bicg && !gmres && !generic && !reg->comm->multi() && nc >= 1 &&
+                       nc <= (int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS) &&
+                       prop("fusedFinalizers", 1.0) != 0.0;
+    DevScalars *s2 = s + 1;
+    props["fusedFinalizersInUse"] = fused ? 1.0 : 0.0;
 
     // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
     const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
@@ -1887,7 +1894,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     chk.n_part = nc;
     chk.n_sums = 2;
     chk.history = d_history.p;
-    if (!gmres) {
+    if (!gmres && !fused) {  // (fused: this check opens the first step_1x_fin)
         OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
         OGL_TRY(finalize(FIN_CG_CHECK, chk));
         OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
@@ -1956,6 +1963,17 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, nullptr, d_part0.p, d_part1.p, s);
                 apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);  // z = M^-1 r and the partials of r.z
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
+            } else if (!bicg && fused) {
+                // check of the previous turn (or of the initial residual) + pending x update + step_1 | SpMV |
+                // beta + step_2r: the scalars go s -> s2 -> s
+                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
+                launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p,
+                                     enq == 0 ? 1 : 0);
+                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+                OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, s2));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+                launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s2, s, d_part2.p);
             } else if (!bicg) {
                 // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once
                 launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s);
@@ -2006,7 +2024,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // ROCm 7.2 it does not pay: 23.7 us per turn with plain stream launches against 24.2 us replayed
     // at 262k rows, 286.1 against 285.3 us at 10M rows -- the ~4.5 us between two dependent kernels
     // is the device's dispatch latency, not host launch cost, and a graph replays the same packets.
-    const bool graphable = !gmres && !bicg && !generic && !reg->comm->multi() && prof_cap == 0 &&
+    const bool graphable = !gmres && !bicg && !generic && !fused && !reg->comm->multi() && prof_cap == 0 &&
                            prop("hipGraph", 0.0) != 0.0;
     auto enqueue_turns = [&](int count) -> int {
         if (!graphable || count != batch) return enqueue_direct(count);
@@ -2054,12 +2072,16 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         }
         OGL_HIP_CHECK(hipEventSynchronize(poll_ev[k & 1]));
         if (h_scal[k & 1].stop) break;
+        if (!more && fused) break;  // (the check of the last enqueued turn is still to come: below)
         if (!more) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
     }
+    if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
+        launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0);
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
     DevScalars fin;
-    OGL_HIP_CHECK(hipMemcpy(&fin, s, sizeof(fin), hipMemcpyDeviceToHost));
+    OGL_HIP_CHECK(hipMemcpy(&fin, fused ? s2 : s, sizeof(fin), hipMemcpyDeviceToHost));
+    if (fused && !fin.stop) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
     if (fin.comm_error)
         return fail(OGL_ERR_COMM, "peer all-reduce timed out: a rank did not take part (check %d)",
                     fin.iter);

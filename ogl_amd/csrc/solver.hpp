@@ -321,7 +321,7 @@ struct ogl_solver {
     ogl::DevBuf<double> d_v, d_s, d_t, d_y, d_z, d_rr;  // BiCGStab
     ogl::DevBuf<double> d_V, d_gm;                      // GMRES: Krylov bases, dense state
     ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T
-    ogl::DevBuf<double> d_part0, d_part1;
+    ogl::DevBuf<double> d_part0, d_part1, d_part2;  // (part2: beta partials of the fused-finaliser turn)
     ogl::DevBuf<ogl::DevScalars> d_scal;
     ogl::DevBuf<double> d_history;
     ogl::DevScalars *h_scal = nullptr;  // pinned, 2 slots

@@ -27,14 +27,19 @@ def system(oracle):
     return case, b, A, oracle.jacobi_generate_scalar(rp, cols, vals)
 
 
+# fused: small systems fold the finalisers into the step kernels (3 launches per turn, the check of a turn runs
+# at the head of the next step_1x, kernels.hip); 0 = the five-launch turn that larger systems run
+@pytest.mark.parametrize("fused", [1.0, 0.0], ids=["fused", "five_launch"])
 @pytest.mark.parametrize("precond", [capi.PRECOND_BJ, capi.PRECOND_NONE])
 @pytest.mark.parametrize("max_iter", [1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 50])
-def test_stop_by_max_iter_anywhere_in_the_batches(reg, oracle, system, precond, max_iter):
+def test_stop_by_max_iter_anywhere_in_the_batches(reg, oracle, system, precond, max_iter, fused):
     case, b, A, inv = system
     kw = dict(tolerance=0.0, rel_tol=0.0, max_iter=max_iter)
-    s = reg.solver(f"dx_{precond}", capi.default_config(
+    s = reg.solver(f"dx_{precond}_{int(fused)}", capi.default_config(
         solver=capi.SOLVER_CG, preconditioner=precond, export_res=1, adapt_min_iter=0, update_init_guess=1, **kw)).set_matrix(case)
+    s.set_property("fusedFinalizers", fused)
     x, perf = s.solve(b, np.zeros_like(b))
+    assert s.get_property("fusedFinalizersInUse") == fused
     with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
         ref = oracle.cg(A, b, np.zeros_like(b), inv if precond else None, **kw)
     assert perf.n_iterations == ref.n_iterations
@@ -42,13 +47,15 @@ def test_stop_by_max_iter_anywhere_in_the_batches(reg, oracle, system, precond, 
     np.testing.assert_array_equal(x, ref.x)
 
 
+@pytest.mark.parametrize("fused", [1.0, 0.0], ids=["fused", "five_launch"])
 @pytest.mark.parametrize("tol", [1e-1, 1e-3, 1e-6, 1e-10])
-def test_stop_by_tolerance(reg, oracle, system, tol):
+def test_stop_by_tolerance(reg, oracle, system, tol, fused):
     case, b, A, inv = system
     kw = dict(tolerance=tol, rel_tol=0.0, max_iter=500)
-    s = reg.solver("dx_tol", capi.default_config(
+    s = reg.solver(f"dx_tol_{int(fused)}", capi.default_config(
         solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, export_res=1, adapt_min_iter=0,
         update_init_guess=1, **kw)).set_matrix(case)
+    s.set_property("fusedFinalizers", fused)
     x, perf = s.solve(b, np.zeros_like(b))
     with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
         ref = oracle.cg(A, b, np.zeros_like(b), inv, **kw)
@@ -56,15 +63,18 @@ def test_stop_by_tolerance(reg, oracle, system, tol):
     np.testing.assert_array_equal(x, ref.x)
 
 
-def test_converged_initial_guess_leaves_x_alone(reg, oracle, system):
+@pytest.mark.parametrize("fused", [1.0, 0.0], ids=["fused", "five_launch"])
+def test_converged_initial_guess_leaves_x_alone(reg, oracle, system, fused):
     case, b, A, inv = system
     kw = dict(tolerance=1e-6, rel_tol=0.0, max_iter=100)
-    s = reg.solver("dx_conv", capi.default_config(
+    s = reg.solver(f"dx_conv_{int(fused)}", capi.default_config(
         solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, export_res=1, adapt_min_iter=0, **kw)).set_matrix(case)
+    s.set_property("fusedFinalizers", fused)
     x1, _ = s.solve(b, np.zeros_like(b))
     cfg2 = capi.default_config(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, export_res=1,
                                adapt_min_iter=0, update_init_guess=1, **kw)
-    s2 = reg.solver("dx_conv2", cfg2).set_matrix(case)
+    s2 = reg.solver(f"dx_conv2_{int(fused)}", cfg2).set_matrix(case)
+    s2.set_property("fusedFinalizers", fused)
     x2, perf2 = s2.solve(b, x1.copy())
     assert perf2.n_iterations == 1          # the initial check already stops
     np.testing.assert_array_equal(x2, x1)
@@ -80,9 +90,40 @@ def test_hipgraph_replay_gives_the_same_bits(reg, oracle, system):
             solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, export_res=1, adapt_min_iter=0,
             update_init_guess=1, **kw)).set_matrix(case)
         s.set_property("hipGraph", 1.0)
+        s.set_property("fusedFinalizers", 0.0)   # (graphs replay the five-launch turn)
         x, perf = s.solve(b, np.zeros_like(b))
         with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
             ref = oracle.cg(A, b, np.zeros_like(b), inv, **kw)
         assert perf.n_iterations == ref.n_iterations
         np.testing.assert_array_equal(s.history(), ref.history)
         np.testing.assert_array_equal(x, ref.x)
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (33, 31, 29), (64, 64, 64), (80, 81, 80), (1, 1, 1), (700, 1, 1)])
+def test_fused_finalisers_same_bits_as_the_five_launch_turn(reg, oracle, shape):
+    """Every workgroup reducing the partials itself (256 threads walking the finaliser's 1024-thread tree) and the
+    check moved to the head of the next kernel change nothing: history, x, counters, with evalFrequency > 1 and
+    minIter in play, up to the largest system the fused turn takes (1024 chunks) and on the first one it leaves
+    to the five-launch turn."""
+    case = synthetic.poisson_block(*shape)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    variants = [dict(tolerance=1e-9, rel_tol=0.0, max_iter=60), dict(tolerance=1e-12, rel_tol=1e-4, max_iter=200),
+                dict(tolerance=1e-7, rel_tol=0.0, max_iter=90, eval_frequency=3, min_iter=7),
+                dict(tolerance=0.0, rel_tol=0.0, max_iter=23, preconditioner=capi.PRECOND_NONE)]
+    for i, kw in enumerate(variants):
+        out = []
+        for fused in (1.0, 0.0):
+            base = dict(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, export_res=1, adapt_min_iter=0,
+                        update_init_guess=1)
+            base.update(kw)
+            s = reg.solver(f"ff_{i}_{int(fused)}", capi.default_config(**base)).set_matrix(case)
+            s.set_property("fusedFinalizers", fused)
+            x, perf = s.solve(b, np.zeros_like(b))
+            n_chunks = -(-case.n_cells // capi.lib().ogl_reduction_chunk_rows())
+            assert s.get_property("fusedFinalizersInUse") == (fused if n_chunks <= 1024 else 0.0)
+            out.append((x, s.history().copy(), perf.n_iterations, perf.n_norm_evals, perf.initial_residual,
+                        perf.final_residual))
+        np.testing.assert_array_equal(out[0][1], out[1][1], err_msg=str((shape, kw)))
+        np.testing.assert_array_equal(out[0][0], out[1][0], err_msg=str((shape, kw)))
+        assert out[0][2:] == out[1][2:], (shape, kw, out[0][2:], out[1][2:])
