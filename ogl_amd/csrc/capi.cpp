@@ -84,6 +84,9 @@ extern "C" int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n
     OGL_HIP_CHECK(hipSetDevice(reg->device));
     auto c = std::make_unique<RcclComm>();
     OGL_TRY(c->init(rank, n_ranks, id));
+    // collective self-test over the links: a transport that does not deliver known numbers is refused here
+    // (the caller keeps / falls back to the host-buffer transport in-process; nothing is re-exec'ed)
+    OGL_TRY(c->self_test(reg->stream));
     reg->comm = std::move(c);
     return OGL_OK;
     OGL_GUARD_END

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -159,6 +160,51 @@ int RcclComm::init(int r, int n, const void *id_bytes)
     comm_ = c;
     rank = r;
     n_ranks = n;
+    return OGL_OK;
+}
+
+int RcclComm::self_test(hipStream_t st)
+{
+    if (n_ranks < 2) return OGL_OK;
+    double *d = nullptr;
+    OGL_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 8 * sizeof(double)));
+    struct Free {
+        double *p;
+        ~Free() { (void)hipFree(p); }
+    } guard{d};
+    // all-reduce: sum of (rank + 1) and of (rank + 1) / 2 over the ranks
+    const double mine[2] = {rank + 1.0, 0.5 * (rank + 1.0)};
+    OGL_HIP_TRY(hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, st));
+    if (int rc = allreduce(d, 2, st)) return rc;
+    double got[2] = {0, 0};
+    OGL_HIP_TRY(hipMemcpyAsync(got, d, sizeof(got), hipMemcpyDeviceToHost, st));
+    OGL_HIP_TRY(hipStreamSynchronize(st));
+    const double tri = 0.5 * n_ranks * (n_ranks + 1.0);
+    if (got[0] != tri || got[1] != 0.5 * tri)
+        return fail(OGL_ERR_COMM, "RCCL self-test: all-reduce over %d ranks gave %g, %g (expected %g, %g)", n_ranks,
+                    got[0], got[1], tri, 0.5 * tri);
+    // ring: every rank sends 1000 * rank + destination to its two ring neighbours and expects theirs
+    const int prev = (rank + n_ranks - 1) % n_ranks, next = (rank + 1) % n_ranks;
+    std::vector<int> nb, cnt;
+    if (prev == next) {
+        nb = {next};
+    } else {
+        nb = {std::min(prev, next), std::max(prev, next)};
+    }
+    cnt.assign(nb.size(), 1);
+    double send[2] = {0, 0}, want[2] = {0, 0}, recv[2] = {-1, -1};
+    for (size_t i = 0; i < nb.size(); ++i) {
+        send[i] = 1000.0 * rank + nb[i];
+        want[i] = 1000.0 * nb[i] + rank;
+    }
+    OGL_HIP_TRY(hipMemcpyAsync(d + 2, send, sizeof(send), hipMemcpyHostToDevice, st));
+    if (int rc = exchange(d + 2, d + 4, nb, cnt, st)) return rc;
+    OGL_HIP_TRY(hipMemcpyAsync(recv, d + 4, sizeof(recv), hipMemcpyDeviceToHost, st));
+    OGL_HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < nb.size(); ++i)
+        if (recv[i] != want[i])
+            return fail(OGL_ERR_COMM, "RCCL self-test: send/recv with rank %d gave %g (expected %g)", nb[i], recv[i],
+                        want[i]);
     return OGL_OK;
 }
 

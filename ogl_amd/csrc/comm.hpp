@@ -70,6 +70,10 @@ public:
     ~RcclComm() override;
     static int unique_id(void *id_out);
     int init(int rank, int n_ranks, const void *id);
+    // COLLECTIVE, right after init: one ncclAllReduce and one ring of ncclSend / ncclRecv with known values over
+    // the links the solves will use; anything but the expected numbers fails loudly (OGL_ERR_COMM) here, not as
+    // a wrong residual later
+    int self_test(hipStream_t st);
     int allreduce(double *dev, int n, hipStream_t st) override;
     int exchange(const double *send, double *recv, const std::vector<int> &neighbours,
                  const std::vector<int> &counts, hipStream_t st) override;

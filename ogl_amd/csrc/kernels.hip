@@ -1051,32 +1051,42 @@ __device__ void criterion_check(DevScalars *s, const DevCriterion &c, double nor
 // (a kernel reads `sin`, writes `sout`), so that no workgroup can see them half-way.  Turn = 3 launches:
 //   [check of the previous turn + pending x update + step_1]  ->  SpMV  ->  [beta + step_2r]
 // ------------------------------------------------------------------------------------------
+constexpr int FIN_VT = FIN_BLOCK / BLOCK;  // virtual finaliser threads per thread
+// the partials this thread's virtual threads own (at most one each: n_part <= FIN_BLOCK), asked for early
 template <int K>
-__device__ __forceinline__ void reduce_partials_as_finaliser(const double *__restrict__ p0,
-                                                             const double *__restrict__ p1, int m, double *lds,
+__device__ __forceinline__ void load_partials_as_finaliser(const double *__restrict__ p0,
+                                                           const double *__restrict__ p1, int m,
+                                                           double (&pv)[2][FIN_VT])
+{
+#pragma unroll
+    for (int j = 0; j < FIN_VT; ++j) {
+        const int i = threadIdx.x + BLOCK * j;
+        pv[0][j] = i < m ? p0[i] : 0.0;
+        pv[1][j] = (K > 1 && i < m) ? p1[i] : 0.0;
+    }
+}
+template <int K>
+__device__ __forceinline__ void reduce_partials_as_finaliser(const double (&pv)[2][FIN_VT], int m, double *lds,
                                                              double (&out)[2])
 {
-    // virtual thread v = t + 256 j of the finaliser's 1024: partials v, v + 1024, ... in order; its wavefront
-    // (v / 64 = t / 64 + 4 j) is summed by the xor tree; then the 16 wavefront sums left to right
-    constexpr int VT = FIN_BLOCK / BLOCK;
+    // virtual thread v = t + 256 j of the finaliser's 1024 sums partials v, v + 1024, ... (here: just v) from 0.0;
+    // its wavefront (v / 64 = t / 64 + 4 j) is summed by the xor tree; then the 16 wavefront sums left to right
     const int t = threadIdx.x;
-    double s[2][VT];
+    double s[2][FIN_VT];
 #pragma unroll
-    for (int j = 0; j < VT; ++j) {
-        s[0][j] = s[1][j] = 0.0;
-        for (int i = t + BLOCK * j; i < m; i += FIN_BLOCK) {
-            s[0][j] += p0[i];
-            if (K > 1) s[1][j] += p1[i];
-        }
+    for (int j = 0; j < FIN_VT; ++j) {
+        const bool has = t + BLOCK * j < m;
+        s[0][j] = has ? 0.0 + pv[0][j] : 0.0;
+        s[1][j] = (K > 1 && has) ? 0.0 + pv[1][j] : 0.0;
     }
 #pragma unroll
-    for (int j = 0; j < VT; ++j) {
+    for (int j = 0; j < FIN_VT; ++j) {
         s[0][j] = wave_sum(s[0][j]);
         if (K > 1) s[1][j] = wave_sum(s[1][j]);
     }
     if ((t & (WAVE - 1)) == 0) {
 #pragma unroll
-        for (int j = 0; j < VT; ++j) {
+        for (int j = 0; j < FIN_VT; ++j) {
             lds[t / WAVE + N_WAVES * j] = s[0][j];
             if (K > 1) lds[FIN_WAVES + t / WAVE + N_WAVES * j] = s[1][j];
         }
@@ -1105,14 +1115,27 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[4];
     __shared__ int sh_stop;
-    if (sin->stop) {  // (the solve has ended: hand the scalars on, nothing else)
-        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = *sin;
+    // everything this workgroup will need is asked for at once -- the scalars, the partials and its own rows of
+    // p, x, r, 1/d: one memory round trip instead of three in a row (scalars -> partials -> vectors)
+    const int stopped = sin->stop;
+    DevScalars L;
+    if (threadIdx.x == 0) L = *sin;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 vp = ld2(p, rp);
+    double2 vx = ld2_stream(x, rp);
+    double2 vz = ld2_stream(r, rp);
+    double2 vi;
+    vi.x = vi.y = 1.0;
+    if (inv_diag) vi = ld2_stream(inv_diag, rp);
+    double pv[2][FIN_VT];
+    load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
+    if (stopped) {  // (the solve has ended: hand the scalars on, nothing else)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = L;
         return;
     }
     double v[2];
-    reduce_partials_as_finaliser<2>(part_rho, part_norm, n_part, red, v);
+    reduce_partials_as_finaliser<2>(pv, n_part, red, v);
     if (threadIdx.x == 0) {
-        DevScalars L = *sin;
         L.prev_rho = L.rho;  // swap(prev_rho, rho) of the previous turn
         L.rho = v[0];
         criterion_check(&L, L.crit, v[1], blockIdx.x == 0 ? history : nullptr);
@@ -1126,20 +1149,15 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
     __syncthreads();
     const double beta = sh[0], prev = sh[1], rho = sh[2];
     const int stop = sh_stop;
-    const RowPair rp = my_rows(blockIdx.x, n);
-    double2 vp = ld2(p, rp);
     if (!first && beta != 0.0) {  // x += t_j p of the turn this check closed (same scalars, same bits as step_2)
         const double t = prev / beta;
-        double2 vx = ld2_stream(x, rp);
         vx.x += t * vp.x;
         vx.y += t * vp.y;
         st2_stream(x, rp, vx);
     }
     if (stop) return;
     const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
-    double2 vz = ld2_stream(r, rp);
     if (inv_diag) {
-        const double2 vi = ld2_stream(inv_diag, rp);
         vz.x = vz.x * vi.x;
         vz.y = vz.y * vi.y;
     }
@@ -1159,36 +1177,43 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restri
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[2];
     __shared__ double slot[N_WAVES];
-    if (sin->stop) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = *sin;
+    // (all loads up front, as in step_1x_fin)
+    const int stopped = sin->stop;
+    DevScalars L;
+    if (threadIdx.x == 0) L = *sin;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vr = ld2(r, rp);
+    const double2 vq = ld2_stream(q, rp);  // q: last use of this turn
+    double2 vi;
+    vi.x = vi.y = 1.0;
+    if (inv_diag) vi = ld2(inv_diag, rp);
+    double pv[2][FIN_VT];
+    load_partials_as_finaliser<1>(part_beta, nullptr, n_part, pv);
+    if (stopped) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = L;
         return;
     }
     double v[2];
-    reduce_partials_as_finaliser<1>(part_beta, nullptr, n_part, red, v);
+    reduce_partials_as_finaliser<1>(pv, n_part, red, v);
     if (threadIdx.x == 0) {
-        sh[0] = sin->rho;
+        sh[0] = L.rho;
         sh[1] = v[0];
         if (blockIdx.x == 0) {
-            DevScalars L = *sin;
             L.beta = v[0];
             *sout = L;
         }
     }
     __syncthreads();
     const double rho = sh[0], beta = sh[1];
-    const int chunk = blockIdx.x;
-    const RowPair rp = my_rows(chunk, n);
-    double2 vr = ld2(r, rp);
     if (beta != 0.0) {
         const double t = rho / beta;
-        const double2 vq = ld2_stream(q, rp);  // q: last use of this turn
         vr.x -= t * vq.x;
         vr.y -= t * vq.y;
         st2(r, rp, vr);
     }
     double2 vz = vr;
     if (inv_diag) {
-        const double2 vi = ld2(inv_diag, rp);
         vz.x = vr.x * vi.x;
         vz.y = vr.y * vi.y;
     }

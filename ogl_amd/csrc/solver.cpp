@@ -218,6 +218,38 @@ int ogl_registry::peer_connect(int rank, int n_ranks, const void *handles)
             return fail(OGL_ERR_COMM, "peer all-reduce self-test failed (round %d: %g %g, timeout %d)",
                         round, got[0], got[1], (int)err);
     }
+    if (n_ranks > 1) {
+        // ... and one put / wait round over the ring, the way the halo exchange moves data: a tagged record stored
+        // into the NEXT rank's control slot by a kernel, the PREVIOUS rank's record awaited in this rank's memory
+        const int next = (rank + 1) % n_ranks, prev = (rank + n_ranks - 1) % n_ranks;
+        const unsigned long long tag = 0xFFFFFFF0ull;  // (no pattern handshake ever uses this epoch)
+        launch_peer_post(stream, peer.box[next] + PEER_BOX_WORDS + (size_t)rank * 4, tag, 1000ull + rank,
+                         2000ull + next, 3000ull);
+        OGL_HIP_CHECK(hipStreamSynchronize(stream));
+        const unsigned long long *src = peer_local + PEER_BOX_WORDS + (size_t)prev * 4;
+        unsigned long long w[4] = {0, 0, 0, 0};
+        const double t0 = now_ms();
+        for (;;) {
+            OGL_HIP_CHECK(hipMemcpy(w, src, sizeof(w), hipMemcpyDeviceToHost));
+            if (w[0] == tag) {
+                OGL_HIP_CHECK(hipMemcpy(w, src, sizeof(w), hipMemcpyDeviceToHost));  // (payload stored before the tag)
+                break;
+            }
+            if (now_ms() - t0 > (double)peer.timeout_ticks / 1e5)
+                return fail(OGL_ERR_COMM, "peer put self-test: nothing arrived from rank %d", prev);
+        }
+        if (w[1] != 1000ull + prev || w[2] != 2000ull + rank || w[3] != 3000ull)
+            return fail(OGL_ERR_COMM, "peer put self-test: record from rank %d is %llu %llu %llu", prev, w[1], w[2], w[3]);
+        // closing all-reduce: nobody leaves (and reuses the control slots) before everybody has read its record
+        const double one = 1.0;
+        OGL_HIP_CHECK(hipMemcpyAsync(d.p, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+        launch_peer_allreduce(stream, peer_next(), d.p, 1, peer_error);
+        double sum = 0;
+        OGL_HIP_CHECK(hipMemcpyAsync(&sum, d.p, sizeof(sum), hipMemcpyDeviceToHost, stream));
+        OGL_HIP_CHECK(hipStreamSynchronize(stream));
+        if (sum != (double)n_ranks) return fail(OGL_ERR_COMM, "peer put self-test: closing all-reduce gave %g", sum);
+        // (the records stay where they are: a pattern handshake compares epochs, which count up from 1)
+    }
     peer_ready = true;
     return OGL_OK;
 }
@@ -1742,7 +1774,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     const bool generic = precond_data && precond_data->kind >= 2;  // block Jacobi, ISAI, GISAI
     // small single-rank GKOCG systems: finalisers folded into the step kernels, 3 launches per turn (kernels.hip)
     const bool fused = !bicg && !gmres && !generic && !reg->comm->multi() && nc >= 1 &&
-                       nc <= (int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS) &&
+                       nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
                        prop("fusedFinalizers", 1.0) != 0.0;
     DevScalars *s2 = s + 1;
     props["fusedFinalizersInUse"] = fused ? 1.0 : 0.0;

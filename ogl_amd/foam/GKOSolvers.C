@@ -63,25 +63,33 @@ struct InstallCommHook {
     {
         OGLDeviceRegistry::commHook() = [](ogl_registry *reg, const dictionary &controls) {
             const bool host = controls.lookupOrDefault<Switch>("forceHostBuffer", false);
-            int rc;
-            if (host) {
-                rc = ogl_registry_set_host_comm(reg, Pstream::myProcNo(), Pstream::nProcs(),
-                                                ogl_allreduce_sum, ogl_neighbour_exchange, nullptr);
-            } else {
+            int rc = OGL_OK;
+            label rccl_ok = 0;
+            if (!host) {
+                // RCCL over xGMI: init runs a collective self-test (one all-reduce, one ring of send / recv with
+                // known values).  A transport that fails it is not used: all ranks step down together to the
+                // host-buffer transport, in this process (nothing is re-exec'ed once the GPU was touched).
                 List<char> id(OGL_RCCL_ID_BYTES, '\0');
                 if (Pstream::master() && ogl_rccl_unique_id(id.begin()) != OGL_OK)
                     FatalErrorInFunction << ogl_last_error() << abort(FatalError);
                 Pstream::scatter(id);
-                rc = ogl_registry_init_rccl(reg, Pstream::myProcNo(), Pstream::nProcs(), id.begin());
+                rccl_ok = ogl_registry_init_rccl(reg, Pstream::myProcNo(), Pstream::nProcs(), id.begin()) == OGL_OK;
+                if (!rccl_ok)
+                    WarningInFunction << "RCCL transport unavailable on this rank: " << ogl_last_error() << endl;
+                reduce(rccl_ok, minOp<label>());
+                if (!rccl_ok) WarningInFunction << "using the host-buffer transport (forceHostBuffer)" << endl;
             }
+            if (!rccl_ok)
+                rc = ogl_registry_set_host_comm(reg, Pstream::myProcNo(), Pstream::nProcs(),
+                                                ogl_allreduce_sum, ogl_neighbour_exchange, nullptr);
             if (rc != OGL_OK) FatalErrorInFunction << ogl_last_error() << abort(FatalError);
-            // Scalar all-reduces and halo puts through peer-written memory over xGMI (hipIpc): opt-in
-            // (`peerAllReduce true`) until a run with one rank per device is on record -- RCCL is the
-            // default transport.  Only tried when every rank sits on the same host (hipIpc does not
-            // cross nodes; without this check the ranks of a multi-node run would sit in the 60 s
-            // self-test time-out before falling back) and with at most 16 ranks.  All-gather the
-            // 64-byte IPC handles, connect (collective self-test), and keep the transport's own
-            // all-reduce and halo exchange if any rank cannot join.
+            // Scalar all-reduces and halo puts through peer-written memory over xGMI (hipIpc), on top of the
+            // transport above (which stays the bootstrap and the fallback): ON by default (`peerAllReduce false`
+            // switches it off) -- connecting runs a collective self-test (two all-reduces through the mailboxes,
+            // one put / wait round over the ring) and any rank that cannot join makes all ranks keep the
+            // transport's own all-reduce and halo exchange.  Only tried when every rank sits on the same host
+            // (hipIpc does not cross nodes; without this check the ranks of a multi-node run would sit in the 60 s
+            // self-test time-out before falling back) and with at most 16 ranks.
             bool one_host = true;
             {
                 List<word> hosts(Pstream::nProcs());
@@ -90,7 +98,7 @@ struct InstallCommHook {
                 Pstream::scatterList(hosts);
                 forAll(hosts, p) one_host = one_host && hosts[p] == hosts[0];
             }
-            if (controls.lookupOrDefault<Switch>("peerAllReduce", false) && one_host &&
+            if (controls.lookupOrDefault<Switch>("peerAllReduce", true) && one_host &&
                 Pstream::nProcs() <= 16) {
                 List<List<char>> handles(Pstream::nProcs());
                 handles[Pstream::myProcNo()].setSize(OGL_PEER_HANDLE_BYTES, '\0');

@@ -37,3 +37,15 @@ def test_host_logic_under_asan_ubsan():
     p = subprocess.run([os.path.join(cpp, "asan_host_logic")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "0 failure(s)" in p.stdout and "ERROR" not in p.stderr
+
+
+@pytest.mark.parametrize("flags", [[], ["-DWITH_ESI_VERSION"]], ids=["Foundation", "ESI"])
+def test_openfoam_translation_unit_parses_against_the_api_stub(flags):
+    """ogl_amd/foam/GKOSolvers.C is compiled in an OpenFOAM tree, which this image does not have.  A header-only
+    stub of the OpenFOAM declarations it uses (tests/cpp/foam_stub, on top of MiniFoam.H) lets `g++ -fsyntax-only`
+    catch typos and signature slips in the adapter translation unit before a maintainer's wmake does."""
+    p = subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", *flags,
+                        "-I", os.path.join(ROOT, "tests", "cpp", "foam_stub"), "-I", os.path.join(ROOT, "ogl_amd", "host"),
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "ogl_amd", "foam", "GKOSolvers.C")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "error" not in p.stderr, p.stderr[-3000:]

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 run() {
   TAG=$1; shift
-  python bench.py --steps 5 --warmup 2 --cpu-iters 0 --no-general-legs "$@" > gpurun_out/small_$TAG.json 2> gpurun_out/small_$TAG.err || { echo "$TAG FAILED"; tail -3 gpurun_out/small_$TAG.err; return; }
+  python bench.py --steps 5 --warmup 2 --cpu-iters 0 --no-general-legs $SMALL_EXTRA "$@" > gpurun_out/small_$TAG.json 2> gpurun_out/small_$TAG.err || { echo "$TAG FAILED"; tail -3 gpurun_out/small_$TAG.err; return; }
   python - "$TAG" <<'PY'
 import json,sys
 d=json.load(open(f"gpurun_out/small_{sys.argv[1]}.json"))

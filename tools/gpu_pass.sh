@@ -75,6 +75,7 @@ for STAGE in "$@"; do
         find gpurun_out -name '*counter_collection.csv' -size +1M -delete
         find gpurun_out -name '*kernel_trace.csv' -size +1M -delete );;
     small) bash tools/gpu_bench_small.sh 2>&1 | tee gpurun_out/${TAG}_small.txt;;
+    small5) SMALL_EXTRA="--prop fusedFinalizers=0" bash tools/gpu_bench_small.sh 2>&1 | tee gpurun_out/${TAG}_small_five_launch.txt;;
     configs) bash tools/gpu_bench_configs.sh $TAG;;
     markers) bash tools/gpu_markers.sh > gpurun_out/markers_$TAG.log 2>&1;;
     ranks)
