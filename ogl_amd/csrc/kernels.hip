@@ -93,6 +93,54 @@ __device__ __forceinline__ void reduce_partials(const double *const (&part)[2], 
     out[1] = K > 1 ? fin_block_sum(s[1], slot) : 0.0;
 }
 
+// Non-local part of a chunk's rows inside the local SpMV kernel (HaloFused, kernels.hpp).  acc0 / acc1: the
+// accumulators of this thread's two rows after the local entries; ys: CHUNK_ROWS doubles of LDS that the
+// kernel does not need any more.  Workgroup-uniform: chunks without boundary rows return at once.
+template <int MODE>
+__device__ __forceinline__ void halo_fused_add(const HaloFused &H, int chunk, double &acc0, double &acc1, double *ys)
+{
+    const int b0 = H.chunk_bptr[chunk], b1 = H.chunk_bptr[chunk + 1];
+    if (b0 == b1) return;
+    __shared__ int halo_timed_out;
+    if (threadIdx.x == 0) halo_timed_out = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < H.n_neigh) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned long long f =
+                __hip_atomic_load(H.local_flag + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((uint32_t)f == H.seq) break;
+            if (wall_clock64() - t0 > H.timeout_ticks) {
+                halo_timed_out = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    ys[ROWS_PER_THREAD * threadIdx.x] = acc0;
+    ys[ROWS_PER_THREAD * threadIdx.x + 1] = acc1;
+    __syncthreads();
+    if (halo_timed_out) {  // a neighbour is gone: end the solve (y stays the local product)
+        if (threadIdx.x == 0) {
+            H.s->comm_error = 1;
+            H.s->stop = 1;
+        }
+        return;
+    }
+    for (int i = b0 + threadIdx.x; i < b1; i += BLOCK) {
+        const int li = H.boundary_rows[i] - chunk * CHUNK_ROWS;
+        double a = ys[li];
+        for (int k = H.entry_ptrs[i]; k < H.entry_ptrs[i + 1]; ++k) {
+            const double t = H.vals[k] * H.recv[H.cols[k]];
+            a = (MODE == SPMV_RESIDUAL) ? a - t : a + t;
+        }
+        ys[li] = a;
+    }
+    __syncthreads();
+    acc0 = ys[ROWS_PER_THREAD * threadIdx.x];
+    acc1 = ys[ROWS_PER_THREAD * threadIdx.x + 1];
+}
+
 // XCD-aware chunk map.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md,
 // "Workgroup dispatch"); each XCD has a private 4 MiB L2.  Measured on the 216^3 case
 // (tools/spmv_tune.hip, profiles/spmv_tune_r01.txt):
@@ -133,7 +181,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ b,
     double *__restrict__ y, const double *__restrict__ w, double *__restrict__ dot_partials,
-    double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup)
+    double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup, HaloFused hf)
 {
     __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
     __shared__ double slot[N_WAVES];
@@ -202,6 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
         __syncthreads();
     }
 
+    if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc[0], acc[1], prod);
     double d = 0.0, d2 = 0.0;
 #pragma unroll
     for (int j = 0; j < ROWS_PER_THREAD; ++j) {
@@ -229,7 +278,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream21(
     int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const Stream21Chunk *__restrict__ chunks21,
     const uint4 *__restrict__ codes, const double *__restrict__ vals, const double *__restrict__ x,
     const double *__restrict__ b, double *__restrict__ y, const double *__restrict__ w,
-    double *__restrict__ dot_partials, double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup)
+    double *__restrict__ dot_partials, double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup,
+    HaloFused hf)
 {
     __shared__ __attribute__((aligned(16))) double prod[STREAM21_TILE];
     __shared__ double slot[N_WAVES];
@@ -306,6 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream21(
         }
         __syncthreads();
     }
+    if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc[0], acc[1], prod);
     double d = 0.0, d2 = 0.0;
 #pragma unroll
     for (int j = 0; j < ROWS_PER_THREAD; ++j) {
@@ -962,11 +1013,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2(int n, double *__restrict__ 
 // check stops the solve, the step_1x of turn j+1 still applies the pending update (it recognises
 // its turn by iter == turn + 1: no check runs after the stop) and leaves p alone; the host flushes
 // with an extra step_1x when the stop came after the last enqueued turn.
+template <bool PUT>
 __global__ __launch_bounds__(BLOCK) void k_cg_step1x(int n, double *__restrict__ p,
                                                      double *__restrict__ x,
                                                      const double *__restrict__ r,
                                                      const double *__restrict__ inv_diag,
-                                                     const DevScalars *s)
+                                                     const DevScalars *s, HaloPutFused put)
 {
     const int stop = s->stop;
     const bool pending = s->x_pending != 0;
@@ -995,6 +1047,35 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x(int n, double *__restrict__
     vp.x = vz.x + tmp * vp.x;
     vp.y = vz.y + tmp * vp.y;
     st2(p, rp, vp);
+    if (PUT) {
+        // halo values of the SpMV that follows: this chunk's send rows go straight into the neighbours' receive
+        // blocks (through LDS: the row's owner holds it in registers), the last such workgroup raises the flags
+        const int s0 = put.chunk_sptr[blockIdx.x], s1 = put.chunk_sptr[blockIdx.x + 1];
+        if (s0 == s1) return;  // (workgroup-uniform)
+        __shared__ double ps[CHUNK_ROWS];
+        __shared__ int last;
+        ps[ROWS_PER_THREAD * threadIdx.x] = vp.x;
+        ps[ROWS_PER_THREAD * threadIdx.x + 1] = vp.y;
+        __syncthreads();
+        for (int k = s0 + threadIdx.x; k < s1; k += BLOCK) {
+            const int j = put.send_pos[k];
+            int i = 0;
+            while (i + 1 < put.P.n_neigh && j >= put.P.send_off[i + 1]) ++i;
+            put.P.remote_recv[i][j - put.P.send_off[i]] = ps[put.send_idxs[j] - (int)blockIdx.x * CHUNK_ROWS];
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            last = atomicAdd(put.ticket, 1u) == (unsigned)put.n_put_chunks - 1;
+            if (last) *put.ticket = 0;
+        }
+        __syncthreads();
+        if (last && (int)threadIdx.x < put.P.n_neigh) {
+            __threadfence_system();
+            __hip_atomic_store(put.P.remote_flag[threadIdx.x], (unsigned long long)put.P.seq, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__ r,
@@ -1116,10 +1197,19 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
     __shared__ double sh[4];
     __shared__ int sh_stop;
     // everything this workgroup will need is asked for at once -- the scalars, the partials and its own rows of
-    // p, x, r, 1/d: one memory round trip instead of three in a row (scalars -> partials -> vectors)
+    // p, x, r, 1/d: one memory round trip instead of three in a row (scalars -> partials -> vectors).  The
+    // scalars are read field by field into registers (a private copy of the struct would live in scratch memory,
+    // and a kernel with scratch costs more to dispatch than the finaliser launch this is meant to save).
     const int stopped = sin->stop;
-    DevScalars L;
-    if (threadIdx.x == 0) L = *sin;
+    const double s_rho = sin->rho, s_beta = sin->beta, s_nf = sin->norm_factor, s_init = sin->init_res;
+    const int s_iter = sin->iter, s_evals = sin->n_evals;
+    const double c_tol = sin->crit.tolerance, c_rel = sin->crit.rel_tol;
+    const int c_min = sin->crit.min_iter, c_max = sin->crit.max_iter, c_freq = sin->crit.frequency,
+              c_exp = sin->crit.export_res;
+    static_assert(sizeof(DevScalars) % 8 == 0, "copied as 8-byte words");
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevScalars) / 8)  // fields this kernel leaves alone
+        reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
+            reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
     const RowPair rp = my_rows(blockIdx.x, n);
     double2 vp = ld2(p, rp);
     double2 vx = ld2_stream(x, rp);
@@ -1129,22 +1219,47 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
     if (inv_diag) vi = ld2_stream(inv_diag, rp);
     double pv[2][FIN_VT];
     load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
-    if (stopped) {  // (the solve has ended: hand the scalars on, nothing else)
-        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = L;
-        return;
-    }
+    if (stopped) return;  // (the solve has ended: workgroup 0 has handed the scalars on, nothing else to do)
     double v[2];
-    reduce_partials_as_finaliser<2>(pv, n_part, red, v);
+    reduce_partials_as_finaliser<2>(pv, n_part, red, v);  // (its barriers order the copy above before the stores below)
     if (threadIdx.x == 0) {
-        L.prev_rho = L.rho;  // swap(prev_rho, rho) of the previous turn
-        L.rho = v[0];
-        criterion_check(&L, L.crit, v[1], blockIdx.x == 0 ? history : nullptr);
-        L.x_pending = 0;
-        sh[0] = L.beta;
-        sh[1] = L.prev_rho;
-        sh[2] = L.rho;
-        sh_stop = L.stop;
-        if (blockIdx.x == 0) *sout = L;
+        // FIN_CG_CHECK: swap(prev_rho, rho) of the previous turn, then criterion_check (StoppingCriterion.C:71-151)
+        const double prev_rho = s_rho, rho = v[0];
+        int iter = s_iter, n_evals = s_evals, stop = 0;
+        double init_res = s_init, res = 0.0;
+        bool evaluated = false;
+        if (iter > 0 && iter < c_min) {           // :77-81
+            iter += 1;
+        } else if (iter % c_freq != 0) {          // :84-87
+            iter += 1;
+        } else {
+            evaluated = true;
+            n_evals += 1;
+            res = v[1];
+            if (iter == 0) init_res = res / s_nf;  // :102-111
+            res /= s_nf;                           // :113
+            if (c_exp && history && blockIdx.x == 0) history[iter] = res;  // :115-117
+            if (iter >= c_max) stop = 1;                                   // :124
+            if (res < c_tol) stop = 1;                                     // :128
+            if (c_rel > 0 && res < c_rel * init_res) stop = 1;             // :132-136
+            iter += 1;                                                     // :143
+        }
+        sh[0] = s_beta;
+        sh[1] = prev_rho;
+        sh[2] = rho;
+        sh_stop = stop;
+        if (blockIdx.x == 0) {
+            sout->prev_rho = prev_rho;
+            sout->rho = rho;
+            sout->iter = iter;
+            sout->x_pending = 0;
+            if (evaluated) {
+                sout->n_evals = n_evals;
+                sout->init_res = init_res;
+                sout->res = res;
+            }
+            if (stop) sout->stop = 1;
+        }
     }
     __syncthreads();
     const double beta = sh[0], prev = sh[1], rho = sh[2];
@@ -1177,10 +1292,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restri
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[2];
     __shared__ double slot[N_WAVES];
-    // (all loads up front, as in step_1x_fin)
+    // (all loads up front and the scalars field by field, as in step_1x_fin)
     const int stopped = sin->stop;
-    DevScalars L;
-    if (threadIdx.x == 0) L = *sin;
+    const double s_rho = sin->rho;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevScalars) / 8)
+        reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
+            reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
     const int chunk = blockIdx.x;
     const RowPair rp = my_rows(chunk, n);
     double2 vr = ld2(r, rp);
@@ -1190,19 +1307,13 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restri
     if (inv_diag) vi = ld2(inv_diag, rp);
     double pv[2][FIN_VT];
     load_partials_as_finaliser<1>(part_beta, nullptr, n_part, pv);
-    if (stopped) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *sout = L;
-        return;
-    }
+    if (stopped) return;
     double v[2];
     reduce_partials_as_finaliser<1>(pv, n_part, red, v);
     if (threadIdx.x == 0) {
-        sh[0] = L.rho;
+        sh[0] = s_rho;
         sh[1] = v[0];
-        if (blockIdx.x == 0) {
-            L.beta = v[0];
-            *sout = L;
-        }
+        if (blockIdx.x == 0) sout->beta = v[0];  // FIN_BETA
     }
     __syncthreads();
     const double rho = sh[0], beta = sh[1];
@@ -1250,9 +1361,10 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, in
                                                     const double *__restrict__ w,
                                                     double *__restrict__ dot_partials,
                                                     double *__restrict__ dot2_partials,
-                                                    const DevScalars *gate)
+                                                    const DevScalars *gate, HaloFused hf)
 {
     __shared__ double slot[N_WAVES];
+    __shared__ double ys[CHUNK_ROWS];
     if (gate && gate->stop) return;
     const int chunk = xcd_chunk(blockIdx.x);
     if (chunk >= n_chunks) return;
@@ -1306,6 +1418,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_ell(int n_rows, int n_chunks, in
             }
         }
     }
+    if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc.x, acc.y, ys);
     st2(y, rp, acc);
     if (NDOT >= 1) {
         const double2 vw = ld2(w, rp);
@@ -1356,9 +1469,10 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
                                                     double *__restrict__ y, const double *__restrict__ w,
                                                     double *__restrict__ dot_partials,
                                                     double *__restrict__ dot2_partials, const DevScalars *gate,
-                                                    const int *__restrict__ block_order)
+                                                    const int *__restrict__ block_order, HaloFused hf)
 {
     __shared__ double slot[N_WAVES];
+    __shared__ double ys[CHUNK_ROWS];
     if (gate && gate->stop) return;
     // banded patterns: the host's order puts the chunks of rows r and r +- d[ND-1] on one XCD (band_block_order)
     const int chunk = block_order ? block_order[blockIdx.x] : xcd_chunk(blockIdx.x);
@@ -1457,6 +1571,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
             acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
         }
     }
+    if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc.x, acc.y, ys);
     st2(y, rp, acc);
     if (NDOT >= 1) {
         const double2 vw = ld2(w, rp);
@@ -1506,7 +1621,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const double *__restrict__ w,
                                                      double *__restrict__ dot_partials,
                                                      double *__restrict__ dot2_partials,
-                                                     const DevScalars *gate, int xgroup)
+                                                     const DevScalars *gate, int xgroup, HaloFused hf)
 {
     __shared__ double slot[N_WAVES];
     __shared__ int stab[SELL_TABLE_INTS];
@@ -1779,6 +1894,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
         acc.x = ys[ROWS_PER_THREAD * t];
         acc.y = ys[ROWS_PER_THREAD * t + 1];
     }
+    if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc.x, acc.y, reinterpret_cast<double *>(stab));
     st2(y, rp, acc);
     if (NDOT >= 1) {
         const double2 vw = ld2(w, rp);
@@ -2490,7 +2606,7 @@ inline int blocks_for(int64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 // launchers
 // ------------------------------------------------------------------------------------------
 void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, const double *b,
-                 double *y, const SpmvDots &dots, const DevScalars *gate)
+                 double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf)
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
@@ -2498,10 +2614,10 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
     const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
 #define OGL_SPMV_K(MODE, NDOT, STREAM)                                                                     \
     hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
-                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg)
+                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf)
 #define OGL_SPMV21_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_stream21<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs, \
-                       A.chunks21, A.codes21, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg)
+                       A.chunks21, A.codes21, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf)
 #define OGL_SPMV(MODE, NDOT)                 \
     do {                                     \
         if (A.codes21 && A.stream)           \
@@ -2528,14 +2644,14 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
 }
 
 void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,
-                     double *y, const SpmvDots &dots, const DevScalars *gate)
+                     double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf)
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const dim3 grid(xcd_grid(nc)), block(BLOCK);
 #define OGL_ELL_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_ell<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.width,      \
-                       (long)A.stride, A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate)
+                       (long)A.stride, A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, hf)
 #define OGL_ELL(MODE, NDOT)               \
     do {                                  \
         if (A.stream)                     \
@@ -2557,7 +2673,7 @@ void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x,
 }
 
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
-                      double *y, const SpmvDots &dots, const DevScalars *gate)
+                      double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf)
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
@@ -2566,7 +2682,7 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
 #define OGL_SELL_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
                        A.dict, A.codes, A.vals, A.spill_chunk_ptr, A.spill_rows, A.spill_ptrs,          \
-                       A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg)
+                       A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf)
 #define OGL_SELL(MODE, NDOT)               \
     do {                                   \
         if (A.stream)                      \
@@ -2588,7 +2704,7 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
 }
 
 void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x, const double *b, double *y,
-                     const SpmvDots &dots, const DevScalars *gate)
+                     const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf)
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
@@ -2600,7 +2716,7 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
     for (int j = 2; j < A.nd; ++j) fast = fast && (A.d[j] % 2 == 0);
 #define OGL_SYM_K(MODE, NDOT, ND, FAST, STREAM)                                                                          \
     hipLaunchKernelGGL((k_spmv_sym<MODE, NDOT, ND, FAST, STREAM>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
-                       x, b, y, dots.with, dots.part, dots.part_yy, gate, A.block_order)
+                       x, b, y, dots.with, dots.part, dots.part_yy, gate, A.block_order, hf)
 #define OGL_SYM_ND(MODE, NDOT, ND)                   \
     do {                                             \
         if (fast && A.stream)                        \
@@ -2834,11 +2950,15 @@ void launch_cg_step1(hipStream_t st, int32_t n, double *p, const double *r, cons
 }
 
 void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
-                      const double *inv_diag, const DevScalars *s)
+                      const double *inv_diag, const DevScalars *s, const HaloPutFused *put)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_cg_step1x, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, s);
+    if (put && put->chunk_sptr)
+        hipLaunchKernelGGL((k_cg_step1x<true>), dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, s, *put);
+    else
+        hipLaunchKernelGGL((k_cg_step1x<false>), dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, s,
+                           HaloPutFused{});
 }
 
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,

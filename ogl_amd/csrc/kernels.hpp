@@ -75,8 +75,25 @@ struct SpmvDots {
     double *part = nullptr;        // per-chunk partials of w.y, or nullptr
     double *part_yy = nullptr;     // per-chunk partials of y.y (needs `part`), or nullptr
 };
+// Non-local part of the product inside the LOCAL kernel (peer-put transport): the workgroup of a chunk that
+// holds boundary rows waits for the neighbours' flags of this SpMV, then continues the accumulators of its
+// boundary rows over their non-local entries in stored order -- local first, then non-local, as
+// distributed::Matrix::apply does -- before y and the fused dot partials are formed.  chunk_bptr == nullptr: none.
+struct HaloFused {
+    const int32_t *chunk_bptr = nullptr;     // [n_chunks + 1] ranges of boundary_rows per chunk
+    const int32_t *boundary_rows = nullptr;  // as DevHalo
+    const int32_t *entry_ptrs = nullptr;
+    const int32_t *cols = nullptr;
+    const double *vals = nullptr;
+    const double *recv = nullptr;                    // this SpMV's receive block
+    const unsigned long long *local_flag = nullptr;  // this rank's flags, one per neighbour
+    int32_t n_neigh = 0;
+    uint32_t seq = 0;
+    long long timeout_ticks = 0;
+    DevScalars *s = nullptr;                 // receives comm_error / stop when a neighbour does not show up
+};
 void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, const double *b,
-                 double *y, const SpmvDots &dots, const DevScalars *gate);
+                 double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});
 
 // matrixFormat Ell (CsrMatrixWrapper.H:146-149): `width` slots per row, slot-major (column-major in
 // Ginkgo's terms) with leading dimension `stride` >= n_rows; padding slots carry column -1 and are
@@ -90,7 +107,7 @@ struct DevEll {
     bool stream = false;            // as DevCsr::stream
 };
 void launch_spmv_ell(hipStream_t st, const DevEll &A, int mode, const double *x, const double *b,
-                     double *y, const SpmvDots &dots, const DevScalars *gate);
+                     double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});
 // Index-compressed chunked ELL (SellChunk, common.hpp), device view.
 struct DevSell {
     int32_t n_rows = 0;
@@ -107,7 +124,7 @@ struct DevSell {
     int32_t xcd_group = 0;  // as DevCsr::xcd_group
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
-                      double *y, const SpmvDots &dots, const DevScalars *gate);
+                      double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});
 // Half storage of a symmetric matrix on a banded pattern (SymLayout, host_matrix.hpp), device view.
 struct DevSym {
     int32_t n_rows = 0;
@@ -121,7 +138,7 @@ struct DevSym {
     int32_t n_blocks = 0;
 };
 void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x, const double *b, double *y,
-                     const SpmvDots &dots, const DevScalars *gate);
+                     const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});
 // out[i] = map[i] >= 0 ? source[map[i]] : 0   (coefficient permutation into the padded ELL slots)
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,
                                  double *out);
@@ -216,8 +233,9 @@ void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const doub
 // The same steps with the x update deferred by one turn (p is then read once per turn):
 //   step_2r: r -= (rho/beta) q + partials;  step_1x(turn): x += (prev_rho/beta) p_old, then step_1.
 // step_1x applies the pending update of turn-1 also when the solve has just stopped.
+struct HaloPutFused;  // (below, after PeerHalo)
 void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
-                      const double *inv_diag, const DevScalars *s);
+                      const double *inv_diag, const DevScalars *s, const HaloPutFused *put = nullptr);
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                       double *part_rho, double *part_norm, const DevScalars *s);
 
@@ -325,6 +343,17 @@ struct PeerHalo {
     double *remote_recv[PEER_MAX_NEIGH] = {};              // neighbour i's segment for this rank
     unsigned long long *remote_flag[PEER_MAX_NEIGH] = {};  // neighbour i's flag for this rank
     const unsigned long long *local_flag = nullptr;        // this rank's flags, one per neighbour
+};
+// launch_cg_step1x's `put` (chunk_sptr != nullptr): the workgroups whose chunks hold send rows store the p they
+// have just formed straight into the neighbours' receive blocks, and the last of them signals -- the pack kernel
+// of the SpMV that follows is folded into the kernel that produces its input.
+struct HaloPutFused {
+    PeerHalo P;
+    const int32_t *chunk_sptr = nullptr;  // [n_chunks + 1] ranges of send_pos per chunk
+    const int32_t *send_pos = nullptr;    // positions in the send list, grouped by the chunk of their row
+    const int32_t *send_idxs = nullptr;   // the send list (rows), as DevHalo
+    unsigned *ticket = nullptr;
+    int32_t n_put_chunks = 0;             // chunks that hold send rows
 };
 void launch_pack_put(hipStream_t st, const DevHalo &H, const PeerHalo &P, const double *x,
                      const DevScalars *gate);

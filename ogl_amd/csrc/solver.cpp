@@ -1311,6 +1311,28 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             if (!bc.empty())
                 OGL_TRY(reg->stager.h2d(d_boundary_chunks.p, bc.data(), bc.size() * sizeof(int32_t), st));
         }
+        {   // per chunk: its boundary rows (HaloFused) and its send rows (HaloPutFused)
+            const size_t nc1 = (size_t)n_chunks(pat.n_rows) + 1;
+            std::vector<int32_t> bptr(nc1, 0), sptr(nc1, 0), spos(pat.send_idxs.size());
+            for (int32_t r : boundary_rows) ++bptr[(size_t)(r / CHUNK_ROWS) + 1];
+            for (int32_t r : pat.send_idxs) ++sptr[(size_t)(r / CHUNK_ROWS) + 1];
+            n_put_chunks = 0;
+            for (size_t c = 1; c < nc1; ++c) {
+                if (sptr[c]) ++n_put_chunks;
+                bptr[c] += bptr[c - 1];
+                sptr[c] += sptr[c - 1];
+            }
+            std::vector<int32_t> fill(sptr.begin(), sptr.end() - 1);
+            for (size_t j = 0; j < pat.send_idxs.size(); ++j)
+                spos[(size_t)fill[(size_t)(pat.send_idxs[j] / CHUNK_ROWS)]++] = (int32_t)j;
+            OGL_TRY(d_chunk_bptr.alloc(nc1, st));
+            OGL_TRY(d_chunk_sptr.alloc(nc1, st));
+            OGL_TRY(d_send_pos.alloc(std::max<size_t>(1, spos.size()), st));
+            OGL_TRY(reg->stager.h2d(d_chunk_bptr.p, bptr.data(), nc1 * sizeof(int32_t), st));
+            OGL_TRY(reg->stager.h2d(d_chunk_sptr.p, sptr.data(), nc1 * sizeof(int32_t), st));
+            if (!spos.empty())
+                OGL_TRY(reg->stager.h2d(d_send_pos.p, spos.data(), spos.size() * sizeof(int32_t), st));
+        }
         OGL_TRY(d_boundary_rows.alloc(boundary_rows.size(), st));
         OGL_TRY(d_boundary_ptrs.alloc(boundary_ptrs.size(), st));
         OGL_TRY(d_nl_cols.alloc(hn, st));
@@ -1647,20 +1669,58 @@ int ogl_solver::init_preconditioner()
 // ------------------------------------------------------------------------------------------
 // distributed::Matrix::apply: y = A_local x (+ dot partials), then y += A_non_local recv
 // ------------------------------------------------------------------------------------------
+// arguments of the next SpMV's halo exchange for a producer kernel that puts the values itself (step_1x)
+HaloPutFused ogl_solver::begin_halo_put()
+{
+    HaloPutFused put;
+    if (!(pat.non_local_nnz > 0 && peer_halo) || prop("haloFused", 1.0) == 0.0) return put;
+    if (++halo_seq == 0) ++halo_seq;
+    cur_halo = peer_halo_args(halo_seq);
+    put.P = cur_halo;
+    put.chunk_sptr = d_chunk_sptr.p;
+    put.send_pos = d_send_pos.p;
+    put.send_idxs = d_send_idxs.p;
+    put.ticket = d_ticket.p;
+    put.n_put_chunks = n_put_chunks;
+    return put;
+}
+
 int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
-                          const SpmvDots &dots, const DevScalars *gate)
+                          const SpmvDots &dots, const DevScalars *gate, bool prepacked)
 {
     hipStream_t st = reg->stream;
     const bool has_halo = pat.non_local_nnz > 0;
     const double *recv = d_recv.p;
     PeerHalo ph;
+    // peer-put transport: by default the non-local part is added inside the local kernel (HaloFused) -- a
+    // distributed SpMV is then 2 launches (pack + put + signal | local + wait + non-local), 1 when the producer
+    // of x has put the values itself; property haloFused 0 keeps the separate finish kernel (A/B)
+    const bool fuse = has_halo && peer_halo && prop("haloFused", 1.0) != 0.0;
+    HaloFused hf;
     if (has_halo && peer_halo) {
         // peer-put: the values go straight into the neighbours' receive blocks over xGMI, then the
         // flags; they fly while the local SpMV below runs
-        if (++halo_seq == 0) ++halo_seq;
-        ph = peer_halo_args(halo_seq);
-        recv = peer_recv(halo_seq);
-        launch_pack_put_signal(st, halo(), ph, x, gate, d_ticket.p);
+        if (prepacked && fuse) {
+            ph = cur_halo;
+        } else {
+            if (++halo_seq == 0) ++halo_seq;
+            ph = peer_halo_args(halo_seq);
+            launch_pack_put_signal(st, halo(), ph, x, gate, d_ticket.p);
+        }
+        recv = peer_recv(ph.seq);
+        if (fuse) {
+            hf.chunk_bptr = d_chunk_bptr.p;
+            hf.boundary_rows = d_boundary_rows.p;
+            hf.entry_ptrs = d_boundary_ptrs.p;
+            hf.cols = d_nl_cols.p;
+            hf.vals = d_nl_vals.p;
+            hf.recv = recv;
+            hf.local_flag = ph.local_flag;
+            hf.n_neigh = ph.n_neigh;
+            hf.seq = ph.seq;
+            hf.timeout_ticks = ph.timeout_ticks;
+            hf.s = d_scal.p;
+        }
     } else if (has_halo) {
         // pack on the compute stream, exchange on the communication stream: the neighbour copies
         // fly while the local SpMV below runs; the non-local kernel waits for their arrival
@@ -1679,18 +1739,18 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     // the few chunks that hold boundary rows are redone after "y += A_non_local recv" (same
     // per-chunk tree, so the sums are bit-identical to a dot over the finished y).
     if (cfg.matrix_format == OGL_FORMAT_ELL && ell_ready && !ell_values_stale)
-        launch_spmv_ell(st, ell(), mode, x, b, y, dots, gate);
+        launch_spmv_ell(st, ell(), mode, x, b, y, dots, gate, hf);
     else if (use_sym())
-        launch_spmv_sym(st, sym(), mode, x, b, y, dots, gate);
+        launch_spmv_sym(st, sym(), mode, x, b, y, dots, gate, hf);
     else if (use_sell())
-        launch_spmv_sell(st, sell(), mode, x, b, y, dots, gate);
+        launch_spmv_sell(st, sell(), mode, x, b, y, dots, gate, hf);
     else
-        launch_spmv(st, csr(), mode, x, b, y, dots, gate);
-    if (has_halo && peer_halo) {
+        launch_spmv(st, csr(), mode, x, b, y, dots, gate, hf);
+    if (has_halo && peer_halo && !fuse) {
         // wait for the neighbours' flags, add the non-local part, redo the touched chunks' partials
         launch_halo_finish(st, halo(), mode, pat.n_rows, d_boundary_chunks.p, d_boundary_chunk_ptr.p,
                            n_boundary_chunks, recv, y, dots, ph, gate, d_scal.p);
-    } else if (has_halo) {
+    } else if (has_halo && !peer_halo) {
         OGL_HIP_CHECK(hipStreamWaitEvent(st, reg->ev_received, 0));
         launch_spmv_non_local(st, halo(), mode, recv, y, gate);
         if (dots.part)
@@ -2008,10 +2068,12 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s2, s, d_part2.p);
             } else if (!bicg) {
                 // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once
-                launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s);
+                // (peer-put transport: the halo values of the SpMV are put by step_1x itself)
+                const HaloPutFused put = begin_halo_put();
+                launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s, &put);
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
-                                  SpmvDots{d_p.p, d_part0.p, nullptr}, s));
+                                  SpmvDots{d_p.p, d_part0.p, nullptr}, s, put.chunk_sptr != nullptr));
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 OGL_TRY(finalize(FIN_BETA, f1));
                 launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s);

@@ -294,6 +294,12 @@ struct ogl_solver {
     std::vector<PeerNeighbour> peer_nb;
     uint32_t halo_seq = 0;
     ogl::DevBuf<int32_t> d_boundary_chunk_ptr;  // ranges of boundary_rows per boundary chunk
+    // the same ranges for EVERY chunk (HaloFused: the local SpMV kernel adds the non-local part itself) and the
+    // send list grouped by the chunk of its rows (HaloPutFused: step_1x puts the halo values it has just formed)
+    ogl::DevBuf<int32_t> d_chunk_bptr, d_chunk_sptr, d_send_pos;
+    int32_t n_put_chunks = 0;
+    ogl::PeerHalo cur_halo{};   // arguments of the SpMV whose halo values a producer kernel has already put
+    ogl::HaloPutFused begin_halo_put();
     ogl::DevBuf<unsigned> d_ticket;             // last-workgroup ticket of k_pack_put_signal
     // a full batch of single-rank GKOCG turns captured as a hipGraph (run_krylov)
     hipGraphExec_t cg_graph = nullptr;
@@ -353,8 +359,9 @@ struct ogl_solver {
     // partials of sum_i in_i * out_i (CG's rho), out of the same kernel
     void apply_preconditioner(const double *in, double *out, const ogl::DevScalars *gate,
                               double *dot_part = nullptr);
+    // prepacked: the kernel that produced x has put the halo values already (begin_halo_put)
     int dist_spmv(int mode, const double *x, const double *b, double *y, const ogl::SpmvDots &dots,
-                  const ogl::DevScalars *gate);
+                  const ogl::DevScalars *gate, bool prepacked = false);
     int finalize(int phase, ogl::FinArgs &a);
     int run_cg(ogl_perf *perf);
     int run_bicgstab(ogl_perf *perf);

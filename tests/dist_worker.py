@@ -159,7 +159,9 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
             matrix_format=capi.FORMAT_CSR, force_host_buffer=int(args.mode != "gpu-rccl"),
             renumber=capi.RENUMBER_ON if args.renumber else capi.RENUMBER_OFF)
         state["reg"] = reg
-        s = reg.solver("p", cfg).set_matrix(case)
+        s = reg.solver("p", cfg)
+        s.set_property("haloFused", float(args.halo_fused))
+        s.set_matrix(case)
         new_id = s.renumbering()
         assert (new_id is not None) == bool(args.renumber and case.n_cells >= 2)
         if new_id is None:
@@ -220,6 +222,9 @@ def main():
     ap.add_argument("--renumber", type=int, default=0,
                     help="1: the library renumbers every rank's device copy (config renumber = on); the "
                          "oracle then solves each rank's system permuted by the numbering the library reports")
+    ap.add_argument("--halo-fused", type=int, default=1,
+                    help="0: property haloFused off -- the peer-put transport's separate pack and finish kernels "
+                         "instead of the puts folded into step_1x and the non-local part into the local SpMV kernel")
     ap.add_argument("--relabel", type=int, default=0,
                     help="1 (gpu modes): after the first solve the LAST rank alone renames its cells (same "
                          "counts, new addressing) and every rank calls set_matrix + solve again: the rebuild "

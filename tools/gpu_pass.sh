@@ -11,6 +11,7 @@
 #   pmc:V              separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC)  -> pmc_TAG_V_summary.json
 #   small | configs | markers      tools/gpu_bench_small.sh / gpu_bench_configs.sh / gpu_markers.sh
 #   ranks:R:EDGE       bench.py with R ranks sharing the box's one GPU (peer mesh on / off)
+#   ranktrace:R:EDGE   rocprofv3 kernel trace of R ranks sharing the GPU, merged time line -> TAG_ranktrace_R_eEDGE.txt
 #   table              one line per TAG_bench_*.json                        -> TAG_table.txt
 # Variants: default fullstorage nocompress shuffle512 shuffle4096 shuffle65536 shuffle65536off
 #           shuffle65536nc drop dropnc long longnc oct15 oct15nc oct4 oct4append vor1m vor3m vor3moff vor3mnc
@@ -85,6 +86,18 @@ for STAGE in "$@"; do
           > gpurun_out/${TAG}_ranks${A1}_e${A2:-128}_peer$PEER.json 2> gpurun_out/${TAG}_ranks${A1}_e${A2:-128}_peer$PEER.err
         echo "ranks $A1 edge ${A2:-128} peer=$PEER rc=$?"
       done;;
+    ranktrace)
+      # kernel trace of R ranks sharing the GPU (each rank under its own rocprofv3: the profiler starts python
+      # directly, nothing re-execs after the GPU was touched), merged into one time line
+      ( cd /tmp && export TMPDIR=/tmp && cd "$OLDPWD"
+        OUT=$PWD/gpurun_out/ranktrace_${TAG}_${A1}_e${A2:-128}; rm -rf $OUT; mkdir -p $OUT
+        timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node=$A1 --master-addr 127.0.0.1 --master-port 29533 \
+          --no-python rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --gpus $A1 --steps 2 --warmup 1 \
+          --edge ${A2:-128} --iters 40 --cpu-iters 0 --no-selfcheck > $OUT/bench.json 2> $OUT/bench.err
+        echo "ranktrace $A1 rc=$?"
+        python3 tools/ranks_trace.py $OUT > gpurun_out/${TAG}_ranktrace_${A1}_e${A2:-128}.txt 2>&1
+        head -50 gpurun_out/${TAG}_ranktrace_${A1}_e${A2:-128}.txt | cut -c1-200
+        find $OUT -name '*kernel_trace.csv' -size +8M -delete );;
     table)
       python - $TAG <<'PY' | tee gpurun_out/${TAG}_table.txt
 import json, glob, sys
