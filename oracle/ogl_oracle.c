@@ -1278,14 +1278,25 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
         for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) sum += -1.0 * vals[k] * x[cols[k]];
         r[row] = sum;
     }
+    /* Passes fused the way the GPU kernels fuse them (a competent OpenMP baseline does not stream r three times
+     * per turn): [x += t p; r -= t q of the turn before; rho = r.z; sum|r|] | check | [p = z + t1 p, z = M^-1 r on
+     * the fly] | [q = A p; beta = p.q].  z is never stored.  Same arithmetic per element as the sequential loop. */
+    int have_update = 0;
+    orc_scalar t2 = 0.0;
     for (;;) {
         rho = 0.0;
         norm = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : rho, norm)
         for (orc_label i = 0; i < n; ++i) {
-            z[i] = inv_diag ? r[i] * inv_diag[i] : r[i];
-            rho += r[i] * z[i];
-            norm += fabs(r[i]);
+            orc_scalar ri = r[i];
+            if (have_update) {
+                x[i] += t2 * p[i];
+                ri -= t2 * q[i];
+                r[i] = ri;
+            }
+            const orc_scalar zi = inv_diag ? ri * inv_diag[i] : ri;
+            rho += ri * zi;
+            norm += fabs(ri);
         }
         /* criterion (same policy as criterion_check, norm already reduced) */
         int stop = 0;
@@ -1322,7 +1333,7 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
         if (stop) break;
         const orc_scalar t1 = (prev_rho == 0.0) ? 0.0 : rho / prev_rho;
 #pragma omp parallel for schedule(static)
-        for (orc_label i = 0; i < n; ++i) p[i] = z[i] + t1 * p[i];
+        for (orc_label i = 0; i < n; ++i) p[i] = (inv_diag ? r[i] * inv_diag[i] : r[i]) + t1 * p[i];
         beta = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : beta)
         for (orc_label row = 0; row < n; ++row) {
@@ -1331,14 +1342,8 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
             q[row] = sum;
             beta += p[row] * sum;
         }
-        if (beta != 0.0) {
-            const orc_scalar t2 = rho / beta;
-#pragma omp parallel for schedule(static)
-            for (orc_label i = 0; i < n; ++i) {
-                x[i] += t2 * p[i];
-                r[i] -= t2 * q[i];
-            }
-        }
+        have_update = beta != 0.0;
+        if (have_update) t2 = rho / beta;
         prev_rho = rho;
     }
     if (t_loop_s) *t_loop_s = omp_get_wtime() - t_loop_begin;

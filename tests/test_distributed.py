@@ -190,10 +190,10 @@ def test_gpu_rebuild_forced_by_one_rank(mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--asym", "1"], ["--gmres", "12"], ["--renumber", "1"]],
+@pytest.mark.parametrize("extra", [[], ["--asym", "1"], ["--gmres", "20"], ["--renumber", "1"]],
                          ids=["cg", "bicgstab", "gmres", "cg_renumbered"])
 def test_gpu_peer_separate_halo_kernels(extra):
     # property haloFused 0: pack + put + signal and wait + non-local + partials as kernels of their own (the
     # default folds the first into step_1x and the second into the local SpMV kernel); same bits either way
     run_ranks(3, "--mode", "gpu-peer", "--random", "15", "--halo-fused", "0", *extra)
-    run_ranks(2, "--mode", "gpu-peer", "--shape", "12,12,20", "--procs", "1,1,2", "--halo-fused", "0", *extra)
+    run_ranks(2, "--mode", "gpu-peer", "--shape", "10,10,10", "--procs", "1,1,2", "--halo-fused", "0", *extra)

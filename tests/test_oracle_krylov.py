@@ -165,3 +165,27 @@ def test_isai_defining_property_with_sparsity_power(oracle, sym, power):
         assert np.abs(R[(W != 0).toarray()]).max() < 1e-13
     with pytest.raises(ValueError):
         oracle.Precond(rp, cols, vals, isai="general", sparsity_power=5)      # rows wider than 64
+
+
+def test_openmp_baseline_follows_the_sequential_oracle(oracle):
+    """cpu_baseline_omp's solver (passes fused as the GPU kernels fuse them, parallel reductions) against the
+    sequential restatement: same iteration counts, same iterates up to the order of the sums; stops by tolerance,
+    by maxIter and at the initial check."""
+    import numpy as np
+    from ogl_amd import synthetic
+    from helpers import oracle_matrix
+    case = synthetic.poisson_case(18)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    for inv in (oracle.jacobi_generate_scalar(rp, cols, vals), None):
+        for kw in (dict(tolerance=1e-10, rel_tol=0.0, max_iter=300), dict(tolerance=0.0, rel_tol=0.0, max_iter=17),
+                   dict(tolerance=1e3, rel_tol=0.0, max_iter=17)):
+            ref = oracle.cg(A, b, np.zeros_like(b), inv, **kw)
+            got = oracle.cg_omp(A, b, np.zeros_like(b), inv, **kw)
+            assert got.n_iterations == ref.n_iterations
+            np.testing.assert_allclose(got.x, ref.x, rtol=0, atol=1e-11)
+            # (the sums run in another order: the difference grows along the recurrence, as for any parallel reduction)
+            big = np.asarray(ref.history) > 1e-5 * ref.history[0]
+            np.testing.assert_allclose(np.asarray(got.history)[big], np.asarray(ref.history)[big], rtol=1e-8)
+            np.testing.assert_allclose(got.history[:10], ref.history[:10], rtol=1e-12)
