@@ -220,3 +220,35 @@ def test_mixed_row_lengths_run_on_the_compressed_layout_after_the_length_sort(re
                             tolerance=0.0, rel_tol=0.0, max_iter=30)
         np.testing.assert_array_equal(s.history(), ref.history)
         np.testing.assert_array_equal(xs, ref.x[new_id])
+
+
+@pytest.mark.parametrize("name,kw", [("cg_bj4", dict(preconditioner=capi.PRECOND_BJ, max_block_size=4)),
+                                     ("cg_isai", dict(preconditioner=capi.PRECOND_ISAI))])
+def test_auto_renumbering_above_its_size_threshold_with_numbering_dependent_preconditioners(reg, oracle, chunk_rows,
+                                                                                            name, kw):
+    """renumber auto at >= 16384 rows: block-Jacobi blocks (runs of consecutive rows) and ISAI(spd)'s
+    tril(A) are taken in the backend's numbering, so the preconditioner is another operator than on the mesh's
+    numbering -- as after renumberMesh.  Bit-exact against the oracle on the system permuted by the reported
+    numbering; against `renumber off` the same solution, iteration counts of the same order (both recorded)."""
+    case = synthetic.renumber_case(synthetic.poisson_case(28), 4096)          # 21,952 rows
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    skw = dict(tolerance=1e-10, rel_tol=0.0, max_iter=400)
+    s = reg.solver("rna_" + name, cfg(solver=capi.SOLVER_CG, renumber=capi.RENUMBER_AUTO, **kw, **skw)).set_matrix(case)
+    new_id = s.renumbering()
+    assert new_id is not None and s.get_property("renumbered") == 1.0
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    P = (oracle.Precond(rp, cols, vals, kw["max_block_size"]) if kw["preconditioner"] == capi.PRECOND_BJ
+         else oracle.Precond(rp, cols, vals, isai="spd"))
+    with blocked(oracle, chunk_rows):
+        ref = oracle.cg(A, to_new(b, new_id), np.zeros_like(b), P, **skw)
+    assert perf.n_iterations == ref.n_iterations
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x[new_id])
+    s0 = reg.solver("rna0_" + name, cfg(solver=capi.SOLVER_CG, renumber=capi.RENUMBER_OFF, **kw, **skw)).set_matrix(case)
+    x0, perf0 = s0.solve(b, np.zeros_like(b))
+    np.testing.assert_allclose(x, x0, atol=1e-8, rtol=0)
+    np.testing.assert_allclose(x, xs, atol=1e-8, rtol=0)
+    print(f"{name}: {perf.n_iterations} iterations in the backend's numbering, {perf0.n_iterations} in the mesh's")
+    assert 0.5 * perf0.n_iterations <= perf.n_iterations <= 2.0 * perf0.n_iterations
