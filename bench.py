@@ -82,6 +82,10 @@ def parse():
                     help="instead of the box: the Voronoi cells of this many random points (a polyhedral mesh, "
                          "15.5 faces per cell on average, random numbering); single rank only; scipy Delaunay "
                          "takes about a minute per million points")
+    ap.add_argument("--blocks", default="",
+                    help="instead of the plain box: a multi-block structured mesh -- comma-separated block lengths along "
+                         "x (e.g. 120,96), each block n x n in y and z, numbered block after block as blockMesh does; "
+                         "single rank only")
     ap.add_argument("--octree", type=float, default=0.0,
                     help="instead of the plain box: an octree (snappyHexMesh-like, hex-dominant) mesh -- the cells "
                          "of the n^3 box within this many cells of a sphere are split 2x2x2, their unsplit "
@@ -193,6 +197,9 @@ def main():
     if args.voronoi:
         assert world == 1, "--voronoi is a single-rank option"
         case = synthetic.voronoi_case(args.voronoi)
+    if args.blocks:
+        assert world == 1 and not args.voronoi and not args.asym, "--blocks is a single-rank, symmetric option"
+        case = synthetic.multi_block_case([int(v) for v in args.blocks.split(",")], n, n)
     if args.octree:
         assert world == 1 and not args.voronoi and not args.asym, "--octree is a single-rank, symmetric option"
         case = synthetic.octree_case(n, args.octree, args.octree_append)
@@ -457,14 +464,17 @@ def main():
         layout = {0.0: "csr", 1.0: "ell", 2.0: "sell", 3.0: "csr21"}[sv.get_property("spmvLayout")]
         if layout == "sell" and prop_or(sv, "symmetricHalf", 0.0) == 1.0:
             layout = "sym"   # half storage of a symmetric matrix on a banded pattern (diagonal + upper planes)
+            if prop_or(sv, "symmetricHalfPerChunk", 0.0) == 1.0:
+                layout = "symx"  # ... with per-chunk distances and explicit exceptions (multi-block meshes)
         stream = "true" if prop_or(sv, "spmvStream", 0.0) == 1.0 else "false"
         kernel = {"csr": f"k_spmv_stream<0, 1, {stream}>", "csr21": f"k_spmv_stream21<0, 1, {stream}>",
                   "ell": f"k_spmv_ell<0, 1, {stream}>",
                   "sell": f"k_spmv_sell<0, 1, {stream}>",
+                  "symx": f"k_spmv_symx<0, 1, {stream}>",
                   "sym": f"k_spmv_sym<0, 1, {int(prop_or(sv, 'spmvSymPlanes', 0))}, "
                          f"{'true' if prop_or(sv, 'spmvSymFast', 0.0) == 1.0 else 'false'}, {stream}>"}[layout]
         # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
-        b_moved = ((sv.get_property("sellMatrixBytes") + 16 * n_rows) if layout in ("sell", "sym") else
+        b_moved = ((sv.get_property("sellMatrixBytes") + 16 * n_rows) if layout in ("sell", "sym", "symx") else
                    (sv.get_property("csr21MatrixBytes") + 16 * n_rows) if layout == "csr21" else b_csr)
         traffic, traffic_src = pmc_traffic(kernel, pmc_variant) if pmc_variant is not None else (None, None)
         moved = b_moved / (spmv_ms * 1e-3) / 1e9
@@ -494,7 +504,7 @@ def main():
         spmv_ms = sum(p.spmv_avg_ms * p.spmv_launches for p in perfs) / max(1, launches)
         spmv_src = (f"{launches} in-loop launches of the timed steps (every "
                     f"{args.profile_stride}th turn), HIP event pairs")
-    plain_box = not (args.voronoi or args.octree or args.drop_faces or args.long_rows or args.asym)
+    plain_box = not (args.voronoi or args.octree or args.drop_faces or args.long_rows or args.asym or args.blocks)
     pmc_variant = None
     if n == 216 and args.format == "Csr" and plain_box and args.renumber == "auto" and not args.rcm \
             and args.shuffle in (0, 65536):
@@ -611,7 +621,9 @@ def main():
                          if args.voronoi else
                          f"octree mesh: {n}^3 hexahedra, those within {args.octree} cells of a sphere split 2x2x2"
                          f"{' (children appended to the cell list)' if args.octree_append else ''} lduMatrix"
-                         if args.octree else f"{n}^3-per-GPU 7-pt Poisson lduMatrix") +
+                         if args.octree else
+                         f"multi-block mesh: blocks of {args.blocks} x {n} x {n} hexahedra lduMatrix"
+                         if args.blocks else f"{n}^3-per-GPU 7-pt Poisson lduMatrix") +
                         f"{' (non-symmetric)' if args.asym else ''}"
                         f"{f' ({args.drop_faces:.0%} of the faces removed at random)' if args.drop_faces else ''}"
                         f"{f' ({args.long_rows:.0%} of the cells with 5 extra couplings)' if args.long_rows else ''}"
@@ -623,13 +635,16 @@ def main():
                            "sym": "fp64 SpMV on the half storage of the symmetric matrix (diagonal + upper planes, "
                                   "as the lduMatrix holds it; lower entries read where their twins live) next to "
                                   "the persistent fp64/int32 device CSR",
+                           "symx": "fp64 SpMV on the half storage of the symmetric matrix with per-chunk distances and "
+                                   "explicit entries for what breaks the bands (multi-block mesh, refinement shell)",
                            "csr": "fp64/int32 persistent device CSR (CSR-stream SpMV)",
                            "csr21": "fp64 persistent device CSR values, columns as 21-bit offsets packed six to a "
                                     "16-byte word (CSR-stream SpMV)",
                            "ell": "fp64/int32 ELL copy of the persistent device CSR"}[layout]
                         + (", device copy renumbered by the library (RCM)" if renumbered else "")
                         + (" (BASELINE.json configs[1])" if not (args.voronoi or args.shuffle or args.drop_faces
-                                                                or args.long_rows or args.octree) else " (proxy of an unstructured mesh)"),
+                                                                or args.long_rows or args.octree or args.blocks)
+                           else " (proxy of a multi-block / unstructured mesh)"),
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
             "rows_sorted_by_length": prop_or(s, "rowsSortedByLength", 0.0) == 1.0,
@@ -653,6 +668,7 @@ def main():
             "avg_kernel_ms -- "
             + {"sym": "diagonal + upper coefficients only: the matrix is symmetric and every lower entry is read "
                       "where its upper twin lives (same bits in y)",
+               "symx": "diagonal + upper planes per chunk and explicit entries where the pattern breaks its bands",
                "sell": "an index-compressed copy of the CSR arrays",
                "ell": "slot-major planes of the CSR arrays",
                "csr21": "the CSR values and row pointers with the columns packed to 21 bits",

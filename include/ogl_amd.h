@@ -385,6 +385,15 @@ int ogl_host_sell_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_l
 int ogl_host_sym_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                        int64_t stats[8]);
 
+/* Half storage with per-chunk distances and explicit exceptions (symmetric matrices that are banded only
+ * locally: multi-block structured meshes, refinement shells): builds the layout of a row-major sorted CSR pattern and
+ * walks every row the way the kernel does, explicit entries merged by column.  stats[0] = 1 if the layout is worth
+ * using (>= 80 % of the entries in planes), stats[1] = plane slots, stats[2] = entries served from planes, stats[3] =
+ * explicit entries, stats[4] = chunks holding explicit entries, stats[5] = chunks.  OGL_ERR_STATE if the walk does
+ * not reproduce the input. */
+int ogl_host_symx_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                        int64_t stats[8]);
+
 #ifdef __cplusplus
 }
 #endif

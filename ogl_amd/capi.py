@@ -91,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "ogl_solver_get_comm_pattern", "ogl_host_init_local_sparsity", "ogl_host_symmetric_update",
     "ogl_host_symmetric_update_w_interface", "ogl_host_non_symmetric_update_w_interface",
     "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
-    "ogl_host_sell_check", "ogl_host_sym_check", "ogl_solver_get_renumbering", "ogl_host_rcm",
+    "ogl_host_sell_check", "ogl_host_sym_check", "ogl_host_symx_check", "ogl_solver_get_renumbering", "ogl_host_rcm",
     "ogl_host_gather_sector_ratio", "ogl_host_pattern_renumbered",
     "ogl_host_addressing_fingerprint", "ogl_registry_comm_info",
 ]
@@ -492,6 +492,17 @@ def host_sym_check(row_ptrs, cols):
     _check(lib().ogl_host_sym_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
                                     cc.ctypes.data_as(C.c_void_p), stats))
     return bool(stats[0]), [int(stats[2 + j]) for j in range(int(stats[1]))], int(stats[6]), int(stats[7])
+
+
+def host_symx_check(row_ptrs, cols):
+    """(qualifies, plane_slots, planar_entries, explicit_entries, chunks_with_explicit, chunks) of the half storage
+    with per-chunk distances and explicit exceptions; raises when the layout does not decode to the input."""
+    rp = np.ascontiguousarray(row_ptrs, np.int32)
+    cc = np.ascontiguousarray(cols, np.int32)
+    st = (C.c_int64 * 8)()
+    _check(lib().ogl_host_symx_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
+                                     cc.ctypes.data_as(C.c_void_p), st))
+    return bool(st[0]), int(st[1]), int(st[2]), int(st[3]), int(st[4]), int(st[5])
 
 
 def host_sell_modes(row_ptrs, cols):

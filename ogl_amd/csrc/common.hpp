@@ -130,6 +130,25 @@ constexpr int32_t SELL_PAD_OFFSET = INT32_MIN;  // pattern mode: unused slot of 
 // half storage of a symmetric matrix on a banded pattern (SymLayout, host_matrix.hpp)
 constexpr int SYM_MAX_OFFSETS = 4;        // diagonal + 3 legs: up to a 7-point stencil in 3-D
 constexpr double SYM_MAX_PADDING = 1.15;  // plane slots / (diagonal + upper entries) above which full storage stays
+// Half storage with exceptions (SymxLayout, host_matrix.hpp): the distances are chosen PER CHUNK (the three
+// most frequent ones of its rows) and whatever does not fit -- the couplings across a block interface of a
+// multi-block mesh, the long rows of a refinement shell -- is kept as explicit entries that the row sum merges in
+// by column.  Header of one chunk, read by scalar loads:
+struct SymxChunk {
+    int64_t val_off;        // first value of the chunk's planes (doubles): [nd][CHUNK_ROWS]
+    int64_t lo_base[3][2];  // lower entries at distance d[j]: A(r, r - d) = planes[lo_base[j][w] + ((r - d) % CHUNK_ROWS)],
+                            // w = 0: r - d lies in the chunk of (first row - d), w = 1: in the next one; -1: not held there
+    int32_t nd;             // planes: diagonal + distances (1..4)
+    int32_t d[3];           // the distances of planes 1..nd-1, ascending
+    int32_t ex_rp_off;      // this chunk's CHUNK_ROWS + 1 row pointers into the explicit entries, -1: it has none
+    int32_t pad_[5];
+};
+static_assert(sizeof(SymxChunk) == 96, "SymxChunk is read as six 16-byte words");
+// mask byte of a row: bit 3 = diagonal, bit 3 - j / 3 + j = the entry at -d[j] / +d[j] (j = 1..3), bit 7 = the row
+// has explicit entries
+constexpr unsigned SYMX_EXTRAS_BIT = 0x80u;
+constexpr double SYMX_MIN_PLANAR = 0.8;  // share of the entries that must live in planes for the layout to be used
+
 // Matrix data that is read once per launch is streamed past the caches when matrix + the turn's five vectors do
 // not fit the 256 MB Infinity Cache (measured: +3-4 % turn rate at 6-10 M rows; at 2 M rows / 1 M polyhedral
 // cells, where everything fits, the hint costs 5-12 %: profiles/spmv_tune_r02.txt section 9)

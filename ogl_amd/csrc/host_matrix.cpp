@@ -1222,6 +1222,137 @@ bool build_sym_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_lab
     return true;
 }
 
+bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymxLayout &out)
+{
+    out = SymxLayout{};
+    if (n_rows <= 0) return false;
+    const int64_t nc = n_chunks(n_rows);
+    const int64_t nnz = row_ptrs[n_rows];
+    out.chunks.assign((size_t)nc, SymxChunk{});
+    // pass 1: the distances of every chunk -- the three most frequent upper distances of its rows (ties: the
+    // shorter one), ascending -- and the place of its planes
+    int64_t slots = 0, upper_entries = 0;
+    parallel_ranges(nc, 64, [&](int64_t c0, int64_t c1) {
+        std::vector<std::pair<int32_t, int32_t>> hist;  // (distance, count)
+        for (int64_t c = c0; c < c1; ++c) {
+            const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS), r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+            hist.clear();
+            for (ogl_label r = r0; r < r1; ++r)
+                for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                    const int64_t d = (int64_t)cols[k] - r;
+                    if (d <= 0 || d > INT32_MAX / 2) continue;
+                    size_t i = 0;
+                    while (i < hist.size() && hist[i].first != (int32_t)d) ++i;
+                    if (i == hist.size()) hist.emplace_back((int32_t)d, 0);
+                    ++hist[i].second;
+                }
+            std::sort(hist.begin(), hist.end(), [](const auto &a, const auto &b) {
+                return a.second != b.second ? a.second > b.second : a.first < b.first;
+            });
+            SymxChunk &h = out.chunks[(size_t)c];
+            h.nd = 1 + (int32_t)std::min<size_t>(3, hist.size());
+            int32_t dd[3] = {0, 0, 0};
+            for (int j = 0; j + 1 < h.nd; ++j) dd[j] = hist[(size_t)j].first;
+            std::sort(dd, dd + (h.nd - 1));
+            for (int j = 0; j < 3; ++j) h.d[j] = dd[j];
+            h.ex_rp_off = -1;
+        }
+    });
+    for (int64_t c = 0; c < nc; ++c) {
+        out.chunks[(size_t)c].val_off = slots;
+        slots += (int64_t)out.chunks[(size_t)c].nd * CHUNK_ROWS;
+    }
+    auto plane_of = [&](int64_t c, int64_t d) {  // plane of distance d in chunk c, 0 = none
+        const SymxChunk &h = out.chunks[(size_t)c];
+        for (int j = 1; j < h.nd; ++j)
+            if (h.d[j - 1] == d) return j;
+        return 0;
+    };
+    for (int64_t c = 0; c < nc; ++c) {  // where the lower entries of a chunk find their twins
+        SymxChunk &h = out.chunks[(size_t)c];
+        for (int j = 1; j < 4; ++j)
+            for (int w = 0; w < 2; ++w) {
+                h.lo_base[j - 1][w] = -1;
+                if (j >= h.nd) continue;
+                const int64_t first = c * CHUNK_ROWS - h.d[j - 1];
+                const int64_t cs = (first >= 0 ? first / CHUNK_ROWS : -((-first + CHUNK_ROWS - 1) / CHUNK_ROWS)) + w;
+                if (cs < 0 || cs >= nc) continue;
+                const int pj = plane_of(cs, h.d[j - 1]);
+                if (pj) h.lo_base[j - 1][w] = out.chunks[(size_t)cs].val_off + (int64_t)pj * CHUNK_ROWS;
+            }
+    }
+    out.mask.assign((size_t)nc * CHUNK_ROWS + 16, 0);
+    out.map.assign((size_t)slots + 2, -1);
+    // pass 2: planes first (a lower entry is planar only if its twin has taken a plane slot), rows independent
+    parallel_ranges(n_rows, 1 << 14, [&](int64_t ra, int64_t rb) {
+        for (ogl_label r = (ogl_label)ra; r < (ogl_label)rb; ++r) {
+            const int64_t c = r / CHUNK_ROWS;
+            const SymxChunk &h = out.chunks[(size_t)c];
+            unsigned m = 0;
+            for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                const int64_t d = (int64_t)cols[k] - r;
+                if (d < 0) continue;
+                const int j = d == 0 ? 0 : plane_of(c, d);
+                if (d > 0 && !j) continue;
+                if (m & (1u << (3 + j))) continue;  // a later entry of the same column: explicit
+                out.map[(size_t)(h.val_off + (int64_t)j * CHUNK_ROWS + r % CHUNK_ROWS)] = k;
+                m |= 1u << (3 + j);
+            }
+            out.mask[(size_t)r] = (uint8_t)m;
+        }
+    });
+    // pass 3: lower entries and the explicit ones, chunk after chunk (the explicit lists are appended in row order)
+    for (int64_t c = 0; c < nc; ++c) {
+        SymxChunk &h = out.chunks[(size_t)c];
+        const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS), r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+        const size_t ex_begin = out.ex_cols.size();
+        std::vector<int32_t> rp(CHUNK_ROWS + 1, 0);
+        for (ogl_label r = r0; r < r1; ++r) {
+            unsigned m = out.mask[(size_t)r];
+            rp[(size_t)(r - r0)] = (int32_t)out.ex_cols.size();
+            for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                const int64_t col = cols[k], d = col - r;
+                bool planar = false;
+                if (d >= 0) {
+                    const int j = d == 0 ? 0 : plane_of(c, d);
+                    planar = (d == 0 || j) && out.map[(size_t)(h.val_off + (int64_t)j * CHUNK_ROWS + r % CHUNK_ROWS)] == k;
+                    if (planar) ++upper_entries;
+                } else {
+                    const int j = plane_of(c, -d);
+                    if (j && !(m & (1u << (3 - j)))) {
+                        const int64_t first = (int64_t)r0 - h.d[j - 1];
+                        const int64_t cs0 = first >= 0 ? first / CHUNK_ROWS : -((-first + CHUNK_ROWS - 1) / CHUNK_ROWS);
+                        const int w = (int)(col / CHUNK_ROWS - cs0);
+                        const int64_t base = (w == 0 || w == 1) ? h.lo_base[j - 1][w] : -1;
+                        // the twin (col, r) must be the entry its row keeps in that plane
+                        if (base >= 0) {
+                            const int32_t tk = out.map[(size_t)(base + col % CHUNK_ROWS)];
+                            planar = tk >= 0 && cols[tk] == r;
+                        }
+                        if (planar) m |= 1u << (3 - j);
+                    }
+                }
+                if (planar) {
+                    ++out.planar;
+                } else {
+                    out.ex_cols.push_back((int32_t)col);
+                    out.ex_map.push_back(k);
+                    m |= SYMX_EXTRAS_BIT;
+                }
+            }
+            out.mask[(size_t)r] = (uint8_t)m;
+        }
+        for (ogl_label lr = r1 - r0; lr <= CHUNK_ROWS; ++lr) rp[(size_t)lr] = (int32_t)out.ex_cols.size();
+        if (out.ex_cols.size() > ex_begin) {
+            h.ex_rp_off = (int32_t)out.ex_rowptr.size();
+            out.ex_rowptr.insert(out.ex_rowptr.end(), rp.begin(), rp.end());
+        }
+    }
+    if ((double)out.planar < SYMX_MIN_PLANAR * (double)nnz) return false;
+    if ((double)slots > SYM_MAX_PADDING * 1.5 * (double)upper_entries + 8.0 * CHUNK_ROWS) return false;
+    return true;
+}
+
 }  // namespace ogl
 
 // ---------------------------------------------------------------------------------------
@@ -1570,6 +1701,76 @@ extern "C" int ogl_host_sym_check(ogl_label n_rows, const ogl_label *row_ptrs, c
     for (int j = 0; j < nd; ++j) stats[2 + j] = L.d[j];
     stats[6] = (int64_t)L.map.size() - 2;
     stats[7] = used;
+    return OGL_OK;
+}
+
+// Half storage with exceptions (build_symx_layout): builds it and walks every row the way k_spmv_symx does,
+// merging the explicit entries by column.  stats: [0] qualifies, [1] plane slots, [2] entries served from planes,
+// [3] explicit entries, [4] chunks with explicit entries, [5] chunks
+extern "C" int ogl_host_symx_check(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
+                                   int64_t stats[8])
+{
+    if (n_rows < 0 || !row_ptrs || !stats || (n_rows > 0 && !cols))
+        return fail(OGL_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    SymxLayout L;
+    const bool ok = n_rows > 0 && build_symx_layout(n_rows, row_ptrs, cols, L);
+    if (n_rows == 0) return OGL_OK;
+    int64_t ex_chunks = 0;
+    for (ogl_label r = 0; r < n_rows; ++r) {
+        const int64_t c = r / CHUNK_ROWS;
+        const SymxChunk &h = L.chunks[(size_t)c];
+        const unsigned m = L.mask[(size_t)r];
+        int32_t ek = 0, ee = 0;
+        if (m & SYMX_EXTRAS_BIT) {
+            if (h.ex_rp_off < 0) return fail(OGL_ERR_STATE, "row %d: explicit entries but the chunk has no row pointers", r);
+            ek = L.ex_rowptr[(size_t)h.ex_rp_off + r % CHUNK_ROWS];
+            ee = L.ex_rowptr[(size_t)h.ex_rp_off + r % CHUNK_ROWS + 1];
+        }
+        ogl_label k = row_ptrs[r];
+        auto take = [&](int64_t col, int32_t csr_pos, const char *what) -> int {
+            if (k >= row_ptrs[r + 1] || cols[k] != col || (csr_pos >= 0 && csr_pos != k))
+                return fail(OGL_ERR_STATE, "row %d: %s entry at column %ld decodes wrongly", r, what, (long)col);
+            ++k;
+            return OGL_OK;
+        };
+        auto flush_before = [&](int64_t limit) -> int {
+            while (ek < ee && L.ex_cols[(size_t)ek] < limit) {
+                if (int rc = take(L.ex_cols[(size_t)ek], L.ex_map[(size_t)ek], "explicit")) return rc;
+                ++ek;
+            }
+            return OGL_OK;
+        };
+        for (int j = h.nd - 1; j >= 1; --j)
+            if (m & (1u << (3 - j))) {
+                const int64_t rr = (int64_t)r - h.d[j - 1];
+                if (int rc = flush_before(rr)) return rc;
+                const int64_t first = c * CHUNK_ROWS - h.d[j - 1];
+                const int64_t cs0 = first >= 0 ? first / CHUNK_ROWS : -((-first + CHUNK_ROWS - 1) / CHUNK_ROWS);
+                const int w = (int)(rr / CHUNK_ROWS - cs0);
+                if (rr < 0 || w < 0 || w > 1 || h.lo_base[j - 1][w] < 0)
+                    return fail(OGL_ERR_STATE, "row %d: lower entry at -%d has no plane to be read from", r, h.d[j - 1]);
+                const int32_t tk = L.map[(size_t)(h.lo_base[j - 1][w] + rr % CHUNK_ROWS)];
+                if (tk < 0 || cols[tk] != r || tk < row_ptrs[rr] || tk >= row_ptrs[rr + 1])
+                    return fail(OGL_ERR_STATE, "row %d: twin of the lower entry at -%d is not in its plane", r, h.d[j - 1]);
+                if (int rc = take(rr, -1, "lower")) return rc;
+            }
+        for (int j = 0; j < h.nd; ++j)
+            if (m & (1u << (3 + j))) {
+                const int64_t col = (int64_t)r + (j ? h.d[j - 1] : 0);
+                if (int rc = flush_before(col)) return rc;
+                if (int rc = take(col, L.map[(size_t)(h.val_off + (int64_t)j * CHUNK_ROWS + r % CHUNK_ROWS)], "plane")) return rc;
+            }
+        if (int rc = flush_before(INT64_MAX)) return rc;
+        if (k != row_ptrs[r + 1] || ek != ee) return fail(OGL_ERR_STATE, "row %d lost entries", r);
+    }
+    for (const SymxChunk &h : L.chunks) ex_chunks += h.ex_rp_off >= 0;
+    stats[0] = ok ? 1 : 0;
+    stats[1] = (int64_t)L.map.size() - 2;
+    stats[2] = L.planar;
+    stats[3] = (int64_t)L.ex_cols.size();
+    stats[4] = ex_chunks;
+    stats[5] = (int64_t)L.chunks.size();
     return OGL_OK;
 }
 

@@ -118,6 +118,26 @@ struct SymLayout {
 // false: the pattern does not qualify (more distances than planes, a lower entry without its upper twin,
 // too much padding).  The VALUES being symmetric is the caller's knowledge (lduMatrix without `lower`).
 bool build_sym_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymLayout &out);
+// ---- half storage with per-chunk distances and explicit exceptions (SymxChunk, common.hpp) ----
+// For symmetric matrices whose pattern is banded only locally: a multi-block structured mesh (every block has its
+// own line and plane lengths, the block interfaces couple at arbitrary distances), a hex mesh with a refinement
+// shell.  Per chunk the three most frequent upper distances get planes; an upper entry is planar when its distance
+// is one of them, a lower entry when, in addition, the chunk of its twin holds that distance too (the twin's plane
+// is where it is read); everything else -- later duplicates of a column included -- is an explicit entry
+// (column + value, per-chunk row pointers) that the kernel merges into the row sum by column, so y keeps the bits of
+// a row-major walk.
+struct SymxLayout {
+    std::vector<SymxChunk> chunks;
+    std::vector<uint8_t> mask;        // [n_chunks * CHUNK_ROWS (+16)]
+    std::vector<int32_t> map;         // plane slot -> position in the CSR values, -1 = none  (+2)
+    std::vector<int32_t> ex_rowptr;   // (CHUNK_ROWS + 1) pointers per chunk that has explicit entries
+    std::vector<int32_t> ex_cols, ex_map;  // explicit entries: column, position in the CSR values
+    int64_t planar = 0;               // entries served from planes
+};
+// false: not worth it (fewer than SYMX_MIN_PLANAR of the entries planar, or more plane slots than
+// SYM_MAX_PADDING x the diagonal + upper entries they hold)
+bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymxLayout &out);
+
 // Order of the SpMV's workgroups for a pattern whose furthest leg couples row r with r +- band: workgroup b
 // works on chunk order[b] (-1: none).  Workgroups go to the XCDs round robin (b % N_XCD); the order gives XCD
 // k the chunks whose first row lies in the k-th eighth of its band period, ascending -- so the chunk of row

@@ -1594,6 +1594,188 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
 }
 
 // ------------------------------------------------------------------------------------------
+// Half storage with per-chunk distances and explicit exceptions (SymxChunk, common.hpp; build_symx_layout).
+// As k_spmv_sym, but the distances are the chunk's own (run-time values from its header, which also says where
+// the twins of its lower entries live: in the planes of the chunk of row r - d or of the next one), and rows
+// flagged in their mask byte carry explicit entries -- column + value lists -- that are merged into the row sum by
+// column, so that every row is still summed in ascending column order and y keeps the bits of the other kernels.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void symx_explicit(double &acc, int &ek, int ee, int limit,
+                                              const int *__restrict__ ex_cols,
+                                              const double *__restrict__ ex_vals, const double *__restrict__ x)
+{
+    while (ek < ee && ex_cols[ek] < limit) {
+        const double p = ex_vals[ek] * x[ex_cols[ek]];
+        acc = (MODE == SPMV_RESIDUAL) ? acc - p : acc + p;
+        ++ek;
+    }
+}
+
+template <int MODE, int NDOT, bool STREAM>
+__global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, const SymxChunk *__restrict__ hdr,
+                                                     const uint8_t *__restrict__ mask,
+                                                     const double *__restrict__ planes,
+                                                     const int *__restrict__ ex_rowptr,
+                                                     const int *__restrict__ ex_cols,
+                                                     const double *__restrict__ ex_vals,
+                                                     const double *__restrict__ x, const double *__restrict__ b,
+                                                     double *__restrict__ y, const double *__restrict__ w,
+                                                     double *__restrict__ dot_partials,
+                                                     double *__restrict__ dot2_partials, const DevScalars *gate,
+                                                     int xgroup, HaloFused hf)
+{
+    __shared__ double slot[N_WAVES];
+    __shared__ double ys[CHUNK_ROWS];
+    if (gate && gate->stop) return;
+    const int chunk = xcd_chunk(blockIdx.x, xgroup);
+    if (chunk >= n_chunks) return;
+    const SymxChunk h = hdr[chunk];
+    const int t = threadIdx.x;
+    const RowPair rp = my_rows(chunk, n_rows);
+    const int row = rp.row, r0 = chunk * CHUNK_ROWS;
+    const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + row);
+    const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
+    double2 acc;
+    acc.x = acc.y = 0.0;
+    if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
+    // own planes: diagonal and upper entries of the two rows (planes beyond the chunk's nd do not exist)
+    double2 up[4];
+    const double *own = planes + h.val_off + t * ROWS_PER_THREAD;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        up[j].x = up[j].y = 0.0;
+        if (j < h.nd)
+            up[j] = (STREAM && j == 0) ? ld_pair_stream(own + (long)j * CHUNK_ROWS)
+                                       : *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
+    }
+    const double2 xd = ld2(x, rp);
+    double2 lo[4], xl[4], xu[4];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        lo[j].x = lo[j].y = xl[j].x = xl[j].y = xu[j].x = xu[j].y = 0.0;
+        if (j < h.nd) {
+            const int d = h.d[j - 1];
+            // first row of the chunk minus d: its chunk (floor division) is lo_base[.][0], the next one [.][1]
+            const int cs0 = (r0 - d) >> 9;
+            if ((m0 >> (3 - j)) & 1u) {
+                const int rs = row - d;
+                lo[j].x = planes[h.lo_base[j - 1][(rs >> 9) - cs0] + (rs & (CHUNK_ROWS - 1))];
+                xl[j].x = x[rs];
+            }
+            if ((m1 >> (3 - j)) & 1u) {
+                const int rs = row + 1 - d;
+                lo[j].y = planes[h.lo_base[j - 1][(rs >> 9) - cs0] + (rs & (CHUNK_ROWS - 1))];
+                xl[j].y = x[rs];
+            }
+            if ((m0 >> (3 + j)) & 1u) xu[j].x = x[row + d];
+            if ((m1 >> (3 + j)) & 1u) xu[j].y = x[row + 1 + d];
+        }
+    }
+    static_assert(CHUNK_ROWS == 512, "row >> 9 above");
+    if (h.ex_rp_off < 0 || !((m0 | m1) & SYMX_EXTRAS_BIT)) {
+        // no explicit entries in these two rows: the straight walk of k_spmv_sym
+#pragma unroll
+        for (int j = 3; j >= 1; --j) {  // ascending columns: the furthest lower entry first
+            if ((m0 >> (3 - j)) & 1u) {
+                const double p = lo[j].x * xl[j].x;
+                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+            }
+            if ((m1 >> (3 - j)) & 1u) {
+                const double p = lo[j].y * xl[j].y;
+                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+            }
+        }
+        if ((m0 >> 3) & 1u) {
+            const double p = up[0].x * xd.x;
+            acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+        }
+        if ((m1 >> 3) & 1u) {
+            const double p = up[0].y * xd.y;
+            acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+        }
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            if ((m0 >> (3 + j)) & 1u) {
+                const double p = up[j].x * xu[j].x;
+                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+            }
+            if ((m1 >> (3 + j)) & 1u) {
+                const double p = up[j].y * xu[j].y;
+                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+            }
+        }
+    } else {
+        // the same walk with the rows' explicit entries merged in by column (a later entry of a column that a
+        // plane holds comes after the plane's: `<` in symx_explicit)
+        const int *rpx = ex_rowptr + h.ex_rp_off + t * ROWS_PER_THREAD;
+        int e0 = rpx[0], e1 = rpx[1];
+        const int e2 = rpx[2];
+        const int e0_end = e1;
+#pragma unroll
+        for (int j = 3; j >= 1; --j) {
+            const int d = j < h.nd ? h.d[j - 1] : 0;
+            if ((m0 >> (3 - j)) & 1u) {
+                symx_explicit<MODE>(acc.x, e0, e0_end, row - d, ex_cols, ex_vals, x);
+                const double p = lo[j].x * xl[j].x;
+                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+            }
+            if ((m1 >> (3 - j)) & 1u) {
+                symx_explicit<MODE>(acc.y, e1, e2, row + 1 - d, ex_cols, ex_vals, x);
+                const double p = lo[j].y * xl[j].y;
+                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+            }
+        }
+        if ((m0 >> 3) & 1u) {
+            symx_explicit<MODE>(acc.x, e0, e0_end, row, ex_cols, ex_vals, x);
+            const double p = up[0].x * xd.x;
+            acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+        }
+        if ((m1 >> 3) & 1u) {
+            symx_explicit<MODE>(acc.y, e1, e2, row + 1, ex_cols, ex_vals, x);
+            const double p = up[0].y * xd.y;
+            acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+        }
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const int d = j < h.nd ? h.d[j - 1] : 0;
+            if ((m0 >> (3 + j)) & 1u) {
+                symx_explicit<MODE>(acc.x, e0, e0_end, row + d, ex_cols, ex_vals, x);
+                const double p = up[j].x * xu[j].x;
+                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+            }
+            if ((m1 >> (3 + j)) & 1u) {
+                symx_explicit<MODE>(acc.y, e1, e2, row + 1 + d, ex_cols, ex_vals, x);
+                const double p = up[j].y * xu[j].y;
+                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+            }
+        }
+        symx_explicit<MODE>(acc.x, e0, e0_end, INT32_MAX, ex_cols, ex_vals, x);
+        symx_explicit<MODE>(acc.y, e1, e2, INT32_MAX, ex_cols, ex_vals, x);
+    }
+    if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc.x, acc.y, ys);
+    st2(y, rp, acc);
+    if (NDOT >= 1) {
+        const double2 vw = ld2(w, rp);
+        double d = 0.0, d2 = 0.0;
+        if (rp.n > 0) {
+            d += vw.x * acc.x;
+            d2 += acc.x * acc.x;
+        }
+        if (rp.n > 1) {
+            d += vw.y * acc.y;
+            d2 += acc.y * acc.y;
+        }
+        const double s = block_sum(d, slot);
+        if (threadIdx.x == 0) dot_partials[chunk] = s;
+        if (NDOT >= 2) {
+            const double s2 = block_sum(d2, slot);
+            if (threadIdx.x == 0) dot2_partials[chunk] = s2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Index-compressed chunked ELL SpMV (SellChunk, common.hpp).  Values: eight 16-byte loads per lane
 // and group of 8 slots.  Columns, per chunk: pattern mode -- one 2-byte load brings the pattern ids
 // of the lane's two rows, the pattern table in LDS gives the offsets; offset mode -- one 16-byte
@@ -2750,6 +2932,37 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
 #undef OGL_SYM
 #undef OGL_SYM_ND
 #undef OGL_SYM_K
+}
+
+void launch_spmv_symx(hipStream_t st, const DevSymx &A, int mode, const double *x, const double *b, double *y,
+                      const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf)
+{
+    if (A.n_rows == 0) return;
+    const int nc = (int)n_chunks(A.n_rows);
+    const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
+    const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
+#define OGL_SYMX_K(MODE, NDOT, STREAM)                                                                         \
+    hipLaunchKernelGGL((k_spmv_symx<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.chunks, A.mask,   \
+                       A.planes, A.ex_rowptr, A.ex_cols, A.ex_vals, x, b, y, dots.with, dots.part, dots.part_yy, \
+                       gate, xg, hf)
+#define OGL_SYMX(MODE, NDOT)               \
+    do {                                   \
+        if (A.stream)                      \
+            OGL_SYMX_K(MODE, NDOT, true);  \
+        else                               \
+            OGL_SYMX_K(MODE, NDOT, false); \
+    } while (0)
+    if (mode == SPMV_RESIDUAL) {
+        OGL_SYMX(SPMV_RESIDUAL, 0);
+    } else if (dots.part && dots.part_yy) {
+        OGL_SYMX(SPMV_PLAIN, 2);
+    } else if (dots.part) {
+        OGL_SYMX(SPMV_PLAIN, 1);
+    } else {
+        OGL_SYMX(SPMV_PLAIN, 0);
+    }
+#undef OGL_SYMX
+#undef OGL_SYMX_K
 }
 
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,

@@ -139,6 +139,19 @@ struct DevSym {
 };
 void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x, const double *b, double *y,
                      const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});
+// Half storage with per-chunk distances and explicit exceptions (SymxChunk, common.hpp), device view.
+struct DevSymx {
+    int32_t n_rows = 0;
+    const SymxChunk *chunks = nullptr;  // [n_chunks]
+    const uint8_t *mask = nullptr;      // [n_chunks * CHUNK_ROWS]
+    const double *planes = nullptr;
+    const int32_t *ex_rowptr = nullptr, *ex_cols = nullptr;  // explicit entries (per-chunk row pointers, columns)
+    const double *ex_vals = nullptr;
+    bool stream = false;
+    int32_t xcd_group = 0;
+};
+void launch_spmv_symx(hipStream_t st, const DevSymx &A, int mode, const double *x, const double *b, double *y,
+                      const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});
 // out[i] = map[i] >= 0 ? source[map[i]] : 0   (coefficient permutation into the padded ELL slots)
 void launch_gather_coeffs_masked(hipStream_t st, int64_t n, const int32_t *map, const double *source,
                                  double *out);

@@ -561,6 +561,66 @@ DevSym ogl_solver::sym() const
     return S;
 }
 
+DevSymx ogl_solver::symx() const
+{
+    DevSymx S;
+    S.n_rows = pat.n_rows;
+    S.chunks = d_symx_chunks.p;
+    S.mask = d_symx_mask.p;
+    S.planes = d_symx_planes.p;
+    S.ex_rowptr = d_symx_ex_rowptr.p;
+    S.ex_cols = d_symx_ex_cols.p;
+    S.ex_vals = d_symx_ex_vals.p;
+    S.stream = symx_bytes + 41.0 * (double)pat.n_rows > stream_above_bytes();
+    S.xcd_group = xcd_group();
+    return S;
+}
+
+// Half storage with per-chunk distances (build_symx_layout, host side: it needs the whole pattern); the planes
+// and the explicit entries are refreshed from the CSR values through their maps.
+int ogl_solver::build_symx()
+{
+    hipStream_t st = reg->stream;
+    symx_state = -1;
+    if (pat.n_rows == 0) return OGL_OK;
+    OGL_TRY(download_local_pattern(pat));
+    SymxLayout L;
+    if (!build_symx_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), L)) return OGL_OK;
+    const size_t nex = L.ex_cols.size();
+    OGL_TRY(d_symx_chunks.alloc(L.chunks.size(), st));
+    OGL_TRY(d_symx_mask.alloc(L.mask.size(), st));
+    OGL_TRY(d_symx_map.alloc(L.map.size(), st));
+    OGL_TRY(d_symx_planes.alloc(L.map.size(), st));
+    OGL_TRY(d_symx_ex_rowptr.alloc(std::max<size_t>(1, L.ex_rowptr.size()), st));
+    OGL_TRY(d_symx_ex_cols.alloc(nex + NNZ_PAD, st));
+    OGL_TRY(d_symx_ex_map.alloc(nex + NNZ_PAD, st));
+    OGL_TRY(d_symx_ex_vals.alloc(nex + NNZ_PAD, st));
+    OGL_TRY(reg->stager.h2d(d_symx_chunks.p, L.chunks.data(), L.chunks.size() * sizeof(SymxChunk), st));
+    OGL_TRY(reg->stager.h2d(d_symx_mask.p, L.mask.data(), L.mask.size(), st));
+    OGL_TRY(reg->stager.h2d(d_symx_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
+    if (!L.ex_rowptr.empty())
+        OGL_TRY(reg->stager.h2d(d_symx_ex_rowptr.p, L.ex_rowptr.data(), L.ex_rowptr.size() * sizeof(int32_t), st));
+    if (nex) {
+        OGL_TRY(reg->stager.h2d(d_symx_ex_cols.p, L.ex_cols.data(), nex * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_symx_ex_map.p, L.ex_map.data(), nex * sizeof(int32_t), st));
+    }
+    symx_state = 1;
+    symx_values_stale = true;
+    // bytes one SpMV reads of this layout: planes, masks, headers, explicit entries (value + column) and their
+    // row pointers
+    symx_bytes = 8.0 * (double)(L.map.size() - 2) + (double)(L.mask.size() - 16) + 96.0 * (double)L.chunks.size() +
+                 12.0 * (double)nex + 4.0 * (double)L.ex_rowptr.size();
+    props["sellMatrixBytes"] = symx_bytes;
+    props["sellReadSlots"] = (double)(L.map.size() - 2);
+    props["sellAllocatedSlots"] = (double)(L.map.size() - 2);
+    props["sellChunksDelta16"] = 0.0;
+    props["sellChunksCol32"] = 0.0;
+    props["sellSpilledEntries"] = 0.0;
+    props["symxPlanarEntries"] = (double)L.planar;
+    props["symxExplicitEntries"] = (double)nex;
+    return OGL_OK;
+}
+
 // Once per sparsity pattern; d_sym_map refreshes the planes from the permuted CSR values on the device.
 int ogl_solver::build_sym(const SymLayout &L)
 {
@@ -1146,6 +1206,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         ell_values_stale = true;
         sell_values_stale = true;
         sym_values_stale = true;
+        symx_values_stale = true;
         return OGL_OK;
     };
     // Has the addressing changed?  Counts first (free); then the hash of every face and interface cell,
@@ -1260,6 +1321,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         sym_state = 0;
         s21_state = 0;
         s21_use = false;
+        symx_state = 0;
         layout_tuned = false;
         d_s21_chunks.release();
         d_s21_codes.release();
@@ -1377,6 +1439,24 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
                 sym_ok = true;
             }
         }
+        props["symmetricHalfPerChunk"] = 0.0;
+        if (!sym_ok && try_sym && pat.symmetric && pat.local_iface_nnz == 0 && !pat.renumbered() &&
+            prop("symmetricHalfPerChunk_enable", 1.0) != 0.0) {
+            // banded only locally (multi-block mesh, refinement shell): per-chunk distances + explicit exceptions
+            OGL_TRY(build_symx());
+            if (symx_state == 1) {
+                sym_ok = true;
+                props["symmetricHalfPerChunk"] = 1.0;
+            }
+        }
+        if (symx_state != 1) {
+            symx_state = -1;
+            for (auto *b : {&d_symx_map, &d_symx_ex_rowptr, &d_symx_ex_cols, &d_symx_ex_map}) b->release();
+            d_symx_chunks.release();
+            d_symx_mask.release();
+            d_symx_planes.release();
+            d_symx_ex_vals.release();
+        }
         if (sym_ok) {
             props["symmetricHalf"] = 1.0;
             sell_state = -1;
@@ -1392,7 +1472,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             d_sym_map.release();
             d_sym_planes.release();
         }
-        if (sym_state != 1 && pre_built && try_sell) OGL_TRY(build_sell(&pre_sell, rep.sell_used));
+        if (sym_state != 1 && symx_state != 1 && pre_built && try_sell) OGL_TRY(build_sell(&pre_sell, rep.sell_used));
         OGL_TRY(setup_peer_halo());  // collective when the peer mesh is up (every rank, every pattern)
     }
 
@@ -1408,6 +1488,13 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         if (sym_values_stale) {
             launch_gather_coeffs_masked(st, (int64_t)d_sym_map.n - 2, d_sym_map.p, d_vals.p, d_sym_planes.p);
             sym_values_stale = false;
+        }
+    } else if (cfg.compress_indices && symx_state == 1) {
+        if (symx_values_stale) {
+            launch_gather_coeffs_masked(st, (int64_t)d_symx_map.n - 2, d_symx_map.p, d_vals.p, d_symx_planes.p);
+            const int32_t nex = (int32_t)(d_symx_ex_cols.n - NNZ_PAD);
+            if (nex > 0) launch_gather_coeffs(st, nex, d_symx_ex_map.p, d_vals.p, d_symx_ex_vals.p);
+            symx_values_stale = false;
         }
     } else if (cfg.compress_indices) {
         if (sell_state == 0) OGL_TRY(build_sell());
@@ -1430,7 +1517,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
     // (2 also for the half storage of a symmetric matrix: property symmetricHalf tells them apart)
     // 3: CSR-stream with packed columns
-    const bool on_csr = cfg.matrix_format != OGL_FORMAT_ELL && !use_sell() && !use_sym();
+    const bool on_csr = cfg.matrix_format != OGL_FORMAT_ELL && !use_sell() && !use_sym() && !use_symx();
     if (!cfg.compress_indices) s21_use = false;
     props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : (!on_csr ? 2.0 : (s21_use && s21_state == 1 ? 3.0 : 0.0));
     {   // ... and which instantiation of its kernel (what a profiler lists; bench.py looks up exactly that one)
@@ -1443,6 +1530,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             fast = S.nd >= 2 && S.d[1] == 1;
             for (int j = 2; j < S.nd; ++j) fast = fast && (S.d[j] % 2 == 0);
             props["spmvSymPlanes"] = (double)S.nd;
+        } else if (use_symx()) {
+            stream = symx().stream;
         } else if (use_sell()) {
             stream = sell().stream;
         } else {
@@ -1742,6 +1831,8 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
         launch_spmv_ell(st, ell(), mode, x, b, y, dots, gate, hf);
     else if (use_sym())
         launch_spmv_sym(st, sym(), mode, x, b, y, dots, gate, hf);
+    else if (use_symx())
+        launch_spmv_symx(st, symx(), mode, x, b, y, dots, gate, hf);
     else if (use_sell())
         launch_spmv_sell(st, sell(), mode, x, b, y, dots, gate, hf);
     else
@@ -2130,7 +2221,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_sell_chunks.p, (uintptr_t)d_sell_dict.p, (uintptr_t)d_sell_codes.p,
             (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
-            (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p};
+            (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
             cg_graph = nullptr;

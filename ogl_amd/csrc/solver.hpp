@@ -236,6 +236,22 @@ struct ogl_solver {
     {
         return cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices && sym_state == 1 && !sym_values_stale;
     }
+    // half storage with per-chunk distances and explicit exceptions (SymxLayout, host_matrix.hpp): symmetric
+    // matrices that are banded only locally (multi-block meshes, refinement shells) -- tried when the global
+    // half storage above does not qualify, before the compressed full-storage copy below
+    ogl::DevBuf<ogl::SymxChunk> d_symx_chunks;
+    ogl::DevBuf<uint8_t> d_symx_mask;
+    ogl::DevBuf<int32_t> d_symx_map, d_symx_ex_rowptr, d_symx_ex_cols, d_symx_ex_map;
+    ogl::DevBuf<double> d_symx_planes, d_symx_ex_vals;
+    int symx_state = 0;  // 0 not tried, 1 built, -1 not worth it
+    bool symx_values_stale = true;
+    double symx_bytes = 0.0;
+    int build_symx();
+    ogl::DevSymx symx() const;
+    bool use_symx() const
+    {
+        return cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices && symx_state == 1 && !symx_values_stale;
+    }
     // index-compressed chunked ELL copy (SellChunk, common.hpp): what the Coo/Csr formats run on when
     // cfg.compress_indices is set and the pattern qualifies.  sell_state: 0 = not tried for this
     // pattern, 1 = built, -1 = pattern does not qualify (CSR-stream kernel runs)

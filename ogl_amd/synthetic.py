@@ -358,6 +358,34 @@ def octree_case(n: int, band: float = 1.5, append_children: bool = False) -> Ldu
                    gi, n_cells)
 
 
+def multi_block_case(blocks, ny: int, nz: int) -> LduCase:
+    """A multi-block structured mesh as blockMesh numbers it: boxes of blocks[b] x ny x nz cells glued along x,
+    the cells of block b numbered (x fastest) after those of block b - 1.  Inside a block the neighbours sit at
+    distances 1, nx_b, nx_b * ny; the faces between two blocks couple cells at distances that vary from cell to
+    cell -- a pattern that is banded block by block, not as a whole."""
+    start = np.concatenate([[0], np.cumsum([nx * ny * nz for nx in blocks])]).astype(np.int64)
+    lo, up = [], []
+    for b, nx in enumerate(blocks):
+        i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+        cell = start[b] + i + nx * (j + ny * k)
+        for (di, dj, dk) in ((1, 0, 0), (0, 1, 0), (0, 0, 1)):
+            ok = (i + di < nx) & (j + dj < ny) & (k + dk < nz)
+            lo.append(cell[ok])
+            up.append((cell + di + nx * (dj + ny * dk))[ok])
+        if b + 1 < len(blocks):   # x-face to the next block: (nx - 1, j, k) <-> (0, j, k)
+            nx2 = blocks[b + 1]
+            jj, kk = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
+            lo.append((start[b] + (nx - 1) + nx * (jj + ny * kk)).ravel())
+            up.append((start[b + 1] + nx2 * (jj + ny * kk)).ravel())
+    lo, up = np.concatenate([a.ravel() for a in lo]), np.concatenate([a.ravel() for a in up])
+    order = np.lexsort((up, lo))
+    lo, up = lo[order].astype(np.int32), up[order].astype(np.int32)
+    n = int(start[-1])
+    gi = np.arange(n, dtype=np.int64)
+    deg = np.bincount(lo, minlength=n) + np.bincount(up, minlength=n)
+    return LduCase(n, lo, up, deg + _delta(gi), np.full(lo.size, -1.0), None, [], gi, n)
+
+
 def rcm_case(case: LduCase) -> LduCase:
     """What OpenFOAM's renumberMesh does: reverse Cuthill-McKee ordering of the cell graph (scipy)."""
     import scipy.sparse as sp

@@ -2,6 +2,7 @@
 ogl_amd/csrc/host_matrix.cpp): ogl_host_sym_check builds the layout and walks every row the way k_spmv_sym
 does -- lower entries read where their upper twins live -- and fails if that does not reproduce the pattern."""
 import numpy as np
+import pytest
 
 from ogl_amd import capi, synthetic
 
@@ -60,3 +61,41 @@ def test_patterns_that_do_not_qualify():
     # an octree mesh: more distances than planes
     rp, cols, _ = pattern(synthetic.octree_case(16, 1.5))
     assert capi.host_sym_check(rp, cols)[0] is False
+
+
+# ---- half storage with per-chunk distances and explicit exceptions (build_symx_layout) ----
+def _rowptr(rows, n):
+    return np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+
+
+SYMX_CASES = [
+    ("two_blocks", lambda: synthetic.multi_block_case([30, 17], 24, 20), True),
+    ("three_blocks", lambda: synthetic.multi_block_case([12, 40, 9], 16, 33), True),
+    ("thin_blocks", lambda: synthetic.multi_block_case([3, 5, 2, 7], 9, 11), None),   # (blocks shorter than a chunk)
+    ("box", lambda: synthetic.poisson_case(20), True),
+    ("line", lambda: synthetic.poisson_block(1000, 1, 1), True),
+    ("one_cell", lambda: synthetic.poisson_block(1, 1, 1), True),
+    ("periodic", lambda: synthetic.poisson_block(16, 15, 14, periodic_x=True), None),   # (cyclic entries: explicit)
+    ("shuffled", lambda: synthetic.renumber_case(synthetic.poisson_case(16), 512), False),
+    ("voronoi", lambda: synthetic.voronoi_case(4000), False),
+    ("octree", lambda: synthetic.octree_case(24, 1.5), None),
+]
+
+
+@pytest.mark.parametrize("name,make,qualifies", SYMX_CASES, ids=[c[0] for c in SYMX_CASES])
+def test_symx_layout_decodes_to_the_pattern(name, make, qualifies):
+    """ogl_host_symx_check builds the layout and walks every row as k_spmv_symx does (lower entries from their
+    twins' planes, explicit entries merged by column): it must reproduce the row-major pattern entry by entry,
+    whether the layout is worth using or not."""
+    case = make()
+    d, loc, _, _ = capi.host_pattern(case)
+    rp = _rowptr(loc[0], d.n_rows)
+    ok, slots, planar, explicit, ex_chunks, chunks = capi.host_symx_check(rp, loc[1])
+    assert planar + explicit == d.local_nnz
+    assert chunks == -(-d.n_rows // 512) and slots % 512 == 0
+    if qualifies is not None:
+        assert ok == qualifies, (name, planar / d.local_nnz)
+    if name in ("box", "line", "one_cell"):
+        assert explicit <= 0.01 * d.local_nnz + 8
+    if name.endswith("blocks"):
+        assert planar >= 0.9 * d.local_nnz and explicit > 0

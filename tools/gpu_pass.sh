@@ -40,6 +40,10 @@ variant() {
     shuffle65536g*) echo "--shuffle 65536 --prop xcdGroup=${1#shuffle65536g}";;
     nocompressg*) echo "--no-compress --prop xcdGroup=${1#nocompressg}";;
     hostsetup) echo "--prop deviceSetup=0";;
+    blocks2) echo "--blocks 120,96";;      blocks2full) echo "--blocks 120,96 --full-storage";;
+    blocks3) echo "--blocks 70,100,46";;   blocks3full) echo "--blocks 70,100,46 --full-storage";;
+    oct15full) echo "--octree 1.5 --full-storage";;  oct15append) echo "--octree 1.5 --octree-append";;
+    oct15appendfull) echo "--octree 1.5 --octree-append --full-storage";;
     vor3mnc) echo "--voronoi 3000000 --no-compress";;
     n32|n64|n100|n128) echo "--edge ${1#n} --iters 200";;
     *) echo "${1//+/ }";;
