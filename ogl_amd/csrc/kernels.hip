@@ -1600,16 +1600,52 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
 // flagged in their mask byte carry explicit entries -- column + value lists -- that are merged into the row sum by
 // column, so that every row is still summed in ascending column order and y keeps the bits of the other kernels.
 // ------------------------------------------------------------------------------------------
+// the explicit entries of one row: the first two are fetched (column, value * x) when the kernel starts, together
+// with everything else; a row with more of them reads the rest as it gets there
+struct SymxRowExtras {
+    int k, n;        // consumed so far, entries of the row
+    int e;           // first entry
+    int ca, cb;      // columns of the first two (INT32_MAX: none)
+    double pa, pb;   // their products
+};
 template <int MODE>
-__device__ __forceinline__ void symx_explicit(double &acc, int &ek, int ee, int limit,
+__device__ __forceinline__ void symx_explicit(double &acc, SymxRowExtras &E, int limit,
                                               const int *__restrict__ ex_cols,
                                               const double *__restrict__ ex_vals, const double *__restrict__ x)
 {
-    while (ek < ee && ex_cols[ek] < limit) {
-        const double p = ex_vals[ek] * x[ex_cols[ek]];
-        acc = (MODE == SPMV_RESIDUAL) ? acc - p : acc + p;
-        ++ek;
+    if (E.k == 0 && E.ca < limit) {
+        acc = (MODE == SPMV_RESIDUAL) ? acc - E.pa : acc + E.pa;
+        E.k = 1;
     }
+    if (E.k == 1 && E.cb < limit) {
+        acc = (MODE == SPMV_RESIDUAL) ? acc - E.pb : acc + E.pb;
+        E.k = 2;
+    }
+    while (E.k >= 2 && E.k < E.n && ex_cols[E.e + E.k] < limit) {
+        const double p = ex_vals[E.e + E.k] * x[ex_cols[E.e + E.k]];
+        acc = (MODE == SPMV_RESIDUAL) ? acc - p : acc + p;
+        ++E.k;
+    }
+}
+template <int MODE>
+__device__ __forceinline__ SymxRowExtras symx_fetch(int e, int ee, const int *__restrict__ ex_cols,
+                                                    const double *__restrict__ ex_vals, const double *__restrict__ x)
+{
+    SymxRowExtras E;
+    E.k = 0;
+    E.n = ee - e;
+    E.e = e;
+    E.ca = E.cb = INT32_MAX;
+    E.pa = E.pb = 0.0;
+    if (E.n > 0) {
+        E.ca = ex_cols[e];
+        E.pa = ex_vals[e] * x[E.ca];
+    }
+    if (E.n > 1) {
+        E.cb = ex_cols[e + 1];
+        E.pb = ex_vals[e + 1] * x[E.cb];
+    }
+    return E;
 }
 
 template <int MODE, int NDOT, bool STREAM>
@@ -1630,12 +1666,23 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
     if (gate && gate->stop) return;
     const int chunk = xcd_chunk(blockIdx.x, xgroup);
     if (chunk >= n_chunks) return;
+    // the header is only ever indexed with compile-time constants (every loop below is fully unrolled): it stays
+    // in scalar registers; a run-time index would push all 96 bytes into scratch memory
     const SymxChunk h = hdr[chunk];
     const int t = threadIdx.x;
     const RowPair rp = my_rows(chunk, n_rows);
     const int row = rp.row, r0 = chunk * CHUNK_ROWS;
     const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + row);
     const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
+    // explicit entries of the two rows (few rows have any): asked for now, consumed in the merge below
+    const bool has_explicit = h.ex_rp_off >= 0 && ((m0 | m1) & SYMX_EXTRAS_BIT);
+    SymxRowExtras E0 = symx_fetch<MODE>(0, 0, ex_cols, ex_vals, x), E1 = E0;
+    if (has_explicit) {
+        const int *rpx = ex_rowptr + h.ex_rp_off + t * ROWS_PER_THREAD;
+        const int ea = rpx[0], eb = rpx[1], ec = rpx[2];
+        E0 = symx_fetch<MODE>(ea, eb, ex_cols, ex_vals, x);
+        E1 = symx_fetch<MODE>(eb, ec, ex_cols, ex_vals, x);
+    }
     double2 acc;
     acc.x = acc.y = 0.0;
     if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
@@ -1651,21 +1698,24 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
     }
     const double2 xd = ld2(x, rp);
     double2 lo[4], xl[4], xu[4];
+    int dj[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
         lo[j].x = lo[j].y = xl[j].x = xl[j].y = xu[j].x = xu[j].y = 0.0;
         if (j < h.nd) {
             const int d = h.d[j - 1];
+            dj[j] = d;
             // first row of the chunk minus d: its chunk (floor division) is lo_base[.][0], the next one [.][1]
             const int cs0 = (r0 - d) >> 9;
+            const long base0 = h.lo_base[j - 1][0], base1 = h.lo_base[j - 1][1];
             if ((m0 >> (3 - j)) & 1u) {
                 const int rs = row - d;
-                lo[j].x = planes[h.lo_base[j - 1][(rs >> 9) - cs0] + (rs & (CHUNK_ROWS - 1))];
+                lo[j].x = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
                 xl[j].x = x[rs];
             }
             if ((m1 >> (3 - j)) & 1u) {
                 const int rs = row + 1 - d;
-                lo[j].y = planes[h.lo_base[j - 1][(rs >> 9) - cs0] + (rs & (CHUNK_ROWS - 1))];
+                lo[j].y = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
                 xl[j].y = x[rs];
             }
             if ((m0 >> (3 + j)) & 1u) xu[j].x = x[row + d];
@@ -1673,85 +1723,47 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
         }
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
-    if (h.ex_rp_off < 0 || !((m0 | m1) & SYMX_EXTRAS_BIT)) {
-        // no explicit entries in these two rows: the straight walk of k_spmv_sym
+    // the row walk in ascending column order: the furthest lower entry first; a row's explicit entries are merged
+    // in by column (one that repeats a column a plane holds comes after the plane's entry: `<` in symx_explicit)
 #pragma unroll
-        for (int j = 3; j >= 1; --j) {  // ascending columns: the furthest lower entry first
-            if ((m0 >> (3 - j)) & 1u) {
-                const double p = lo[j].x * xl[j].x;
-                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
-            }
-            if ((m1 >> (3 - j)) & 1u) {
-                const double p = lo[j].y * xl[j].y;
-                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
-            }
-        }
-        if ((m0 >> 3) & 1u) {
-            const double p = up[0].x * xd.x;
+    for (int j = 3; j >= 1; --j) {
+        if ((m0 >> (3 - j)) & 1u) {
+            if (has_explicit) symx_explicit<MODE>(acc.x, E0, row - dj[j], ex_cols, ex_vals, x);
+            const double p = lo[j].x * xl[j].x;
             acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
         }
-        if ((m1 >> 3) & 1u) {
-            const double p = up[0].y * xd.y;
+        if ((m1 >> (3 - j)) & 1u) {
+            if (has_explicit) symx_explicit<MODE>(acc.y, E1, row + 1 - dj[j], ex_cols, ex_vals, x);
+            const double p = lo[j].y * xl[j].y;
             acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
         }
+    }
+    if ((m0 >> 3) & 1u) {
+        if (has_explicit) symx_explicit<MODE>(acc.x, E0, row, ex_cols, ex_vals, x);
+        const double p = up[0].x * xd.x;
+        acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
+    }
+    if ((m1 >> 3) & 1u) {
+        if (has_explicit) symx_explicit<MODE>(acc.y, E1, row + 1, ex_cols, ex_vals, x);
+        const double p = up[0].y * xd.y;
+        acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
+    }
 #pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            if ((m0 >> (3 + j)) & 1u) {
-                const double p = up[j].x * xu[j].x;
-                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
-            }
-            if ((m1 >> (3 + j)) & 1u) {
-                const double p = up[j].y * xu[j].y;
-                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
-            }
-        }
-    } else {
-        // the same walk with the rows' explicit entries merged in by column (a later entry of a column that a
-        // plane holds comes after the plane's: `<` in symx_explicit)
-        const int *rpx = ex_rowptr + h.ex_rp_off + t * ROWS_PER_THREAD;
-        int e0 = rpx[0], e1 = rpx[1];
-        const int e2 = rpx[2];
-        const int e0_end = e1;
-#pragma unroll
-        for (int j = 3; j >= 1; --j) {
-            const int d = j < h.nd ? h.d[j - 1] : 0;
-            if ((m0 >> (3 - j)) & 1u) {
-                symx_explicit<MODE>(acc.x, e0, e0_end, row - d, ex_cols, ex_vals, x);
-                const double p = lo[j].x * xl[j].x;
-                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
-            }
-            if ((m1 >> (3 - j)) & 1u) {
-                symx_explicit<MODE>(acc.y, e1, e2, row + 1 - d, ex_cols, ex_vals, x);
-                const double p = lo[j].y * xl[j].y;
-                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
-            }
-        }
-        if ((m0 >> 3) & 1u) {
-            symx_explicit<MODE>(acc.x, e0, e0_end, row, ex_cols, ex_vals, x);
-            const double p = up[0].x * xd.x;
+    for (int j = 1; j < 4; ++j) {
+        if ((m0 >> (3 + j)) & 1u) {
+            if (has_explicit) symx_explicit<MODE>(acc.x, E0, row + dj[j], ex_cols, ex_vals, x);
+            const double p = up[j].x * xu[j].x;
             acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
         }
-        if ((m1 >> 3) & 1u) {
-            symx_explicit<MODE>(acc.y, e1, e2, row + 1, ex_cols, ex_vals, x);
-            const double p = up[0].y * xd.y;
+        if ((m1 >> (3 + j)) & 1u) {
+            if (has_explicit) symx_explicit<MODE>(acc.y, E1, row + 1 + dj[j], ex_cols, ex_vals, x);
+            const double p = up[j].y * xu[j].y;
             acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
         }
-#pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            const int d = j < h.nd ? h.d[j - 1] : 0;
-            if ((m0 >> (3 + j)) & 1u) {
-                symx_explicit<MODE>(acc.x, e0, e0_end, row + d, ex_cols, ex_vals, x);
-                const double p = up[j].x * xu[j].x;
-                acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
-            }
-            if ((m1 >> (3 + j)) & 1u) {
-                symx_explicit<MODE>(acc.y, e1, e2, row + 1 + d, ex_cols, ex_vals, x);
-                const double p = up[j].y * xu[j].y;
-                acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
-            }
-        }
-        symx_explicit<MODE>(acc.x, e0, e0_end, INT32_MAX, ex_cols, ex_vals, x);
-        symx_explicit<MODE>(acc.y, e1, e2, INT32_MAX, ex_cols, ex_vals, x);
+    }
+    if (has_explicit) {
+        symx_explicit<MODE>(acc.x, E0, INT32_MAX, ex_cols, ex_vals, x);
+        symx_explicit<MODE>(acc.y, E1, INT32_MAX, ex_cols, ex_vals, x);
     }
     if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc.x, acc.y, ys);
     st2(y, rp, acc);
