@@ -650,8 +650,9 @@ def main():
             "rows_sorted_by_length": prop_or(s, "rowsSortedByLength", 0.0) == 1.0,
             # irregular patterns: both SpMV kernels timed once per pattern at set_matrix, the faster one runs
             "layout_tuned_us": ({"csr": prop_or(s, "spmvTunedCsrUs", None), "sell": prop_or(s, "spmvTunedSellUs", None),
-                                 "csr21": prop_or(s, "spmvTunedCsr21Us", None)}
-                                if prop_or(s, "spmvTunedCsrUs", None) is not None else None),
+                                 "csr21": prop_or(s, "spmvTunedCsr21Us", None), "symx": prop_or(s, "spmvTunedSymxUs", None)}
+                                if (prop_or(s, "spmvTunedCsrUs", None) is not None
+                                    or prop_or(s, "spmvTunedSymxUs", None) is not None) else None),
             "spilled_entries": prop_or(s, "sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
                                          "in_use": s.get_property("gatherSectorRatio")},

@@ -1348,6 +1348,12 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
             out.ex_rowptr.insert(out.ex_rowptr.end(), rp.begin(), rp.end());
         }
     }
+    out.all_fast = true;
+    for (const SymxChunk &h : out.chunks) {
+        if (h.nd >= 2 && h.d[0] != 1) out.all_fast = false;
+        for (int j = 2; j < h.nd; ++j)
+            if (h.d[j - 1] % 2 != 0) out.all_fast = false;
+    }
     if ((double)out.planar < SYMX_MIN_PLANAR * (double)nnz) return false;
     if ((double)slots > SYM_MAX_PADDING * 1.5 * (double)upper_entries + 8.0 * CHUNK_ROWS) return false;
     return true;

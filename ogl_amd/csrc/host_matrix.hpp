@@ -133,6 +133,7 @@ struct SymxLayout {
     std::vector<int32_t> ex_rowptr;   // (CHUNK_ROWS + 1) pointers per chunk that has explicit entries
     std::vector<int32_t> ex_cols, ex_map;  // explicit entries: column, position in the CSR values
     int64_t planar = 0;               // entries served from planes
+    bool all_fast = false;            // every chunk with distances: the first is 1, the others are even
 };
 // false: not worth it (fewer than SYMX_MIN_PLANAR of the entries planar, or more plane slots than
 // SYM_MAX_PADDING x the diagonal + upper entries they hold)

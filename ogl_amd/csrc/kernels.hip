@@ -1648,7 +1648,11 @@ __device__ __forceinline__ SymxRowExtras symx_fetch(int e, int ee, const int *__
     return E;
 }
 
-template <int MODE, int NDOT, bool STREAM>
+// FAST (as in k_spmv_sym; known per layout: every chunk's first distance is 1 and its further ones are even --
+// blocks with even line lengths): the two rows of a lane are an aligned pair in every strip, so x and the lower
+// values of the even distances come as one 16-byte load per pair and the d = 1 neighbours from the lane's own
+// diagonal pair and plane-1 value.
+template <int MODE, int NDOT, bool STREAM, bool FAST>
 __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, const SymxChunk *__restrict__ hdr,
                                                      const uint8_t *__restrict__ mask,
                                                      const double *__restrict__ planes,
@@ -1708,18 +1712,40 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
             // first row of the chunk minus d: its chunk (floor division) is lo_base[.][0], the next one [.][1]
             const int cs0 = (r0 - d) >> 9;
             const long base0 = h.lo_base[j - 1][0], base1 = h.lo_base[j - 1][1];
-            if ((m0 >> (3 - j)) & 1u) {
+            const bool l0 = (m0 >> (3 - j)) & 1u, l1 = (m1 >> (3 - j)) & 1u;
+            const bool u0 = (m0 >> (3 + j)) & 1u, u1 = (m1 >> (3 + j)) & 1u;
+            if (FAST && j >= 2) {  // even distance: rows (row - d, row + 1 - d) are an aligned pair of one chunk's plane
                 const int rs = row - d;
-                lo[j].x = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
-                xl[j].x = x[rs];
+                if (l0 || l1) {
+                    lo[j] = *reinterpret_cast<const double2 *>(planes + ((rs >> 9) == cs0 ? base0 : base1) +
+                                                               (rs & (CHUNK_ROWS - 1)));
+                    xl[j] = *reinterpret_cast<const double2 *>(x + rs);
+                }
+                if (u0 || u1) xu[j] = *reinterpret_cast<const double2 *>(x + row + d);
+            } else if (FAST) {     // d = 1: A(row + 1, row) is this lane's own plane-1 value of row
+                if (l0) {
+                    const int rs = row - 1;
+                    lo[j].x = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
+                    xl[j].x = x[rs];
+                }
+                lo[j].y = up[1].x;
+                xl[j].y = xd.x;
+                xu[j].x = xd.y;
+                if (u1) xu[j].y = x[row + 2];
+            } else {
+                if (l0) {
+                    const int rs = row - d;
+                    lo[j].x = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
+                    xl[j].x = x[rs];
+                }
+                if (l1) {
+                    const int rs = row + 1 - d;
+                    lo[j].y = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
+                    xl[j].y = x[rs];
+                }
+                if (u0) xu[j].x = x[row + d];
+                if (u1) xu[j].y = x[row + 1 + d];
             }
-            if ((m1 >> (3 - j)) & 1u) {
-                const int rs = row + 1 - d;
-                lo[j].y = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
-                xl[j].y = x[rs];
-            }
-            if ((m0 >> (3 + j)) & 1u) xu[j].x = x[row + d];
-            if ((m1 >> (3 + j)) & 1u) xu[j].y = x[row + 1 + d];
         }
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
@@ -2953,16 +2979,20 @@ void launch_spmv_symx(hipStream_t st, const DevSymx &A, int mode, const double *
     const int nc = (int)n_chunks(A.n_rows);
     const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
     const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
-#define OGL_SYMX_K(MODE, NDOT, STREAM)                                                                         \
-    hipLaunchKernelGGL((k_spmv_symx<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.chunks, A.mask,   \
-                       A.planes, A.ex_rowptr, A.ex_cols, A.ex_vals, x, b, y, dots.with, dots.part, dots.part_yy, \
+#define OGL_SYMX_K(MODE, NDOT, STREAM, FAST)                                                                       \
+    hipLaunchKernelGGL((k_spmv_symx<MODE, NDOT, STREAM, FAST>), grid, block, 0, st, A.n_rows, nc, A.chunks, A.mask,  \
+                       A.planes, A.ex_rowptr, A.ex_cols, A.ex_vals, x, b, y, dots.with, dots.part, dots.part_yy,     \
                        gate, xg, hf)
-#define OGL_SYMX(MODE, NDOT)               \
-    do {                                   \
-        if (A.stream)                      \
-            OGL_SYMX_K(MODE, NDOT, true);  \
-        else                               \
-            OGL_SYMX_K(MODE, NDOT, false); \
+#define OGL_SYMX(MODE, NDOT)                      \
+    do {                                          \
+        if (A.stream && A.fast)                   \
+            OGL_SYMX_K(MODE, NDOT, true, true);   \
+        else if (A.stream)                        \
+            OGL_SYMX_K(MODE, NDOT, true, false);  \
+        else if (A.fast)                          \
+            OGL_SYMX_K(MODE, NDOT, false, true);  \
+        else                                      \
+            OGL_SYMX_K(MODE, NDOT, false, false); \
     } while (0)
     if (mode == SPMV_RESIDUAL) {
         OGL_SYMX(SPMV_RESIDUAL, 0);

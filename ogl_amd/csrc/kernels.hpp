@@ -148,6 +148,7 @@ struct DevSymx {
     const int32_t *ex_rowptr = nullptr, *ex_cols = nullptr;  // explicit entries (per-chunk row pointers, columns)
     const double *ex_vals = nullptr;
     bool stream = false;
+    bool fast = false;  // every chunk: first distance 1, further distances even (pair-load instantiation)
     int32_t xcd_group = 0;
 };
 void launch_spmv_symx(hipStream_t st, const DevSymx &A, int mode, const double *x, const double *b, double *y,

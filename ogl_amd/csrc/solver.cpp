@@ -27,6 +27,16 @@ double *sums_ptr(DevScalars *s)
     return reinterpret_cast<double *>(reinterpret_cast<char *>(s) + offsetof(DevScalars, sums));
 }
 
+struct EventPair {  // destroyed on every return path
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~EventPair()
+    {
+        for (auto &x : e)
+            if (x) (void)hipEventDestroy(x);
+    }
+    hipEvent_t &operator[](int i) { return e[i]; }
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -572,8 +582,65 @@ DevSymx ogl_solver::symx() const
     S.ex_cols = d_symx_ex_cols.p;
     S.ex_vals = d_symx_ex_vals.p;
     S.stream = symx_bytes + 41.0 * (double)pat.n_rows > stream_above_bytes();
+    S.fast = symx_fast;
     S.xcd_group = xcd_group();
     return S;
+}
+
+// Per-chunk half storage against the compressed full-storage copy, once per pattern (same bits either way): the
+// former moves about a third fewer bytes, but rows with explicit entries cost it a merge; the faster one stays.
+int ogl_solver::tune_symx()
+{
+    hipStream_t st = reg->stream;
+    EventPair ev;
+    OGL_HIP_CHECK(hipEventCreate(&ev[0]));
+    OGL_HIP_CHECK(hipEventCreate(&ev[1]));
+    OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, ((size_t)pat.n_rows + 2) * sizeof(double), st));
+    SpmvDots dots;
+    dots.with = d_p.p;
+    dots.part = d_part0.p;
+    constexpr int WARM = 2, TIMED = 5;
+    float best[2] = {1e30f, 1e30f};  // [0] compressed full storage, [1] per-chunk half storage
+    for (int round = 0; round < WARM + TIMED; ++round)
+        for (int which = 0; which < 2; ++which) {
+            OGL_HIP_CHECK(hipEventRecord(ev[0], st));
+            if (which)
+                launch_spmv_symx(st, symx(), SPMV_PLAIN, d_p.p, nullptr, d_q.p, dots, nullptr);
+            else
+                launch_spmv_sell(st, sell(), SPMV_PLAIN, d_p.p, nullptr, d_q.p, dots, nullptr);
+            OGL_HIP_CHECK(hipEventRecord(ev[1], st));
+            OGL_HIP_CHECK(hipEventSynchronize(ev[1]));
+            float ms = 0;
+            OGL_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            if (round >= WARM) best[which] = std::min(best[which], ms);
+        }
+    OGL_HIP_CHECK(hipGetLastError());
+    props["spmvTunedSellUs"] = 1e3 * best[0];
+    props["spmvTunedSymxUs"] = 1e3 * best[1];
+    OGL_HIP_CHECK(hipStreamSynchronize(st));
+    if (best[1] <= best[0]) {  // half storage stays
+        for (auto *b : {&d_sell_dict, &d_sell_map, &d_spill_rows, &d_spill_ptrs, &d_spill_cols, &d_spill_map,
+                        &d_spill_chunks})
+            b->release();
+        d_sell_chunks.release();
+        d_sell_codes.release();
+        d_sell_vals.release();
+        d_spill_vals.release();
+        n_spill = n_spill_rows = 0;
+        sell_state = -1;
+        props["sellMatrixBytes"] = symx_bytes;
+    } else {                   // full storage stays
+        symx_state = -1;
+        for (auto *b : {&d_symx_map, &d_symx_ex_rowptr, &d_symx_ex_cols, &d_symx_ex_map}) b->release();
+        d_symx_chunks.release();
+        d_symx_mask.release();
+        d_symx_planes.release();
+        d_symx_ex_vals.release();
+        props["symmetricHalf"] = 0.0;
+        props["symmetricHalfPerChunk"] = 0.0;
+        props["sellMatrixBytes"] = sell_bytes;
+    }
+    return OGL_OK;
 }
 
 // Half storage with per-chunk distances (build_symx_layout, host side: it needs the whole pattern); the planes
@@ -605,6 +672,7 @@ int ogl_solver::build_symx()
         OGL_TRY(reg->stager.h2d(d_symx_ex_map.p, L.ex_map.data(), nex * sizeof(int32_t), st));
     }
     symx_state = 1;
+    symx_fast = L.all_fast;
     symx_values_stale = true;
     // bytes one SpMV reads of this layout: planes, masks, headers, explicit entries (value + column) and their
     // row pointers
@@ -1040,17 +1108,6 @@ int ogl_solver::download_rows(double *dst, const double *src)
     return reg->stager.d2h(dst, d_perm_tmp.p, bytes, reg->stream);
 }
 
-namespace {
-struct EventPair {  // destroyed on every return path
-    hipEvent_t e[2] = {nullptr, nullptr};
-    ~EventPair()
-    {
-        for (auto &x : e)
-            if (x) (void)hipEventDestroy(x);
-    }
-    hipEvent_t &operator[](int i) { return e[i]; }
-};
-}  // namespace
 
 // Which kernel runs the in-loop SpMV of a pattern with irregular chunks: measured, once per pattern.  Both
 // read the same matrix and give the same bits (y and the fused dot partials), so this is a speed choice
@@ -1457,14 +1514,24 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             d_symx_planes.release();
             d_symx_ex_vals.release();
         }
+        symx_tune_pending = false;
         if (sym_ok) {
             props["symmetricHalf"] = 1.0;
-            sell_state = -1;
-            d_sell_chunks.release();
-            d_sell_codes.release();
-            d_sell_vals.release();
-            d_sell_map.release();
-            d_sell_dict.release();
+            // (per-chunk half storage of a system that is not launch-bound: timed once against the compressed full
+            //  storage the numbering policy has laid out on the way, after the first values are in)
+            symx_tune_pending = symx_state == 1 && cfg.compress_indices == 1 && pat.n_rows >= SPMV_TUNE_MIN_ROWS &&
+                                pre_built && rep.sell_used;
+            if (symx_tune_pending) {
+                OGL_TRY(build_sell(&pre_sell, true));
+                props["sellMatrixBytes"] = symx_bytes;
+            } else {
+                sell_state = -1;
+                d_sell_chunks.release();
+                d_sell_codes.release();
+                d_sell_vals.release();
+                d_sell_map.release();
+                d_sell_dict.release();
+            }
         }
         if (sym_state != 1) {
             sym_state = -1;
@@ -1495,6 +1562,15 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             const int32_t nex = (int32_t)(d_symx_ex_cols.n - NNZ_PAD);
             if (nex > 0) launch_gather_coeffs(st, nex, d_symx_ex_map.p, d_vals.p, d_symx_ex_vals.p);
             symx_values_stale = false;
+        }
+        if (symx_tune_pending) {
+            symx_tune_pending = false;
+            if (sell_state == 1) {
+                launch_gather_sell(st, (int32_t)d_sell_chunks.n, d_sell_chunks.p, d_sell_map.p, d_vals.p, d_sell_vals.p);
+                if (n_spill) launch_gather_coeffs(st, n_spill, d_spill_map.p, d_vals.p, d_spill_vals.p);
+                sell_values_stale = false;
+                OGL_TRY(tune_symx());
+            }
         }
     } else if (cfg.compress_indices) {
         if (sell_state == 0) OGL_TRY(build_sell());

@@ -244,6 +244,11 @@ struct ogl_solver {
     ogl::DevBuf<int32_t> d_symx_map, d_symx_ex_rowptr, d_symx_ex_cols, d_symx_ex_map;
     ogl::DevBuf<double> d_symx_planes, d_symx_ex_vals;
     int symx_state = 0;  // 0 not tried, 1 built, -1 not worth it
+    bool symx_fast = false;
+    // built next to the compressed full-storage copy and still to be timed against it (once per pattern, systems
+    // of >= SPMV_TUNE_MIN_ROWS rows with compress_indices 1): the faster one stays
+    bool symx_tune_pending = false;
+    int tune_symx();
     bool symx_values_stale = true;
     double symx_bytes = 0.0;
     int build_symx();

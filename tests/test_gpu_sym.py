@@ -47,8 +47,10 @@ def test_spmv_same_bits_half_or_full_storage(reg, oracle, kw):
     ref = oracle.spmv(rp, cols, vals, x)
     half = reg.solver("sym_half", cfg(1)).set_matrix(case)
     full = reg.solver("sym_full", cfg(0)).set_matrix(case)
-    qualifies = capi.host_sym_check(rp, cols)[0]
+    # (one set of distances for the whole matrix, else the per-chunk variant with explicit exceptions)
+    qualifies = capi.host_sym_check(rp, cols)[0] or capi.host_symx_check(rp, cols)[0]
     assert half.get_property("symmetricHalf") == (1.0 if qualifies else 0.0)
+    assert half.get_property("symmetricHalfPerChunk") == (0.0 if capi.host_sym_check(rp, cols)[0] or not qualifies else 1.0)
     assert full.get_property("symmetricHalf") == 0.0
     assert half.get_property("spmvLayout") == full.get_property("spmvLayout") == 2.0
     np.testing.assert_array_equal(half.spmv(x), ref)
@@ -131,7 +133,7 @@ def test_random_boxes_same_bits_as_the_oracle(reg, oracle):
         case = randomise(synthetic.poisson_block(gx=gx, gy=gy, gz=gz), 100 + i)
         rp, cols, vals = oracle_csr(oracle, case)
         s = reg.solver("sym_rand", cfg(1, max_iter=12)).set_matrix(case)
-        qualifies = capi.host_sym_check(rp, cols)[0]
+        qualifies = capi.host_sym_check(rp, cols)[0] or capi.host_symx_check(rp, cols)[0]
         assert s.get_property("symmetricHalf") == (1.0 if qualifies else 0.0), (gx, gy, gz)
         x = rng.uniform(-1, 1, case.n_cells)
         np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x), err_msg=str((gx, gy, gz)))
