@@ -141,7 +141,10 @@ struct SymxChunk {
     int32_t nd;             // planes: diagonal + distances (1..4)
     int32_t d[3];           // the distances of planes 1..nd-1, ascending
     int32_t ex_rp_off;      // this chunk's CHUNK_ROWS + 1 row pointers into the explicit entries, -1: it has none
-    int32_t pad_[5];
+    int32_t merge;          // 1: some row has an explicit entry BETWEEN its planar ones (full merge by column);
+                            // 0: explicit entries only before the first / after the last planar entry of their rows
+                            // (the coupling across a block face): added ahead of / behind the plane walk
+    int32_t pad_[4];
 };
 static_assert(sizeof(SymxChunk) == 96, "SymxChunk is read as six 16-byte words");
 // mask byte of a row: bit 3 = diagonal, bit 3 - j / 3 + j = the entry at -d[j] / +d[j] (j = 1..3), bit 7 = the row

@@ -1346,6 +1346,28 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         if (out.ex_cols.size() > ex_begin) {
             h.ex_rp_off = (int32_t)out.ex_rowptr.size();
             out.ex_rowptr.insert(out.ex_rowptr.end(), rp.begin(), rp.end());
+            // does any row keep an explicit entry between its planar ones?
+            for (ogl_label r = r0; r < r1 && !h.merge; ++r) {
+                const unsigned m = out.mask[(size_t)r];
+                if (!(m & SYMX_EXTRAS_BIT)) continue;
+                int64_t first = INT64_MAX, last = INT64_MIN;  // columns of the row's first / last planar entry
+                for (int j = 1; j < h.nd; ++j) {
+                    if (m & (1u << (3 - j))) first = std::min<int64_t>(first, (int64_t)r - h.d[j - 1]);
+                    if (m & (1u << (3 + j))) last = std::max<int64_t>(last, (int64_t)r + h.d[j - 1]);
+                }
+                if (m & (1u << 3)) {
+                    first = std::min<int64_t>(first, r);
+                    last = std::max<int64_t>(last, r);
+                }
+                for (int j = 1; j < h.nd; ++j) {
+                    if (m & (1u << (3 - j))) last = std::max<int64_t>(last, (int64_t)r - h.d[j - 1]);
+                    if (m & (1u << (3 + j))) first = std::min<int64_t>(first, (int64_t)r + h.d[j - 1]);
+                }
+                for (int32_t e = rp[(size_t)(r - r0)]; e < rp[(size_t)(r - r0) + 1]; ++e) {
+                    const int64_t col = out.ex_cols[(size_t)e];
+                    if (col >= first && col <= last) h.merge = 1;  // (a repeated column of a planar entry included)
+                }
+            }
         }
     }
     out.all_fast = true;

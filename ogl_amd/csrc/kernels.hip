@@ -1749,40 +1749,61 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
         }
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
-    // the row walk in ascending column order: the furthest lower entry first; a row's explicit entries are merged
-    // in by column (one that repeats a column a plane holds comes after the plane's entry: `<` in symx_explicit)
+    // the row walk in ascending column order: the furthest lower entry first.  Explicit entries: in most chunks
+    // they only sit before the first or behind the last planar entry of their rows (the coupling across a block
+    // face) -- added ahead of and behind the walk; a chunk with one in between (h.merge, workgroup-uniform) merges
+    // them by column (one that repeats a column a plane holds comes after the plane's entry: `<` in symx_explicit)
+    const bool merge = has_explicit && h.merge != 0;
+    if (has_explicit && !merge) {
+        // column of the first planar entry of each row
+        int f0 = INT32_MAX, f1 = INT32_MAX;
+#pragma unroll
+        for (int j = 3; j >= 1; --j) {
+            if (((m0 >> (3 + j)) & 1u)) f0 = row + dj[j];
+            if (((m1 >> (3 + j)) & 1u)) f1 = row + 1 + dj[j];
+        }
+        if ((m0 >> 3) & 1u) f0 = row;
+        if ((m1 >> 3) & 1u) f1 = row + 1;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            if (((m0 >> (3 - j)) & 1u)) f0 = row - dj[j];
+            if (((m1 >> (3 - j)) & 1u)) f1 = row + 1 - dj[j];
+        }
+        symx_explicit<MODE>(acc.x, E0, f0, ex_cols, ex_vals, x);
+        symx_explicit<MODE>(acc.y, E1, f1, ex_cols, ex_vals, x);
+    }
 #pragma unroll
     for (int j = 3; j >= 1; --j) {
         if ((m0 >> (3 - j)) & 1u) {
-            if (has_explicit) symx_explicit<MODE>(acc.x, E0, row - dj[j], ex_cols, ex_vals, x);
+            if (merge) symx_explicit<MODE>(acc.x, E0, row - dj[j], ex_cols, ex_vals, x);
             const double p = lo[j].x * xl[j].x;
             acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
         }
         if ((m1 >> (3 - j)) & 1u) {
-            if (has_explicit) symx_explicit<MODE>(acc.y, E1, row + 1 - dj[j], ex_cols, ex_vals, x);
+            if (merge) symx_explicit<MODE>(acc.y, E1, row + 1 - dj[j], ex_cols, ex_vals, x);
             const double p = lo[j].y * xl[j].y;
             acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
         }
     }
     if ((m0 >> 3) & 1u) {
-        if (has_explicit) symx_explicit<MODE>(acc.x, E0, row, ex_cols, ex_vals, x);
+        if (merge) symx_explicit<MODE>(acc.x, E0, row, ex_cols, ex_vals, x);
         const double p = up[0].x * xd.x;
         acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
     }
     if ((m1 >> 3) & 1u) {
-        if (has_explicit) symx_explicit<MODE>(acc.y, E1, row + 1, ex_cols, ex_vals, x);
+        if (merge) symx_explicit<MODE>(acc.y, E1, row + 1, ex_cols, ex_vals, x);
         const double p = up[0].y * xd.y;
         acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
     }
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
         if ((m0 >> (3 + j)) & 1u) {
-            if (has_explicit) symx_explicit<MODE>(acc.x, E0, row + dj[j], ex_cols, ex_vals, x);
+            if (merge) symx_explicit<MODE>(acc.x, E0, row + dj[j], ex_cols, ex_vals, x);
             const double p = up[j].x * xu[j].x;
             acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
         }
         if ((m1 >> (3 + j)) & 1u) {
-            if (has_explicit) symx_explicit<MODE>(acc.y, E1, row + 1 + dj[j], ex_cols, ex_vals, x);
+            if (merge) symx_explicit<MODE>(acc.y, E1, row + 1 + dj[j], ex_cols, ex_vals, x);
             const double p = up[j].y * xu[j].y;
             acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
         }

@@ -1519,12 +1519,16 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             props["symmetricHalf"] = 1.0;
             // (per-chunk half storage of a system that is not launch-bound: timed once against the compressed full
             //  storage the numbering policy has laid out on the way, after the first values are in)
-            symx_tune_pending = symx_state == 1 && cfg.compress_indices == 1 && pat.n_rows >= SPMV_TUNE_MIN_ROWS &&
-                                pre_built && rep.sell_used;
+            symx_tune_pending = symx_state == 1 && cfg.compress_indices == 1 && pat.n_rows >= SPMV_TUNE_MIN_ROWS;
             if (symx_tune_pending) {
-                OGL_TRY(build_sell(&pre_sell, true));
+                if (pre_built)
+                    OGL_TRY(build_sell(&pre_sell, rep.sell_used));
+                else
+                    OGL_TRY(build_sell());
+                symx_tune_pending = sell_state == 1;  // (nothing to time against when the compressed copy does not qualify)
                 props["sellMatrixBytes"] = symx_bytes;
-            } else {
+            }
+            if (!symx_tune_pending) {
                 sell_state = -1;
                 d_sell_chunks.release();
                 d_sell_codes.release();

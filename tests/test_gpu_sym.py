@@ -191,7 +191,8 @@ def test_multi_block_meshes_run_on_per_chunk_half_storage(reg, oracle, name, mak
         with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
             ref = fn(A, b, x.copy(), inv, tolerance=1e-11, rel_tol=0.0, max_iter=25)
         for half in (1, 0):
-            s = reg.solver(f"symx_{name}_{solver}_{half}_{int(stream > 0)}", cfg(half, solver=solver, max_iter=25))
+            s = reg.solver(f"symx_{name}_{solver}_{half}_{int(stream > 0)}",
+                           cfg(half, solver=solver, max_iter=25, update_init_guess=1))
             s.set_property("streamAboveBytes", stream)
             s.set_matrix(case)
             assert s.get_property("symmetricHalf") == float(half)
@@ -204,7 +205,10 @@ def test_multi_block_meshes_run_on_per_chunk_half_storage(reg, oracle, name, mak
     P = oracle.Precond(rp, cols, vals, 1)
     with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
         ref = oracle.gmres(A, b, x.copy(), P, krylov_dim=10, tolerance=1e-11, rel_tol=0.0, max_iter=25)
-    s = reg.solver(f"symx_{name}_gmres", cfg(1, solver=capi.SOLVER_GMRES, krylov_dim=10, max_iter=25)).set_matrix(case)
+    s = reg.solver(f"symx_{name}_gmres_{int(stream > 0)}",
+                   cfg(1, solver=capi.SOLVER_GMRES, krylov_dim=10, max_iter=25, update_init_guess=1))
+    s.set_property("streamAboveBytes", stream)
+    s.set_matrix(case)
     xs, perf = s.solve(b, x.copy())
     np.testing.assert_array_equal(s.history(), ref.history)
     np.testing.assert_array_equal(xs, ref.x)
