@@ -112,8 +112,12 @@ typedef struct ogl_config {
                                    structured mesh: at most 3 distances from the diagonal) is kept
                                    the OpenFOAM way on the device too -- diagonal + upper coefficients
                                    only; the SpMV reads A(r, r-d) where it reads A(r-d, r).  Same bits
-                                   in y, a third fewer bytes from DRAM.  Needs compress_indices; 0 =
-                                   full storage.  NOT a reference keyword: "symmetricStorage"        */
+                                   in y, a third fewer bytes from DRAM.  A pattern that is banded only
+                                   locally (multi-block mesh, refinement shell) gets the distances per
+                                   chunk of 512 rows and explicit entries for what breaks the bands,
+                                   and is timed once against the full-storage copy (the faster stays).
+                                   Needs compress_indices; 0 = full storage.  NOT a reference keyword:
+                                   "symmetricStorage"                                               */
 } ogl_config;
 
 /* Fill with the reference code's defaults. */

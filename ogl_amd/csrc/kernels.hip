@@ -1678,14 +1678,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
     const int row = rp.row, r0 = chunk * CHUNK_ROWS;
     const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + row);
     const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
-    // explicit entries of the two rows (few rows have any): asked for now, consumed in the merge below
     const bool has_explicit = h.ex_rp_off >= 0 && ((m0 | m1) & SYMX_EXTRAS_BIT);
-    SymxRowExtras E0 = symx_fetch<MODE>(0, 0, ex_cols, ex_vals, x), E1 = E0;
+    // (their row pointers: the first link of a chain of three dependent loads -- pointers, column + value, x --
+    //  whose later links are issued only after the plane and x loads below, so that they wait together)
+    int ea = 0, eb = 0, ec = 0;
     if (has_explicit) {
         const int *rpx = ex_rowptr + h.ex_rp_off + t * ROWS_PER_THREAD;
-        const int ea = rpx[0], eb = rpx[1], ec = rpx[2];
-        E0 = symx_fetch<MODE>(ea, eb, ex_cols, ex_vals, x);
-        E1 = symx_fetch<MODE>(eb, ec, ex_cols, ex_vals, x);
+        ea = rpx[0];
+        eb = rpx[1];
+        ec = rpx[2];
     }
     double2 acc;
     acc.x = acc.y = 0.0;
@@ -1749,6 +1750,12 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
         }
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
+    // explicit entries of the two rows (few rows have any): the first two of each are fetched here
+    SymxRowExtras E0 = symx_fetch<MODE>(0, 0, ex_cols, ex_vals, x), E1 = E0;
+    if (has_explicit) {
+        E0 = symx_fetch<MODE>(ea, eb, ex_cols, ex_vals, x);
+        E1 = symx_fetch<MODE>(eb, ec, ex_cols, ex_vals, x);
+    }
     // the row walk in ascending column order: the furthest lower entry first.  Explicit entries: in most chunks
     // they only sit before the first or behind the last planar entry of their rows (the coupling across a block
     // face) -- added ahead of and behind the walk; a chunk with one in between (h.merge, workgroup-uniform) merges
