@@ -2289,10 +2289,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // ROCm 7.2 it does not pay: 23.7 us per turn with plain stream launches against 24.2 us replayed
     // at 262k rows, 286.1 against 285.3 us at 10M rows -- the ~4.5 us between two dependent kernels
     // is the device's dispatch latency, not host launch cost, and a graph replays the same packets.
-    const bool graphable = !gmres && !bicg && !generic && !fused && !reg->comm->multi() && prof_cap == 0 &&
+    const bool graphable = !gmres && !bicg && !generic && !reg->comm->multi() && prof_cap == 0 &&
                            prop("hipGraph", 0.0) != 0.0;
     auto enqueue_turns = [&](int count) -> int {
-        if (!graphable || count != batch) return enqueue_direct(count);
+        // (the fused-finaliser turn: its first step_1x_fin differs from the later ones -- the first batch runs direct)
+        if (!graphable || count != batch || (fused && enq == 0)) return enqueue_direct(count);
         const std::vector<uintptr_t> key{
             (uintptr_t)n, (uintptr_t)batch, (uintptr_t)cfg.matrix_format, (uintptr_t)use_sell(),
             (uintptr_t)d_p.p, (uintptr_t)d_x.p, (uintptr_t)d_r.p, (uintptr_t)d_q.p, (uintptr_t)precond,
@@ -2301,7 +2302,8 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_sell_chunks.p, (uintptr_t)d_sell_dict.p, (uintptr_t)d_sell_codes.p,
             (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
-            (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p};
+            (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p,
+            (uintptr_t)fused, (uintptr_t)d_part2.p};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
             cg_graph = nullptr;

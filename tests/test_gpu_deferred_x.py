@@ -80,17 +80,19 @@ def test_converged_initial_guess_leaves_x_alone(reg, oracle, system, fused):
     np.testing.assert_array_equal(x2, x1)
 
 
-def test_hipgraph_replay_gives_the_same_bits(reg, oracle, system):
+@pytest.mark.parametrize("fused", [0.0, 1.0], ids=["five_launch", "fused"])
+def test_hipgraph_replay_gives_the_same_bits(reg, oracle, system, fused):
     """property hipGraph: full batches of 16 turns are captured once and replayed; the stop may fall
-    anywhere inside a replayed batch."""
+    anywhere inside a replayed batch.  (The fused-finaliser turn runs its first batch direct: the first
+    step_1x_fin of a solve differs from the later ones.)"""
     case, b, A, inv = system
     for max_iter in (16, 17, 40, 64, 65):
         kw = dict(tolerance=0.0, rel_tol=0.0, max_iter=max_iter)
-        s = reg.solver("dx_graph", capi.default_config(
+        s = reg.solver(f"dx_graph_{int(fused)}", capi.default_config(
             solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, export_res=1, adapt_min_iter=0,
             update_init_guess=1, **kw)).set_matrix(case)
         s.set_property("hipGraph", 1.0)
-        s.set_property("fusedFinalizers", 0.0)   # (graphs replay the five-launch turn)
+        s.set_property("fusedFinalizers", fused)
         x, perf = s.solve(b, np.zeros_like(b))
         with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
             ref = oracle.cg(A, b, np.zeros_like(b), inv, **kw)
