@@ -2283,14 +2283,16 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // all-reduced), hence enqueues the same number of batches and of RCCL calls.
     const int batch = bicg ? 8 : 16;
 
-    // hipGraph replay of a full batch of single-rank GKOCG turns (property "hipGraph", default off).
-    // Nothing in the captured launches depends on the turn or on the solve (criterion and flags live
-    // in the device scalars); the key lists every pointer they do bake in.  Measured on MI355X /
-    // ROCm 7.2 it does not pay: 23.7 us per turn with plain stream launches against 24.2 us replayed
-    // at 262k rows, 286.1 against 285.3 us at 10M rows -- the ~4.5 us between two dependent kernels
-    // is the device's dispatch latency, not host launch cost, and a graph replays the same packets.
+    // hipGraph replay of a full batch of single-rank GKOCG turns (property "hipGraph").  Nothing in the
+    // captured launches depends on the turn or on the solve (criterion and flags live in the device
+    // scalars); the key lists every pointer they do bake in.  For the 5-launch turn it does not pay on
+    // MI355X / ROCm 7.2 (23.7 us per turn with plain stream launches against 24.2 us replayed at 262k rows,
+    // 286.1 against 285.3 us at 10M rows: the gap between two dependent kernels is the device's dispatch
+    // latency, not host launch cost) and stays off by default.
     const bool graphable = !gmres && !bicg && !generic && !reg->comm->multi() && prof_cap == 0 &&
-                           prop("hipGraph", 0.0) != 0.0;
+                           prop("hipGraph", fused ? 1.0 : 0.0) != 0.0;
+    // (on by default for the 3-launch turn of small systems, where the host's launch rate shows: 32^3 15.1 -> 13.0 us
+    //  per turn, 64^3 17.3 -> 16.7; the 5-launch turn of larger systems measures the same either way)
     auto enqueue_turns = [&](int count) -> int {
         // (the fused-finaliser turn: its first step_1x_fin differs from the later ones -- the first batch runs direct)
         if (!graphable || count != batch || (fused && enq == 0)) return enqueue_direct(count);
