@@ -99,9 +99,11 @@ def parse():
     ap.add_argument("--renumber", default="auto", choices=["auto", "on", "off"],
                     help="keyword `renumber`: the library's own RCM numbering of its device copy "
                          "(auto = only when the numbering it is handed gathers x badly)")
-    ap.add_argument("--graph", default="off", choices=["on", "off"],
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay batches of GKOCG turns as a hipGraph (needs --no-profile: event-timed "
-                         "SpMVs cannot be captured); measured no faster than stream launches")
+                         "SpMVs cannot be captured).  auto = the library's default: on for the 3-launch "
+                         "turn of systems of <= 1024 chunks, where it takes 2 us off a turn; off above, "
+                         "where it measured no faster than stream launches")
     ap.add_argument("--cpu-iters", type=int, default=-1,
                     help="oracle iterations for cpu_baseline (-1: sized for ~15 s, 0: skip)")
     ap.add_argument("--profile-stride", type=int, default=4,
@@ -358,7 +360,8 @@ def main():
     def load(reg):
         """The benchmark's own system on a connected registry: matrix and b resident, warm-up done."""
         s = reg.solver("p", cfg)
-        s.set_property("hipGraph", 1.0 if args.graph == "on" else 0.0)
+        if args.graph != "auto":
+            s.set_property("hipGraph", 1.0 if args.graph == "on" else 0.0)
         for kv in args.prop:
             k, v = kv.split("=", 1)
             s.set_property(k, float(v))
