@@ -47,6 +47,28 @@ __device__ __forceinline__ double block_sum(double v, double *slot)
     return s;
 }
 
+// Two block totals in one pass (same tree for each, one barrier pair instead of two).  `slot` = 2 N_WAVES doubles.
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *slot)
+{
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    if (lane == 0) {
+        slot[wave] = a;
+        slot[N_WAVES + wave] = b;
+    }
+    __syncthreads();
+    double sa = slot[0], sb = slot[N_WAVES];
+#pragma unroll
+    for (int w = 1; w < N_WAVES; ++w) {
+        sa += slot[w];
+        sb += slot[N_WAVES + w];
+    }
+    __syncthreads();
+    a = sa;
+    b = sb;
+}
+
 // Finaliser tree (one workgroup of FIN_BLOCK = 1024 threads = 16 wavefronts): thread t adds
 // partials t, t+1024, ... in that order, then the 64-lane xor tree, then the 16 wave sums left to
 // right.  The loads of a batch are issued together (they are independent) and only the adds stay
@@ -1162,6 +1184,7 @@ __device__ __forceinline__ void reduce_partials_as_finaliser(const double (&pv)[
     }
 #pragma unroll
     for (int j = 0; j < FIN_VT; ++j) {
+        if (BLOCK * j >= m) continue;  // (nothing but 0.0 in these virtual wavefronts: their tree gives 0.0)
         s[0][j] = wave_sum(s[0][j]);
         if (K > 1) s[1][j] = wave_sum(s[1][j]);
     }
@@ -1287,11 +1310,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restri
                                                          double *__restrict__ part_rho,
                                                          double *__restrict__ part_norm, const DevScalars *sin,
                                                          DevScalars *sout, const double *__restrict__ part_beta,
-                                                         int n_part)
+                                                         int n_part, double *__restrict__ z_out)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[2];
-    __shared__ double slot[N_WAVES];
+    __shared__ double slot[2 * N_WAVES];
     // (all loads up front and the scalars field by field, as in step_1x_fin)
     const int stopped = sin->stop;
     const double s_rho = sin->rho;
@@ -1328,6 +1351,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restri
         vz.x = vr.x * vi.x;
         vz.y = vr.y * vi.y;
     }
+    if (z_out) st2(z_out, rp, vz);  // (the 2-launch turn gathers z at the columns of its rows)
     double d = 0.0, a = 0.0;
     if (rp.n > 0) {
         d += vr.x * vz.x;
@@ -1337,11 +1361,10 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restri
         d += vr.y * vz.y;
         a += fabs(vr.y);
     }
-    const double s0 = block_sum(d, slot);
-    const double s1 = block_sum(a, slot);
+    block_sum2(d, a, slot);
     if (threadIdx.x == 0) {
-        part_rho[chunk] = s0;
-        part_norm[chunk] = s1;
+        part_rho[chunk] = d;
+        part_norm[chunk] = a;
     }
 }
 
@@ -1591,6 +1614,189 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
             if (threadIdx.x == 0) dot2_partials[chunk] = s2;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small systems on half storage, two launches per GKOCG turn: step_1x_fin and the SpMV in one kernel.  The SpMV
+// needs p_new = z + (rho/rho') p at the columns of its rows, which other workgroups own -- but p_new is an
+// elementwise function of z (which step_2r_fin leaves behind for this; r itself without a preconditioner) and the
+// old p, so every workgroup recomputes it for the columns it gathers (same expression, same rounding:
+// -ffp-contract=off) instead of waiting for a kernel boundary.  The new p of the
+// own rows goes to the other of two p buffers (neighbours still read the old one).  Everything else -- check of
+// the previous turn, pending x update, row sums in ascending column order, partial of p.q -- is what
+// k_cg_step1x_fin followed by k_spmv_sym<SPMV_PLAIN, 1> does, bit for bit.
+//   turn = [this kernel] -> k_cg_step2r_fin
+// ------------------------------------------------------------------------------------------
+template <int ND, bool FAST>
+__global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks, SymOffsets off,
+                                                       const uint8_t *__restrict__ mask,
+                                                       const double *__restrict__ planes,
+                                                       const double *__restrict__ p_in, double *__restrict__ p_out,
+                                                       double *__restrict__ x, const double *__restrict__ z,
+                                                       double *__restrict__ q,
+                                                       double *__restrict__ part_beta, const DevScalars *sin,
+                                                       DevScalars *sout, const double *__restrict__ part_rho,
+                                                       const double *__restrict__ part_norm, int n_part,
+                                                       double *history, int first,
+                                                       const int *__restrict__ block_order)
+{
+    __shared__ double red[2 * FIN_WAVES];
+    __shared__ double sh[4];
+    __shared__ int sh_stop;
+    __shared__ double slot[N_WAVES];
+    const int chunk = block_order ? block_order[blockIdx.x] : xcd_chunk(blockIdx.x);
+    if (chunk < 0 || chunk >= n_chunks) return;
+    const bool lead = chunk == 0;  // the workgroup that stores the scalars and the history entry
+    // scalars field by field (k_cg_step1x_fin), and every load of the kernel asked for before the first wait
+    const int stopped = sin->stop;
+    const double s_rho = sin->rho, s_beta = sin->beta, s_nf = sin->norm_factor, s_init = sin->init_res;
+    const int s_iter = sin->iter, s_evals = sin->n_evals;
+    const double c_tol = sin->crit.tolerance, c_rel = sin->crit.rel_tol;
+    const int c_min = sin->crit.min_iter, c_max = sin->crit.max_iter, c_freq = sin->crit.frequency,
+              c_exp = sin->crit.export_res;
+    if (lead && threadIdx.x < sizeof(DevScalars) / 8)
+        reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
+            reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
+    const RowPair rp = my_rows(chunk, n_rows);
+    const int row = rp.row;
+    const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + row);
+    const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
+    double pv[2][FIN_VT];
+    load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
+    double2 vx = ld2(x, rp);
+    // own rows and gathered columns of the two vectors p_new is made of: [0] p, [1] z.  The gathers do
+    // not wait for the mask (a system this small is all latency: mask -> gathers would be two round trips): every
+    // one is issued, at an index clamped into the vector, and the mask decides later what is used.
+    const double *src[2] = {p_in, z};
+    double2 vd[2], vl[2][ND], vu[2][ND];
+    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const double *__restrict__ v = src[a];
+        vd[a] = ld2(v, rp);
+#pragma unroll
+        for (int j = 1; j < ND; ++j) {
+            if (FAST && j >= 2) {
+                vl[a][j] = *reinterpret_cast<const double2 *>(v + max(row - off.d[j], 0));
+                vu[a][j] = *reinterpret_cast<const double2 *>(v + min(row + off.d[j], last_pair));
+            } else if (FAST) {
+                vl[a][j].x = v[max(row - 1, 0)];
+                vl[a][j].y = vd[a].x;
+                vu[a][j].x = vd[a].y;
+                vu[a][j].y = v[min(row + 2, last)];
+            } else {
+                vl[a][j].x = v[max(row - off.d[j], 0)];
+                vl[a][j].y = v[min(max(row + 1 - off.d[j], 0), last)];
+                vu[a][j].x = v[min(row + off.d[j], last)];
+                vu[a][j].y = v[min(row + 1 + off.d[j], last)];
+            }
+        }
+    }
+    // the matrix: own planes (diagonal, upper entries) and the twins of the lower entries, as k_spmv_sym
+    double2 up[ND], lo[ND];
+    const double *own = planes + (long)chunk * (ND * CHUNK_ROWS) + threadIdx.x * ROWS_PER_THREAD;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) up[j] = *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        const int r0 = max(row - off.d[j], 0), r1 = max(row + 1 - off.d[j], 0);
+        const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
+        const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
+        if (FAST && j >= 2) {
+            lo[j] = *reinterpret_cast<const double2 *>(planes + a0);
+        } else if (FAST) {
+            lo[j].x = planes[a0];
+            lo[j].y = up[1].x;
+        } else {
+            lo[j].x = planes[a0];
+            lo[j].y = planes[a1];
+        }
+    }
+    if (stopped) return;  // (the solve has ended: the lead workgroup has handed the scalars on)
+    double v[2];
+    reduce_partials_as_finaliser<2>(pv, n_part, red, v);
+    if (threadIdx.x == 0) {
+        // FIN_CG_CHECK as in k_cg_step1x_fin (StoppingCriterion.C:71-151)
+        const double prev_rho = s_rho, rho = v[0];
+        int iter = s_iter, n_evals = s_evals, stop = 0;
+        double init_res = s_init, res = 0.0;
+        bool evaluated = false;
+        if (iter > 0 && iter < c_min) {           // :77-81
+            iter += 1;
+        } else if (iter % c_freq != 0) {          // :84-87
+            iter += 1;
+        } else {
+            evaluated = true;
+            n_evals += 1;
+            res = v[1];
+            if (iter == 0) init_res = res / s_nf;  // :102-111
+            res /= s_nf;                           // :113
+            if (c_exp && history && lead) history[iter] = res;  // :115-117
+            if (iter >= c_max) stop = 1;                        // :124
+            if (res < c_tol) stop = 1;                          // :128
+            if (c_rel > 0 && res < c_rel * init_res) stop = 1;  // :132-136
+            iter += 1;                                          // :143
+        }
+        sh[0] = s_beta;
+        sh[1] = prev_rho;
+        sh[2] = rho;
+        sh_stop = stop;
+        if (lead) {
+            sout->prev_rho = prev_rho;
+            sout->rho = rho;
+            sout->iter = iter;
+            sout->x_pending = 0;
+            if (evaluated) {
+                sout->n_evals = n_evals;
+                sout->init_res = init_res;
+                sout->res = res;
+            }
+            if (stop) sout->stop = 1;
+        }
+    }
+    __syncthreads();
+    const double beta = sh[0], prev = sh[1], rho = sh[2];
+    const int stop = sh_stop;
+    if (!first && beta != 0.0) {  // x += t_j p of the turn this check closed
+        const double t = prev / beta;
+        vx.x += t * vd[0].x;
+        vx.y += t * vd[0].y;
+        st2(x, rp, vx);
+    }
+    if (stop) return;
+    const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
+    // p_new = z + tmp p for the own rows and for every gathered column
+    double2 xd, xl[ND], xu[ND];
+    xd.x = vd[1].x + tmp * vd[0].x;
+    xd.y = vd[1].y + tmp * vd[0].y;
+    st2(p_out, rp, xd);
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        xl[j].x = vl[1][j].x + tmp * vl[0][j].x;
+        xl[j].y = vl[1][j].y + tmp * vl[0][j].y;
+        xu[j].x = vu[1][j].x + tmp * vu[0][j].x;
+        xu[j].y = vu[1][j].y + tmp * vu[0][j].y;
+    }
+    double2 acc;
+    acc.x = acc.y = 0.0;
+#pragma unroll
+    for (int j = ND - 1; j >= 1; --j) {  // ascending columns: the furthest lower entry first
+        if ((m0 >> (ND - 1 - j)) & 1u) acc.x = acc.x + lo[j].x * xl[j].x;
+        if ((m1 >> (ND - 1 - j)) & 1u) acc.y = acc.y + lo[j].y * xl[j].y;
+    }
+    if ((m0 >> (ND - 1)) & 1u) acc.x = acc.x + up[0].x * xd.x;
+    if ((m1 >> (ND - 1)) & 1u) acc.y = acc.y + up[0].y * xd.y;
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        if ((m0 >> (ND - 1 + j)) & 1u) acc.x = acc.x + up[j].x * xu[j].x;
+        if ((m1 >> (ND - 1 + j)) & 1u) acc.y = acc.y + up[j].y * xu[j].y;
+    }
+    st2(q, rp, acc);
+    double d = 0.0;
+    if (rp.n > 0) d += xd.x * acc.x;
+    if (rp.n > 1) d += xd.y * acc.y;
+    const double sd = block_sum(d, slot);
+    if (threadIdx.x == 0) part_beta[chunk] = sd;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3263,14 +3469,45 @@ void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const
                        part_norm, nc, history, first);
 }
 
+void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x, const double *z,
+                        double *q, double *part_beta, const DevScalars *sin, DevScalars *sout,
+                        const double *part_rho, const double *part_norm, double *history, int first)
+{
+    if (A.n_rows == 0) return;
+    const int nc = (int)n_chunks(A.n_rows);
+    const dim3 grid(A.block_order ? A.n_blocks : xcd_grid(nc)), block(BLOCK);
+    SymOffsets off;
+    for (int j = 0; j < SYM_MAX_OFFSETS; ++j) off.d[j] = A.d[j];
+    bool fast = A.nd >= 2 && A.d[1] == 1;
+    for (int j = 2; j < A.nd; ++j) fast = fast && (A.d[j] % 2 == 0);
+#define OGL_TURN_K(ND, FAST)                                                                                        \
+    hipLaunchKernelGGL((k_cg_turn_sym<ND, FAST>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, p_in, p_out, \
+                       x, z, q, part_beta, sin, sout, part_rho, part_norm, nc, history, first, A.block_order)
+#define OGL_TURN_ND(ND)              \
+    do {                             \
+        if (fast)                    \
+            OGL_TURN_K(ND, true);    \
+        else                         \
+            OGL_TURN_K(ND, false);   \
+    } while (0)
+    if (A.nd == 2)
+        OGL_TURN_ND(2);
+    else if (A.nd == 3)
+        OGL_TURN_ND(3);
+    else
+        OGL_TURN_ND(4);
+#undef OGL_TURN_ND
+#undef OGL_TURN_K
+}
+
 void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                           double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
-                          const double *part_beta)
+                          const double *part_beta, double *z_out)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
     hipLaunchKernelGGL(k_cg_step2r_fin, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho, part_norm, sin,
-                       sout, part_beta, nc);
+                       sout, part_beta, nc, z_out);
 }
 
 void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const double *p,

@@ -263,8 +263,14 @@ void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const
                           const double *part_norm, double *history, int first);
 void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                           double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
-                          const double *part_beta);
+                          const double *part_beta, double *z_out = nullptr);  // z_out: z = r / d kept for k_cg_turn_sym
 constexpr int FUSED_FIN_MAX_CHUNKS = 1024;  // up to 524,288 rows: one partial per virtual finaliser thread
+// step_1x_fin and the SpMV on half storage in one launch (p_new = z + (rho/rho') p recomputed at the gathered
+// columns; it goes to p_out != p_in for the own rows): a turn is this + step_2r_fin.  z: what step_2r_fin's z_out
+// (or, before the first turn, launch_mul) has left; r itself without a preconditioner
+void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x, const double *z,
+                        double *q, double *part_beta, const DevScalars *sin, DevScalars *sout,
+                        const double *part_rho, const double *part_norm, double *history, int first);
 
 // --- BiCGStab steps ([UPSTREAM] bicgstab::step_1/2/3, finalize) ---
 void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,

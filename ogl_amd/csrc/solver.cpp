@@ -2009,6 +2009,14 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                        prop("fusedFinalizers", 1.0) != 0.0;
     DevScalars *s2 = s + 1;
     props["fusedFinalizersInUse"] = fused ? 1.0 : 0.0;
+    // ... and on half storage step_1x_fin and the SpMV are one kernel (k_cg_turn_sym): 2 launches per turn, p
+    // alternating between two buffers
+    const bool fused2 = fused && use_sym() && cfg.matrix_format != OGL_FORMAT_ELL && prop("fusedTurn", 1.0) != 0.0;
+    props["fusedTurnInUse"] = fused2 ? 1.0 : 0.0;
+    if (fused2) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
+    if (fused2 && precond) OGL_TRY(d_z.alloc((size_t)n + 2, st));
+    double *z_kept = fused2 && precond ? d_z.p : nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
+    auto p_of_turn = [&](int turn) { return (fused2 && (turn & 1)) ? d_p2.p : d_p.p; };  // p that turn `turn` reads
 
     // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
     const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
@@ -2147,6 +2155,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     } else {
         // p = q = 0 ([UPSTREAM] cg::initialize); z is never materialised (z = r * inv_diag on the fly)
         launch_cg_rho_norm(st, n, d_r.p, precond, d_part0.p, d_part1.p, s);
+        if (z_kept) launch_mul(st, n, z_kept, d_r.p, precond, nullptr);  // (the z of the first k_cg_turn_sym)
         if (generic) {  // rho = r . (M^-1 r) with the block preconditioner
             apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);
         }
@@ -2226,6 +2235,15 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, nullptr, d_part0.p, d_part1.p, s);
                 apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);  // z = M^-1 r and the partials of r.z
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
+            } else if (!bicg && fused2) {
+                // [check of the previous turn + pending x update + step_1 + SpMV] | beta + step_2r
+                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+                launch_cg_turn_sym(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p, z_kept ? z_kept : d_r.p,
+                                   d_q.p, d_part2.p, s, s2, d_part0.p, d_part1.p, d_history.p, enq == 0 ? 1 : 0);
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+                launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s2, s, d_part2.p, z_kept);
             } else if (!bicg && fused) {
                 // check of the previous turn (or of the initial residual) + pending x update + step_1 | SpMV |
                 // beta + step_2r: the scalars go s -> s2 -> s
@@ -2305,7 +2323,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
             (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p,
-            (uintptr_t)fused, (uintptr_t)d_part2.p};
+            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)fused2, (uintptr_t)d_p2.p, (uintptr_t)z_kept};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
             cg_graph = nullptr;
@@ -2345,7 +2363,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         if (!more) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
     }
     if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
-        launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0);
+        launch_cg_step1x_fin(st, n, p_of_turn(enq), d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0);
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
     DevScalars fin;

@@ -345,6 +345,7 @@ struct ogl_solver {
 
     // ---- vectors: "<field>_rhs", "<field>_solution" + Krylov work vectors ----
     ogl::DevBuf<double> d_x, d_b, d_r, d_p, d_q, d_w, d_inv_diag;
+    ogl::DevBuf<double> d_p2;  // second p buffer of the 2-launch turn (k_cg_turn_sym)
     ogl::DevBuf<double> d_v, d_s, d_t, d_y, d_z, d_rr;  // BiCGStab
     ogl::DevBuf<double> d_V, d_gm;                      // GMRES: Krylov bases, dense state
     ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T
