@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__
                                                      const double *__restrict__ inv_diag,
                                                      double *__restrict__ part_rho,
                                                      double *__restrict__ part_norm,
-                                                     const DevScalars *s)
+                                                     const DevScalars *s, double *__restrict__ z_out)
 {
     __shared__ double slot[N_WAVES];
     if (s->stop) return;
@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__
         vz.x = vr.x * vi.x;
         vz.y = vr.y * vi.y;
     }
+    if (z_out) st2(z_out, rp, vz);  // (kept for the gathers of k_cg_turn_sym_big)
     double d = 0.0, a = 0.0;
     if (rp.n > 0) {
         d += vr.x * vz.x;
@@ -1627,6 +1628,105 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
 // k_cg_step1x_fin followed by k_spmv_sym<SPMV_PLAIN, 1> does, bit for bit.
 //   turn = [this kernel] -> k_cg_step2r_fin
 // ------------------------------------------------------------------------------------------
+// what a thread of the merged kernels holds of its two rows: [0] p, [1] z at the rows and at the gathered columns,
+// own planes (diagonal, upper entries) and the twins of the lower entries
+template <int ND>
+struct TurnSymRegs {
+    double2 vd[2], vl[2][ND], vu[2][ND], up[ND], lo[ND];
+};
+// Every load is issued without waiting for the mask (mask -> gathers would be two round trips, and a small system
+// is all latency), at an index clamped into the vector; the mask decides later what is used.
+template <int ND, bool FAST, bool STREAM>
+__device__ __forceinline__ void turn_sym_load(TurnSymRegs<ND> &R, int chunk, const RowPair &rp, int n_rows,
+                                              const SymOffsets &off, const double *__restrict__ planes,
+                                              const double *__restrict__ p_in, const double *__restrict__ z)
+{
+    const int row = rp.row;
+    const double *src[2] = {p_in, z};
+    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const double *__restrict__ v = src[a];
+        R.vd[a] = ld2(v, rp);
+#pragma unroll
+        for (int j = 1; j < ND; ++j) {
+            if (FAST && j >= 2) {
+                R.vl[a][j] = *reinterpret_cast<const double2 *>(v + max(row - off.d[j], 0));
+                R.vu[a][j] = *reinterpret_cast<const double2 *>(v + min(row + off.d[j], last_pair));
+            } else if (FAST) {
+                R.vl[a][j].x = v[max(row - 1, 0)];
+                R.vl[a][j].y = R.vd[a].x;
+                R.vu[a][j].x = R.vd[a].y;
+                R.vu[a][j].y = v[min(row + 2, last)];
+            } else {
+                R.vl[a][j].x = v[max(row - off.d[j], 0)];
+                R.vl[a][j].y = v[min(max(row + 1 - off.d[j], 0), last)];
+                R.vu[a][j].x = v[min(row + off.d[j], last)];
+                R.vu[a][j].y = v[min(row + 1 + off.d[j], last)];
+            }
+        }
+    }
+    // the matrix, as k_spmv_sym reads it (STREAM: the planes read once per launch go past the caches)
+    const double *own = planes + (long)chunk * (ND * CHUNK_ROWS) + threadIdx.x * ROWS_PER_THREAD;
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+        R.up[j] = (STREAM && (j == 0 || (FAST && j == 1))) ? ld_pair_stream(own + (long)j * CHUNK_ROWS)
+                                                           : *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        const int r0 = max(row - off.d[j], 0), r1 = max(row + 1 - off.d[j], 0);
+        const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
+        const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
+        if (FAST && j >= 2) {
+            R.lo[j] = *reinterpret_cast<const double2 *>(planes + a0);
+        } else if (FAST) {
+            if (STREAM) {  // A(row, row - 1) is the previous lane's second plane-1 value (lane 0: from memory)
+                const double prev = __shfl_up(R.up[1].y, 1, WAVE);
+                R.lo[j].x = prev;
+                if ((threadIdx.x & (WAVE - 1)) == 0) R.lo[j].x = planes[a0];
+            } else {
+                R.lo[j].x = planes[a0];
+            }
+            R.lo[j].y = R.up[1].x;
+        } else {
+            R.lo[j].x = planes[a0];
+            R.lo[j].y = planes[a1];
+        }
+    }
+}
+// p_new = z + tmp p for the own rows (-> xd) and for every gathered column, then the two row sums in ascending
+// column order (k_spmv_sym's)
+template <int ND>
+__device__ __forceinline__ double2 turn_sym_rows(const TurnSymRegs<ND> &R, unsigned m0, unsigned m1, double tmp,
+                                                 double2 &xd)
+{
+    double2 xl[ND], xu[ND];
+    xd.x = R.vd[1].x + tmp * R.vd[0].x;
+    xd.y = R.vd[1].y + tmp * R.vd[0].y;
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        xl[j].x = R.vl[1][j].x + tmp * R.vl[0][j].x;
+        xl[j].y = R.vl[1][j].y + tmp * R.vl[0][j].y;
+        xu[j].x = R.vu[1][j].x + tmp * R.vu[0][j].x;
+        xu[j].y = R.vu[1][j].y + tmp * R.vu[0][j].y;
+    }
+    double2 acc;
+    acc.x = acc.y = 0.0;
+#pragma unroll
+    for (int j = ND - 1; j >= 1; --j) {  // ascending columns: the furthest lower entry first
+        if ((m0 >> (ND - 1 - j)) & 1u) acc.x = acc.x + R.lo[j].x * xl[j].x;
+        if ((m1 >> (ND - 1 - j)) & 1u) acc.y = acc.y + R.lo[j].y * xl[j].y;
+    }
+    if ((m0 >> (ND - 1)) & 1u) acc.x = acc.x + R.up[0].x * xd.x;
+    if ((m1 >> (ND - 1)) & 1u) acc.y = acc.y + R.up[0].y * xd.y;
+#pragma unroll
+    for (int j = 1; j < ND; ++j) {
+        if ((m0 >> (ND - 1 + j)) & 1u) acc.x = acc.x + R.up[j].x * xu[j].x;
+        if ((m1 >> (ND - 1 + j)) & 1u) acc.y = acc.y + R.up[j].y * xu[j].y;
+    }
+    return acc;
+}
+
 template <int ND, bool FAST>
 __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks, SymOffsets off,
                                                        const uint8_t *__restrict__ mask,
@@ -1658,60 +1758,13 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks,
         reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
             reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
     const RowPair rp = my_rows(chunk, n_rows);
-    const int row = rp.row;
-    const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + row);
+    const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + rp.row);
     const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
     double pv[2][FIN_VT];
     load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
     double2 vx = ld2(x, rp);
-    // own rows and gathered columns of the two vectors p_new is made of: [0] p, [1] z.  The gathers do
-    // not wait for the mask (a system this small is all latency: mask -> gathers would be two round trips): every
-    // one is issued, at an index clamped into the vector, and the mask decides later what is used.
-    const double *src[2] = {p_in, z};
-    double2 vd[2], vl[2][ND], vu[2][ND];
-    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const double *__restrict__ v = src[a];
-        vd[a] = ld2(v, rp);
-#pragma unroll
-        for (int j = 1; j < ND; ++j) {
-            if (FAST && j >= 2) {
-                vl[a][j] = *reinterpret_cast<const double2 *>(v + max(row - off.d[j], 0));
-                vu[a][j] = *reinterpret_cast<const double2 *>(v + min(row + off.d[j], last_pair));
-            } else if (FAST) {
-                vl[a][j].x = v[max(row - 1, 0)];
-                vl[a][j].y = vd[a].x;
-                vu[a][j].x = vd[a].y;
-                vu[a][j].y = v[min(row + 2, last)];
-            } else {
-                vl[a][j].x = v[max(row - off.d[j], 0)];
-                vl[a][j].y = v[min(max(row + 1 - off.d[j], 0), last)];
-                vu[a][j].x = v[min(row + off.d[j], last)];
-                vu[a][j].y = v[min(row + 1 + off.d[j], last)];
-            }
-        }
-    }
-    // the matrix: own planes (diagonal, upper entries) and the twins of the lower entries, as k_spmv_sym
-    double2 up[ND], lo[ND];
-    const double *own = planes + (long)chunk * (ND * CHUNK_ROWS) + threadIdx.x * ROWS_PER_THREAD;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) up[j] = *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
-#pragma unroll
-    for (int j = 1; j < ND; ++j) {
-        const int r0 = max(row - off.d[j], 0), r1 = max(row + 1 - off.d[j], 0);
-        const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
-        const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
-        if (FAST && j >= 2) {
-            lo[j] = *reinterpret_cast<const double2 *>(planes + a0);
-        } else if (FAST) {
-            lo[j].x = planes[a0];
-            lo[j].y = up[1].x;
-        } else {
-            lo[j].x = planes[a0];
-            lo[j].y = planes[a1];
-        }
-    }
+    TurnSymRegs<ND> R;
+    turn_sym_load<ND, FAST, false>(R, chunk, rp, n_rows, off, planes, p_in, z);
     if (stopped) return;  // (the solve has ended: the lead workgroup has handed the scalars on)
     double v[2];
     reduce_partials_as_finaliser<2>(pv, n_part, red, v);
@@ -1759,38 +1812,75 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks,
     const int stop = sh_stop;
     if (!first && beta != 0.0) {  // x += t_j p of the turn this check closed
         const double t = prev / beta;
-        vx.x += t * vd[0].x;
-        vx.y += t * vd[0].y;
+        vx.x += t * R.vd[0].x;
+        vx.y += t * R.vd[0].y;
         st2(x, rp, vx);
     }
     if (stop) return;
     const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
-    // p_new = z + tmp p for the own rows and for every gathered column
-    double2 xd, xl[ND], xu[ND];
-    xd.x = vd[1].x + tmp * vd[0].x;
-    xd.y = vd[1].y + tmp * vd[0].y;
+    double2 xd;
+    const double2 acc = turn_sym_rows<ND>(R, m0, m1, tmp, xd);
     st2(p_out, rp, xd);
-#pragma unroll
-    for (int j = 1; j < ND; ++j) {
-        xl[j].x = vl[1][j].x + tmp * vl[0][j].x;
-        xl[j].y = vl[1][j].y + tmp * vl[0][j].y;
-        xu[j].x = vu[1][j].x + tmp * vu[0][j].x;
-        xu[j].y = vu[1][j].y + tmp * vu[0][j].y;
+    st2(q, rp, acc);
+    double d = 0.0;
+    if (rp.n > 0) d += xd.x * acc.x;
+    if (rp.n > 1) d += xd.y * acc.y;
+    const double sd = block_sum(d, slot);
+    if (threadIdx.x == 0) part_beta[chunk] = sd;
+}
+
+// The same merge for systems of any size, between the single-workgroup finalisers of the five-launch turn (which
+// becomes four): the scalars are read where k_cg_step1x reads them, the pending x update included.  Per turn the
+// vectors cost 8 N bytes less than step_1x + SpMV + step_2r (p is read once, z written once and read once instead of
+// r and 1/d read twice), and one kernel boundary goes.
+template <int ND, bool FAST, bool STREAM>
+__global__ __launch_bounds__(BLOCK) void k_cg_turn_sym_big(int n_rows, int n_chunks, SymOffsets off,
+                                                           const uint8_t *__restrict__ mask,
+                                                           const double *__restrict__ planes,
+                                                           const double *__restrict__ p_in,
+                                                           double *__restrict__ p_out, double *__restrict__ x,
+                                                           const double *__restrict__ z, double *__restrict__ q,
+                                                           double *__restrict__ part_beta, const DevScalars *s,
+                                                           const int *__restrict__ block_order)
+{
+    __shared__ double slot[N_WAVES];
+    const int stop = s->stop;
+    const bool pending = s->x_pending != 0;
+    if (stop && !pending) return;
+    const int chunk = block_order ? block_order[blockIdx.x] : xcd_chunk(blockIdx.x);
+    if (chunk < 0 || chunk >= n_chunks) return;
+    const RowPair rp = my_rows(chunk, n_rows);
+    if (stop) {  // the solve has ended with an update still to apply: that only
+        const double beta = s->beta;
+        if (beta != 0.0) {
+            const double t = s->prev_rho / beta;
+            const double2 vp = ld2(p_in, rp);
+            double2 vx = ld2_stream(x, rp);
+            vx.x += t * vp.x;
+            vx.y += t * vp.y;
+            st2_stream(x, rp, vx);
+        }
+        return;
     }
-    double2 acc;
-    acc.x = acc.y = 0.0;
-#pragma unroll
-    for (int j = ND - 1; j >= 1; --j) {  // ascending columns: the furthest lower entry first
-        if ((m0 >> (ND - 1 - j)) & 1u) acc.x = acc.x + lo[j].x * xl[j].x;
-        if ((m1 >> (ND - 1 - j)) & 1u) acc.y = acc.y + lo[j].y * xl[j].y;
+    const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + rp.row);
+    const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
+    TurnSymRegs<ND> R;
+    turn_sym_load<ND, FAST, STREAM>(R, chunk, rp, n_rows, off, planes, p_in, z);
+    if (pending) {
+        const double beta = s->beta;
+        if (beta != 0.0) {
+            const double t = s->prev_rho / beta;
+            double2 vx = ld2_stream(x, rp);  // x is touched once per turn
+            vx.x += t * R.vd[0].x;
+            vx.y += t * R.vd[0].y;
+            st2_stream(x, rp, vx);
+        }
     }
-    if ((m0 >> (ND - 1)) & 1u) acc.x = acc.x + up[0].x * xd.x;
-    if ((m1 >> (ND - 1)) & 1u) acc.y = acc.y + up[0].y * xd.y;
-#pragma unroll
-    for (int j = 1; j < ND; ++j) {
-        if ((m0 >> (ND - 1 + j)) & 1u) acc.x = acc.x + up[j].x * xu[j].x;
-        if ((m1 >> (ND - 1 + j)) & 1u) acc.y = acc.y + up[j].y * xu[j].y;
-    }
+    const double rho = s->rho, prev = s->prev_rho;
+    const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
+    double2 xd;
+    const double2 acc = turn_sym_rows<ND>(R, m0, m1, tmp, xd);
+    st2(p_out, rp, xd);
     st2(q, rp, acc);
     double d = 0.0;
     if (rp.n > 0) d += xd.x * acc.x;
@@ -3451,12 +3541,12 @@ void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const dou
 }
 
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
-                      double *part_rho, double *part_norm, const DevScalars *s)
+                      double *part_rho, double *part_norm, const DevScalars *s, double *z_out)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
     hipLaunchKernelGGL(k_cg_step2r, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho,
-                       part_norm, s);
+                       part_norm, s, z_out);
 }
 
 void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
@@ -3489,6 +3579,40 @@ void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, dou
             OGL_TURN_K(ND, true);    \
         else                         \
             OGL_TURN_K(ND, false);   \
+    } while (0)
+    if (A.nd == 2)
+        OGL_TURN_ND(2);
+    else if (A.nd == 3)
+        OGL_TURN_ND(3);
+    else
+        OGL_TURN_ND(4);
+#undef OGL_TURN_ND
+#undef OGL_TURN_K
+}
+
+void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x,
+                            const double *z, double *q, double *part_beta, const DevScalars *s)
+{
+    if (A.n_rows == 0) return;
+    const int nc = (int)n_chunks(A.n_rows);
+    const dim3 grid(A.block_order ? A.n_blocks : xcd_grid(nc)), block(BLOCK);
+    SymOffsets off;
+    for (int j = 0; j < SYM_MAX_OFFSETS; ++j) off.d[j] = A.d[j];
+    bool fast = A.nd >= 2 && A.d[1] == 1;
+    for (int j = 2; j < A.nd; ++j) fast = fast && (A.d[j] % 2 == 0);
+#define OGL_TURN_K(ND, FAST, STREAM)                                                                              \
+    hipLaunchKernelGGL((k_cg_turn_sym_big<ND, FAST, STREAM>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
+                       p_in, p_out, x, z, q, part_beta, s, A.block_order)
+#define OGL_TURN_ND(ND)                     \
+    do {                                    \
+        if (fast && A.stream)               \
+            OGL_TURN_K(ND, true, true);     \
+        else if (fast)                      \
+            OGL_TURN_K(ND, true, false);    \
+        else if (A.stream)                  \
+            OGL_TURN_K(ND, false, true);    \
+        else                                \
+            OGL_TURN_K(ND, false, false);   \
     } while (0)
     if (A.nd == 2)
         OGL_TURN_ND(2);

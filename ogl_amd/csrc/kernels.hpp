@@ -251,7 +251,7 @@ struct HaloPutFused;  // (below, after PeerHalo)
 void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
                       const double *inv_diag, const DevScalars *s, const HaloPutFused *put = nullptr);
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
-                      double *part_rho, double *part_norm, const DevScalars *s);
+                      double *part_rho, double *part_norm, const DevScalars *s, double *z_out = nullptr);
 
 // Small systems: the same pair with the finalisers folded in (kernels.hip).  Every workgroup reduces the
 // per-chunk partials itself in the finaliser's order; the scalars are read from `sin` and written to `sout`.
@@ -271,6 +271,10 @@ constexpr int FUSED_FIN_MAX_CHUNKS = 1024;  // up to 524,288 rows: one partial p
 void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x, const double *z,
                         double *q, double *part_beta, const DevScalars *sin, DevScalars *sout,
                         const double *part_rho, const double *part_norm, double *history, int first);
+// ... and between the single-workgroup finalisers of larger systems (scalars as k_cg_step1x reads them):
+// turn = this | FIN_BETA | step_2r (z_out) | FIN_CG_CHECK
+void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x,
+                            const double *z, double *q, double *part_beta, const DevScalars *s);
 
 // --- BiCGStab steps ([UPSTREAM] bicgstab::step_1/2/3, finalize) ---
 void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,

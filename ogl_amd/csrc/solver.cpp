@@ -2009,14 +2009,20 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                        prop("fusedFinalizers", 1.0) != 0.0;
     DevScalars *s2 = s + 1;
     props["fusedFinalizersInUse"] = fused ? 1.0 : 0.0;
-    // ... and on half storage step_1x_fin and the SpMV are one kernel (k_cg_turn_sym): 2 launches per turn, p
-    // alternating between two buffers
-    const bool fused2 = fused && use_sym() && cfg.matrix_format != OGL_FORMAT_ELL && prop("fusedTurn", 1.0) != 0.0;
-    props["fusedTurnInUse"] = fused2 ? 1.0 : 0.0;
-    if (fused2) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
-    if (fused2 && precond) OGL_TRY(d_z.alloc((size_t)n + 2, st));
-    double *z_kept = fused2 && precond ? d_z.p : nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
-    auto p_of_turn = [&](int turn) { return (fused2 && (turn & 1)) ? d_p2.p : d_p.p; };  // p that turn `turn` reads
+    // ... and on half storage step_1x(_fin) and the SpMV are one kernel (k_cg_turn_sym, k_cg_turn_sym_big): 2 launches
+    // per turn for small systems, 4 for larger ones, p alternating between two buffers (single rank: with halos the
+    // put and the wait for the neighbours' puts would sit in one kernel)
+    // (larger systems: property fusedTurnBig, off by default -- 216^3 measured 4190 against 4149 turns/s: the merged
+    //  kernel runs 152 us where step_1x + SpMV take 162, and step_2r pays 8 N more bytes for keeping z)
+    const bool merged = !bicg && !gmres && !generic && !reg->comm->multi() && nc >= 1 && use_sym() &&
+                        cfg.matrix_format != OGL_FORMAT_ELL &&
+                        (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", 0.0) != 0.0);
+    const bool fused2 = fused && merged;
+    props["fusedTurnInUse"] = merged ? 1.0 : 0.0;
+    if (merged) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
+    if (merged && precond) OGL_TRY(d_z.alloc((size_t)n + 2, st));
+    auto p_of_turn = [&](int turn) { return (merged && (turn & 1)) ? d_p2.p : d_p.p; };  // p that turn `turn` reads
+    double *z_kept = merged && precond ? d_z.p : nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
 
     // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
     const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
@@ -2255,6 +2261,16 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, s2));
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s2, s, d_part2.p);
+            } else if (!bicg && merged) {
+                // [pending x update + step_1 + SpMV] | beta | step_2r (keeps z) | check
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+                launch_cg_turn_sym_big(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p, z_kept ? z_kept : d_r.p,
+                                       d_q.p, d_part0.p, s);
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+                OGL_TRY(finalize(FIN_BETA, f1));
+                launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, z_kept);
+                chk.turn = 1;  // this check leaves an x update pending for the next turn's kernel
+                OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else if (!bicg) {
                 // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once
                 // (peer-put transport: the halo values of the SpMV are put by step_1x itself)
@@ -2323,7 +2339,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
             (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p,
-            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)fused2, (uintptr_t)d_p2.p, (uintptr_t)z_kept};
+            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)merged, (uintptr_t)d_p2.p, (uintptr_t)z_kept};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
             cg_graph = nullptr;
@@ -2375,7 +2391,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     if (fin.x_pending) {
         // the stop came with the check of the last enqueued turn: no step_1x followed to apply
         // that turn's x update
-        launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s);
+        launch_cg_step1x(st, n, p_of_turn(enq), d_x.p, d_r.p, precond, s);
         OGL_HIP_CHECK(hipStreamSynchronize(st));
         OGL_HIP_CHECK(hipGetLastError());
     }

@@ -29,22 +29,26 @@ def system(oracle):
 
 # The three shapes of a GKOCG turn (kernels.hip): small systems fold the finalisers into the step kernels (the check of
 # a turn runs at the head of the next one) -- 3 launches, or 2 on half storage, where step_1x and the SpMV are one
-# kernel (k_cg_turn_sym: p_new recomputed at the gathered columns); larger systems run the five-launch turn
-TURNS = {"two_launch": (1.0, 1.0), "three_launch": (1.0, 0.0), "five_launch": (0.0, 0.0)}
+# kernel (k_cg_turn_sym: p_new recomputed at the gathered columns); larger systems run the five-launch turn, or with
+# property fusedTurnBig the same merge between the single-workgroup finalisers (four launches, k_cg_turn_sym_big)
+TURNS = {"two_launch": (1.0, 1.0, 0.0), "three_launch": (1.0, 0.0, 0.0), "four_launch": (0.0, 0.0, 1.0),
+         "five_launch": (0.0, 0.0, 0.0)}
 
 
 def set_turn(s, turn):
-    fused, merged = TURNS[turn]
+    fused, merged, merged_big = TURNS[turn]
     s.set_property("fusedFinalizers", fused)
     s.set_property("fusedTurn", merged)
+    s.set_property("fusedTurnBig", merged_big)
     return s
 
 
 def check_turn(s, turn, small=True):
-    fused, merged = TURNS[turn]
+    fused, merged, merged_big = TURNS[turn]
     assert s.get_property("fusedFinalizersInUse") == (fused if small else 0.0)
-    assert s.get_property("fusedTurnInUse") == (merged if small and s.get_property("symmetricHalf") == 1.0
-                                                  and s.get_property("symmetricHalfPerChunk") == 0.0 else 0.0)
+    half = s.get_property("symmetricHalf") == 1.0 and s.get_property("symmetricHalfPerChunk") == 0.0
+    want = (merged if small and fused else merged_big) if half else 0.0
+    assert s.get_property("fusedTurnInUse") == want
 
 
 @pytest.mark.parametrize("turn", list(TURNS))
@@ -142,7 +146,7 @@ def test_fused_turns_same_bits_as_the_five_launch_turn(reg, oracle, shape):
             check_turn(s, turn, small=n_chunks <= 1024)
             out.append((x, s.history().copy(), perf.n_iterations, perf.n_norm_evals, perf.initial_residual,
                         perf.final_residual))
-        for o in out[:2]:
-            np.testing.assert_array_equal(o[1], out[2][1], err_msg=str((shape, kw)))
-            np.testing.assert_array_equal(o[0], out[2][0], err_msg=str((shape, kw)))
-            assert o[2:] == out[2][2:], (shape, kw, o[2:], out[2][2:])
+        for o in out[:-1]:
+            np.testing.assert_array_equal(o[1], out[-1][1], err_msg=str((shape, kw)))
+            np.testing.assert_array_equal(o[0], out[-1][0], err_msg=str((shape, kw)))
+            assert o[2:] == out[-1][2:], (shape, kw, o[2:], out[-1][2:])

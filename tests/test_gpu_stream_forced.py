@@ -47,6 +47,36 @@ LAYOUTS = {"sym": dict(compress_indices=1, symmetric_half=1), "sell": dict(compr
            "csr": dict(compress_indices=0), "ell": dict(matrix_format=capi.FORMAT_ELL)}
 
 
+def test_four_launch_turn_on_half_storage_stream_and_plain(reg, oracle):
+    """k_cg_turn_sym_big (property fusedTurnBig: step_1x and the SpMV of larger systems in one kernel) in its STREAM
+    and plain instantiations, every distance table of BOXES: history and x as the oracle's."""
+    rng = np.random.default_rng(20241017)
+    for i, (gx, gy, gz) in enumerate(BOXES):
+        case = randomise(synthetic.poisson_block(gx=gx, gy=gy, gz=gz), 60 + i)
+        if case.n_cells < 2:
+            continue
+        rp, cols, vals = oracle_csr(oracle, case)
+        x = rng.uniform(-1, 1, case.n_cells)
+        b = rng.uniform(-1, 1, case.n_cells)
+        A, _ = oracle_matrix(oracle, case)
+        for precond in (capi.PRECOND_BJ, capi.PRECOND_NONE):
+            inv = oracle.jacobi_generate_scalar(rp, cols, vals) if precond else None
+            with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+                ref = oracle.cg(A, b, x.copy(), inv, tolerance=1e-11, rel_tol=0.0, max_iter=19)
+            for forced in (1, 0):
+                s = reg.solver(f"big_{forced}_{precond}", cfg(max_iter=19, preconditioner=precond, update_init_guess=1,
+                                                              **LAYOUTS["sym"]))
+                s.set_property("streamAboveBytes", 0.0 if forced else 1e18)
+                s.set_property("fusedFinalizers", 0.0)
+                s.set_property("fusedTurnBig", 1.0)
+                s.set_matrix(case)
+                xs, perf = s.solve(b, x.copy())
+                if s.get_property("symmetricHalfPerChunk") == 0.0:
+                    assert s.get_property("fusedTurnInUse") == 1.0 and s.get_property("spmvStream") == float(forced)
+                np.testing.assert_array_equal(s.history(), ref.history, err_msg=str((forced, precond, gx, gy, gz)))
+                np.testing.assert_array_equal(xs, ref.x, err_msg=str((forced, precond, gx, gy, gz)))
+
+
 @pytest.mark.parametrize("layout", list(LAYOUTS))
 def test_stream_kernels_same_bits_as_the_oracle(reg, oracle, layout):
     rng = np.random.default_rng(20241016)
