@@ -458,7 +458,7 @@ def main():
         except capi.OglError:
             return default
 
-    def spmv_roofline(sv, n_rows, n_nnz, spmv_ms, timing, pmc_variant):
+    def spmv_roofline(sv, n_rows, n_nnz, spmv_ms, timing, pmc_variant, in_loop=True):
         """roofline object of the in-loop SpMV of solver `sv`: `achieved` / `frac` on the bytes the layout in
         use has to move (matrix data + x read once + y written), the CSR-equivalent rate apart."""
         b_csr = 12 * n_nnz + 20 * n_rows + 4            # SURVEY.md §8d: values + columns + row pointers + x + y
@@ -479,10 +479,21 @@ def main():
         # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)
         b_moved = ((sv.get_property("sellMatrixBytes") + 16 * n_rows) if layout in ("sell", "sym", "symx") else
                    (sv.get_property("csr21MatrixBytes") + 16 * n_rows) if layout == "csr21" else b_csr)
+        merged = None
+        if (in_loop and layout == "sym" and args.solver == "GKOCG" and prop_or(sv, "fusedTurnInUse", 0.0) == 1.0):
+            # the in-loop kernel on half storage is step_1x + SpMV in one launch (k_cg_turn_sym / _big, kernels.hip):
+            # besides the SpMV's bytes it reads z and x and writes x and the new p of its rows
+            nd, fast = int(prop_or(sv, 'spmvSymPlanes', 0)), 'true' if prop_or(sv, 'spmvSymFast', 0.0) == 1.0 else 'false'
+            small = prop_or(sv, "fusedFinalizersInUse", 0.0) == 1.0
+            kernel = f"k_cg_turn_sym<{nd}, {fast}>" if small else f"k_cg_turn_sym_big<{nd}, {fast}, {stream}>"
+            merged = {"with": "step_1x" + ("_fin (check of the previous turn, partial sums)" if small else ""),
+                      "extra_bytes_per_launch": 32 * n_rows}
+            b_moved += 32 * n_rows
+            b_csr += 32 * n_rows
         traffic, traffic_src = pmc_traffic(kernel, pmc_variant) if pmc_variant is not None else (None, None)
         moved = b_moved / (spmv_ms * 1e-3) / 1e9
         return layout, b_moved, b_csr, {
-            "kernel": kernel, "layout": layout, "bound": "hbm",
+            "kernel": kernel, "layout": layout, "merged": merged, "bound": "hbm",
             "achieved": moved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": moved / HBM_PEAK_GBPS,
             "bytes_per_launch": b_moved,
             "frac_of_measured_copy_peak": moved / HBM_COPY_GBPS,
@@ -513,7 +524,8 @@ def main():
             and args.shuffle in (0, 65536):
         pmc_variant = ("_shuffle65536" if args.shuffle else "_fullstorage" if args.full_storage else
                        "_nocompress" if args.no_compress else "")
-    layout, b_moved, b_spmv, roofline = spmv_roofline(s, N, nnz, spmv_ms, spmv_src, pmc_variant)
+    layout, b_moved, b_spmv, roofline = spmv_roofline(s, N, nnz, spmv_ms, spmv_src, pmc_variant,
+                                                      in_loop=not args.no_profile)
     renumbered = s.get_property("renumbered") == 1.0
     if world > 1 and s.get_property("peerHalo") == 1.0:
         # the transport above was only the bootstrap: halo values are put straight into the
@@ -526,6 +538,11 @@ def main():
                    and args.block_size == 1)
     b_cg = b_moved + (80 if precond == capi.PRECOND_BJ else 64) * N if cg_headline else None
     b_cg_csr = b_spmv + (88 if precond == capi.PRECOND_BJ else 72) * N if cg_headline else None
+    if cg_headline and roofline["merged"]:
+        # step_1x merged into the SpMV kernel (its 32 N are in b_moved already): what is left is step_2r, which
+        # also keeps z for the next turn's gathers -- 72 N / 56 N per turn besides the SpMV's own bytes
+        b_cg = b_moved + (40 if precond == capi.PRECOND_BJ else 24) * N
+        b_cg_csr = b_spmv + (56 if precond == capi.PRECOND_BJ else 40) * N   # (SURVEY's unit of work is unchanged)
 
     def turn_model(b_mat):
         """Bytes of ONE solver turn: the SpMV(s) priced at `b_mat` + every vector pass the Ginkgo step order
@@ -555,8 +572,9 @@ def main():
         per_col = b_mat + (apply_b + 16 * N if not materialised else apply_b) + 32 * N * (m + 1) / 2 + 40 * N
         per_cycle = b_mat + (8 * m + 48) * N + (apply_b if materialised else 8 * N)
         return per_col + per_cycle / m, "B_spmv + M^-1 + (m+1)/2 MGS links of 32 N + cycle overhead / m"
-    b_turn, b_turn_what = turn_model(b_moved)
-    b_turn_csr, _ = turn_model(b_spmv)
+    merged_extra = roofline["merged"]["extra_bytes_per_launch"] if roofline["merged"] else 0
+    b_turn, b_turn_what = turn_model(b_moved - merged_extra)   # (the model prices the SpMV alone)
+    b_turn_csr, _ = turn_model(b_spmv - merged_extra)
     # end-to-end plug-in call incl. PCIe (reported, never `value`): one solve() with H2D/D2H
     # (host arrays prepared outside the timed region: the C ABI borrows the caller's arrays, it allocates nothing)
     ldu_arrays = capi.LduArrays(case)
@@ -684,7 +702,9 @@ def main():
             "bytes": b_cg, "ms": 1e3 * elapsed / max(1, iters),
             "achieved_GBps": None if b_cg is None else b_cg * iters / elapsed / 1e9,
             "frac_of_peak": None if b_cg is None else b_cg * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
-            "model": "bytes the kernels of one turn move: SpMV layout bytes + 16 N + 80 N (scalar Jacobi; 64 N without)",
+            "model": ("bytes the kernels of one turn move: SpMV layout bytes + 16 N + 72 N (scalar Jacobi; 56 N "
+                      "without) -- step_1x merged into the SpMV kernel, z kept by step_2r" if roofline["merged"] else
+                      "bytes the kernels of one turn move: SpMV layout bytes + 16 N + 80 N (scalar Jacobi; 64 N without)"),
             "csr_equivalent_bytes": b_cg_csr,
             "csr_equivalent_frac_of_peak": None if b_cg_csr is None else
                                            b_cg_csr * iters / elapsed / 1e9 / HBM_PEAK_GBPS,
