@@ -473,7 +473,10 @@ def main():
         kernel = {"csr": f"k_spmv_stream<0, 1, {stream}>", "csr21": f"k_spmv_stream21<0, 1, {stream}>",
                   "ell": f"k_spmv_ell<0, 1, {stream}>",
                   "sell": f"k_spmv_sell<0, 1, {stream}>",
-                  "symx": f"k_spmv_symx<0, 1, {stream}>",
+                  # (the lean instantiation -- chunks without explicit entries or with simple ones; the general one runs
+                  #  in a second launch on the chunks property symxGeneralChunks counts)
+                  "symx": f"k_spmv_symx<0, 1, {stream}, "
+                          f"{'true' if prop_or(sv, 'spmvSymFast', 0.0) == 1.0 else 'false'}, false>",
                   "sym": f"k_spmv_sym<0, 1, {int(prop_or(sv, 'spmvSymPlanes', 0))}, "
                          f"{'true' if prop_or(sv, 'spmvSymFast', 0.0) == 1.0 else 'false'}, {stream}>"}[layout]
         # bytes the kernel has to move for the layout it runs on (matrix + x read once + y written)

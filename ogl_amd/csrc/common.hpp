@@ -141,15 +141,21 @@ struct SymxChunk {
     int32_t nd;             // planes: diagonal + distances (1..4)
     int32_t d[3];           // the distances of planes 1..nd-1, ascending
     int32_t ex_rp_off;      // this chunk's CHUNK_ROWS + 1 row pointers into the explicit entries, -1: it has none
-    int32_t merge;          // 1: some row has an explicit entry BETWEEN its planar ones (full merge by column);
-                            // 0: explicit entries only before the first / after the last planar entry of their rows
-                            // (the coupling across a block face): added ahead of / behind the plane walk
-    int32_t pad_[4];
+    int32_t merge;          // 0: every row has at most one explicit entry before its first planar entry and at most one
+                            // behind its last (the coupling across a block face): the lean kernel adds them ahead of /
+                            // behind the plane walk; 1: anything else -- the general kernel merges by column
+    int32_t chunk;          // device copy (kept in dispatch order: workgroup b reads header b): the chunk this header
+                            // describes, -1: workgroup b has nothing to do
+    int32_t ex_begin;       // its explicit entries: [ex_begin, ex_begin + ex_count) of the explicit arrays
+    int32_t ex_count;
+    int32_t pad_[1];
 };
 static_assert(sizeof(SymxChunk) == 96, "SymxChunk is read as six 16-byte words");
 // mask byte of a row: bit 3 = diagonal, bit 3 - j / 3 + j = the entry at -d[j] / +d[j] (j = 1..3), bit 7 = the row
 // has explicit entries
 constexpr unsigned SYMX_EXTRAS_BIT = 0x80u;
+constexpr int32_t SYMX_BEHIND_BIT = 1 << 16;  // SymxLayout::ex_lrow: the entry comes behind the row's last planar entry
+constexpr int SYMX_LDS_ENTRIES = 1024;   // explicit entries of a chunk staged through LDS by its workgroup (more: read from memory)
 constexpr double SYMX_MIN_PLANAR = 0.8;  // share of the entries that must live in planes for the layout to be used
 
 // Matrix data that is read once per launch is streamed past the caches when matrix + the turn's five vectors do

@@ -1167,6 +1167,38 @@ void band_block_order(ogl_label n_rows, int64_t band, std::vector<int32_t> &orde
         for (size_t i = 0; i < lists[(size_t)x].size(); ++i) order[i * N_XCD + (size_t)x] = lists[(size_t)x][i];
 }
 
+void symx_block_order(const SymxLayout &L, bool general, std::vector<int32_t> &order)
+{
+    order.clear();
+    const int64_t nc = (int64_t)L.chunks.size();
+    std::vector<std::vector<int32_t>> lists(N_XCD);
+    int64_t banded = 0, taken = 0;
+    auto wanted = [&](const SymxChunk &h) { return (h.ex_rp_off >= 0 && h.merge != 0) == general; };
+    for (int64_t c = 0; c < nc; ++c) {
+        const SymxChunk &h = L.chunks[(size_t)c];
+        if (!wanted(h)) continue;
+        ++taken;
+        const int64_t band = h.nd >= 2 ? h.d[h.nd - 2] : 0;
+        int x = (int)((c / 4) % N_XCD);  // as the default map does (groups of 4)
+        if (band >= (int64_t)N_XCD * CHUNK_ROWS) {
+            const int64_t ph = (c * CHUNK_ROWS) % band;  // the chunks of rows r and r +- band share a phase, hence an XCD
+            x = (int)std::min<int64_t>(N_XCD - 1, ph * N_XCD / band);
+            ++banded;
+        }
+        lists[(size_t)x].push_back((int32_t)c);
+    }
+    if (banded * 2 < taken) {  // mostly short bands: the default map is as good
+        for (auto &l : lists) l.clear();
+        for (int64_t c = 0; c < nc; ++c)
+            if (wanted(L.chunks[(size_t)c])) lists[(size_t)((c / 4) % N_XCD)].push_back((int32_t)c);
+    }
+    size_t longest = 0;
+    for (auto &l : lists) longest = std::max(longest, l.size());
+    order.assign(longest * N_XCD, -1);
+    for (int x = 0; x < N_XCD; ++x)
+        for (size_t i = 0; i < lists[(size_t)x].size(); ++i) order[i * N_XCD + (size_t)x] = lists[(size_t)x][i];
+}
+
 bool build_sym_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, SymLayout &out)
 {
     out = SymLayout{};
@@ -1337,6 +1369,7 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
                 } else {
                     out.ex_cols.push_back((int32_t)col);
                     out.ex_map.push_back(k);
+                    out.ex_lrow.push_back((int32_t)(r - r0));
                     m |= SYMX_EXTRAS_BIT;
                 }
             }
@@ -1345,8 +1378,11 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         for (ogl_label lr = r1 - r0; lr <= CHUNK_ROWS; ++lr) rp[(size_t)lr] = (int32_t)out.ex_cols.size();
         if (out.ex_cols.size() > ex_begin) {
             h.ex_rp_off = (int32_t)out.ex_rowptr.size();
+            h.ex_begin = (int32_t)ex_begin;
+            h.ex_count = (int32_t)(out.ex_cols.size() - ex_begin);
             out.ex_rowptr.insert(out.ex_rowptr.end(), rp.begin(), rp.end());
-            // does any row keep an explicit entry between its planar ones?
+            // simple chunk: every row has at most one explicit entry before its first planar entry and at most one
+            // behind its last, none in between (the coupling across a block face) -- anything else: h.merge
             for (ogl_label r = r0; r < r1 && !h.merge; ++r) {
                 const unsigned m = out.mask[(size_t)r];
                 if (!(m & SYMX_EXTRAS_BIT)) continue;
@@ -1363,10 +1399,19 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
                     if (m & (1u << (3 - j))) last = std::max<int64_t>(last, (int64_t)r - h.d[j - 1]);
                     if (m & (1u << (3 + j))) first = std::min<int64_t>(first, (int64_t)r + h.d[j - 1]);
                 }
+                int ahead = 0, behind = 0;
                 for (int32_t e = rp[(size_t)(r - r0)]; e < rp[(size_t)(r - r0) + 1]; ++e) {
                     const int64_t col = out.ex_cols[(size_t)e];
-                    if (col >= first && col <= last) h.merge = 1;  // (a repeated column of a planar entry included)
+                    if (first == INT64_MAX ? col < r : col < first) {
+                        ++ahead;
+                    } else if (first == INT64_MAX || col > last) {
+                        ++behind;
+                        out.ex_lrow[(size_t)e] |= SYMX_BEHIND_BIT;  // (what the lean kernel goes by)
+                    } else {
+                        h.merge = 1;  // (a repeated column of a planar entry included)
+                    }
                 }
+                if (ahead > 1 || behind > 1) h.merge = 1;
             }
         }
     }

@@ -132,6 +132,7 @@ struct SymxLayout {
     std::vector<int32_t> map;         // plane slot -> position in the CSR values, -1 = none  (+2)
     std::vector<int32_t> ex_rowptr;   // (CHUNK_ROWS + 1) pointers per chunk that has explicit entries
     std::vector<int32_t> ex_cols, ex_map;  // explicit entries: column, position in the CSR values
+    std::vector<int32_t> ex_lrow;          // ... and the row, counted from the chunk's first
     int64_t planar = 0;               // entries served from planes
     bool all_fast = false;            // every chunk with distances: the first is 1, the others are even
 };
@@ -146,6 +147,11 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
 // that two of them read are fetched over the fabric once.  Empty when the band is too short to give every
 // XCD a chunk per period or too long to recur.
 void band_block_order(ogl_label n_rows, int64_t band, std::vector<int32_t> &order);
+// the same with every chunk's own band (its largest distance): multi-block meshes (chunks without a band worth it:
+// groups of 4 per XCD, as the default map of the other kernels).  k_spmv_symx reads its headers in this order.
+// general = false: the chunks the lean kernel takes (no explicit entries, or simple ones: SymxChunk::merge == 0),
+// true: the others.  Empty when there is no such chunk.
+void symx_block_order(const SymxLayout &L, bool general, std::vector<int32_t> &order);
 
 // ---- renumbering (no reference counterpart: OpenFOAM users run `renumberMesh`; here the backend
 // does it for itself when the numbering it is handed gathers x badly) ----

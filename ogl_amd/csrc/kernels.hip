@@ -1896,166 +1896,199 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym_big(int n_rows, int n_chu
 // flagged in their mask byte carry explicit entries -- column + value lists -- that are merged into the row sum by
 // column, so that every row is still summed in ascending column order and y keeps the bits of the other kernels.
 // ------------------------------------------------------------------------------------------
-// the explicit entries of one row: the first two are fetched (column, value * x) when the kernel starts, together
-// with everything else; a row with more of them reads the rest as it gets there
-struct SymxRowExtras {
-    int k, n;        // consumed so far, entries of the row
-    int e;           // first entry
-    int ca, cb;      // columns of the first two (INT32_MAX: none)
-    double pa, pb;   // their products
-};
-template <int MODE>
-__device__ __forceinline__ void symx_explicit(double &acc, SymxRowExtras &E, int limit,
-                                              const int *__restrict__ ex_cols,
+// The explicit entries of a chunk (few: the couplings across block faces) are staged by its workgroup -- thread i
+// takes entry i: column and value * x[column] into LDS -- while the plane loads are in flight; a row then walks its
+// own entries in LDS.  Per row that costs two registers (next entry, end) where prefetching the first entries into
+// registers cost 40 for the kernel, i.e. three of eight wavefronts per SIMD.  A chunk with more than
+// SYMX_LDS_ENTRIES of them reads them from memory as it goes.
+template <int MODE, bool IN_LDS>
+__device__ __forceinline__ void symx_explicit(double &acc, int &k, int end, int limit, const int *lds_cols,
+                                              const double *lds_prod, const int *__restrict__ ex_cols,
                                               const double *__restrict__ ex_vals, const double *__restrict__ x)
 {
-    if (E.k == 0 && E.ca < limit) {
-        acc = (MODE == SPMV_RESIDUAL) ? acc - E.pa : acc + E.pa;
-        E.k = 1;
-    }
-    if (E.k == 1 && E.cb < limit) {
-        acc = (MODE == SPMV_RESIDUAL) ? acc - E.pb : acc + E.pb;
-        E.k = 2;
-    }
-    while (E.k >= 2 && E.k < E.n && ex_cols[E.e + E.k] < limit) {
-        const double p = ex_vals[E.e + E.k] * x[ex_cols[E.e + E.k]];
+    while (k < end) {
+        const int c = IN_LDS ? lds_cols[k] : ex_cols[k];
+        if (c >= limit) break;
+        const double p = IN_LDS ? lds_prod[k] : ex_vals[k] * x[c];
         acc = (MODE == SPMV_RESIDUAL) ? acc - p : acc + p;
-        ++E.k;
+        ++k;
     }
-}
-template <int MODE>
-__device__ __forceinline__ SymxRowExtras symx_fetch(int e, int ee, const int *__restrict__ ex_cols,
-                                                    const double *__restrict__ ex_vals, const double *__restrict__ x)
-{
-    SymxRowExtras E;
-    E.k = 0;
-    E.n = ee - e;
-    E.e = e;
-    E.ca = E.cb = INT32_MAX;
-    E.pa = E.pb = 0.0;
-    if (E.n > 0) {
-        E.ca = ex_cols[e];
-        E.pa = ex_vals[e] * x[E.ca];
-    }
-    if (E.n > 1) {
-        E.cb = ex_cols[e + 1];
-        E.pb = ex_vals[e + 1] * x[E.cb];
-    }
-    return E;
 }
 
 // FAST (as in k_spmv_sym; known per layout: every chunk's first distance is 1 and its further ones are even --
 // blocks with even line lengths): the two rows of a lane are an aligned pair in every strip, so x and the lower
 // values of the even distances come as one 16-byte load per pair and the d = 1 neighbours from the lane's own
 // diagonal pair and plane-1 value.
-template <int MODE, int NDOT, bool STREAM, bool FAST>
+template <int MODE, int NDOT, bool STREAM, bool FAST, bool GENERAL>
 __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, const SymxChunk *__restrict__ hdr,
                                                      const uint8_t *__restrict__ mask,
                                                      const double *__restrict__ planes,
                                                      const int *__restrict__ ex_rowptr,
                                                      const int *__restrict__ ex_cols,
                                                      const double *__restrict__ ex_vals,
+                                                     const int *__restrict__ ex_lrow,
                                                      const double *__restrict__ x, const double *__restrict__ b,
                                                      double *__restrict__ y, const double *__restrict__ w,
                                                      double *__restrict__ dot_partials,
                                                      double *__restrict__ dot2_partials, const DevScalars *gate,
-                                                     int xgroup, HaloFused hf)
+                                                     HaloFused hf)
 {
     __shared__ double slot[N_WAVES];
     __shared__ double ys[CHUNK_ROWS];
+    // GENERAL: the chunk's explicit entries as a list (column, product), walked by their rows; lean kernel: at most
+    // one ahead of and one behind the planar entries of a row -- a slot per row for each, and a flag that says it is taken
+    __shared__ int ex_c[GENERAL ? SYMX_LDS_ENTRIES : 1];
+    __shared__ double ex_p[GENERAL ? SYMX_LDS_ENTRIES : 1];
+    __shared__ double ex_a[GENERAL ? 1 : CHUNK_ROWS], ex_b[GENERAL ? 1 : CHUNK_ROWS];
+    __shared__ unsigned char ex_fa[GENERAL ? 2 : CHUNK_ROWS], ex_fb[GENERAL ? 2 : CHUNK_ROWS];
     if (gate && gate->stop) return;
-    const int chunk = xcd_chunk(blockIdx.x, xgroup);
-    if (chunk >= n_chunks) return;
-    // the header is only ever indexed with compile-time constants (every loop below is fully unrolled): it stays
-    // in scalar registers; a run-time index would push all 96 bytes into scratch memory
-    const SymxChunk h = hdr[chunk];
+    // the headers are stored in dispatch order and name their chunk: one round trip (header -> data) instead of
+    // two (order -> header -> data) in front of the loads.  The header is only ever indexed with compile-time
+    // constants (every loop below is fully unrolled): it stays in scalar registers; a run-time index would push all
+    // 96 bytes into scratch memory
+    const SymxChunk h = hdr[blockIdx.x];
+    const int chunk = h.chunk;
+    if (chunk < 0 || chunk >= n_chunks) return;
     const int t = threadIdx.x;
     const RowPair rp = my_rows(chunk, n_rows);
     const int row = rp.row, r0 = chunk * CHUNK_ROWS;
     const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + row);
     const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
-    const bool has_explicit = h.ex_rp_off >= 0 && ((m0 | m1) & SYMX_EXTRAS_BIT);
-    // (their row pointers: the first link of a chain of three dependent loads -- pointers, column + value, x --
-    //  whose later links are issued only after the plane and x loads below, so that they wait together)
-    int ea = 0, eb = 0, ec = 0;
+    const bool chunk_explicit = h.ex_rp_off >= 0;                                   // (workgroup-uniform)
+    const bool has_explicit = GENERAL && chunk_explicit && ((m0 | m1) & SYMX_EXTRAS_BIT);   // this lane's rows
+    const bool in_lds = h.ex_count <= SYMX_LDS_ENTRIES;
+    // GENERAL: next explicit entry / end of the two rows, as indices into the staged entries (or into the arrays)
+    int k0 = 0, e0 = 0, k1 = 0, e1 = 0;
     if (has_explicit) {
         const int *rpx = ex_rowptr + h.ex_rp_off + t * ROWS_PER_THREAD;
-        ea = rpx[0];
-        eb = rpx[1];
-        ec = rpx[2];
+        const int shift = in_lds ? h.ex_begin : 0;
+        k0 = rpx[0] - shift;
+        e0 = k1 = rpx[1] - shift;
+        e1 = rpx[2] - shift;
+    }
+    // the entry this thread stages (entry t of the chunk; the few chunks with more than 256 loop)
+    int my_col = 0, my_lrow = 0;
+    double my_val = 0.0;
+    const bool stage = chunk_explicit && (in_lds || !GENERAL) && t < h.ex_count;
+    if (stage) {
+        my_col = ex_cols[h.ex_begin + t];
+        my_val = ex_vals[h.ex_begin + t];
+        if (!GENERAL) my_lrow = ex_lrow[h.ex_begin + t];
+    }
+    if (!GENERAL && chunk_explicit) {  // (own rows' flags down; the barrier below orders this before the staging)
+        *reinterpret_cast<unsigned short *>(ex_fa + ROWS_PER_THREAD * t) = 0;
+        *reinterpret_cast<unsigned short *>(ex_fb + ROWS_PER_THREAD * t) = 0;
     }
     double2 acc;
     acc.x = acc.y = 0.0;
     if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
-    // own planes: diagonal and upper entries of the two rows (planes beyond the chunk's nd do not exist)
+    // Distances, plane positions and twin bases padded to three with dummies (distance 0, plane 0) that no mask bit
+    // refers to, and every load issued whatever the mask says, at an index clamped into its array: straight-line
+    // code -- a run-time "does this plane exist" in front of each group of loads splits them into basic blocks that
+    // wait for each other (tools/sym_tune.hip var1/var2; 118 -> 1xx us on the 216^3 box)
+    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
+    int dj[4] = {0, 0, 0, 0};
+    long pj[4] = {0, 0, 0, 0}, b0[4], b1[4];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const bool have = j < h.nd;
+        dj[j] = have ? h.d[j - 1] : 0;
+        pj[j] = have ? (long)j * CHUNK_ROWS : 0;
+        b0[j] = (have && h.lo_base[j - 1][0] >= 0) ? h.lo_base[j - 1][0] : h.val_off;
+        b1[j] = (have && h.lo_base[j - 1][1] >= 0) ? h.lo_base[j - 1][1] : h.val_off;
+    }
+    // own planes: diagonal and upper entries of the two rows
     double2 up[4];
     const double *own = planes + h.val_off + t * ROWS_PER_THREAD;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        up[j].x = up[j].y = 0.0;
-        if (j < h.nd)
-            up[j] = (STREAM && j == 0) ? ld_pair_stream(own + (long)j * CHUNK_ROWS)
-                                       : *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
-    }
+    for (int j = 0; j < 4; ++j)
+        up[j] = (STREAM && (j == 0 || (FAST && j == 1))) ? ld_pair_stream(own + pj[j])
+                                                         : *reinterpret_cast<const double2 *>(own + pj[j]);
     const double2 xd = ld2(x, rp);
     double2 lo[4], xl[4], xu[4];
-    int dj[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
-        lo[j].x = lo[j].y = xl[j].x = xl[j].y = xu[j].x = xu[j].y = 0.0;
-        if (j < h.nd) {
-            const int d = h.d[j - 1];
-            dj[j] = d;
-            // first row of the chunk minus d: its chunk (floor division) is lo_base[.][0], the next one [.][1]
-            const int cs0 = (r0 - d) >> 9;
-            const long base0 = h.lo_base[j - 1][0], base1 = h.lo_base[j - 1][1];
-            const bool l0 = (m0 >> (3 - j)) & 1u, l1 = (m1 >> (3 - j)) & 1u;
-            const bool u0 = (m0 >> (3 + j)) & 1u, u1 = (m1 >> (3 + j)) & 1u;
-            if (FAST && j >= 2) {  // even distance: rows (row - d, row + 1 - d) are an aligned pair of one chunk's plane
-                const int rs = row - d;
-                if (l0 || l1) {
-                    lo[j] = *reinterpret_cast<const double2 *>(planes + ((rs >> 9) == cs0 ? base0 : base1) +
-                                                               (rs & (CHUNK_ROWS - 1)));
-                    xl[j] = *reinterpret_cast<const double2 *>(x + rs);
-                }
-                if (u0 || u1) xu[j] = *reinterpret_cast<const double2 *>(x + row + d);
-            } else if (FAST) {     // d = 1: A(row + 1, row) is this lane's own plane-1 value of row
-                if (l0) {
-                    const int rs = row - 1;
-                    lo[j].x = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
-                    xl[j].x = x[rs];
-                }
-                lo[j].y = up[1].x;
-                xl[j].y = xd.x;
-                xu[j].x = xd.y;
-                if (u1) xu[j].y = x[row + 2];
+        const int d = dj[j];
+        // first row of the chunk minus d: its chunk (floor division) is lo_base[.][0], the next one [.][1]
+        const int cs0 = (r0 - d) >> 9;
+        if (FAST && j >= 2) {  // even distance: rows (row - d, row + 1 - d) are an aligned pair of one chunk's plane
+            const int rs = row - d;
+            lo[j] = *reinterpret_cast<const double2 *>(planes + ((rs >> 9) == cs0 ? b0[j] : b1[j]) +
+                                                       (rs & (CHUNK_ROWS - 1)));
+            xl[j] = *reinterpret_cast<const double2 *>(x + min(max(rs, 0), last_pair));
+            xu[j] = *reinterpret_cast<const double2 *>(x + min(row + d, last_pair));
+        } else if (FAST) {     // d = 1: A(row + 1, row) is this lane's own plane-1 value of row
+            const int rs = row - 1;
+            const long at = ((rs >> 9) == cs0 ? b0[j] : b1[j]) + (rs & (CHUNK_ROWS - 1));
+            if (STREAM) {      // A(row, row - 1) is the previous lane's second plane-1 value (lane 0: from memory)
+                lo[j].x = __shfl_up(up[1].y, 1, WAVE);
+                if ((t & (WAVE - 1)) == 0) lo[j].x = planes[at];
             } else {
-                if (l0) {
-                    const int rs = row - d;
-                    lo[j].x = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
-                    xl[j].x = x[rs];
-                }
-                if (l1) {
-                    const int rs = row + 1 - d;
-                    lo[j].y = planes[((rs >> 9) == cs0 ? base0 : base1) + (rs & (CHUNK_ROWS - 1))];
-                    xl[j].y = x[rs];
-                }
-                if (u0) xu[j].x = x[row + d];
-                if (u1) xu[j].y = x[row + 1 + d];
+                lo[j].x = planes[at];
             }
+            xl[j].x = x[min(max(rs, 0), last)];
+            lo[j].y = up[1].x;
+            xl[j].y = xd.x;
+            xu[j].x = xd.y;
+            xu[j].y = x[min(row + 2, last)];
+        } else {
+            const int ra = row - d, rb = row + 1 - d;
+            lo[j].x = planes[((ra >> 9) == cs0 ? b0[j] : b1[j]) + (ra & (CHUNK_ROWS - 1))];
+            lo[j].y = planes[((rb >> 9) == cs0 ? b0[j] : b1[j]) + (rb & (CHUNK_ROWS - 1))];
+            xl[j].x = x[min(max(ra, 0), last)];
+            xl[j].y = x[min(max(rb, 0), last)];
+            xu[j].x = x[min(row + d, last)];
+            xu[j].y = x[min(row + 1 + d, last)];
         }
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
-    // explicit entries of the two rows (few rows have any): the first two of each are fetched here
-    SymxRowExtras E0 = symx_fetch<MODE>(0, 0, ex_cols, ex_vals, x), E1 = E0;
-    if (has_explicit) {
-        E0 = symx_fetch<MODE>(ea, eb, ex_cols, ex_vals, x);
-        E1 = symx_fetch<MODE>(eb, ec, ex_cols, ex_vals, x);
+    // staging of the chunk's explicit entries (their x gather is the last link of the header -> entry -> x chain; the
+    // plane and x loads above are in flight meanwhile)
+    if (GENERAL && chunk_explicit && in_lds) {
+        for (int i = t; i < h.ex_count; i += BLOCK) {
+            const int c = i == t ? my_col : ex_cols[h.ex_begin + i];
+            const double v = i == t ? my_val : ex_vals[h.ex_begin + i];
+            ex_c[i] = c;
+            ex_p[i] = v * x[c];
+        }
+        __syncthreads();
+    }
+    if (!GENERAL && chunk_explicit) {
+        __syncthreads();
+        for (int i = t; i < h.ex_count; i += BLOCK) {
+            const int c = i == t ? my_col : ex_cols[h.ex_begin + i];
+            const double v = i == t ? my_val : ex_vals[h.ex_begin + i];
+            const int lr = i == t ? my_lrow : ex_lrow[h.ex_begin + i];
+            const double p = v * x[c];
+            if (lr & SYMX_BEHIND_BIT) {
+                ex_b[lr & (CHUNK_ROWS - 1)] = p;
+                ex_fb[lr & (CHUNK_ROWS - 1)] = 1;
+            } else {
+                ex_a[lr] = p;
+                ex_fa[lr] = 1;
+            }
+        }
+        __syncthreads();
+        const int l0 = ROWS_PER_THREAD * t;
+        if (ex_fa[l0]) acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - ex_a[l0] : acc.x + ex_a[l0];
+        if (ex_fa[l0 + 1]) acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - ex_a[l0 + 1] : acc.y + ex_a[l0 + 1];
     }
     // the row walk in ascending column order: the furthest lower entry first.  Explicit entries: in most chunks
     // they only sit before the first or behind the last planar entry of their rows (the coupling across a block
     // face) -- added ahead of and behind the walk; a chunk with one in between (h.merge, workgroup-uniform) merges
     // them by column (one that repeats a column a plane holds comes after the plane's entry: `<` in symx_explicit)
+    auto ex_row0 = [&](int limit) {
+        if (in_lds)
+            symx_explicit<MODE, true>(acc.x, k0, e0, limit, ex_c, ex_p, ex_cols, ex_vals, x);
+        else
+            symx_explicit<MODE, false>(acc.x, k0, e0, limit, ex_c, ex_p, ex_cols, ex_vals, x);
+    };
+    auto ex_row1 = [&](int limit) {
+        if (in_lds)
+            symx_explicit<MODE, true>(acc.y, k1, e1, limit, ex_c, ex_p, ex_cols, ex_vals, x);
+        else
+            symx_explicit<MODE, false>(acc.y, k1, e1, limit, ex_c, ex_p, ex_cols, ex_vals, x);
+    };
     const bool merge = has_explicit && h.merge != 0;
     if (has_explicit && !merge) {
         // column of the first planar entry of each row
@@ -2072,48 +2105,53 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
             if (((m0 >> (3 - j)) & 1u)) f0 = row - dj[j];
             if (((m1 >> (3 - j)) & 1u)) f1 = row + 1 - dj[j];
         }
-        symx_explicit<MODE>(acc.x, E0, f0, ex_cols, ex_vals, x);
-        symx_explicit<MODE>(acc.y, E1, f1, ex_cols, ex_vals, x);
+        ex_row0(f0);
+        ex_row1(f1);
     }
 #pragma unroll
     for (int j = 3; j >= 1; --j) {
         if ((m0 >> (3 - j)) & 1u) {
-            if (merge) symx_explicit<MODE>(acc.x, E0, row - dj[j], ex_cols, ex_vals, x);
+            if (merge) ex_row0(row - dj[j]);
             const double p = lo[j].x * xl[j].x;
             acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
         }
         if ((m1 >> (3 - j)) & 1u) {
-            if (merge) symx_explicit<MODE>(acc.y, E1, row + 1 - dj[j], ex_cols, ex_vals, x);
+            if (merge) ex_row1(row + 1 - dj[j]);
             const double p = lo[j].y * xl[j].y;
             acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
         }
     }
     if ((m0 >> 3) & 1u) {
-        if (merge) symx_explicit<MODE>(acc.x, E0, row, ex_cols, ex_vals, x);
+        if (merge) ex_row0(row);
         const double p = up[0].x * xd.x;
         acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
     }
     if ((m1 >> 3) & 1u) {
-        if (merge) symx_explicit<MODE>(acc.y, E1, row + 1, ex_cols, ex_vals, x);
+        if (merge) ex_row1(row + 1);
         const double p = up[0].y * xd.y;
         acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
     }
 #pragma unroll
     for (int j = 1; j < 4; ++j) {
         if ((m0 >> (3 + j)) & 1u) {
-            if (merge) symx_explicit<MODE>(acc.x, E0, row + dj[j], ex_cols, ex_vals, x);
+            if (merge) ex_row0(row + dj[j]);
             const double p = up[j].x * xu[j].x;
             acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - p : acc.x + p;
         }
         if ((m1 >> (3 + j)) & 1u) {
-            if (merge) symx_explicit<MODE>(acc.y, E1, row + 1 + dj[j], ex_cols, ex_vals, x);
+            if (merge) ex_row1(row + 1 + dj[j]);
             const double p = up[j].y * xu[j].y;
             acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - p : acc.y + p;
         }
     }
     if (has_explicit) {
-        symx_explicit<MODE>(acc.x, E0, INT32_MAX, ex_cols, ex_vals, x);
-        symx_explicit<MODE>(acc.y, E1, INT32_MAX, ex_cols, ex_vals, x);
+        ex_row0(INT32_MAX);
+        ex_row1(INT32_MAX);
+    }
+    if (!GENERAL && chunk_explicit) {
+        const int l0 = ROWS_PER_THREAD * t;
+        if (ex_fb[l0]) acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - ex_b[l0] : acc.x + ex_b[l0];
+        if (ex_fb[l0 + 1]) acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - ex_b[l0 + 1] : acc.y + ex_b[l0 + 1];
     }
     if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc.x, acc.y, ys);
     st2(y, rp, acc);
@@ -3301,22 +3339,27 @@ void launch_spmv_symx(hipStream_t st, const DevSymx &A, int mode, const double *
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
-    const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
-    const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
-#define OGL_SYMX_K(MODE, NDOT, STREAM, FAST)                                                                       \
-    hipLaunchKernelGGL((k_spmv_symx<MODE, NDOT, STREAM, FAST>), grid, block, 0, st, A.n_rows, nc, A.chunks, A.mask,  \
-                       A.planes, A.ex_rowptr, A.ex_cols, A.ex_vals, x, b, y, dots.with, dots.part, dots.part_yy,     \
-                       gate, xg, hf)
-#define OGL_SYMX(MODE, NDOT)                      \
-    do {                                          \
-        if (A.stream && A.fast)                   \
-            OGL_SYMX_K(MODE, NDOT, true, true);   \
-        else if (A.stream)                        \
-            OGL_SYMX_K(MODE, NDOT, true, false);  \
-        else if (A.fast)                          \
-            OGL_SYMX_K(MODE, NDOT, false, true);  \
-        else                                      \
-            OGL_SYMX_K(MODE, NDOT, false, false); \
+    const dim3 block(BLOCK);
+    // two launches at most: the chunks without explicit entries or with simple ones (lean kernel), then the others
+#define OGL_SYMX_K(MODE, NDOT, STREAM, FAST, GENERAL, HDR, NB)                                                       \
+    hipLaunchKernelGGL((k_spmv_symx<MODE, NDOT, STREAM, FAST, GENERAL>), dim3(NB), block, 0, st, A.n_rows, nc, HDR,    \
+                       A.mask, A.planes, A.ex_rowptr, A.ex_cols, A.ex_vals, A.ex_lrow, x, b, y, dots.with, dots.part, \
+                       dots.part_yy, gate, hf)
+#define OGL_SYMX_G(MODE, NDOT, GENERAL, HDR, NB)               \
+    do {                                                       \
+        if (A.stream && A.fast)                                \
+            OGL_SYMX_K(MODE, NDOT, true, true, GENERAL, HDR, NB);   \
+        else if (A.stream)                                     \
+            OGL_SYMX_K(MODE, NDOT, true, false, GENERAL, HDR, NB);  \
+        else if (A.fast)                                       \
+            OGL_SYMX_K(MODE, NDOT, false, true, GENERAL, HDR, NB);  \
+        else                                                   \
+            OGL_SYMX_K(MODE, NDOT, false, false, GENERAL, HDR, NB); \
+    } while (0)
+#define OGL_SYMX(MODE, NDOT)                                                             \
+    do {                                                                                 \
+        if (A.n_blocks > 0) OGL_SYMX_G(MODE, NDOT, false, A.chunks, A.n_blocks);         \
+        if (A.n_blocks_general > 0) OGL_SYMX_G(MODE, NDOT, true, A.chunks_general, A.n_blocks_general); \
     } while (0)
     if (mode == SPMV_RESIDUAL) {
         OGL_SYMX(SPMV_RESIDUAL, 0);
@@ -3328,6 +3371,7 @@ void launch_spmv_symx(hipStream_t st, const DevSymx &A, int mode, const double *
         OGL_SYMX(SPMV_PLAIN, 0);
     }
 #undef OGL_SYMX
+#undef OGL_SYMX_G
 #undef OGL_SYMX_K
 }
 

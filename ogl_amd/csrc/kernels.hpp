@@ -142,14 +142,19 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
 // Half storage with per-chunk distances and explicit exceptions (SymxChunk, common.hpp), device view.
 struct DevSymx {
     int32_t n_rows = 0;
-    const SymxChunk *chunks = nullptr;  // [n_chunks]
+    // headers in dispatch order (symx_block_order): workgroup b works on chunks[b].chunk.  Two lists: the chunks the
+    // lean kernel takes (no explicit entries or simple ones) and the ones the general kernel takes
+    const SymxChunk *chunks = nullptr, *chunks_general = nullptr;
+    int32_t n_blocks_general = 0;
     const uint8_t *mask = nullptr;      // [n_chunks * CHUNK_ROWS]
     const double *planes = nullptr;
     const int32_t *ex_rowptr = nullptr, *ex_cols = nullptr;  // explicit entries (per-chunk row pointers, columns)
+    const int32_t *ex_lrow = nullptr;                        // ... their rows within the chunk | SYMX_BEHIND_BIT
     const double *ex_vals = nullptr;
     bool stream = false;
     bool fast = false;  // every chunk: first distance 1, further distances even (pair-load instantiation)
     int32_t xcd_group = 0;
+    int32_t n_blocks = 0;
 };
 void launch_spmv_symx(hipStream_t st, const DevSymx &A, int mode, const double *x, const double *b, double *y,
                       const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});

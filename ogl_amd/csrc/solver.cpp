@@ -583,6 +583,10 @@ DevSymx ogl_solver::symx() const
     S.ex_vals = d_symx_ex_vals.p;
     S.stream = symx_bytes + 41.0 * (double)pat.n_rows > stream_above_bytes();
     S.fast = symx_fast;
+    S.n_blocks = (int32_t)d_symx_chunks.n;
+    S.chunks_general = d_symx_chunks_general.p;
+    S.n_blocks_general = (int32_t)d_symx_chunks_general.n;
+    S.ex_lrow = d_symx_ex_lrow.p;
     S.xcd_group = xcd_group();
     return S;
 }
@@ -631,8 +635,9 @@ int ogl_solver::tune_symx()
         props["sellMatrixBytes"] = symx_bytes;
     } else {                   // full storage stays
         symx_state = -1;
-        for (auto *b : {&d_symx_map, &d_symx_ex_rowptr, &d_symx_ex_cols, &d_symx_ex_map}) b->release();
+        for (auto *b : {&d_symx_map, &d_symx_ex_rowptr, &d_symx_ex_cols, &d_symx_ex_map, &d_symx_ex_lrow}) b->release();
         d_symx_chunks.release();
+        d_symx_chunks_general.release();
         d_symx_mask.release();
         d_symx_planes.release();
         d_symx_ex_vals.release();
@@ -654,7 +659,23 @@ int ogl_solver::build_symx()
     SymxLayout L;
     if (!build_symx_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), L)) return OGL_OK;
     const size_t nex = L.ex_cols.size();
-    OGL_TRY(d_symx_chunks.alloc(L.chunks.size(), st));
+    // headers in dispatch order, each naming its chunk (symx_block_order): the lean kernel's list, the general one's
+    std::vector<SymxChunk> hdr_ord[2];
+    int64_t general_chunks = 0;
+    for (int g = 0; g < 2; ++g) {
+        std::vector<int32_t> order;
+        symx_block_order(L, g == 1, order);
+        hdr_ord[g].resize(order.size());
+        for (size_t b = 0; b < order.size(); ++b) {
+            if (order[b] >= 0) hdr_ord[g][b] = L.chunks[(size_t)order[b]];
+            else hdr_ord[g][b] = SymxChunk{};
+            hdr_ord[g][b].chunk = order[b];
+            if (g == 1 && order[b] >= 0) ++general_chunks;
+        }
+    }
+    OGL_TRY(d_symx_chunks.alloc(hdr_ord[0].size(), st));
+    OGL_TRY(d_symx_chunks_general.alloc(hdr_ord[1].size(), st));
+    OGL_TRY(d_symx_ex_lrow.alloc(nex + NNZ_PAD, st));
     OGL_TRY(d_symx_mask.alloc(L.mask.size(), st));
     OGL_TRY(d_symx_map.alloc(L.map.size(), st));
     OGL_TRY(d_symx_planes.alloc(L.map.size(), st));
@@ -662,7 +683,10 @@ int ogl_solver::build_symx()
     OGL_TRY(d_symx_ex_cols.alloc(nex + NNZ_PAD, st));
     OGL_TRY(d_symx_ex_map.alloc(nex + NNZ_PAD, st));
     OGL_TRY(d_symx_ex_vals.alloc(nex + NNZ_PAD, st));
-    OGL_TRY(reg->stager.h2d(d_symx_chunks.p, L.chunks.data(), L.chunks.size() * sizeof(SymxChunk), st));
+    if (!hdr_ord[0].empty())
+        OGL_TRY(reg->stager.h2d(d_symx_chunks.p, hdr_ord[0].data(), hdr_ord[0].size() * sizeof(SymxChunk), st));
+    if (!hdr_ord[1].empty())
+        OGL_TRY(reg->stager.h2d(d_symx_chunks_general.p, hdr_ord[1].data(), hdr_ord[1].size() * sizeof(SymxChunk), st));
     OGL_TRY(reg->stager.h2d(d_symx_mask.p, L.mask.data(), L.mask.size(), st));
     OGL_TRY(reg->stager.h2d(d_symx_map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
     if (!L.ex_rowptr.empty())
@@ -670,14 +694,16 @@ int ogl_solver::build_symx()
     if (nex) {
         OGL_TRY(reg->stager.h2d(d_symx_ex_cols.p, L.ex_cols.data(), nex * sizeof(int32_t), st));
         OGL_TRY(reg->stager.h2d(d_symx_ex_map.p, L.ex_map.data(), nex * sizeof(int32_t), st));
+        OGL_TRY(reg->stager.h2d(d_symx_ex_lrow.p, L.ex_lrow.data(), nex * sizeof(int32_t), st));
     }
+    props["symxGeneralChunks"] = (double)general_chunks;
     symx_state = 1;
     symx_fast = L.all_fast;
     symx_values_stale = true;
-    // bytes one SpMV reads of this layout: planes, masks, headers, explicit entries (value + column) and their
+    // bytes one SpMV reads of this layout: planes, masks, headers, explicit entries (value + column + row) and their
     // row pointers
     symx_bytes = 8.0 * (double)(L.map.size() - 2) + (double)(L.mask.size() - 16) + 96.0 * (double)L.chunks.size() +
-                 12.0 * (double)nex + 4.0 * (double)L.ex_rowptr.size();
+                 16.0 * (double)nex + 4.0 * (double)L.ex_rowptr.size();
     props["sellMatrixBytes"] = symx_bytes;
     props["sellReadSlots"] = (double)(L.map.size() - 2);
     props["sellAllocatedSlots"] = (double)(L.map.size() - 2);
@@ -1334,7 +1360,9 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         // keep anyway): everything stays on the device then
         SymDistances sym_dist{};
         bool sym_on_device = false, sym_tried = false, renumbered_on_device = false;
-        if (built_on_device && try_sym && np.symmetric && np.local_iface_nnz == 0 && cfg.renumber != 1) {
+        // (symmetricHalfWhole_enable 0: an experiment switch -- the per-chunk variant on a pattern the whole-matrix one takes)
+        const bool whole_sym = prop("symmetricHalfWhole_enable", 1.0) != 0.0;
+        if (built_on_device && whole_sym && try_sym && np.symmetric && np.local_iface_nnz == 0 && cfg.renumber != 1) {
             sym_tried = true;
             OGL_TRY(build_sym_on_device(np, &sym_dist, &sym_on_device));
         }
@@ -1489,7 +1517,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         if (sym_on_device) {
             OGL_TRY(finish_sym(sym_dist.nd, sym_dist.d));
             sym_ok = true;
-        } else if (!sym_tried && try_sym && pat.symmetric && pat.local_iface_nnz == 0 && !pat.renumbered()) {
+        } else if (!sym_tried && prop("symmetricHalfWhole_enable", 1.0) != 0.0 && try_sym && pat.symmetric &&
+                   pat.local_iface_nnz == 0 && !pat.renumbered()) {
             SymLayout symL;
             if (build_sym_layout(pat.n_rows, pat.row_ptrs.data(), pat.cols.data(), symL)) {
                 OGL_TRY(build_sym(symL));
@@ -1508,8 +1537,9 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         }
         if (symx_state != 1) {
             symx_state = -1;
-            for (auto *b : {&d_symx_map, &d_symx_ex_rowptr, &d_symx_ex_cols, &d_symx_ex_map}) b->release();
+            for (auto *b : {&d_symx_map, &d_symx_ex_rowptr, &d_symx_ex_cols, &d_symx_ex_map, &d_symx_ex_lrow}) b->release();
             d_symx_chunks.release();
+            d_symx_chunks_general.release();
             d_symx_mask.release();
             d_symx_planes.release();
             d_symx_ex_vals.release();
@@ -1612,6 +1642,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             props["spmvSymPlanes"] = (double)S.nd;
         } else if (use_symx()) {
             stream = symx().stream;
+            fast = symx().fast;
         } else if (use_sell()) {
             stream = sell().stream;
         } else {

@@ -239,9 +239,9 @@ struct ogl_solver {
     // half storage with per-chunk distances and explicit exceptions (SymxLayout, host_matrix.hpp): symmetric
     // matrices that are banded only locally (multi-block meshes, refinement shells) -- tried when the global
     // half storage above does not qualify, before the compressed full-storage copy below
-    ogl::DevBuf<ogl::SymxChunk> d_symx_chunks;
+    ogl::DevBuf<ogl::SymxChunk> d_symx_chunks, d_symx_chunks_general;  // (dispatch order: lean kernel's list, general one's)
     ogl::DevBuf<uint8_t> d_symx_mask;
-    ogl::DevBuf<int32_t> d_symx_map, d_symx_ex_rowptr, d_symx_ex_cols, d_symx_ex_map;
+    ogl::DevBuf<int32_t> d_symx_map, d_symx_ex_rowptr, d_symx_ex_cols, d_symx_ex_map, d_symx_ex_lrow;
     ogl::DevBuf<double> d_symx_planes, d_symx_ex_vals;
     int symx_state = 0;  // 0 not tried, 1 built, -1 not worth it
     bool symx_fast = false;
