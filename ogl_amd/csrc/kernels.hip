@@ -1518,51 +1518,47 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
         up[j] = (STREAM && (j == 0 || (FAST && j == 1))) ? ld_pair_stream(own + (long)j * CHUNK_ROWS)
                                                          : *reinterpret_cast<const double2 *>(own + (long)j * CHUNK_ROWS);
     const double2 xd = ld2(x, rp);
-    // lower entries: plane j at rows row - d[j], row + 1 - d[j]
+    // lower entries: plane j at rows row - d[j], row + 1 - d[j].  Every load is issued whatever the mask says, at an
+    // index clamped into its array (the mask decides below what is used): the loads do not wait for the mask
+    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
     double2 lo[ND];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
-        const bool ok0 = (m0 >> (ND - 1 - j)) & 1u, ok1 = (m1 >> (ND - 1 - j)) & 1u;
-        const int r0 = row - off.d[j], r1 = r0 + 1;
+        const int r0 = max(row - off.d[j], 0), r1 = max(row + 1 - off.d[j], 0);
         const long a0 = (long)(r0 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r0 & (CHUNK_ROWS - 1));
         const long a1 = (long)(r1 >> 9) * (ND * CHUNK_ROWS) + (long)j * CHUNK_ROWS + (r1 & (CHUNK_ROWS - 1));
-        lo[j].x = lo[j].y = 0.0;
         if (FAST && j >= 2) {  // even distance: rows r0, r0 + 1 are an aligned pair of one chunk's plane
-            if (ok0 || ok1) lo[j] = *reinterpret_cast<const double2 *>(planes + a0);
+            lo[j] = *reinterpret_cast<const double2 *>(planes + a0);
         } else if (FAST) {     // d = 1: A(row + 1, row) is this lane's own upper entry of row
             if (STREAM) {      // A(row, row - 1) is the previous lane's second plane-1 value (lane 0: from memory)
-                const double prev = __shfl_up(up[1].y, 1, WAVE);
-                lo[j].x = prev;
-                if ((t & (WAVE - 1)) == 0 && ok0) lo[j].x = planes[a0];
-            } else if (ok0) {
+                lo[j].x = __shfl_up(up[1].y, 1, WAVE);
+                if ((t & (WAVE - 1)) == 0) lo[j].x = planes[a0];
+            } else {
                 lo[j].x = planes[a0];
             }
             lo[j].y = up[1].x;
         } else {
-            if (ok0) lo[j].x = planes[a0];
-            if (ok1) lo[j].y = planes[a1];
+            lo[j].x = planes[a0];
+            lo[j].y = planes[a1];
         }
     }
     static_assert(CHUNK_ROWS == 512, "row >> 9 above");
     double2 xl[ND], xu[ND];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
-        const bool l0 = (m0 >> (ND - 1 - j)) & 1u, l1 = (m1 >> (ND - 1 - j)) & 1u;
-        const bool u0 = (m0 >> (ND - 1 + j)) & 1u, u1 = (m1 >> (ND - 1 + j)) & 1u;
-        xl[j].x = xl[j].y = xu[j].x = xu[j].y = 0.0;
         if (FAST && j >= 2) {
-            if (l0 || l1) xl[j] = *reinterpret_cast<const double2 *>(x + row - off.d[j]);
-            if (u0 || u1) xu[j] = *reinterpret_cast<const double2 *>(x + row + off.d[j]);
+            xl[j] = *reinterpret_cast<const double2 *>(x + max(row - off.d[j], 0));
+            xu[j] = *reinterpret_cast<const double2 *>(x + min(row + off.d[j], last_pair));
         } else if (FAST) {     // the neighbours of a pair at distance 1: the pair itself + one on each side
-            if (l0) xl[j].x = x[row - 1];
+            xl[j].x = x[max(row - 1, 0)];
             xl[j].y = xd.x;
             xu[j].x = xd.y;
-            if (u1) xu[j].y = x[row + 2];
+            xu[j].y = x[min(row + 2, last)];
         } else {
-            if (l0) xl[j].x = x[row - off.d[j]];
-            if (l1) xl[j].y = x[row + 1 - off.d[j]];
-            if (u0) xu[j].x = x[row + off.d[j]];
-            if (u1) xu[j].y = x[row + 1 + off.d[j]];
+            xl[j].x = x[max(row - off.d[j], 0)];
+            xl[j].y = x[min(max(row + 1 - off.d[j], 0), last)];
+            xu[j].x = x[min(row + off.d[j], last)];
+            xu[j].y = x[min(row + 1 + off.d[j], last)];
         }
     }
 #pragma unroll
