@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
     const double2 xd = ld2(x, rp);
     // lower entries: plane j at rows row - d[j], row + 1 - d[j].  Every load is issued whatever the mask says, at an
     // index clamped into its array (the mask decides below what is used): the loads do not wait for the mask
-    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
+    const int last = n_rows - 1, last_pair = last & ~1;  // (a pair load at the last even row: the vectors are allocated two past n_rows)
     double2 lo[ND];
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
@@ -1639,7 +1639,7 @@ __device__ __forceinline__ void turn_sym_load(TurnSymRegs<ND> &R, int chunk, con
 {
     const int row = rp.row;
     const double *src[2] = {p_in, z};
-    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
+    const int last = n_rows - 1, last_pair = last & ~1;  // (a pair load at the last even row: the vectors are allocated two past n_rows)
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const double *__restrict__ v = src[a];
@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
     // refers to, and every load issued whatever the mask says, at an index clamped into its array: straight-line
     // code -- a run-time "does this plane exist" in front of each group of loads splits them into basic blocks that
     // wait for each other (tools/sym_tune.hip var1/var2; 118 -> 1xx us on the 216^3 box)
-    const int last = n_rows - 1, last_pair = n_rows >= 2 ? (n_rows - 2) & ~1 : 0;
+    const int last = n_rows - 1, last_pair = last & ~1;  // (a pair load at the last even row: the vectors are allocated two past n_rows)
     int dj[4] = {0, 0, 0, 0};
     long pj[4] = {0, 0, 0, 0}, b0[4], b1[4];
 #pragma unroll

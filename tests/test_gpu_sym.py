@@ -227,3 +227,66 @@ def test_per_chunk_half_storage_follows_updates_and_pattern_changes(reg, oracle)
         rp, cols, vals = oracle_csr(oracle, case)
         x = rng.uniform(-1, 1, case.n_cells)
         np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+
+
+def with_extra_faces(case, first_row, last_row, count, seed):
+    """`count` more faces between random cells of [first_row, last_row): couplings no plane holds."""
+    rng = np.random.default_rng(seed)
+    have = set(zip(case.lower_addr.tolist(), case.upper_addr.tolist()))
+    lo, up = [], []
+    while len(lo) < count:
+        a, b = sorted(int(v) for v in rng.integers(first_row, last_row, 2))
+        if a != b and (a, b) not in have:
+            have.add((a, b))
+            lo.append(a)
+            up.append(b)
+    la = np.concatenate([case.lower_addr, np.array(lo, np.int32)])
+    ua = np.concatenate([case.upper_addr, np.array(up, np.int32)])
+    coef = np.concatenate([case.upper, rng.uniform(-1.0, -0.25, count)])
+    order = np.lexsort((ua, la))
+    diag = case.diag.copy()
+    np.add.at(diag, np.array(lo), 1.0)
+    np.add.at(diag, np.array(up), 1.0)
+    return synthetic.LduCase(case.n_cells, la[order].astype(np.int32), ua[order].astype(np.int32), diag, coef[order], None,
+                             [], case.global_index, case.global_n)
+
+
+SYMX_IRREGULAR = [
+    # (name, case, chunks the general kernel takes: few (<= 2) / some)
+    ("random_band_odd_n", lambda: synthetic.random_global_case(1029, 3, 4, seed=8), "some"),
+    ("random_band_even_n", lambda: synthetic.random_global_case(2050, 2, 4, seed=3), "some"),
+    ("blocks_plus_scattered_faces", lambda: with_extra_faces(synthetic.multi_block_case([30, 17], 24, 20), 0, 3000, 400, 4), "some"),
+    ("blocks_only", lambda: synthetic.multi_block_case([30, 17], 24, 20), "few"),   # (the chunk that straddles the two blocks)
+]
+
+
+@pytest.mark.parametrize("name,make,general", SYMX_IRREGULAR, ids=[m[0] for m in SYMX_IRREGULAR])
+def test_per_chunk_half_storage_lean_and_general_chunks(reg, oracle, name, make, general):
+    """The lean kernel takes the chunks whose rows have at most one explicit entry ahead of and one behind their
+    planar ones, the general kernel (a second launch) the others; systems with an odd number of rows end in a pair
+    load at the last even row.  SpMV, residual SpMV and a CG history as the oracle's, streamed and cached."""
+    case = make()
+    if name.startswith("blocks"):
+        case = randomise(case, 23) if name == "blocks_only" else case
+    ok, _, planar, explicit, _, chunks = capi.host_symx_check(*oracle_csr(oracle, case)[:2])
+    if not ok:
+        pytest.skip("layout does not qualify")
+    rp, cols, vals = oracle_csr(oracle, case)
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-1, 1, case.n_cells)
+    b = rng.uniform(-1, 1, case.n_cells)
+    A, _ = oracle_matrix(oracle, case)
+    inv = oracle.jacobi_generate_scalar(rp, cols, vals)
+    with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+        ref = oracle.cg(A, b, x.copy(), inv, tolerance=1e-11, rel_tol=0.0, max_iter=25)
+    for stream in (1e18, 0.0):
+        s = reg.solver(f"symx_irr_{name}_{int(stream > 0)}", cfg(1, max_iter=25, update_init_guess=1))
+        s.set_property("streamAboveBytes", stream)
+        s.set_matrix(case)
+        assert s.get_property("symmetricHalfPerChunk") == 1.0
+        g = s.get_property("symxGeneralChunks")
+        assert {"few": g <= 2, "some": 0 < g}[general], (g, chunks)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+        xs, perf = s.solve(b, x.copy())
+        np.testing.assert_array_equal(s.history(), ref.history)
+        np.testing.assert_array_equal(xs, ref.x)
