@@ -505,6 +505,16 @@ def host_symx_check(row_ptrs, cols):
     return bool(st[0]), int(st[1]), int(st[2]), int(st[3]), int(st[4]), int(st[5])
 
 
+def host_symx_kernels(row_ptrs, cols):
+    """(every chunk takes the pair-load instantiation, chunks the general kernel takes) of the same layout."""
+    rp = np.ascontiguousarray(row_ptrs, np.int32)
+    cc = np.ascontiguousarray(cols, np.int32)
+    st = (C.c_int64 * 8)()
+    _check(lib().ogl_host_symx_check(C.c_int32(len(rp) - 1), rp.ctypes.data_as(C.c_void_p),
+                                     cc.ctypes.data_as(C.c_void_p), st))
+    return bool(st[6]), int(st[7])
+
+
 def host_sell_modes(row_ptrs, cols):
     """(qualifies, chunks in 16-bit delta mode, chunks in 32-bit column mode)."""
     rp, cc = _l(row_ptrs), _l(cols)

@@ -1262,34 +1262,57 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
     const int64_t nnz = row_ptrs[n_rows];
     out.chunks.assign((size_t)nc, SymxChunk{});
     // pass 1: the distances of every chunk -- the three most frequent upper distances of its rows (ties: the
-    // shorter one), ascending -- and the place of its planes
+    // shorter one), ascending -- and the place of its planes.  pair_only: only distance 1 and even distances are
+    // eligible, and none without distance 1 (what the pair-load instantiation of the kernel can address).
     int64_t slots = 0, upper_entries = 0;
+    auto pair_shaped = [](const SymxChunk &h) {
+        if (h.nd >= 2 && h.d[0] != 1) return false;
+        for (int j = 2; j < h.nd; ++j)
+            if (h.d[j - 1] % 2 != 0) return false;
+        return true;
+    };
+    auto pick_distances = [&](int64_t c, bool pair_only, std::vector<std::pair<int32_t, int32_t>> &hist) {
+        const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS), r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
+        hist.clear();
+        for (ogl_label r = r0; r < r1; ++r)
+            for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                const int64_t d = (int64_t)cols[k] - r;
+                if (d <= 0 || d > INT32_MAX / 2) continue;
+                if (pair_only && d != 1 && d % 2 != 0) continue;
+                size_t i = 0;
+                while (i < hist.size() && hist[i].first != (int32_t)d) ++i;
+                if (i == hist.size()) hist.emplace_back((int32_t)d, 0);
+                ++hist[i].second;
+            }
+        std::sort(hist.begin(), hist.end(), [](const auto &a, const auto &b) {
+            return a.second != b.second ? a.second > b.second : a.first < b.first;
+        });
+        SymxChunk &h = out.chunks[(size_t)c];
+        h.nd = 1 + (int32_t)std::min<size_t>(3, hist.size());
+        int32_t dd[3] = {0, 0, 0};
+        for (int j = 0; j + 1 < h.nd; ++j) dd[j] = hist[(size_t)j].first;
+        std::sort(dd, dd + (h.nd - 1));
+        for (int j = 0; j < 3; ++j) h.d[j] = dd[j];
+        if (pair_only && h.nd >= 2 && h.d[0] != 1) {  // no distance 1 among them: nothing planar but the diagonal
+            h.nd = 1;
+            h.d[0] = h.d[1] = h.d[2] = 0;
+        }
+        h.ex_rp_off = -1;
+    };
     parallel_ranges(nc, 64, [&](int64_t c0, int64_t c1) {
         std::vector<std::pair<int32_t, int32_t>> hist;  // (distance, count)
-        for (int64_t c = c0; c < c1; ++c) {
-            const ogl_label r0 = (ogl_label)(c * CHUNK_ROWS), r1 = (ogl_label)std::min<int64_t>(n_rows, (c + 1) * (int64_t)CHUNK_ROWS);
-            hist.clear();
-            for (ogl_label r = r0; r < r1; ++r)
-                for (ogl_label k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
-                    const int64_t d = (int64_t)cols[k] - r;
-                    if (d <= 0 || d > INT32_MAX / 2) continue;
-                    size_t i = 0;
-                    while (i < hist.size() && hist[i].first != (int32_t)d) ++i;
-                    if (i == hist.size()) hist.emplace_back((int32_t)d, 0);
-                    ++hist[i].second;
-                }
-            std::sort(hist.begin(), hist.end(), [](const auto &a, const auto &b) {
-                return a.second != b.second ? a.second > b.second : a.first < b.first;
-            });
-            SymxChunk &h = out.chunks[(size_t)c];
-            h.nd = 1 + (int32_t)std::min<size_t>(3, hist.size());
-            int32_t dd[3] = {0, 0, 0};
-            for (int j = 0; j + 1 < h.nd; ++j) dd[j] = hist[(size_t)j].first;
-            std::sort(dd, dd + (h.nd - 1));
-            for (int j = 0; j < 3; ++j) h.d[j] = dd[j];
-            h.ex_rp_off = -1;
-        }
+        for (int64_t c = c0; c < c1; ++c) pick_distances(c, false, hist);
     });
+    {   // a few chunks out of shape (block seams) must not cost all the others the pair-load instantiation: they
+        // keep what fits it and hold the rest as explicit entries
+        int64_t odd = 0;
+        for (const SymxChunk &h : out.chunks) odd += !pair_shaped(h);
+        if (odd > 0 && odd * 20 <= nc) {
+            std::vector<std::pair<int32_t, int32_t>> hist;
+            for (int64_t c = 0; c < nc; ++c)
+                if (!pair_shaped(out.chunks[(size_t)c])) pick_distances(c, true, hist);
+        }
+    }
     for (int64_t c = 0; c < nc; ++c) {
         out.chunks[(size_t)c].val_off = slots;
         slots += (int64_t)out.chunks[(size_t)c].nd * CHUNK_ROWS;
@@ -1416,11 +1439,7 @@ bool build_symx_layout(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_la
         }
     }
     out.all_fast = true;
-    for (const SymxChunk &h : out.chunks) {
-        if (h.nd >= 2 && h.d[0] != 1) out.all_fast = false;
-        for (int j = 2; j < h.nd; ++j)
-            if (h.d[j - 1] % 2 != 0) out.all_fast = false;
-    }
+    for (const SymxChunk &h : out.chunks) out.all_fast = out.all_fast && pair_shaped(h);
     if ((double)out.planar < SYMX_MIN_PLANAR * (double)nnz) return false;
     if ((double)slots > SYM_MAX_PADDING * 1.5 * (double)upper_entries + 8.0 * CHUNK_ROWS) return false;
     return true;
@@ -1844,6 +1863,8 @@ extern "C" int ogl_host_symx_check(ogl_label n_rows, const ogl_label *row_ptrs, 
     stats[3] = (int64_t)L.ex_cols.size();
     stats[4] = ex_chunks;
     stats[5] = (int64_t)L.chunks.size();
+    stats[6] = L.all_fast ? 1 : 0;
+    for (const SymxChunk &h : L.chunks) stats[7] += h.ex_rp_off >= 0 && h.merge != 0;  // chunks the general kernel takes
     return OGL_OK;
 }
 
