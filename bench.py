@@ -743,12 +743,33 @@ def main():
             if p.returncode != 0:
                 raise SystemExit("cpu_baseline leg failed:\n" + p.stderr[-2000:])
             return json.loads(p.stdout.strip().splitlines()[-1])
-        # which placement and thread count move the most bytes on this host: bound one per core, or left
-        # to the scheduler (containers with a CPU quota below their CPU count do better unbound)
+        # Which placement and thread count run the CG loop fastest on this host.  The triad probe (bound one per
+        # core, or left to the scheduler) names a thread count; but a container with a CPU quota (cgroup cpu.max)
+        # below its CPU count is throttled for most of every period when all cores run -- there a thread per quota
+        # CPU, spread over the sockets and core complexes, is what a user would configure.  Decided by short trials
+        # of the loop itself, all reported.
         probes = [child(["--probe", "--bind", str(bnd)], 300) for bnd in (1, 0)]
         best = max(probes, key=lambda q: q["GBps"])
-        legs = child(["--bind", str(best["bind"]), "--threads", str(best["threads"])], 900)
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q == "max" else max(1, int(round(int(q) / int(per))))
+        except (OSError, ValueError):
+            pass
+        candidates = [(best["bind"], best["threads"])]
+        host_cpus = best["host_cpus"]
+        if quota is not None and quota < host_cpus:
+            candidates += [(2, t) for t in (quota, 2 * quota) if t <= host_cpus]
+        trials = []
+        for bnd, thr in candidates:
+            t = child(["--omp-only", "--bind", str(bnd), "--threads", str(thr), "--seconds", "4"], 600)["omp"]
+            trials.append({"bind": bnd, "threads_tried": t["iters_per_s_by_thread_count"], "iter_per_s": t["value"],
+                           "threads": t["cores"]})
+        pick = max(trials, key=lambda t: t["iter_per_s"])
+        legs = child(["--bind", str(pick["bind"]), "--threads", str(pick["threads"])], 900)
         legs["omp"]["placement_probe"] = probes
+        legs["omp"]["placement_trials"] = trials
+        legs["omp"]["cpu_quota_cpus"] = quota
         out["cpu_baseline"] = legs["seq"]
         out["cpu_baseline_omp"] = legs["omp"]
 

@@ -25,16 +25,19 @@ def main():
     ap.add_argument("--seq-iters", type=int, default=-1, help="-1: sized for about --seconds of work")
     ap.add_argument("--seconds", type=float, default=15.0)
     ap.add_argument("--bind", type=int, default=1,
-                    help="1: OMP_PROC_BIND=close OMP_PLACES=cores (set before libgomp loads); 0: leave the "
-                         "threads to the scheduler")
+                    help="1: OMP_PROC_BIND=close OMP_PLACES=cores (set before libgomp loads); 2: spread; 0: leave "
+                         "the threads to the scheduler")
     ap.add_argument("--probe", action="store_true",
                     help="only the thread-count probe: STREAM-like triad over a ladder of thread counts "
                          "under this binding; prints {threads, GBps} of the best")
     ap.add_argument("--threads", type=int, default=0, help="OpenMP threads of the omp leg (0: probe)")
+    ap.add_argument("--omp-only", action="store_true", help="skip the sequential leg (placement trials)")
     args = ap.parse_args()
     cores = len(os.sched_getaffinity(0))
     if args.bind:
-        os.environ["OMP_PROC_BIND"] = "close"
+        # (2: one thread per core, spread over the sockets and core complexes -- what a thread count below the core
+        #  count wants: every thread brings its own L3 slice and memory channel share)
+        os.environ["OMP_PROC_BIND"] = "spread" if args.bind == 2 else "close"
         os.environ["OMP_PLACES"] = "cores"
     else:
         os.environ.pop("OMP_PROC_BIND", None)
@@ -80,20 +83,22 @@ def main():
     t_build = time.perf_counter() - t0
     b_cg = 12 * nnz + 20 * n + 4 + (88 if inv is not None else 72) * n
 
-    seq_iters = args.seq_iters
+    out = {}
+    seq_iters = 0 if args.omp_only else args.seq_iters
     if seq_iters < 0:                      # probe with 2 iterations
         t0 = time.perf_counter()
         orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=2, export_res=False)
         per_it = (time.perf_counter() - t0) / 3.0
         seq_iters = int(max(3, min(args.iters, args.seconds / max(per_it, 1e-6))))
-    t0 = time.perf_counter()
-    r = orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=seq_iters, export_res=False)
-    t_seq = time.perf_counter() - t0
-    done = r.n_iterations - 1
-    out = {"seq": {"value": done / t_seq, "unit": "iter/s", "cores": 1, "kind": "port",
-                   "GBps": b_cg * done / t_seq / 1e9,
-                   "sample": f"{done} CG iterations of the same {args.edge}^3 system, oracle (sequential "
-                             f"reference-executor restatement), {t_seq:.1f} s (+{t_build:.1f} s LDU->CSR)"}}
+    if not args.omp_only:
+        t0 = time.perf_counter()
+        r = orc.cg(A, b, np.zeros_like(b), inv, tolerance=0.0, rel_tol=0.0, max_iter=seq_iters, export_res=False)
+        t_seq = time.perf_counter() - t0
+        done = r.n_iterations - 1
+        out["seq"] = {"value": done / t_seq, "unit": "iter/s", "cores": 1, "kind": "port",
+                      "GBps": b_cg * done / t_seq / 1e9,
+                      "sample": f"{done} CG iterations of the same {args.edge}^3 system, oracle (sequential "
+                                f"reference-executor restatement), {t_seq:.1f} s (+{t_build:.1f} s LDU->CSR)"}
 
     if args.threads > 0:
         threads, triad = args.threads, None
@@ -106,9 +111,9 @@ def main():
     for t in sorted({threads, max(1, threads // 2)}, reverse=True):
         _, _, t3 = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=3, threads=t)
         its = int(max(3, min(args.iters, 0.5 * args.seconds / max(t3 / 4.0, 1e-6))))
-        runs[t] = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=its, threads=t)
+        runs[t] = orc.cg_omp_timed(A, b, np.zeros_like(b), inv, max_iter=its, threads=t) + (orc.cg_omp_phases(),)
     threads = max(runs, key=lambda t: (runs[t][0].n_iterations - 1) / runs[t][2])
-    res, t_setup, t_loop = runs[threads]
+    res, t_setup, t_loop, phases = runs[threads]
     trials = {t: (r[0].n_iterations - 1) / r[2] for t, r in runs.items()}
     if triad is None:
         triad = orc.stream_triad_omp(1 << 26, 3, threads)
@@ -117,11 +122,15 @@ def main():
                   "GBps": b_cg * done / t_loop / 1e9, "stream_triad_GBps": triad,
                   "host_cpus": cores, "build": omp_build,
                   "iters_per_s_by_thread_count": {str(k): v for k, v in trials.items()},
+                  # where the loop's time goes, with the bytes each pass streams (scalar Jacobi: 56 N, 32 N, 12 nnz + 28 N)
+                  "passes": {name: {"s_per_iter": sec / max(done, 1), "GBps": nbytes * done / max(sec, 1e-12) / 1e9}
+                             for name, sec, nbytes in (("x_r_update_rho_norm", phases[0], 56 * n), ("p_update", phases[1], 32 * n),
+                                                       ("spmv_pq", phases[2], 12 * nnz + 28 * n))},
                   "thread_binding": (f"OMP_PROC_BIND={os.environ['OMP_PROC_BIND']} OMP_PLACES="
                                      f"{os.environ['OMP_PLACES']} (set before libgomp loads)") if args.bind
                   else "none (scheduler)",
-                  "sample": f"{done} iterations, OpenMP variant on {threads} threads (the faster of the triad-optimal count and its "
-                            f"half; {cores} CPUs), loop {t_loop:.2f} s "
+                  "sample": f"{done} iterations, OpenMP variant on {threads} threads (the faster of the count asked for and its "
+                            f"half; {cores} CPUs in the affinity mask), loop {t_loop:.2f} s "
                             f"(first-touch copy of the matrix {t_setup:.2f} s, not counted)"}
     print(json.dumps(out))
 

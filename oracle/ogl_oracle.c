@@ -1219,6 +1219,17 @@ double orc_stream_triad_omp(long n, int reps, int n_threads) {
 #endif
 }
 
+__attribute__((unused)) static void *orc_skewed_alloc(size_t bytes, void **owned, int *n_owned) {
+    void *base = xmalloc(bytes + 8192);
+    owned[*n_owned] = base;
+    *n_owned += 1;
+    return (char *)base + 576 * (size_t)*n_owned;
+}
+
+/* seconds the last orc_cg_omp_timed spent in its three passes: [0] x/r update + rho + sum|r|, [1] p update, [2] SpMV + p.q */
+static double omp_phase_s[3];
+void orc_cg_omp_phases(double out[3]) { out[0] = omp_phase_s[0]; out[1] = omp_phase_s[1]; out[2] = omp_phase_s[2]; }
+
 /* The OpenMP CG with its two phases timed apart: t_setup_s = allocation + first-touch copy of the
  * matrix and vectors (once per matrix in a real run), t_loop_s = initial residual, norm factor and
  * the iterations (what a solve costs).  The norm factor is computed with the same parallel loops. */
@@ -1236,20 +1247,27 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
     if (n_threads > 0) omp_set_num_threads(n_threads);
     const orc_label n = A->n;
     const size_t cnt = n ? (size_t)n : 1;
-    orc_scalar *r = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
-    orc_scalar *z = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
-    orc_scalar *p = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
-    orc_scalar *q = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
+    /* The vectors of a pass are walked in lock step: allocated page-aligned one after the other they would sit at
+     * the same offset within a 4 KiB page, and every store of a pass would alias the loads of the next elements of
+     * the other vectors.  Each vector starts a different number of cache lines into its allocation. */
+    void *owned[10];
+    int n_owned = 0;
+#define ORC_SKEWED(T, count) ((T *)orc_skewed_alloc(sizeof(T) * (count), owned, &n_owned))
+    orc_scalar *r = ORC_SKEWED(orc_scalar, cnt);
+    orc_scalar *z = ORC_SKEWED(orc_scalar, cnt);
+    orc_scalar *p = ORC_SKEWED(orc_scalar, cnt);
+    orc_scalar *q = ORC_SKEWED(orc_scalar, cnt);
     /* First-touch placement: the caller's arrays were allocated (and touched) by one thread, i.e.
      * on one NUMA node.  Every thread copies the slice it will stream later (same static
      * schedule), so a multi-socket host serves the loop from all of its memory controllers. */
     const orc_label nnz_all = A->rowptr[n];
-    orc_label *rowptr = (orc_label *)xmalloc(sizeof(orc_label) * (cnt + 1));
-    orc_label *cols = (orc_label *)xmalloc(sizeof(orc_label) * (size_t)(nnz_all ? nnz_all : 1));
-    orc_scalar *vals = (orc_scalar *)xmalloc(sizeof(orc_scalar) * (size_t)(nnz_all ? nnz_all : 1));
-    orc_scalar *bb = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
-    orc_scalar *xx = (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt);
-    orc_scalar *inv_copy = inv_diag ? (orc_scalar *)xmalloc(sizeof(orc_scalar) * cnt) : 0;
+    orc_label *rowptr = ORC_SKEWED(orc_label, cnt + 1);
+    orc_label *cols = ORC_SKEWED(orc_label, (size_t)(nnz_all ? nnz_all : 1));
+    orc_scalar *vals = ORC_SKEWED(orc_scalar, (size_t)(nnz_all ? nnz_all : 1));
+    orc_scalar *bb = ORC_SKEWED(orc_scalar, cnt);
+    orc_scalar *xx = ORC_SKEWED(orc_scalar, cnt);
+    orc_scalar *inv_copy = inv_diag ? ORC_SKEWED(orc_scalar, cnt) : 0;
+#undef ORC_SKEWED
 #pragma omp parallel for schedule(static)
     for (orc_label row = 0; row < n; ++row) {
         rowptr[row] = A->rowptr[row];
@@ -1283,9 +1301,11 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
      * the fly] | [q = A p; beta = p.q].  z is never stored.  Same arithmetic per element as the sequential loop. */
     int have_update = 0;
     orc_scalar t2 = 0.0;
+    omp_phase_s[0] = omp_phase_s[1] = omp_phase_s[2] = 0.0;
     for (;;) {
         rho = 0.0;
         norm = 0.0;
+        double tp = omp_get_wtime();
 #pragma omp parallel for schedule(static) reduction(+ : rho, norm)
         for (orc_label i = 0; i < n; ++i) {
             orc_scalar ri = r[i];
@@ -1298,6 +1318,7 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
             rho += ri * zi;
             norm += fabs(ri);
         }
+        omp_phase_s[0] += omp_get_wtime() - tp;
         /* criterion (same policy as criterion_check, norm already reduced) */
         int stop = 0;
         if (st->iter > 0 && st->iter < crit->min_iter) {
@@ -1332,8 +1353,11 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
         }
         if (stop) break;
         const orc_scalar t1 = (prev_rho == 0.0) ? 0.0 : rho / prev_rho;
+        tp = omp_get_wtime();
 #pragma omp parallel for schedule(static)
         for (orc_label i = 0; i < n; ++i) p[i] = (inv_diag ? r[i] * inv_diag[i] : r[i]) + t1 * p[i];
+        omp_phase_s[1] += omp_get_wtime() - tp;
+        tp = omp_get_wtime();
         beta = 0.0;
 #pragma omp parallel for schedule(static) reduction(+ : beta)
         for (orc_label row = 0; row < n; ++row) {
@@ -1342,14 +1366,14 @@ orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_sc
             q[row] = sum;
             beta += p[row] * sum;
         }
+        omp_phase_s[2] += omp_get_wtime() - tp;
         have_update = beta != 0.0;
         if (have_update) t2 = rho / beta;
         prev_rho = rho;
     }
     if (t_loop_s) *t_loop_s = omp_get_wtime() - t_loop_begin;
     memcpy(x_out, x, sizeof(orc_scalar) * (size_t)n);
-    free(r); free(z); free(p); free(q);
-    free(rowptr); free(cols); free(vals); free(bb); free(xx); free(inv_copy);
+    for (int i = 0; i < n_owned; ++i) free(owned[i]);
     return st->iter;
 #endif
 }

@@ -301,6 +301,8 @@ orc_label orc_cg_omp(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *
                      orc_criterion_state *st, int n_threads);
 int orc_omp_max_threads(void);
 /* the same solve with set-up (allocation + first-touch copy) and loop timed apart, in seconds */
+/* seconds the last orc_cg_omp_timed spent in [0] the x/r update + reductions, [1] the p update, [2] SpMV + p.q */
+void orc_cg_omp_phases(double out[3]);
 orc_label orc_cg_omp_timed(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                            const orc_scalar *inv_diag, const orc_criterion *crit,
                            orc_criterion_state *st, int n_threads, double *t_setup_s,

@@ -589,6 +589,13 @@ def cg_omp_timed(A, b, x0, inv_diag=None, tolerance=0.0, rel_tol=0.0, max_iter=1
     return Result(x, st, np.zeros(1), False), t_setup.value, t_loop.value
 
 
+def cg_omp_phases():
+    """Seconds the last cg_omp_timed spent in (x/r update + reductions, p update, SpMV + p.q)."""
+    out = (C.c_double * 3)()
+    lib(True).orc_cg_omp_phases(out)
+    return float(out[0]), float(out[1]), float(out[2])
+
+
 def stream_triad_omp(n, reps=5, threads=0):
     return float(lib(True).orc_stream_triad_omp(C.c_long(n), C.c_int(reps), C.c_int(threads)))
 
