@@ -256,6 +256,8 @@ SYMX_IRREGULAR = [
     ("random_band_odd_n", lambda: synthetic.random_global_case(1029, 3, 4, seed=8), "some"),
     ("random_band_even_n", lambda: synthetic.random_global_case(2050, 2, 4, seed=3), "some"),
     ("blocks_plus_scattered_faces", lambda: with_extra_faces(synthetic.multi_block_case([30, 17], 24, 20), 0, 3000, 400, 4), "some"),
+    # 1400 explicit entries in the first chunk: more than the general kernel stages through LDS (it reads them from memory)
+    ("blocks_plus_dense_patch", lambda: with_extra_faces(synthetic.multi_block_case([30, 17], 24, 20), 0, 512, 700, 5), "some"),
     ("blocks_only", lambda: synthetic.multi_block_case([30, 17], 24, 20), "few"),   # (the chunk that straddles the two blocks)
 ]
 
