@@ -99,3 +99,28 @@ def test_symx_layout_decodes_to_the_pattern(name, make, qualifies):
         assert explicit <= 0.01 * d.local_nnz + 8
     if name in ("two_blocks", "three_blocks"):
         assert planar >= 0.9 * d.local_nnz and explicit > 0
+
+
+def test_symx_kernel_split_and_pair_shape():
+    """Which kernel instantiation the per-chunk half storage ends up on (host side of the decision): blocks with even
+    line lengths stay on the pair-load instantiation even though the chunks at their seams see odd distances (those
+    keep only pair-addressable ones); the lean kernel takes every chunk whose rows have at most one explicit entry
+    ahead of and one behind their planar ones -- block faces -- and the general kernel the rest."""
+    def kernels(case):
+        d, loc, _, _ = capi.host_pattern(case)
+        rp = _rowptr(loc[0], d.n_rows)
+        ok = capi.host_symx_check(rp, loc[1])
+        return ok, capi.host_symx_kernels(rp, loc[1])
+
+    # even line lengths everywhere: pair-shaped, and only the seam chunks are general
+    ok, (fast, general) = kernels(synthetic.multi_block_case([60, 40], 48, 30))
+    assert ok[0] and fast and 0 < general <= 8 and ok[4] == ok[5]        # (every chunk has explicit entries)
+    # an odd line length in one block: that block's chunks cannot pair their rows
+    ok, (fast, general) = kernels(synthetic.multi_block_case([30, 17], 24, 20))
+    assert ok[0] and not fast and general <= 2
+    # a plain box: nothing for the general kernel (the last, partly filled chunk keeps a few entries explicit)
+    ok, (fast, general) = kernels(synthetic.poisson_case(20))
+    assert ok[0] and fast and general == 0 and ok[3] <= 0.01 * (ok[2] + ok[3])
+    # random couplings inside a band: rows with several explicit entries between their planar ones
+    ok, (fast, general) = kernels(synthetic.random_global_case(1029, 3, 4, seed=8))
+    assert ok[0] and general > 0
