@@ -18,6 +18,13 @@ matrix, b and x already resident in HBM.
               symmetric matrix; index-compressed copy): the rate on SURVEY §8d's CSR bytes over the same
               time is reported apart as `csr_equivalent_achieved` / `csr_equivalent_frac` (may exceed 1: it
               is a unit-of-work rate, not a bandwidth).
+              `traffic` = HBM-side bytes per launch from the PMC counters (2*FETCH_SIZE + WRITE_SIZE, KiB; the
+              gfx950 correction of MI355X_MICROARCH.md), collected in THIS run at N = 1: after the timed region
+              two short child runs of this command under `rocprofv3 --kernel-trace --pmc <counter>` (separate
+              passes, children of this process, nothing exec'ed in place); when that is not possible (no
+              rocprofv3, this process itself profiled, a pass fails) the committed summary of exactly these
+              kernels (profiles/r*_pmc*_summary.json, refused when kernels.hip has changed) is quoted instead
+              and `traffic_measured_in_this_run` says so.
   roofline_general = the same measurement for the general layouts on the same system, after the headline
               and outside its timed region: --full-storage (k_spmv_sell, pattern codes), --no-compress
               (k_spmv_stream, the kernel north_star describes), --shuffle 65536 (irregular numbering: the
@@ -119,6 +126,12 @@ def parse():
                     help="skip the roofline_general legs (full storage, CSR-stream, shuffled cells) that follow the "
                          "headline measurement of the default run")
     ap.add_argument("--general-steps", type=int, default=5, help="timed steps of each roofline_general leg")
+    ap.add_argument("--live-pmc", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic measured in THIS run: after the timed region two short child runs of this "
+                         "command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, ~25 s each). "
+                         "auto: the default headline run at N = 1 when rocprofv3 is there and this process is not "
+                         "itself profiled; otherwise (and whenever a pass fails) the committed summary of the same "
+                         "kernels is quoted")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not event-time the in-loop SpMV (roofline then comes from a "
                          "separate back-to-back SpMV loop)")
@@ -153,6 +166,53 @@ def pmc_traffic(kernel, variant=""):
         return None, f"{rel} holds no counters for {kernel}"
     total = (2.0 * k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
     return total, rel + " (2*FETCH_SIZE + WRITE_SIZE) KiB, separate passes, head " + str(meta.get("head"))
+
+
+def live_pmc_traffic(kernel, argv_tail):
+    """HBM-side bytes per launch of `kernel`, collected now: one child run of this script per counter under
+    rocprofv3 (--pmc passes are separate, as MI355X_MICROARCH.md prescribes; --kernel-trace only, no other trace
+    domain).  The children are started as ordinary child processes of this one (nothing is exec'ed in place), from
+    /tmp.  Returns (bytes or None, how)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="ogl_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", OGL_BENCH_CHILD="1")
+    means = {}
+    try:
+        for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, cnt)
+            cmd = [exe, "--kernel-trace", "--pmc", cnt, "--output-format", "csv", "-d", out, "--", "python3",
+                   os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--iters", "20", "--cpu-iters", "0",
+                   "--no-general-legs", "--live-pmc", "off"] + argv_tail
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {cnt} pass failed (rc {p.returncode}): {p.stderr[-300:]}"
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        m = re.search(r"namespace\)::(k_\w+(?:<[^>]*>)?)\(", row["Kernel_Name"])
+                        if m and m.group(1) == kernel and row["Counter_Name"] == cnt:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"the --pmc {cnt} pass saw no dispatch of {kernel}"
+            real = [v for v in vals if v > 0.05 * max(vals)]       # (gated no-op launches after the stop)
+            means[cnt] = (sum(real) / len(real), len(real))
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return None, f"live PMC passes failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0
+    return total, (f"measured in this run: two child runs of this command (--steps 1 --iters 20) under rocprofv3 "
+                   f"--kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean over "
+                   f"{means['FETCH_SIZE'][1]} / {means['WRITE_SIZE'][1]} working launches, (2*FETCH_SIZE + WRITE_SIZE) KiB")
 
 
 def main():
@@ -500,9 +560,9 @@ def main():
             "achieved": moved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": moved / HBM_PEAK_GBPS,
             "bytes_per_launch": b_moved,
             "frac_of_measured_copy_peak": moved / HBM_COPY_GBPS,
+            # (the committed summary of exactly this kernel instantiation; replaced in main() by counters collected
+            #  in this run when the live PMC passes are on)
             "traffic": traffic, "traffic_source": traffic_src,
-            # the PMC passes are separate rocprofv3 runs of this same command (tools/gpu_pmc.sh); the number is
-            # read from the committed summary of exactly this kernel instantiation, not collected by this process
             "traffic_measured_in_this_run": False,
             "traffic_over_model": None if traffic is None else traffic / b_moved,
             # the same time priced in SURVEY.md 8(d)'s CSR bytes (the unit of work `matrixFormat Csr` names):
@@ -529,6 +589,19 @@ def main():
                        "_nocompress" if args.no_compress else "")
     layout, b_moved, b_spmv, roofline = spmv_roofline(s, N, nnz, spmv_ms, spmv_src, pmc_variant,
                                                       in_loop=not args.no_profile)
+    profiled = any(k in os.environ.get("LD_PRELOAD", "") for k in ("rocprof", "roctracer")) or \
+        any(k.startswith("ROCPROF") for k in os.environ)
+    live_tail = ["--edge", str(n), "--precond", args.precond, "--solver", args.solver]
+    want_live = args.live_pmc == "on" or (args.live_pmc == "auto" and pmc_variant == "" and not args.no_profile
+                                          and not args.prop and not profiled)
+    if want_live and world == 1 and rank == 0 and not os.environ.get("OGL_BENCH_CHILD"):
+        live, how = live_pmc_traffic(roofline["kernel"], live_tail)
+        roofline["traffic_committed_summary"] = {"bytes": roofline["traffic"], "source": roofline["traffic_source"]}
+        if live is not None:
+            roofline.update({"traffic": live, "traffic_source": how, "traffic_measured_in_this_run": True,
+                             "traffic_over_model": live / roofline["bytes_per_launch"]})
+        else:
+            roofline["traffic_live_attempt"] = how
     renumbered = s.get_property("renumbered") == 1.0
     if world > 1 and s.get_property("peerHalo") == 1.0:
         # the transport above was only the bootstrap: halo values are put straight into the
@@ -631,6 +704,16 @@ def main():
                       "first_set_matrix_s": t_first,
                       "renumbered": sv.get_property("renumbered") == 1.0,
                       "moved_frac": r["frac"]})
+            if want_live and world == 1 and rank == 0 and not os.environ.get("OGL_BENCH_CHILD"):
+                leg_flags = {"full_storage": ["--full-storage"], "no_compress": ["--no-compress"],
+                             "shuffle65536": ["--shuffle", "65536"]}[name]
+                live, how = live_pmc_traffic(r["kernel"], live_tail + leg_flags)
+                r["traffic_committed_summary"] = {"bytes": r["traffic"], "source": r["traffic_source"]}
+                if live is not None:
+                    r.update({"traffic": live, "traffic_source": how, "traffic_measured_in_this_run": True,
+                              "traffic_over_model": live / r["bytes_per_launch"]})
+                else:
+                    r["traffic_live_attempt"] = how
             general.append(r)
             del sv
 
