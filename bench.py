@@ -168,6 +168,9 @@ def pmc_traffic(kernel, variant=""):
     return total, rel + " (2*FETCH_SIZE + WRITE_SIZE) KiB, separate passes, head " + str(meta.get("head"))
 
 
+_LIVE_PMC_STATE = {"broken": None}
+
+
 def live_pmc_traffic(kernel, argv_tail):
     """HBM-side bytes per launch of `kernel`, collected now: one child run of this script per counter under
     rocprofv3 (--pmc passes are separate, as MI355X_MICROARCH.md prescribes; --kernel-trace only, no other trace
@@ -179,8 +182,11 @@ def live_pmc_traffic(kernel, argv_tail):
     import shutil
     import subprocess
     import tempfile
+    if _LIVE_PMC_STATE["broken"]:    # (one failed pass: the rest of the run quotes the committed summaries)
+        return None, "skipped: " + _LIVE_PMC_STATE["broken"]
     exe = shutil.which("rocprofv3")
     if exe is None:
+        _LIVE_PMC_STATE["broken"] = "rocprofv3 not found"
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="ogl_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", OGL_BENCH_CHILD="1")
@@ -191,9 +197,10 @@ def live_pmc_traffic(kernel, argv_tail):
             cmd = [exe, "--kernel-trace", "--pmc", cnt, "--output-format", "csv", "-d", out, "--", "python3",
                    os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--iters", "20", "--cpu-iters", "0",
                    "--no-general-legs", "--live-pmc", "off"] + argv_tail
-            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             if p.returncode != 0:
-                return None, f"rocprofv3 --pmc {cnt} pass failed (rc {p.returncode}): {p.stderr[-300:]}"
+                _LIVE_PMC_STATE["broken"] = f"rocprofv3 --pmc {cnt} pass failed (rc {p.returncode}): {p.stderr[-300:]}"
+                return None, _LIVE_PMC_STATE["broken"]
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
@@ -206,7 +213,8 @@ def live_pmc_traffic(kernel, argv_tail):
             real = [v for v in vals if v > 0.05 * max(vals)]       # (gated no-op launches after the stop)
             means[cnt] = (sum(real) / len(real), len(real))
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
-        return None, f"live PMC passes failed: {e!r}"
+        _LIVE_PMC_STATE["broken"] = f"live PMC passes failed: {e!r}"
+        return None, _LIVE_PMC_STATE["broken"]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     total = (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0
