@@ -1981,7 +1981,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
     // Distances, plane positions and twin bases padded to three with dummies (distance 0, plane 0) that no mask bit
     // refers to, and every load issued whatever the mask says, at an index clamped into its array: straight-line
     // code -- a run-time "does this plane exist" in front of each group of loads splits them into basic blocks that
-    // wait for each other (tools/sym_tune.hip var1/var2; 118 -> 1xx us on the 216^3 box)
+    // wait for each other (tools/sym_tune.hip var1/var2)
     const int last = n_rows - 1, last_pair = last & ~1;  // (a pair load at the last even row: the vectors are allocated two past n_rows)
     int dj[4] = {0, 0, 0, 0};
     long pj[4] = {0, 0, 0, 0}, b0[4], b1[4];
@@ -2069,10 +2069,10 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
         if (ex_fa[l0]) acc.x = (MODE == SPMV_RESIDUAL) ? acc.x - ex_a[l0] : acc.x + ex_a[l0];
         if (ex_fa[l0 + 1]) acc.y = (MODE == SPMV_RESIDUAL) ? acc.y - ex_a[l0 + 1] : acc.y + ex_a[l0 + 1];
     }
-    // the row walk in ascending column order: the furthest lower entry first.  Explicit entries: in most chunks
-    // they only sit before the first or behind the last planar entry of their rows (the coupling across a block
-    // face) -- added ahead of and behind the walk; a chunk with one in between (h.merge, workgroup-uniform) merges
-    // them by column (one that repeats a column a plane holds comes after the plane's entry: `<` in symx_explicit)
+    // the row walk in ascending column order: the furthest lower entry first.  Explicit entries: the lean kernel has
+    // added the one ahead of the planar entries above and adds the one behind them below; the general kernel merges
+    // a row's list by column (an entry that repeats a column a plane holds comes after the plane's entry: `<` in
+    // symx_explicit)
     auto ex_row0 = [&](int limit) {
         if (in_lds)
             symx_explicit<MODE, true>(acc.x, k0, e0, limit, ex_c, ex_p, ex_cols, ex_vals, x);
@@ -2085,25 +2085,8 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_symx(int n_rows, int n_chunks, c
         else
             symx_explicit<MODE, false>(acc.y, k1, e1, limit, ex_c, ex_p, ex_cols, ex_vals, x);
     };
-    const bool merge = has_explicit && h.merge != 0;
-    if (has_explicit && !merge) {
-        // column of the first planar entry of each row
-        int f0 = INT32_MAX, f1 = INT32_MAX;
-#pragma unroll
-        for (int j = 3; j >= 1; --j) {
-            if (((m0 >> (3 + j)) & 1u)) f0 = row + dj[j];
-            if (((m1 >> (3 + j)) & 1u)) f1 = row + 1 + dj[j];
-        }
-        if ((m0 >> 3) & 1u) f0 = row;
-        if ((m1 >> 3) & 1u) f1 = row + 1;
-#pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            if (((m0 >> (3 - j)) & 1u)) f0 = row - dj[j];
-            if (((m1 >> (3 - j)) & 1u)) f1 = row + 1 - dj[j];
-        }
-        ex_row0(f0);
-        ex_row1(f1);
-    }
+    // (the general kernel only sees chunks with SymxChunk::merge set: its rows' explicit entries are merged by column)
+    const bool merge = has_explicit;
 #pragma unroll
     for (int j = 3; j >= 1; --j) {
         if ((m0 >> (3 - j)) & 1u) {
