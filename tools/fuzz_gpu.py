@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the GPU path against the oracle (run by hand on a GPU box; the committed tests are the fixed
+cases): random patterns (boxes, multi-block meshes, random bands, scattered extra faces; odd and even row counts),
+random solver / preconditioner / layout switches / turn shapes.  Every case: SpMV bit-identical to the oracle's, the
+residual history and x of a short solve bit-identical to the oracle run in the device's reduction tree.
+
+  python tools/fuzz_gpu.py [cases] [seed]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ogl_amd import capi, synthetic          # noqa: E402
+from oracle import oracle as orc              # noqa: E402
+from helpers import blocked, oracle_csr, oracle_matrix   # noqa: E402
+
+
+def extra_faces(case, count, rng):
+    have = set(zip(case.lower_addr.tolist(), case.upper_addr.tolist()))
+    lo, up = [], []
+    n = case.n_cells
+    while len(lo) < count and n > 2:
+        a, b = sorted(int(v) for v in rng.integers(0, n, 2))
+        if a != b and (a, b) not in have:
+            have.add((a, b)); lo.append(a); up.append(b)
+    if not lo:
+        return case
+    la = np.concatenate([case.lower_addr, np.array(lo, np.int32)])
+    ua = np.concatenate([case.upper_addr, np.array(up, np.int32)])
+    coef = np.concatenate([case.upper, rng.uniform(-1.0, -0.25, len(lo))])
+    low = None if case.lower is None else np.concatenate([case.lower, rng.uniform(-1.0, -0.25, len(lo))])
+    order = np.lexsort((ua, la))
+    diag = case.diag.copy()
+    np.add.at(diag, np.array(lo), 1.1); np.add.at(diag, np.array(up), 1.1)
+    return synthetic.LduCase(n, la[order].astype(np.int32), ua[order].astype(np.int32), diag, coef[order],
+                             None if low is None else low[order], [], case.global_index, case.global_n)
+
+
+SCALE = int(os.environ.get("OGL_FUZZ_SCALE", "1"))   # 2-3: systems of several hundred chunks
+
+
+def random_case(rng):
+    kind = rng.choice(["box", "blocks", "band", "box+faces", "blocks+faces", "line"])
+    sym = bool(rng.integers(0, 4) != 0)
+    if kind.startswith("box"):
+        g = [int(rng.integers(1, 40 * SCALE)) for _ in range(3)]
+        c = synthetic.poisson_block(*g, symmetric=sym, **({} if sym else dict(off_upper=-0.9, off_lower=-1.1)))
+    elif kind.startswith("blocks"):
+        nb = int(rng.integers(2, 4))
+        c = synthetic.multi_block_case([int(rng.integers(2, 40 * SCALE)) for _ in range(nb)], int(rng.integers(1, 20 * SCALE)),
+                                      int(rng.integers(1, 20 * SCALE)))
+        if not sym:
+            c.lower = c.upper * 1.2
+    elif kind == "line":
+        c = synthetic.poisson_block(int(rng.integers(1, 3000 * SCALE * SCALE)), 1, 1, symmetric=sym, **({} if sym else dict(off_upper=-0.9, off_lower=-1.1)))
+    else:
+        c = synthetic.random_global_case(int(rng.integers(2, 3000 * SCALE)), int(rng.integers(1, 5)), int(rng.choice([2, 4, 9, 60])),
+                                         symmetric=sym, seed=int(rng.integers(0, 1 << 30)))
+    if kind.endswith("+faces"):
+        c = extra_faces(c, int(rng.integers(1, 60 * SCALE * SCALE)), rng)
+    # random coefficients, diagonally dominant
+    c.upper = rng.uniform(-1.0, -0.25, c.upper.size)
+    if c.lower is not None:
+        c.lower = rng.uniform(-1.0, -0.25, c.upper.size)
+    deg = np.bincount(c.lower_addr, minlength=c.n_cells) + np.bincount(c.upper_addr, minlength=c.n_cells)
+    c.diag = deg * 1.0 + rng.uniform(0.5, 1.5, c.n_cells)
+    return kind, c
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    orc.build()
+    reg = capi.Registry()
+    chunk = capi.lib().ogl_reduction_chunk_rows()
+    bad = 0
+    for it in range(n_cases):
+        kind, case = random_case(rng)
+        solver = rng.choice(["cg", "bicg", "gmres"]) if case.lower is None else rng.choice(["bicg", "gmres"])
+        pc = str(rng.choice(["none", "bj1", "bj1", "bjk", "isai", "gisai"]))
+        if pc == "isai" and case.lower is not None:
+            pc = "gisai"                                  # (ISAI is the SPD variant)
+        precond = {"none": capi.PRECOND_NONE, "bj1": capi.PRECOND_BJ, "bjk": capi.PRECOND_BJ, "isai": capi.PRECOND_ISAI,
+                   "gisai": capi.PRECOND_GISAI}[pc]
+        block = int(rng.integers(2, 9)) if pc == "bjk" else 1
+        cfgkw = dict(max_block_size=block, solver={"cg": capi.SOLVER_CG, "bicg": capi.SOLVER_BICGSTAB, "gmres": capi.SOLVER_GMRES}[solver],
+                     preconditioner=precond, tolerance=1e-12, rel_tol=0.0, max_iter=int(rng.integers(1, 40)), export_res=1,
+                     adapt_min_iter=0, update_init_guess=1, renumber=capi.RENUMBER_OFF,
+                     compress_indices=int(rng.integers(0, 4) != 0), symmetric_half=int(rng.integers(0, 4) != 0),
+                     matrix_format=int(rng.choice([capi.FORMAT_CSR, capi.FORMAT_CSR, capi.FORMAT_ELL])))
+        if solver == "gmres":
+            cfgkw["krylov_dim"] = int(rng.integers(2, 12))
+        props = {"streamAboveBytes": float(rng.choice([0.0, 1e18])), "fusedFinalizers": float(rng.integers(0, 2)),
+                 "fusedTurn": float(rng.integers(0, 2)), "fusedTurnBig": float(rng.integers(0, 2)),
+                 "hipGraph": float(rng.integers(0, 2))}
+        tag = f"case {it}: {kind} n={case.n_cells} sym={case.lower is None} {solver} precond={pc}/{block} " \
+              f"{ {k: cfgkw[k] for k in ('compress_indices', 'symmetric_half', 'matrix_format', 'max_iter')} } {props}"
+        only = os.environ.get("OGL_FUZZ_ONLY")
+        if only is not None and it != int(only):
+            for _ in range(2):
+                rng.uniform(-1, 1, case.n_cells)      # (keep the random stream of the skipped case's x and b)
+            continue
+        try:
+            s = reg.solver(f"f{it}", capi.default_config(**cfgkw))
+            for k, v in props.items():
+                s.set_property(k, v)
+            s.set_matrix(case)
+            rp, cols, vals = oracle_csr(orc, case)
+            x = rng.uniform(-1, 1, case.n_cells)
+            b = rng.uniform(-1, 1, case.n_cells)
+            y = s.spmv(x)
+            assert np.array_equal(y, orc.spmv(rp, cols, vals, x)), "spmv differs"
+            A, _ = oracle_matrix(orc, case)
+            kw = dict(tolerance=1e-12, rel_tol=0.0, max_iter=cfgkw["max_iter"])
+            if pc == "none":
+                P = None
+            elif pc == "bj1":
+                P = orc.Precond(rp, cols, vals, 1) if solver == "gmres" else orc.jacobi_generate_scalar(rp, cols, vals)
+            elif pc == "bjk":
+                P = orc.Precond(rp, cols, vals, block)
+            else:
+                P = orc.Precond(rp, cols, vals, isai="spd" if pc == "isai" else "general")
+            with blocked(orc, chunk):
+                if solver == "cg":
+                    ref = orc.cg(A, b, x.copy(), P, **kw)
+                elif solver == "bicg":
+                    ref = orc.bicgstab(A, b, x.copy(), P, **kw)
+                else:
+                    ref = orc.gmres(A, b, x.copy(), P, krylov_dim=cfgkw["krylov_dim"], **kw)
+            xs, perf = s.solve(b, x.copy())
+            if solver != "bicg":   # (GKOBiCGStab reports half of its checks, as the reference does)
+                assert perf.n_iterations == ref.n_iterations, f"iterations {perf.n_iterations} vs {ref.n_iterations}"
+            if only is not None:
+                print("gpu history", s.history(), "\noracle history", ref.history, "\ngpu x", xs, "oracle x", ref.x)
+            assert np.array_equal(s.history(), ref.history, equal_nan=True), "history differs"
+            assert np.array_equal(xs, ref.x, equal_nan=True), "x differs"
+        except Exception as e:   # noqa: BLE001
+            bad += 1
+            print("FAIL", tag, "->", repr(e)[:300], flush=True)
+    print(f"{n_cases - bad} / {n_cases} cases bit-identical (seed {seed})")
+    reg.close()
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
