@@ -2356,8 +2356,9 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // latency, not host launch cost) and stays off by default.
     const bool graphable = !gmres && !bicg && !generic && !reg->comm->multi() && prof_cap == 0 &&
                            prop("hipGraph", fused ? 1.0 : 0.0) != 0.0;
-    // (on by default for the 3-launch turn of small systems, where the host's launch rate shows: 32^3 15.1 -> 13.0 us
-    //  per turn, 64^3 17.3 -> 16.7; the 5-launch turn of larger systems measures the same either way)
+    // (on by default for the folded 2- / 3-launch turns of small systems, where the host's launch rate shows: 32^3
+    //  15.1 -> 13.0 us per 3-launch turn, 64^3 17.3 -> 16.7; the 5-launch turn of larger systems measures the same either way;
+    //  a batch of 16 turns leaves the two p buffers of the 2-launch turn where it found them)
     auto enqueue_turns = [&](int count) -> int {
         // (the fused-finaliser turn: its first step_1x_fin differs from the later ones -- the first batch runs direct)
         if (!graphable || count != batch || (fused && enq == 0)) return enqueue_direct(count);
