@@ -3041,7 +3041,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
     // round trips would otherwise cost more than the reduction itself
     DevScalars L;
     if (threadIdx.x == 0 && a.do_logic) L = *s;
-    double v0 = 0.0, v1 = 0.0;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
     if (a.do_reduce) {
         const double *const parts[2] = {a.part[0], a.part[1]};
         double r[2];
@@ -3051,6 +3051,11 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
             reduce_partials<1>(parts, a.n_part, slot, r);
         v0 = r[0];
         v1 = r[1];
+        if (PHASE == FIN_BICG_CHECK2_OMEGA) {  // (single rank: nothing of this goes through an all-reduce)
+            const double *const extra[2] = {a.part_extra, nullptr};
+            reduce_partials<1>(extra, a.n_part, slot, r);
+            v2 = r[0];
+        }
         if (PHASE == FIN_MEAN) {
             // distributed compute_mean [UPSTREAM]: local mean, weighted by n_local / n_global
             v0 /= a.n_local;
@@ -3095,6 +3100,16 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
         if (L.stop) {
             L.stop_phase = 1;
             L.stop_turn = a.turn;
+        }
+    } else if (PHASE == FIN_BICG_CHECK2_OMEGA) {  // the two phases around the second SpMV in one
+        criterion_check(&L, L.crit, v2, a.history);
+        if (L.stop) {
+            L.stop_phase = 1;
+            L.stop_turn = a.turn;
+        } else {
+            L.gamma = v0;
+            L.beta = v1;
+            L.omega = (v1 != 0.0) ? v0 / v1 : 0.0;
         }
     } else if (PHASE == FIN_BICG_OMEGA) {  // gamma = s.t ; beta = t.t ; omega = gamma / beta
         L.gamma = v0;
@@ -3760,6 +3775,9 @@ void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
         break;
     case FIN_BICG_OMEGA:
         hipLaunchKernelGGL((k_finalize<FIN_BICG_OMEGA>), grid, block, 0, st, s, a);
+        break;
+    case FIN_BICG_CHECK2_OMEGA:
+        hipLaunchKernelGGL((k_finalize<FIN_BICG_CHECK2_OMEGA>), grid, block, 0, st, s, a);
         break;
     case FIN_GMRES_RESTART:
         hipLaunchKernelGGL((k_finalize<FIN_GMRES_RESTART>), grid, block, 0, st, s, a);

@@ -325,7 +325,10 @@ enum FinPhase {
     FIN_GMRES_H = 9,        // H(k, it) = sum0                                        (finish_arnoldi)
     FIN_GMRES_COL = 10,     // H(it+1, it) = sqrt(sum0) -> beta ; Givens ; rnc        (givens_rotation)
     FIN_GMRES_CHECK = 11,   // criterion check on stale_norm
-    FIN_GMRES_SOLVE = 12    // y = R^-1 rnc for `turn` columns                        (solve_krylov)
+    FIN_GMRES_SOLVE = 12,   // y = R^-1 rnc for `turn` columns                        (solve_krylov)
+    // single rank: FIN_BICG_CHECK2 and FIN_BICG_OMEGA in one launch, after the second SpMV (which then runs even when
+    // the mid-turn check stops the solve: its result is not used); sums: s.t, t.t and, from part_extra, sum|s|
+    FIN_BICG_CHECK2_OMEGA = 13
 };
 // GMRES small dense state in one device array of doubles:
 //   H[(m+1) x m] column-major | givens_sin[m] | givens_cos[m] | rnc[m+1] | y[m]
@@ -405,8 +408,9 @@ void launch_peer_post(hipStream_t st, unsigned long long *dst, unsigned long lon
 struct FinArgs {
     PeerArgs peer{};  // world > 1: all-reduce the sums inside the kernel (do_reduce && do_logic)
     const double *part[2] = {nullptr, nullptr};
+    const double *part_extra = nullptr;  // third partial array (FIN_BICG_CHECK2_OMEGA)
     int32_t n_part = 0;     // entries per partial array
-    int32_t n_sums = 1;     // 1 or 2
+    int32_t n_sums = 1;     // 1 or 2 (3 with part_extra)
     int32_t do_reduce = 1;  // reduce partials -> s->sums
     int32_t do_logic = 1;   // scalar logic from s->sums (after the all-reduce when multi-rank)
     double n_local = 0, n_global = 0;  // FIN_MEAN

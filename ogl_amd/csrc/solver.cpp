@@ -2323,13 +2323,27 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                                   SpmvDots{d_rr.p, d_part0.p, nullptr}, s));
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 OGL_TRY(finalize(FIN_BICG_ALPHA, f1));
-                launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part0.p, s);
-                if (generic) apply_preconditioner(d_s.p, z, s);
-                f1.turn = enq;
-                OGL_TRY(finalize(FIN_BICG_CHECK2, f1));
-                OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
-                                  SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
-                OGL_TRY(finalize(FIN_BICG_OMEGA, f2));
+                if (!reg->comm->multi() && prop("bicgMergedCheck", 1.0) != 0.0) {
+                    // single rank: the mid-turn check moves behind the second SpMV and shares its finaliser (8 launches
+                    // per turn instead of 9; when it stops the solve that SpMV ran for nothing)
+                    launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part2.p, s);
+                    if (generic) apply_preconditioner(d_s.p, z, s);
+                    OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
+                                      SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
+                    FinArgs f3 = f2;
+                    f3.part_extra = d_part2.p;
+                    f3.n_sums = 3;
+                    f3.turn = enq;
+                    OGL_TRY(finalize(FIN_BICG_CHECK2_OMEGA, f3));
+                } else {
+                    launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part0.p, s);
+                    if (generic) apply_preconditioner(d_s.p, z, s);
+                    f1.turn = enq;
+                    OGL_TRY(finalize(FIN_BICG_CHECK2, f1));
+                    OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
+                                      SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
+                    OGL_TRY(finalize(FIN_BICG_OMEGA, f2));
+                }
                 launch_bicg_step3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p,
                                   d_part1.p, s, enq);
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
