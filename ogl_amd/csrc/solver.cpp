@@ -2043,11 +2043,12 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // ... and on half storage step_1x(_fin) and the SpMV are one kernel (k_cg_turn_sym, k_cg_turn_sym_big): 2 launches
     // per turn for small systems, 4 for larger ones, p alternating between two buffers (single rank: with halos the
     // put and the wait for the neighbours' puts would sit in one kernel)
-    // (larger systems: property fusedTurnBig, off by default -- 216^3 measured 4190 against 4149 turns/s: the merged
-    //  kernel runs 152 us where step_1x + SpMV take 162, and step_2r pays 8 N more bytes for keeping z)
+    // (larger systems, property fusedTurnBig: on while matrix and vectors live in the Infinity Cache -- 128^3 58.8 -> 54.7 us
+    //  per turn, 136^3 66.3 -> 61.5 -- and off once they are streamed: 160^3 105.1 -> 104.5, 216^3 4149 -> 4190 turns/s,
+    //  where the merged kernel runs 152 us for the 162 of step_1x + SpMV and step_2r pays 8 N more bytes for keeping z)
     const bool merged = !bicg && !gmres && !generic && !reg->comm->multi() && nc >= 1 && use_sym() &&
                         cfg.matrix_format != OGL_FORMAT_ELL &&
-                        (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", 0.0) != 0.0);
+                        (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
     const bool fused2 = fused && merged;
     props["fusedTurnInUse"] = merged ? 1.0 : 0.0;
     if (merged) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
