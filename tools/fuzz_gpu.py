@@ -44,7 +44,7 @@ SCALE = int(os.environ.get("OGL_FUZZ_SCALE", "1"))   # 2-3: systems of several h
 
 
 def random_case(rng):
-    kind = rng.choice(["box", "blocks", "band", "box+faces", "blocks+faces", "line"])
+    kind = rng.choice(["box", "blocks", "band", "box+faces", "blocks+faces", "line", "periodic"])
     sym = bool(rng.integers(0, 4) != 0)
     if kind.startswith("box"):
         g = [int(rng.integers(1, 40 * SCALE)) for _ in range(3)]
@@ -55,6 +55,9 @@ def random_case(rng):
                                       int(rng.integers(1, 20 * SCALE)))
         if not sym:
             c.lower = c.upper * 1.2
+    elif kind == "periodic":   # a cyclic patch pair on the same rank: its entries are merged into the local rows
+        g = [int(rng.integers(2, 30 * SCALE)) for _ in range(3)]
+        c = synthetic.poisson_block(*g, symmetric=sym, periodic_x=True, **({} if sym else dict(off_upper=-0.9, off_lower=-1.1)))
     elif kind == "line":
         c = synthetic.poisson_block(int(rng.integers(1, 3000 * SCALE * SCALE)), 1, 1, symmetric=sym, **({} if sym else dict(off_upper=-0.9, off_lower=-1.1)))
     else:
@@ -62,6 +65,8 @@ def random_case(rng):
                                          symmetric=sym, seed=int(rng.integers(0, 1 << 30)))
     if kind.endswith("+faces"):
         c = extra_faces(c, int(rng.integers(1, 60 * SCALE * SCALE)), rng)
+    if c.interfaces:
+        return kind, c
     # random coefficients, diagonally dominant
     c.upper = rng.uniform(-1.0, -0.25, c.upper.size)
     if c.lower is not None:
