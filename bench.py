@@ -339,6 +339,11 @@ def main():
         if world == 1:
             return reg, "single GPU"
         ok, why = True, ""
+        if kind == "rccl" and not all_ok(reg.rccl_ready()):
+            # init_rccl is collective and has no time-out: nobody enters it unless everybody can
+            print(f"bench.py: rank {rank}: RCCL not loadable on every rank", file=sys.stderr)
+            reg.close()
+            return None
         try:
             if kind == "rccl":
                 uid = [capi.rccl_unique_id() if rank == 0 else None]

@@ -38,7 +38,8 @@ typedef enum {
     OGL_ERR_HIP = -3,         /* a HIP runtime call failed */
     OGL_ERR_COMM = -4,        /* RCCL / host transport failure */
     OGL_ERR_STATE = -5,       /* call order violated (e.g. solve before set_matrix) */
-    OGL_ERR_UNSUPPORTED = -6  /* e.g. AMI/ACMI interfaces (HostMatrix.C:339-341,367-369) */
+    OGL_ERR_UNSUPPORTED = -6, /* e.g. AMI/ACMI interfaces (HostMatrix.C:339-341,367-369) */
+    OGL_ERR_COMM_SELFTEST = -7 /* a transport's collectives completed but delivered wrong numbers: the caller may step down */
 } ogl_status;
 
 const char *ogl_last_error(void);
@@ -198,6 +199,12 @@ int ogl_registry_set_host_comm(ogl_registry *reg, int32_t rank, int32_t n_ranks,
  * unique id is produced on rank 0 and broadcast by the host (MPI_Bcast in OpenFOAM). */
 #define OGL_RCCL_ID_BYTES 128
 int ogl_rccl_unique_id(void *id_out);
+/* Local, non-collective: can this rank enter ogl_registry_init_rccl at all (librccl loads, the device can be
+ * selected)?  init_rccl is collective (ncclCommInitRank, then a self-test) and has no time-out: the host agrees
+ * on this answer over its own message passing FIRST (a min-reduce in OpenFOAM), so that a rank which cannot
+ * join makes every rank step down to the host-buffer transport instead of leaving the others inside the
+ * collective (the reference aborts the job in that situation: a Ginkgo exception, ExecutorHandler.H:83-110). */
+int ogl_registry_rccl_ready(ogl_registry *reg);
 int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n_ranks, const void *id);
 
 /* Peer mesh over xGMI (hipIpc): the scalar reductions of the Krylov loop (the MPI_Allreduce behind

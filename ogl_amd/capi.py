@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OGL_AMD_LIB") or os.path.join(_HERE, "lib", "libogl_amd.so")
 
 OK = 0
-ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_COMM, ERR_STATE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_COMM, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM_SELFTEST = -1, -2, -3, -4, -5, -6, -7
 SOLVER_CG, SOLVER_BICGSTAB, SOLVER_GMRES = 0, 1, 2
 PRECOND_NONE, PRECOND_BJ, PRECOND_ISAI, PRECOND_GISAI = 0, 1, 2, 3
 FORMAT_COO, FORMAT_CSR, FORMAT_ELL = 0, 1, 2
@@ -80,7 +80,7 @@ EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, _LP, _LP, _SP, _SP)
 EXPORTED_SYMBOLS = [
     "ogl_last_error", "ogl_abi_version", "ogl_config_default", "ogl_registry_create",
     "ogl_registry_destroy", "ogl_registry_set_host_comm", "ogl_rccl_unique_id",
-    "ogl_registry_init_rccl", "ogl_registry_peer_handle", "ogl_registry_peer_connect",
+    "ogl_registry_rccl_ready", "ogl_registry_init_rccl", "ogl_registry_peer_handle", "ogl_registry_peer_connect",
     "ogl_registry_peer_disable", "ogl_solver_get_or_create", "ogl_solver_set_matrix",
     "ogl_solver_solve", "ogl_solver_history", "ogl_solver_export_system",
     "ogl_solver_get_property",
@@ -214,6 +214,10 @@ class Registry:
         self._cbs = (ALLREDUCE_FN(_ar), EXCHANGE_FN(_ex))
         _check(lib().ogl_registry_set_host_comm(self._h, rank, n_ranks, self._cbs[0], self._cbs[1],
                                                 None))
+
+    def rccl_ready(self):
+        """Local check to agree on BEFORE the collective init_rccl (no time-out in there)."""
+        return lib().ogl_registry_rccl_ready(self._h) == OK
 
     def init_rccl(self, rank, n_ranks, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, RCCL_ID_BYTES)

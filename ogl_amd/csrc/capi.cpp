@@ -75,6 +75,15 @@ extern "C" int ogl_rccl_unique_id(void *id_out)
     OGL_GUARD_END
 }
 
+extern "C" int ogl_registry_rccl_ready(ogl_registry *reg)
+{
+    OGL_GUARD_BEGIN
+    if (!reg) return fail(OGL_ERR_INVALID, "registry is NULL");
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    return RcclComm::library_ready();
+    OGL_GUARD_END
+}
+
 extern "C" int ogl_registry_init_rccl(ogl_registry *reg, int32_t rank, int32_t n_ranks,
                                       const void *id)
 {

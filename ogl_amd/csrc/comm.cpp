@@ -138,6 +138,13 @@ RcclApi &rccl()
 
 }  // namespace
 
+int RcclComm::library_ready()
+{
+    RcclApi &api = rccl();
+    if (!api.error.empty()) return fail(OGL_ERR_COMM, "%s", api.error.c_str());
+    return OGL_OK;
+}
+
 int RcclComm::unique_id(void *id_out)
 {
     RcclApi &api = rccl();
@@ -181,7 +188,7 @@ int RcclComm::self_test(hipStream_t st)
     OGL_HIP_TRY(hipStreamSynchronize(st));
     const double tri = 0.5 * n_ranks * (n_ranks + 1.0);
     if (got[0] != tri || got[1] != 0.5 * tri)
-        return fail(OGL_ERR_COMM, "RCCL self-test: all-reduce over %d ranks gave %g, %g (expected %g, %g)", n_ranks,
+        return fail(OGL_ERR_COMM_SELFTEST, "RCCL self-test: all-reduce over %d ranks gave %g, %g (expected %g, %g)", n_ranks,
                     got[0], got[1], tri, 0.5 * tri);
     // ring: every rank sends 1000 * rank + destination to its two ring neighbours and expects theirs
     const int prev = (rank + n_ranks - 1) % n_ranks, next = (rank + 1) % n_ranks;
@@ -203,7 +210,7 @@ int RcclComm::self_test(hipStream_t st)
     OGL_HIP_TRY(hipStreamSynchronize(st));
     for (size_t i = 0; i < nb.size(); ++i)
         if (recv[i] != want[i])
-            return fail(OGL_ERR_COMM, "RCCL self-test: send/recv with rank %d gave %g (expected %g)", nb[i], recv[i],
+            return fail(OGL_ERR_COMM_SELFTEST, "RCCL self-test: send/recv with rank %d gave %g (expected %g)", nb[i], recv[i],
                         want[i]);
     return OGL_OK;
 }

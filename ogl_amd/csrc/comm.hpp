@@ -68,6 +68,7 @@ class RcclComm final : public Comm {
 public:
     RcclComm() = default;
     ~RcclComm() override;
+    static int library_ready();  // (local: librccl loads and has every symbol)
     static int unique_id(void *id_out);
     int init(int rank, int n_ranks, const void *id);
     // COLLECTIVE, right after init: one ncclAllReduce and one ring of ncclSend / ncclRecv with known values over

@@ -118,8 +118,14 @@ __device__ __forceinline__ void reduce_partials(const double *const (&part)[2], 
 // Non-local part of a chunk's rows inside the local SpMV kernel (HaloFused, kernels.hpp).  acc0 / acc1: the
 // accumulators of this thread's two rows after the local entries; ys: CHUNK_ROWS doubles of LDS that the
 // kernel does not need any more.  Workgroup-uniform: chunks without boundary rows return at once.
-template <int MODE>
-__device__ __forceinline__ void halo_fused_add(const HaloFused &H, int chunk, double &acc0, double &acc1, double *ys)
+// TURN (the merged step_1x + SpMV kernel of a multi-rank GKOCG turn): what the neighbours have put is z, not p -- the
+// new p of a halo column is recomputed here from it and the OLD p of that column, which this rank keeps
+// (p_new = z + tmp p_old: the expression, scalars and operands of the owner's own update, hence its bits), and left
+// behind in the other of two halo-p buffers for the next turn.
+template <int MODE, bool TURN = false>
+__device__ __forceinline__ void halo_fused_add(const HaloFused &H, int chunk, double &acc0, double &acc1, double *ys,
+                                               double tmp = 0.0, const double *__restrict__ ph_in = nullptr,
+                                               double *__restrict__ ph_out = nullptr)
 {
     const int b0 = H.chunk_bptr[chunk], b1 = H.chunk_bptr[chunk + 1];
     if (b0 == b1) return;
@@ -153,7 +159,13 @@ __device__ __forceinline__ void halo_fused_add(const HaloFused &H, int chunk, do
         const int li = H.boundary_rows[i] - chunk * CHUNK_ROWS;
         double a = ys[li];
         for (int k = H.entry_ptrs[i]; k < H.entry_ptrs[i + 1]; ++k) {
-            const double t = H.vals[k] * H.recv[H.cols[k]];
+            const int c = H.cols[k];
+            double v = H.recv[c];
+            if (TURN) {
+                v = v + tmp * ph_in[c];
+                ph_out[c] = v;
+            }
+            const double t = H.vals[k] * v;
             a = (MODE == SPMV_RESIDUAL) ? a - t : a + t;
         }
         ys[li] = a;
@@ -1035,6 +1047,37 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2(int n, double *__restrict__ 
 // check stops the solve, the step_1x of turn j+1 still applies the pending update (it recognises
 // its turn by iter == turn + 1: no check runs after the stop) and leaves p alone; the host flushes
 // with an extra step_1x when the stop came after the last enqueued turn.
+// Halo values of the SpMV that follows, put by the kernel that produces them: this chunk's send rows (v0, v1 = the
+// two rows of the thread) go straight into the neighbours' receive blocks -- through LDS, the row's owner holds it in
+// registers -- and the last such workgroup of the launch raises the flags.  Workgroup-uniform.
+__device__ __forceinline__ void halo_put_chunk(const HaloPutFused &put, int chunk, double v0, double v1, double *ps,
+                                               int *last)
+{
+    const int s0 = put.chunk_sptr[chunk], s1 = put.chunk_sptr[chunk + 1];
+    if (s0 == s1) return;
+    ps[ROWS_PER_THREAD * threadIdx.x] = v0;
+    ps[ROWS_PER_THREAD * threadIdx.x + 1] = v1;
+    __syncthreads();
+    for (int k = s0 + threadIdx.x; k < s1; k += BLOCK) {
+        const int j = put.send_pos[k];
+        int i = 0;
+        while (i + 1 < put.P.n_neigh && j >= put.P.send_off[i + 1]) ++i;
+        put.P.remote_recv[i][j - put.P.send_off[i]] = ps[put.send_idxs[j] - chunk * CHUNK_ROWS];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *last = atomicAdd(put.ticket, 1u) == (unsigned)put.n_put_chunks - 1;
+        if (*last) *put.ticket = 0;
+    }
+    __syncthreads();
+    if (*last && (int)threadIdx.x < put.P.n_neigh) {
+        __threadfence_system();
+        __hip_atomic_store(put.P.remote_flag[threadIdx.x], (unsigned long long)put.P.seq, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <bool PUT>
 __global__ __launch_bounds__(BLOCK) void k_cg_step1x(int n, double *__restrict__ p,
                                                      double *__restrict__ x,
@@ -1069,43 +1112,23 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x(int n, double *__restrict__
     vp.x = vz.x + tmp * vp.x;
     vp.y = vz.y + tmp * vp.y;
     st2(p, rp, vp);
-    if (PUT) {
-        // halo values of the SpMV that follows: this chunk's send rows go straight into the neighbours' receive
-        // blocks (through LDS: the row's owner holds it in registers), the last such workgroup raises the flags
-        const int s0 = put.chunk_sptr[blockIdx.x], s1 = put.chunk_sptr[blockIdx.x + 1];
-        if (s0 == s1) return;  // (workgroup-uniform)
+    if (PUT) {  // the halo values of the SpMV that follows
         __shared__ double ps[CHUNK_ROWS];
         __shared__ int last;
-        ps[ROWS_PER_THREAD * threadIdx.x] = vp.x;
-        ps[ROWS_PER_THREAD * threadIdx.x + 1] = vp.y;
-        __syncthreads();
-        for (int k = s0 + threadIdx.x; k < s1; k += BLOCK) {
-            const int j = put.send_pos[k];
-            int i = 0;
-            while (i + 1 < put.P.n_neigh && j >= put.P.send_off[i + 1]) ++i;
-            put.P.remote_recv[i][j - put.P.send_off[i]] = ps[put.send_idxs[j] - (int)blockIdx.x * CHUNK_ROWS];
-        }
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            last = atomicAdd(put.ticket, 1u) == (unsigned)put.n_put_chunks - 1;
-            if (last) *put.ticket = 0;
-        }
-        __syncthreads();
-        if (last && (int)threadIdx.x < put.P.n_neigh) {
-            __threadfence_system();
-            __hip_atomic_store(put.P.remote_flag[threadIdx.x], (unsigned long long)put.P.seq, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        halo_put_chunk(put, blockIdx.x, vp.x, vp.y, ps, &last);
     }
 }
 
+// PUT (multi-rank merged turn): the z of this chunk's send rows goes to the neighbours, whose next merged kernel
+// forms p_new = z + tmp p_old at its halo columns itself (halo_fused_add<.., TURN>)
+template <bool PUT>
 __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__ r,
                                                      const double *__restrict__ q,
                                                      const double *__restrict__ inv_diag,
                                                      double *__restrict__ part_rho,
                                                      double *__restrict__ part_norm,
-                                                     const DevScalars *s, double *__restrict__ z_out)
+                                                     const DevScalars *s, double *__restrict__ z_out,
+                                                     HaloPutFused put)
 {
     __shared__ double slot[N_WAVES];
     if (s->stop) return;
@@ -1141,6 +1164,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__
     if (threadIdx.x == 0) {
         part_rho[chunk] = s0;
         part_norm[chunk] = s1;
+    }
+    if (PUT) {
+        __shared__ double ps[CHUNK_ROWS];
+        __shared__ int last;
+        halo_put_chunk(put, chunk, vz.x, vz.y, ps, &last);
     }
 }
 
@@ -1547,15 +1575,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sym(int n_rows, int n_chunks, Sy
 #pragma unroll
     for (int j = 1; j < ND; ++j) {
         if (FAST && j >= 2) {
-            xl[j] = *reinterpret_cast<const double2 *>(x + max(row - off.d[j], 0));
+            xl[j] = *reinterpret_cast<const double2 *>(x + min(max(row - off.d[j], 0), last_pair));
             xu[j] = *reinterpret_cast<const double2 *>(x + min(row + off.d[j], last_pair));
         } else if (FAST) {     // the neighbours of a pair at distance 1: the pair itself + one on each side
-            xl[j].x = x[max(row - 1, 0)];
+            xl[j].x = x[min(max(row - 1, 0), last)];
             xl[j].y = xd.x;
             xu[j].x = xd.y;
             xu[j].y = x[min(row + 2, last)];
         } else {
-            xl[j].x = x[max(row - off.d[j], 0)];
+            xl[j].x = x[min(max(row - off.d[j], 0), last)];
             xl[j].y = x[min(max(row + 1 - off.d[j], 0), last)];
             xu[j].x = x[min(row + off.d[j], last)];
             xu[j].y = x[min(row + 1 + off.d[j], last)];
@@ -1647,15 +1675,15 @@ __device__ __forceinline__ void turn_sym_load(TurnSymRegs<ND> &R, int chunk, con
 #pragma unroll
         for (int j = 1; j < ND; ++j) {
             if (FAST && j >= 2) {
-                R.vl[a][j] = *reinterpret_cast<const double2 *>(v + max(row - off.d[j], 0));
+                R.vl[a][j] = *reinterpret_cast<const double2 *>(v + min(max(row - off.d[j], 0), last_pair));
                 R.vu[a][j] = *reinterpret_cast<const double2 *>(v + min(row + off.d[j], last_pair));
             } else if (FAST) {
-                R.vl[a][j].x = v[max(row - 1, 0)];
+                R.vl[a][j].x = v[min(max(row - 1, 0), last)];
                 R.vl[a][j].y = R.vd[a].x;
                 R.vu[a][j].x = R.vd[a].y;
                 R.vu[a][j].y = v[min(row + 2, last)];
             } else {
-                R.vl[a][j].x = v[max(row - off.d[j], 0)];
+                R.vl[a][j].x = v[min(max(row - off.d[j], 0), last)];
                 R.vl[a][j].y = v[min(max(row + 1 - off.d[j], 0), last)];
                 R.vu[a][j].x = v[min(row + off.d[j], last)];
                 R.vu[a][j].y = v[min(row + 1 + off.d[j], last)];
@@ -1829,7 +1857,10 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks,
 // becomes four): the scalars are read where k_cg_step1x reads them, the pending x update included.  Per turn the
 // vectors cost 8 N bytes less than step_1x + SpMV + step_2r (p is read once, z written once and read once instead of
 // r and 1/d read twice), and one kernel boundary goes.
-template <int ND, bool FAST, bool STREAM>
+// HALO (several ranks, peer-put transport): the neighbours' step_2r has put z of the halo columns; a workgroup whose
+// chunk holds boundary rows waits for it, forms p_new at those columns from the old halo p it keeps (ph_in -> ph_out)
+// and continues its boundary rows over their non-local entries -- no put and no wait for a put of THIS launch here.
+template <int ND, bool FAST, bool STREAM, bool HALO>
 __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym_big(int n_rows, int n_chunks, SymOffsets off,
                                                            const uint8_t *__restrict__ mask,
                                                            const double *__restrict__ planes,
@@ -1837,7 +1868,9 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym_big(int n_rows, int n_chu
                                                            double *__restrict__ p_out, double *__restrict__ x,
                                                            const double *__restrict__ z, double *__restrict__ q,
                                                            double *__restrict__ part_beta, const DevScalars *s,
-                                                           const int *__restrict__ block_order)
+                                                           const int *__restrict__ block_order, HaloFused hf,
+                                                           const double *__restrict__ ph_in,
+                                                           double *__restrict__ ph_out)
 {
     __shared__ double slot[N_WAVES];
     const int stop = s->stop;
@@ -1875,8 +1908,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym_big(int n_rows, int n_chu
     const double rho = s->rho, prev = s->prev_rho;
     const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
     double2 xd;
-    const double2 acc = turn_sym_rows<ND>(R, m0, m1, tmp, xd);
+    double2 acc = turn_sym_rows<ND>(R, m0, m1, tmp, xd);
     st2(p_out, rp, xd);
+    if (HALO) {
+        __shared__ double ys[CHUNK_ROWS];
+        if (hf.chunk_bptr) halo_fused_add<SPMV_PLAIN, true>(hf, chunk, acc.x, acc.y, ys, tmp, ph_in, ph_out);
+    }
     st2(q, rp, acc);
     double d = 0.0;
     if (rp.n > 0) d += xd.x * acc.x;
@@ -3579,12 +3616,17 @@ void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const dou
 }
 
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
-                      double *part_rho, double *part_norm, const DevScalars *s, double *z_out)
+                      double *part_rho, double *part_norm, const DevScalars *s, double *z_out,
+                      const HaloPutFused *put)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_cg_step2r, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho,
-                       part_norm, s, z_out);
+    if (put && put->chunk_sptr)
+        hipLaunchKernelGGL((k_cg_step2r<true>), dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho,
+                           part_norm, s, z_out, *put);
+    else
+        hipLaunchKernelGGL((k_cg_step2r<false>), dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho,
+                           part_norm, s, z_out, HaloPutFused{});
 }
 
 void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
@@ -3629,7 +3671,8 @@ void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, dou
 }
 
 void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x,
-                            const double *z, double *q, double *part_beta, const DevScalars *s)
+                            const double *z, double *q, double *part_beta, const DevScalars *s,
+                            const HaloFused &hf, const double *p_halo_in, double *p_halo_out)
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
@@ -3638,9 +3681,17 @@ void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in,
     for (int j = 0; j < SYM_MAX_OFFSETS; ++j) off.d[j] = A.d[j];
     bool fast = A.nd >= 2 && A.d[1] == 1;
     for (int j = 2; j < A.nd; ++j) fast = fast && (A.d[j] % 2 == 0);
-#define OGL_TURN_K(ND, FAST, STREAM)                                                                              \
-    hipLaunchKernelGGL((k_cg_turn_sym_big<ND, FAST, STREAM>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, \
-                       p_in, p_out, x, z, q, part_beta, s, A.block_order)
+#define OGL_TURN_K(ND, FAST, STREAM)                                                                                \
+    do {                                                                                                            \
+        if (hf.chunk_bptr)                                                                                          \
+            hipLaunchKernelGGL((k_cg_turn_sym_big<ND, FAST, STREAM, true>), grid, block, 0, st, A.n_rows, nc, off,  \
+                               A.mask, A.planes, p_in, p_out, x, z, q, part_beta, s, A.block_order, hf, p_halo_in,  \
+                               p_halo_out);                                                                         \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_cg_turn_sym_big<ND, FAST, STREAM, false>), grid, block, 0, st, A.n_rows, nc, off, \
+                               A.mask, A.planes, p_in, p_out, x, z, q, part_beta, s, A.block_order, HaloFused{},    \
+                               nullptr, nullptr);                                                                   \
+    } while (0)
 #define OGL_TURN_ND(ND)                     \
     do {                                    \
         if (fast && A.stream)               \

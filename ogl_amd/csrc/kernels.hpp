@@ -255,8 +255,10 @@ void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const doub
 struct HaloPutFused;  // (below, after PeerHalo)
 void launch_cg_step1x(hipStream_t st, int32_t n, double *p, double *x, const double *r,
                       const double *inv_diag, const DevScalars *s, const HaloPutFused *put = nullptr);
+// put (chunk_sptr != nullptr): z of the send rows goes to the neighbours (multi-rank merged turn)
 void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
-                      double *part_rho, double *part_norm, const DevScalars *s, double *z_out = nullptr);
+                      double *part_rho, double *part_norm, const DevScalars *s, double *z_out = nullptr,
+                      const HaloPutFused *put = nullptr);
 
 // Small systems: the same pair with the finalisers folded in (kernels.hip).  Every workgroup reduces the
 // per-chunk partials itself in the finaliser's order; the scalars are read from `sin` and written to `sout`.
@@ -278,8 +280,14 @@ void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, dou
                         const double *part_rho, const double *part_norm, double *history, int first);
 // ... and between the single-workgroup finalisers of larger systems (scalars as k_cg_step1x reads them):
 // turn = this | FIN_BETA | step_2r (z_out) | FIN_CG_CHECK
+// Several ranks (hf.chunk_bptr != nullptr; peer-put transport): the neighbours have put the z of the halo columns
+// (step_2r's `put`, launch_pack_put_signal before the first turn); p_halo_in = this rank's copy of the OLD p at its
+// halo columns (zero before the first turn), p_halo_out receives the new one:
+// turn = this (waits for z, nothing to put) | FIN_BETA | step_2r (z_out, puts z) | FIN_CG_CHECK
 void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x,
-                            const double *z, double *q, double *part_beta, const DevScalars *s);
+                            const double *z, double *q, double *part_beta, const DevScalars *s,
+                            const HaloFused &hf = HaloFused{}, const double *p_halo_in = nullptr,
+                            double *p_halo_out = nullptr);
 
 // --- BiCGStab steps ([UPSTREAM] bicgstab::step_1/2/3, finalize) ---
 void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,

@@ -394,9 +394,16 @@ int ogl_registry::allreduce(double *dev, int n)
     return OGL_OK;
 }
 
-ogl_solver::~ogl_solver()
+void ogl_solver::drop_cg_graph()
 {
     if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
+    cg_graph = nullptr;
+    cg_graph_key.clear();
+}
+
+ogl_solver::~ogl_solver()
+{
+    drop_cg_graph();
     if (h_scal) (void)hipHostFree(h_scal);
     for (auto &e : poll_ev)
         if (e) (void)hipEventDestroy(e);
@@ -1328,6 +1335,12 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     // uploaded speculatively above is gone
     if (first) coefficients_done = false;
     if (first) {  // :79-87
+        // Nothing of the old pattern survives from here on (the value arrays are re-created below before the new
+        // pattern is validated): a failure inside this block must not leave the old fingerprint in charge of
+        // buffers of another size, and a captured turn must not be replayed on the new layouts
+        have_pattern = false;
+        matrix_set = false;
+        drop_cg_graph();
         HostPattern np;
         // Where the pattern is built: on the device from the face addressing (setup_kernels.hip), unless the
         // environment / property says otherwise or the addressing is not conforming; host_matrix.cpp then
@@ -1885,6 +1898,24 @@ HaloPutFused ogl_solver::begin_halo_put()
     return put;
 }
 
+// what a kernel needs to wait for exchange `ph` and to add the non-local part itself
+HaloFused ogl_solver::halo_fused_args(const PeerHalo &ph) const
+{
+    HaloFused hf;
+    hf.chunk_bptr = d_chunk_bptr.p;
+    hf.boundary_rows = d_boundary_rows.p;
+    hf.entry_ptrs = d_boundary_ptrs.p;
+    hf.cols = d_nl_cols.p;
+    hf.vals = d_nl_vals.p;
+    hf.recv = peer_recv(ph.seq);
+    hf.local_flag = ph.local_flag;
+    hf.n_neigh = ph.n_neigh;
+    hf.seq = ph.seq;
+    hf.timeout_ticks = ph.timeout_ticks;
+    hf.s = d_scal.p;
+    return hf;
+}
+
 int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
                           const SpmvDots &dots, const DevScalars *gate, bool prepacked)
 {
@@ -1908,19 +1939,7 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
             launch_pack_put_signal(st, halo(), ph, x, gate, d_ticket.p);
         }
         recv = peer_recv(ph.seq);
-        if (fuse) {
-            hf.chunk_bptr = d_chunk_bptr.p;
-            hf.boundary_rows = d_boundary_rows.p;
-            hf.entry_ptrs = d_boundary_ptrs.p;
-            hf.cols = d_nl_cols.p;
-            hf.vals = d_nl_vals.p;
-            hf.recv = recv;
-            hf.local_flag = ph.local_flag;
-            hf.n_neigh = ph.n_neigh;
-            hf.seq = ph.seq;
-            hf.timeout_ticks = ph.timeout_ticks;
-            hf.s = d_scal.p;
-        }
+        if (fuse) hf = halo_fused_args(ph);
     } else if (has_halo) {
         // pack on the compute stream, exchange on the communication stream: the neighbour copies
         // fly while the local SpMV below runs; the non-local kernel waits for their arrival
@@ -2046,13 +2065,39 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // (larger systems, property fusedTurnBig: on while matrix and vectors live in the Infinity Cache -- 128^3 58.8 -> 54.7 us
     //  per turn, 136^3 66.3 -> 61.5 -- and off once they are streamed: 160^3 105.1 -> 104.5, 216^3 4149 -> 4190 turns/s,
     //  where the merged kernel runs 152 us for the 162 of step_1x + SpMV and step_2r pays 8 N more bytes for keeping z)
-    const bool merged = !bicg && !gmres && !generic && !reg->comm->multi() && nc >= 1 && use_sym() &&
-                        cfg.matrix_format != OGL_FORMAT_ELL &&
-                        (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
+    // Several ranks (peer-put transport with the non-local part inside the local kernel): the same merge, 4 launches
+    // per turn instead of 5 -- the neighbours' step_2r puts z of their send rows, this rank keeps the old p of its halo
+    // columns and forms p_new there itself (kernels.hip, k_cg_turn_sym_big<.., HALO>), so the merged kernel has
+    // nothing to put and only waits for a put of the PREVIOUS launch.  Every rank must run the same turn (what the
+    // neighbours put differs): agreed below together with the global row count.
+    const bool multi = reg->comm->multi();
+    bool merged = !bicg && !gmres && !generic && nc >= 1 && use_sym() && cfg.matrix_format != OGL_FORMAT_ELL &&
+                  (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
+    if (multi) merged = merged && peer_halo && prop("haloFused", 1.0) != 0.0 && prop("fusedTurnMulti", 1.0) != 0.0;
+    double n_global = (double)n;
+    if (multi) {
+        // global row count (Partition.H:118-121) and the agreement on the turn, through the device all-reduce
+        const double mine[2] = {(double)n, merged ? 0.0 : 1.0};
+        double got[2] = {0.0, 0.0};
+        OGL_HIP_CHECK(hipMemcpyAsync(sums_ptr(s), mine, sizeof(mine), hipMemcpyHostToDevice, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        OGL_TRY(reg->allreduce(sums_ptr(s), 2));
+        OGL_HIP_CHECK(hipMemcpyAsync(got, sums_ptr(s), sizeof(got), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        n_global = got[0];
+        merged = got[1] == 0.0;
+    }
     const bool fused2 = fused && merged;
+    const bool merged_halo = merged && multi && pat.non_local_nnz > 0;  // (a rank without neighbours: the single-rank kernel)
     props["fusedTurnInUse"] = merged ? 1.0 : 0.0;
     if (merged) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
     if (merged && precond) OGL_TRY(d_z.alloc((size_t)n + 2, st));
+    const size_t n_halo = (size_t)pat.non_local_nnz;
+    if (merged_halo) {  // old p at the halo columns, two buffers like p itself; p = 0 before the first turn
+        OGL_TRY(d_p_halo.alloc(2 * n_halo + 2, st));
+        OGL_HIP_CHECK(hipMemsetAsync(d_p_halo.p, 0, d_p_halo.n * sizeof(double), st));
+    }
+    auto p_halo_of_turn = [&](int turn) { return d_p_halo.p + (size_t)(turn & 1) * n_halo; };
     auto p_of_turn = [&](int turn) { return (merged && (turn & 1)) ? d_p2.p : d_p.p; };  // p that turn `turn` reads
     double *z_kept = merged && precond ? d_z.p : nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
 
@@ -2118,17 +2163,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     fa.n_part = nc;
     fa.n_sums = 1;
     fa.n_local = (double)n;
-    fa.n_global = (double)n;
-    if (reg->comm->multi()) {
-        // global row count (Partition.H:118-121), via the same device all-reduce
-        double nn = (double)n;
-        OGL_HIP_CHECK(hipMemcpyAsync(sums_ptr(s), &nn, sizeof(double), hipMemcpyHostToDevice, st));
-        OGL_HIP_CHECK(hipStreamSynchronize(st));
-        OGL_TRY(reg->allreduce(sums_ptr(s), 1));
-        OGL_HIP_CHECK(hipMemcpyAsync(&nn, sums_ptr(s), sizeof(double), hipMemcpyDeviceToHost, st));
-        OGL_HIP_CHECK(hipStreamSynchronize(st));
-        fa.n_global = nn;
-    }
+    fa.n_global = n_global;  // (all-reduced above)
     OGL_TRY(finalize(FIN_MEAN, fa));
     // Axref = A * (xbar 1) (:24-29) into q
     launch_fill_xbar(st, n, d_w.p, s);
@@ -2208,6 +2243,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
         OGL_TRY(finalize(FIN_CG_CHECK, chk));
         OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+    }
+    if (merged_halo) {  // the z of the first merged turn (later ones: put by step_2r)
+        if (++halo_seq == 0) ++halo_seq;
+        cur_halo = peer_halo_args(halo_seq);
+        launch_pack_put_signal(st, halo(), cur_halo, z_kept ? z_kept : d_r.p, s, d_ticket.p);
     }
 
     FinArgs f1{};  // one partial array
@@ -2296,11 +2336,23 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             } else if (!bicg && merged) {
                 // [pending x update + step_1 + SpMV] | beta | step_2r (keeps z) | check
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                launch_cg_turn_sym_big(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p, z_kept ? z_kept : d_r.p,
-                                       d_q.p, d_part0.p, s);
+                if (merged_halo) {
+                    // (waits for the z the neighbours put one kernel -- or, before turn 0, one launch -- earlier)
+                    launch_cg_turn_sym_big(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p,
+                                           z_kept ? z_kept : d_r.p, d_q.p, d_part0.p, s,
+                                           halo_fused_args(cur_halo), p_halo_of_turn(enq), p_halo_of_turn(enq + 1));
+                } else {
+                    launch_cg_turn_sym_big(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p,
+                                           z_kept ? z_kept : d_r.p, d_q.p, d_part0.p, s);
+                }
                 if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
                 OGL_TRY(finalize(FIN_BETA, f1));
-                launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, z_kept);
+                if (merged_halo) {
+                    const HaloPutFused put = begin_halo_put();  // z of the next turn
+                    launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, z_kept, &put);
+                } else {
+                    launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, z_kept);
+                }
                 chk.turn = 1;  // this check leaves an x update pending for the next turn's kernel
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
             } else if (!bicg) {
@@ -2386,7 +2438,17 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
             (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p,
-            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)merged, (uintptr_t)d_p2.p, (uintptr_t)z_kept};
+            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)merged, (uintptr_t)d_p2.p, (uintptr_t)z_kept,
+            // what the captured kernels take BY VALUE: the pattern the layouts belong to, the distances / mask / order
+            // of the half storage, the cache policy and the workgroup order (a rebuild with the same sizes usually
+            // gets the same pointers back: 32x64x32 -> 64x32x32)
+            (uintptr_t)pat_id, (uintptr_t)sym_nd, (uintptr_t)sym_d[0], (uintptr_t)sym_d[1], (uintptr_t)sym_d[2],
+            (uintptr_t)sym_d[3], (uintptr_t)d_sym_mask.p, (uintptr_t)d_sym_order.p, (uintptr_t)d_sym_order.n,
+            (uintptr_t)band_order_off, (uintptr_t)(int64_t)stream_above_bytes(), (uintptr_t)xcd_group(),
+            (uintptr_t)d_s21_chunks.p, (uintptr_t)d_symx_chunks.p, (uintptr_t)d_symx_chunks.n,
+            (uintptr_t)d_symx_chunks_general.p, (uintptr_t)d_symx_chunks_general.n, (uintptr_t)d_symx_mask.p,
+            (uintptr_t)d_symx_ex_rowptr.p, (uintptr_t)d_symx_ex_cols.p, (uintptr_t)d_symx_ex_vals.p,
+            (uintptr_t)d_symx_ex_lrow.p, (uintptr_t)symx_fast, (uintptr_t)d_spill_chunks.p, (uintptr_t)d_z.p};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
             cg_graph = nullptr;

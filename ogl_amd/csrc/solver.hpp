@@ -321,10 +321,12 @@ struct ogl_solver {
     int32_t n_put_chunks = 0;
     ogl::PeerHalo cur_halo{};   // arguments of the SpMV whose halo values a producer kernel has already put
     ogl::HaloPutFused begin_halo_put();
+    ogl::HaloFused halo_fused_args(const ogl::PeerHalo &ph) const;
     ogl::DevBuf<unsigned> d_ticket;             // last-workgroup ticket of k_pack_put_signal
     // a full batch of single-rank GKOCG turns captured as a hipGraph (run_krylov)
     hipGraphExec_t cg_graph = nullptr;
     std::vector<uintptr_t> cg_graph_key;
+    void drop_cg_graph();  // (every pattern / layout rebuild)
     int setup_peer_halo();
     ogl::PeerHalo peer_halo_args(uint32_t seq) const;
     double *peer_recv(uint32_t seq) const;
@@ -346,6 +348,7 @@ struct ogl_solver {
     // ---- vectors: "<field>_rhs", "<field>_solution" + Krylov work vectors ----
     ogl::DevBuf<double> d_x, d_b, d_r, d_p, d_q, d_w, d_inv_diag;
     ogl::DevBuf<double> d_p2;  // second p buffer of the 2-launch turn (k_cg_turn_sym)
+    ogl::DevBuf<double> d_p_halo;  // multi-rank merged turn: old / new p at the halo columns
     ogl::DevBuf<double> d_v, d_s, d_t, d_y, d_z, d_rr;  // BiCGStab
     ogl::DevBuf<double> d_V, d_gm;                      // GMRES: Krylov bases, dense state
     ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T

@@ -73,10 +73,25 @@ struct InstallCommHook {
                 if (Pstream::master() && ogl_rccl_unique_id(id.begin()) != OGL_OK)
                     FatalErrorInFunction << ogl_last_error() << abort(FatalError);
                 Pstream::scatter(id);
-                rccl_ok = ogl_registry_init_rccl(reg, Pstream::myProcNo(), Pstream::nProcs(), id.begin()) == OGL_OK;
+                // init_rccl is collective and has no time-out: agree FIRST that every rank can enter it (library
+                // loaded, device selected) -- a rank that cannot would leave the others inside ncclCommInitRank
+                rccl_ok = ogl_registry_rccl_ready(reg) == OGL_OK;
                 if (!rccl_ok)
                     WarningInFunction << "RCCL transport unavailable on this rank: " << ogl_last_error() << endl;
                 reduce(rccl_ok, minOp<label>());
+                if (rccl_ok) {
+                    // past this point a local failure means the collective itself broke on this rank while others
+                    // may still be inside it: abort the job, as the reference does (uncaught Ginkgo exception)
+                    const int rci =
+                        ogl_registry_init_rccl(reg, Pstream::myProcNo(), Pstream::nProcs(), id.begin());
+                    if (rci == OGL_ERR_COMM_SELFTEST) {
+                        rccl_ok = 0;  // the collectives completed and delivered wrong numbers: every rank sees that
+                        WarningInFunction << "RCCL self-test failed: " << ogl_last_error() << endl;
+                    } else if (rci != OGL_OK) {
+                        FatalErrorInFunction << ogl_last_error() << abort(FatalError);
+                    }
+                    reduce(rccl_ok, minOp<label>());
+                }
                 if (!rccl_ok) WarningInFunction << "using the host-buffer transport (forceHostBuffer)" << endl;
             }
             if (!rccl_ok)
@@ -84,8 +99,10 @@ struct InstallCommHook {
                                                 ogl_allreduce_sum, ogl_neighbour_exchange, nullptr);
             if (rc != OGL_OK) FatalErrorInFunction << ogl_last_error() << abort(FatalError);
             // Scalar all-reduces and halo puts through peer-written memory over xGMI (hipIpc), on top of the
-            // transport above (which stays the bootstrap and the fallback): ON by default (`peerAllReduce false`
-            // switches it off) -- connecting runs a collective self-test (two all-reduces through the mailboxes,
+            // transport above (which stays the bootstrap and the fallback): OPT-IN (`peerAllReduce true`) until a
+            // run with one rank per device is on record -- every multi-rank run so far shared one GPU, and the
+            // connect-time self-test does not exercise the wait inside the SpMV kernel under real xGMI latency.
+            // Connecting runs a collective self-test (two all-reduces through the mailboxes,
             // one put / wait round over the ring) and any rank that cannot join makes all ranks keep the
             // transport's own all-reduce and halo exchange.  Only tried when every rank sits on the same host
             // (hipIpc does not cross nodes; without this check the ranks of a multi-node run would sit in the 60 s
@@ -98,7 +115,7 @@ struct InstallCommHook {
                 Pstream::scatterList(hosts);
                 forAll(hosts, p) one_host = one_host && hosts[p] == hosts[0];
             }
-            if (controls.lookupOrDefault<Switch>("peerAllReduce", true) && one_host &&
+            if (controls.lookupOrDefault<Switch>("peerAllReduce", false) && one_host &&
                 Pstream::nProcs() <= 16) {
                 List<List<char>> handles(Pstream::nProcs());
                 handles[Pstream::myProcNo()].setSize(OGL_PEER_HANDLE_BYTES, '\0');

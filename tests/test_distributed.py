@@ -197,3 +197,40 @@ def test_gpu_peer_separate_halo_kernels(extra):
     # default folds the first into step_1x and the second into the local SpMV kernel); same bits either way
     run_ranks(3, "--mode", "gpu-peer", "--random", "15", "--halo-fused", "0", *extra)
     run_ranks(2, "--mode", "gpu-peer", "--shape", "10,10,10", "--procs", "1,1,2", "--halo-fused", "0", *extra)
+
+
+# The merged multi-rank GKOCG turn: step_1x inside the half-storage SpMV kernel, the neighbours'
+# step_2r puts z of their send rows, every rank keeps the old p of its halo columns and forms p_new there itself --
+# 4 launches per turn, bit-equal to the 5-launch turn (p put by step_1x) and to the distributed oracle.
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,procs,n,precond,both", [("16,16,16", "1,1,2", 2, 1, True), ("12,12,12", "2,2,1", 4, 0, True),
+                                                        ("33,17,12", "1,1,3", 3, 1, False), ("20,20,40", "1,2,2", 4, 1, False)])
+def test_gpu_peer_merged_turn(shape, procs, n, precond, both):
+    run_ranks(n, "--mode", "gpu-peer", "--shape", shape, "--procs", procs, "--precond", str(precond),
+              "--expect-merged", "1")
+    if both:
+        run_ranks(n, "--mode", "gpu-peer", "--shape", shape, "--procs", procs, "--precond", str(precond),
+                  "--fused-turn-multi", "0", "--expect-merged", "0")
+
+
+@pytest.mark.gpu
+def test_gpu_peer_merged_turn_stands_down():
+    # host-buffer transport / separate halo kernels: all ranks run the 5-launch turn -- what the neighbours put must
+    # be the same on every rank (an irregular share on ONE rank: test_gpu_peer_merged_turn_relabel's second solve)
+    run_ranks(2, "--mode", "gpu-host", "--shape", "16,16,16", "--procs", "1,1,2", "--expect-merged", "0")
+    run_ranks(2, "--mode", "gpu-peer", "--shape", "16,16,16", "--procs", "1,1,2", "--halo-fused", "0",
+              "--expect-merged", "0")
+
+
+@pytest.mark.gpu
+def test_gpu_peer_merged_turn_relabel():
+    # a rebuild one rank forces between two solves: the second solve's first z put starts from a fresh pattern
+    run_ranks(2, "--mode", "gpu-peer", "--shape", "10,10,12", "--procs", "1,1,2", "--relabel", "1")
+
+
+# 2 ranks x 2.1 M rows (the largest multi-rank oracle comparison was 16^3), 20 turns, both turns
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [1, 0])
+def test_gpu_peer_two_ranks_2m_rows_each(fused):
+    run_ranks(2, "--mode", "gpu-peer", "--shape", "128,128,256", "--procs", "1,1,2", "--max-iter", "20",
+              "--fused-turn-multi", str(fused), "--expect-merged", str(fused), timeout=900)
