@@ -44,7 +44,7 @@ extern "C" int ogl_registry_create(ogl_registry **out, int device_id, void *hip_
         reg->own_stream = true;
     }
     reg->comm = std::make_unique<SelfComm>();
-    OGL_TRY(reg->stager.init(size_t(32) << 20));
+    OGL_TRY(reg->stager.init(size_t(16) << 20));  // x Stager::NBUF pinned buffers
     *out = reg.release();
     return OGL_OK;
     OGL_GUARD_END

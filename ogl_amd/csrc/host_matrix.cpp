@@ -124,7 +124,15 @@ void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
     block_ptrs.assign(1, 0);
     row_block.assign(n, 0);
     if (n == 0) return;
+    // A renumbered pattern: the blocks are formed on the CALLER's numbering, position i there being row
+    // p.new_id[i] here (two rows have the same column set in one numbering exactly when they have it in the other,
+    // and both are stored in ascending order of THIS numbering)
+    const bool rn = p.renumbered();
     auto same_pattern = [&](ogl_label a, ogl_label b) {
+        if (rn) {
+            a = p.new_id[a];
+            b = p.new_id[b];
+        }
         const ogl_label la = p.row_ptrs[a + 1] - p.row_ptrs[a], lb = p.row_ptrs[b + 1] - p.row_ptrs[b];
         if (la != lb) return false;
         return std::equal(p.cols.begin() + p.row_ptrs[a], p.cols.begin() + p.row_ptrs[a + 1],
@@ -423,7 +431,12 @@ bool isai_pattern(const HostPattern &p, bool spd, int power, int max_row, std::v
     w_cols.clear();
     w_cols.reserve((size_t)p.local_nnz);
     std::vector<ogl_label> seen((size_t)N, -1), row, next;
-    auto in_s = [&](ogl_label r, ogl_label c) { return !spd || c <= r; };
+    // spd: tril(A) of the matrix OpenFOAM hands over (Preconditioner.H:225-241) -- on a renumbered pattern the
+    // triangle is taken by the caller's index, i.e. W gets the pattern P tril(A) P^T
+    const bool rn = p.renumbered();
+    auto in_s = [&](ogl_label r, ogl_label c) {
+        return !spd || (rn ? p.old_of[(size_t)c] <= p.old_of[(size_t)r] : c <= r);
+    };
     for (ogl_label i = 0; i < N; ++i) {
         row.clear();
         for (ogl_label k = p.row_ptrs[i]; k < p.row_ptrs[i + 1]; ++k) {

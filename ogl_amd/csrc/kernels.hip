@@ -506,18 +506,23 @@ __global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__r
                                                     const int *__restrict__ row_ptrs,
                                                     const int *__restrict__ cols,
                                                     const double *__restrict__ vals,
-                                                    double *__restrict__ blocks, int ld)
+                                                    double *__restrict__ blocks, int ld,
+                                                    const int *__restrict__ rows, const int *__restrict__ pos)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_blocks) return;
     const int r0 = block_ptrs[b], bs = block_ptrs[b + 1] - r0;
     double a[LD * LD];
     for (int i = 0; i < LD * LD; ++i) a[i] = 0.0;
-    for (int i = 0; i < bs; ++i)
-        for (int k = row_ptrs[r0 + i]; k < row_ptrs[r0 + i + 1]; ++k) {
-            const int c = cols[k] - r0;
+    // rows != nullptr (the device copy is renumbered): block members r0 .. r0 + bs are positions in the CALLER's
+    // numbering -- member i is device row rows[r0 + i], a device column c sits at position pos[c]
+    for (int i = 0; i < bs; ++i) {
+        const int r = rows ? rows[r0 + i] : r0 + i;
+        for (int k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+            const int c = (rows ? pos[cols[k]] : cols[k]) - r0;
             if (c >= 0 && c < bs) a[i * LD + c] = vals[k];
         }
+    }
     int perm[LD];
     for (int k = 0; k < bs; ++k) perm[k] = k;
     for (int k = 0; k < bs; ++k) {
@@ -828,7 +833,8 @@ __global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply(int n_rows,
                                                          const double *__restrict__ in,
                                                          double *__restrict__ out,
                                                          double *__restrict__ dot_part,
-                                                         const DevScalars *gate)
+                                                         const DevScalars *gate, const int *__restrict__ rows,
+                                                         const int *__restrict__ pos)
 {
     __shared__ double prod[CHUNK_ROWS];
     __shared__ double slot[N_WAVES];
@@ -837,18 +843,24 @@ __global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply(int n_rows,
     const int row = chunk * CHUNK_ROWS + threadIdx.x;
     double sum = 0.0, mine = 0.0;
     if (row < n_rows) {
+        // (renumbered device copy: blocks are runs of rows of the CALLER's numbering -- this row is position
+        //  pos[row] there, the block's j-th member is device row rows[r0 + j])
+        const int at = rows ? pos[row] : row;
         int b, r0, bs;
         if (uniform) {  // blocks of exactly `ld` rows (the last one may be shorter)
-            b = row / ld;
+            b = at / ld;
             r0 = b * ld;
             bs = min(ld, n_rows - r0);
         } else {
-            b = row_block[row];
+            b = row_block[at];
             r0 = block_ptrs[b];
             bs = block_ptrs[b + 1] - r0;
         }
-        const double *a = blocks + (size_t)b * ld * ld + (size_t)(row - r0) * ld;
-        for (int j = 0; j < bs; ++j) sum += a[j] * in[r0 + j];
+        const double *a = blocks + (size_t)b * ld * ld + (size_t)(at - r0) * ld;
+        if (rows)
+            for (int j = 0; j < bs; ++j) sum += a[j] * in[rows[r0 + j]];
+        else
+            for (int j = 0; j < bs; ++j) sum += a[j] * in[r0 + j];
         out[row] = sum;
         mine = in[row];
     }
@@ -3472,7 +3484,7 @@ void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J
     const dim3 grid((J.n_blocks + 63) / 64), block(64);
 #define OGL_BJ(LD)                                                                              \
     hipLaunchKernelGGL((k_bj_generate<LD>), grid, block, 0, st, J.n_blocks, J.block_ptrs,        \
-                       A.row_ptrs, A.cols, A.vals, J.blocks, J.stride)
+                       A.row_ptrs, A.cols, A.vals, J.blocks, J.stride, J.rows, J.pos)
     if (J.stride <= 2)
         OGL_BJ(2);
     else if (J.stride <= 4)
@@ -3493,10 +3505,10 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
     const dim3 grid((unsigned)n_chunks(J.n_rows)), block(CHUNK_ROWS);
     if (dot_part)
         hipLaunchKernelGGL((k_bj_apply<1>), grid, block, 0, st, J.n_rows, J.block_ptrs, J.row_block,
-                           J.blocks, J.stride, J.uniform, in, out, dot_part, gate);
+                           J.blocks, J.stride, J.uniform, in, out, dot_part, gate, J.rows, J.pos);
     else
         hipLaunchKernelGGL((k_bj_apply<0>), grid, block, 0, st, J.n_rows, J.block_ptrs, J.row_block,
-                           J.blocks, J.stride, J.uniform, in, out, dot_part, gate);
+                           J.blocks, J.stride, J.uniform, in, out, dot_part, gate, J.rows, J.pos);
 }
 
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,

@@ -191,6 +191,10 @@ struct DevBlockJacobi {
     // every block but the last holds exactly `stride` rows (what agglomeration gives on a mesh without
     // repeated row patterns): block and first row follow from the row index, no index loads in the apply
     int32_t uniform = 0;
+    // renumbered device copy: the blocks are those of the CALLER's numbering (Preconditioner.H:91-105 generates on
+    // the matrix OpenFOAM hands over) -- block_ptrs / row_block refer to positions there, rows[position] = device
+    // row, pos[device row] = position.  nullptr: the device copy is in the caller's numbering.
+    const int32_t *rows = nullptr, *pos = nullptr;
 };
 constexpr int MAX_JACOBI_BLOCK = 32;
 // blocks[b] = inverse of A(block b, block b) by Gauss-Jordan with partial pivoting

@@ -6,10 +6,13 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstddef>
 #include <cstring>
 #include <future>
+#include <immintrin.h>
+#include <mutex>
 #include <thread>
 
 using namespace ogl;
@@ -42,9 +45,114 @@ struct EventPair {  // destroyed on every return path
 // ------------------------------------------------------------------------------------------
 // Stager
 // ------------------------------------------------------------------------------------------
+// ---- the host side of a transfer: [caller's pageable array] <-> [pinned buffer], split over helper threads ----
+namespace {
+// 32-byte non-temporal stores (AVX2, checked at run time: the library travels as generic x86-64 code); head and
+// tail, or the whole range without AVX2, by memcpy
+__attribute__((target("avx2"))) void stream_copy_avx2(char *d, const char *s, size_t len)
+{
+    const size_t head = std::min(len, (size_t)(-(uintptr_t)d & 31));
+    if (head) std::memcpy(d, s, head);
+    d += head;
+    s += head;
+    len -= head;
+    size_t i = 0;
+    for (; i + 128 <= len; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i + 64));
+        const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i *>(d + i + 96), e);
+    }
+    _mm_sfence();
+    if (i < len) std::memcpy(d + i, s + i, len - i);
+}
+void stream_copy(void *d, const void *s, size_t len)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2") && std::getenv("OGL_STAGE_PLAIN_STORES") == nullptr;
+    if (avx2 && len >= 4096)
+        stream_copy_avx2(static_cast<char *>(d), static_cast<const char *>(s), len);
+    else
+        std::memcpy(d, s, len);
+}
+}  // namespace
+
+// Persistent helpers: a copy is cut into one part per thread (the caller takes part 0); the helpers sleep on a
+// condition variable between copies, so a refresh does not pay a thread start per buffer.
+class ogl::CopyPool {
+public:
+    explicit CopyPool(int n_threads) : n_(std::max(1, n_threads))
+    {
+        for (int t = 1; t < n_; ++t) helpers_.emplace_back([this, t] { run(t); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &h : helpers_) h.join();
+    }
+    void copy(void *dst, const void *src, size_t len)
+    {
+        if (n_ == 1 || len < (size_t(1) << 20)) {
+            stream_copy(dst, src, len);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            dst_ = static_cast<char *>(dst);
+            src_ = static_cast<const char *>(src);
+            len_ = len;
+            part_ = ((len + n_ - 1) / n_ + 4095) / 4096 * 4096;
+            pending_ = n_ - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        stream_copy(dst_, src_, std::min(part_, len_));
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+    }
+
+private:
+    void run(int t)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> g(m_);
+            cv_.wait(g, [&] { return quit_ || gen_ != seen; });
+            if (quit_) return;
+            seen = gen_;
+            char *d = dst_;
+            const char *s = src_;
+            const size_t len = len_, part = part_;
+            g.unlock();
+            const size_t off = (size_t)t * part;
+            if (off < len) stream_copy(d + off, s + off, std::min(part, len - off));
+            g.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    int n_;
+    std::vector<std::thread> helpers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    char *dst_ = nullptr;
+    const char *src_ = nullptr;
+    size_t len_ = 0, part_ = 0;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool quit_ = false;
+};
+
 Stager::~Stager()
 {
-    for (int i = 0; i < 2; ++i) {
+    delete pool_;
+    for (int i = 0; i < NBUF; ++i) {
         if (pin_[i]) (void)hipHostFree(pin_[i]);
         if (ev_[i]) (void)hipEventDestroy(ev_[i]);
     }
@@ -53,38 +161,16 @@ Stager::~Stager()
 int Stager::init(size_t chunk_bytes)
 {
     if (chunk_) return OGL_OK;
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBUF; ++i) {
         OGL_HIP_CHECK(hipHostMalloc(&pin_[i], chunk_bytes, 0));
         OGL_HIP_CHECK(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
     }
     chunk_ = chunk_bytes;
+    const char *e = std::getenv("OGL_STAGE_THREADS");
+    int n_threads = std::max(1, std::min(32, e ? atoi(e) : 8));
+    n_threads = std::min(n_threads, std::max(1, (int)std::thread::hardware_concurrency()));
+    pool_ = new CopyPool(n_threads);
     return OGL_OK;
-}
-
-// memcpy between pageable and pinned memory, split over a few threads: one core moves ~25 GB/s on the
-// test box's host, the PCIe 5 x16 link takes twice that (OGL_STAGE_THREADS, default 4)
-static void parallel_memcpy(void *dst, const void *src, size_t len)
-{
-    static const int n_threads = [] {
-        const char *e = std::getenv("OGL_STAGE_THREADS");
-        return std::max(1, std::min(16, e ? atoi(e) : 4));
-    }();
-    if (n_threads == 1 || len < (size_t(4) << 20)) {
-        std::memcpy(dst, src, len);
-        return;
-    }
-    const size_t part = ((len + n_threads - 1) / n_threads + 4095) / 4096 * 4096;
-    std::vector<std::thread> helpers;
-    for (int t = 1; t < n_threads; ++t) {
-        const size_t off = (size_t)t * part;
-        if (off >= len) break;
-        helpers.emplace_back([=] {
-            std::memcpy(static_cast<char *>(dst) + off, static_cast<const char *>(src) + off,
-                        std::min(part, len - off));
-        });
-    }
-    std::memcpy(dst, src, std::min(part, len));
-    for (auto &h : helpers) h.join();
 }
 
 int Stager::h2d(void *dst, const void *src, size_t bytes, hipStream_t st)
@@ -94,9 +180,9 @@ int Stager::h2d(void *dst, const void *src, size_t bytes, hipStream_t st)
     for (size_t off = 0; off < bytes; off += chunk_) {
         const size_t len = std::min(chunk_, bytes - off);
         const int k = next_;
-        next_ ^= 1;
+        next_ = (next_ + 1) % NBUF;
         if (busy_[k]) OGL_HIP_CHECK(hipEventSynchronize(ev_[k]));
-        parallel_memcpy(pin_[k], s + off, len);  // the borrowed host array is free again after this
+        pool_->copy(pin_[k], s + off, len);  // the borrowed host array is free again after this
         OGL_HIP_CHECK(hipMemcpyAsync(d + off, pin_[k], len, hipMemcpyHostToDevice, st));
         OGL_HIP_CHECK(hipEventRecord(ev_[k], st));
         busy_[k] = true;
@@ -108,29 +194,29 @@ int Stager::d2h(void *dst, const void *src, size_t bytes, hipStream_t st)
 {
     const char *s = static_cast<const char *>(src);
     char *d = static_cast<char *>(dst);
-    // two chunks in flight: copy chunk i+1 over PCIe while chunk i is memcpy'd out
-    size_t off_prev = 0, len_prev = 0;
-    int k_prev = -1;
-    for (size_t off = 0; off < bytes || k_prev >= 0; off += chunk_) {
-        int k = -1;
-        size_t len = 0;
-        if (off < bytes) {
-            len = std::min(chunk_, bytes - off);
-            k = next_;
-            next_ ^= 1;
+    // up to NBUF - 1 device-to-pinned copies in flight while the oldest buffer is copied out to the caller
+    struct Flight {
+        int k;
+        size_t off, len;
+    };
+    std::vector<Flight> fl;
+    size_t head = 0, off = 0;
+    while (off < bytes || head < fl.size()) {
+        while (off < bytes && fl.size() - head < (size_t)NBUF - 1) {
+            const size_t len = std::min(chunk_, bytes - off);
+            const int k = next_;
+            next_ = (next_ + 1) % NBUF;
             if (busy_[k]) OGL_HIP_CHECK(hipEventSynchronize(ev_[k]));
             OGL_HIP_CHECK(hipMemcpyAsync(pin_[k], s + off, len, hipMemcpyDeviceToHost, st));
             OGL_HIP_CHECK(hipEventRecord(ev_[k], st));
             busy_[k] = true;
+            fl.push_back({k, off, len});
+            off += len;
         }
-        if (k_prev >= 0) {
-            OGL_HIP_CHECK(hipEventSynchronize(ev_[k_prev]));
-            parallel_memcpy(d + off_prev, pin_[k_prev], len_prev);
-            busy_[k_prev] = false;
-        }
-        k_prev = k;
-        off_prev = off;
-        len_prev = len;
+        const Flight f = fl[head++];
+        OGL_HIP_CHECK(hipEventSynchronize(ev_[f.k]));
+        pool_->copy(d + f.off, pin_[f.k], f.len);
+        busy_[f.k] = false;
     }
     return OGL_OK;
 }
@@ -1522,6 +1608,9 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             OGL_TRY(d_new_id.alloc((size_t)pat.n_rows, st));
             OGL_TRY(d_perm_tmp.alloc((size_t)pat.n_rows + 2, st));
             OGL_TRY(reg->stager.h2d(d_new_id.p, pat.new_id.data(), (size_t)pat.n_rows * sizeof(int32_t), st));
+            // (the inverse: block-Jacobi blocks stay those of the caller's numbering, generate_preconditioner)
+            OGL_TRY(d_old_of.alloc((size_t)pat.n_rows, st));
+            OGL_TRY(reg->stager.h2d(d_old_of.p, pat.old_of.data(), (size_t)pat.n_rows * sizeof(int32_t), st));
         }
         // a symmetric lduMatrix on a banded pattern keeps the OpenFOAM storage (diagonal + upper); the
         // compressed full-storage copy is then not built at all
@@ -1788,6 +1877,10 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         J.block_ptrs = P.block_ptrs.p;
         J.row_block = P.row_block.p;
         J.blocks = P.values.p;
+        if (pat.renumbered()) {  // blocks of the caller's numbering, reached through the permutation
+            J.rows = d_new_id.p;
+            J.pos = d_old_of.p;
+        }
         launch_bj_generate(st, csr(), J);
         P.kind = 2;
         P.stride = cfg.max_block_size;
@@ -1841,6 +1934,10 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
     J.row_block = precond_data->row_block.p;
     J.blocks = precond_data->values.p;
     J.uniform = precond_data->uniform_blocks ? 1 : 0;
+    if (pat.renumbered()) {
+        J.rows = d_new_id.p;
+        J.pos = d_old_of.p;
+    }
     launch_bj_apply(st, J, in, out, dot_part, gate);
 }
 

@@ -66,19 +66,27 @@ struct DevBuf {
 };
 
 // Pinned double-buffered staging for pageable host arrays (K10/K12: "pinned async copies").
+// Pageable host arrays <-> device through a ring of pinned buffers.  The copy between the caller's array and a
+// pinned buffer is what limits a coefficient refresh (one core moves 10-25 GB/s, the PCIe 5 x16 link takes 55): it
+// is split over a small pool of persistent helper threads (OGL_STAGE_THREADS, default 8) that store past the
+// caches (non-temporal: the DMA engine -- or, coming down, the caller -- reads the data from DRAM anyway, and a
+// plain store would first read the destination line), while the DMA of the previous buffers is in flight.
+class CopyPool;
 class Stager {
 public:
+    static constexpr int NBUF = 4;
     ~Stager();
     int init(size_t chunk_bytes);
     int h2d(void *dst, const void *src, size_t bytes, hipStream_t st);
     int d2h(void *dst, const void *src, size_t bytes, hipStream_t st);  // returns after completion
 
 private:
-    void *pin_[2] = {nullptr, nullptr};
-    hipEvent_t ev_[2] = {nullptr, nullptr};
-    bool busy_[2] = {false, false};
+    void *pin_[NBUF] = {};
+    hipEvent_t ev_[NBUF] = {};
+    bool busy_[NBUF] = {};
     size_t chunk_ = 0;
     int next_ = 0;
+    CopyPool *pool_ = nullptr;
 };
 
 class Stager;
@@ -296,7 +304,7 @@ struct ogl_solver {
     ogl::DevSell sell() const;
     // renumbering (config `renumber`): pat.new_id on the device + a staging vector, so that host
     // vectors cross the boundary in the caller's cell order
-    ogl::DevBuf<int32_t> d_new_id;
+    ogl::DevBuf<int32_t> d_new_id, d_old_of;
     ogl::DevBuf<double> d_perm_tmp;
     int pat_renumber_mode = -1;  // cfg.renumber / layout eligibility the pattern was built under
     bool pat_try_sell = false, pat_try_sym = false;

@@ -813,8 +813,9 @@ static void solve_dense(orc_label bs, orc_scalar *a, orc_label ld, orc_scalar *r
  * ([UPSTREAM] isai extend_sparsity; Preconditioner.H:227 `sparsityPower`).  Returns the number of
  * entries, -1 if a row gets more than ORC_ISAI_MAX_ROW of them; p_cols == NULL: sizes only. */
 #define ORC_ISAI_MAX_ROW 64
+#define ISAI_IN_S(r, c) (!spd || (key ? key[c] <= key[r] : (c) <= (r)))
 static orc_label isai_pattern(orc_label n, const orc_label *rowptr, const orc_label *cols, int spd,
-                              int power, orc_label *p_rowptr, orc_label *p_cols) {
+                              int power, const orc_label *key, orc_label *p_rowptr, orc_label *p_cols) {
     orc_label *mark = (orc_label *)xmalloc(sizeof(orc_label) * ((size_t)n + 1));
     orc_label row[ORC_ISAI_MAX_ROW + 1], next[ORC_ISAI_MAX_ROW + 1];
     for (orc_label i = 0; i < n; ++i) mark[i] = -1;
@@ -822,7 +823,7 @@ static orc_label isai_pattern(orc_label n, const orc_label *rowptr, const orc_la
     for (orc_label i = 0; i < n; ++i) {
         orc_label len = 0;
         for (orc_label k = rowptr[i]; k < rowptr[i + 1]; ++k)
-            if ((!spd || cols[k] <= i) && mark[cols[k]] != i) { /* S(i,:), duplicates once */
+            if (ISAI_IN_S(i, cols[k]) && mark[cols[k]] != i) { /* S(i,:), duplicates once */
                 if (len == ORC_ISAI_MAX_ROW) { free(mark); return -1; }
                 mark[cols[k]] = i;
                 row[len++] = cols[k];
@@ -833,7 +834,7 @@ static orc_label isai_pattern(orc_label n, const orc_label *rowptr, const orc_la
             for (orc_label e = 0; e < len; ++e) {
                 const orc_label j = row[e];
                 for (orc_label k = rowptr[j]; k < rowptr[j + 1]; ++k)
-                    if ((!spd || cols[k] <= j) && mark[cols[k]] != i) {
+                    if (ISAI_IN_S(j, cols[k]) && mark[cols[k]] != i) {
                         if (nl == ORC_ISAI_MAX_ROW) { free(mark); return -1; }
                         mark[cols[k]] = i;
                         next[nl++] = cols[k];
@@ -862,9 +863,15 @@ static orc_label isai_pattern(orc_label n, const orc_label *rowptr, const orc_la
 orc_label orc_isai_generate_p(orc_label n, const orc_label *rowptr, const orc_label *cols,
                               const orc_scalar *vals, int spd, int power, orc_label *w_rowptr,
                               orc_label *w_cols, orc_scalar *w_vals) {
+    return orc_isai_generate_pk(n, rowptr, cols, vals, spd, power, 0, w_rowptr, w_cols, w_vals);
+}
+
+orc_label orc_isai_generate_pk(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                               const orc_scalar *vals, int spd, int power, const orc_label *key,
+                               orc_label *w_rowptr, orc_label *w_cols, orc_scalar *w_vals) {
     if (power < 1) return -1;
-    if (!w_vals) return isai_pattern(n, rowptr, cols, spd, power, w_rowptr, 0);
-    if (isai_pattern(n, rowptr, cols, spd, power, w_rowptr, w_cols) < 0) return -1;
+    if (!w_vals) return isai_pattern(n, rowptr, cols, spd, power, key, w_rowptr, 0);
+    if (isai_pattern(n, rowptr, cols, spd, power, key, w_rowptr, w_cols) < 0) return -1;
     enum { LD = ORC_ISAI_MAX_ROW };
     orc_scalar *a = (orc_scalar *)xmalloc(sizeof(orc_scalar) * LD * LD);
     orc_scalar rhs[LD];
@@ -932,10 +939,11 @@ static void precond_apply(orc_label n, const orc_precond *P, const orc_scalar *r
         for (orc_label b = 0; b < P->n_blocks; ++b) {
             const orc_label r0 = P->block_ptrs[b], bs = P->block_ptrs[b + 1] - r0;
             const orc_scalar *a = P->blocks + (size_t)b * P->stride * P->stride;
+            const orc_label *rows = P->block_rows;
             for (orc_label i = 0; i < bs; ++i) {
                 orc_scalar sum = 0.0;
-                for (orc_label j = 0; j < bs; ++j) sum += a[i * P->stride + j] * r[r0 + j];
-                z[r0 + i] = sum;
+                for (orc_label j = 0; j < bs; ++j) sum += a[i * P->stride + j] * r[rows ? rows[r0 + j] : r0 + j];
+                z[rows ? rows[r0 + i] : r0 + i] = sum;
             }
         }
     }
@@ -947,7 +955,7 @@ static void precond_apply(orc_label n, const orc_precond *P, const orc_scalar *r
 orc_label orc_cg(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                  const orc_scalar *inv_diag, const orc_criterion *crit,
                  orc_criterion_state *st) {
-    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return orc_cg_p(A, b, x, &P, crit, st);
 }
 
@@ -998,7 +1006,7 @@ orc_label orc_cg_p(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
 orc_label orc_bicgstab(const orc_dist_matrix *A, const orc_scalar *b, orc_scalar *x,
                        const orc_scalar *inv_diag, const orc_criterion *crit,
                        orc_criterion_state *st) {
-    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    orc_precond P = {inv_diag ? ORC_PRECOND_SCALAR : ORC_PRECOND_NONE, inv_diag, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return orc_bicgstab_p(A, b, x, &P, crit, st);
 }
 

@@ -249,6 +249,10 @@ typedef struct {
     const orc_scalar *w_vals;
     const orc_label *wt_rowptr, *wt_cols;
     const orc_scalar *wt_vals;
+    /* BLOCK on a system whose rows were renumbered after the blocks were formed (the backend's `renumber`): the
+     * blocks are those of the caller's numbering (Preconditioner.H:91-105 generates on the matrix OpenFOAM hands
+     * over); block_rows[r0 + i] = row of the block's i-th member in the system at hand.  NULL: r0 + i itself. */
+    const orc_label *block_rows;
 } orc_precond;
 
 /* ISAI with sparsityPower 1 ([UPSTREAM] gko::preconditioner::Isai).  spd != 0: W has the pattern
@@ -260,6 +264,12 @@ typedef struct {
 orc_label orc_isai_generate_p(orc_label n, const orc_label *rowptr, const orc_label *cols,
                               const orc_scalar *vals, int spd, int power, orc_label *w_rowptr,
                               orc_label *w_cols, orc_scalar *w_vals);
+/* ... with the triangle of the spd variant taken in ANOTHER numbering of the same rows: S(r, c) is kept when
+ * key[c] <= key[r] (key = the caller's index of every row; NULL = the row index itself): P tril(A) P^T of a
+ * system renumbered by the backend, so that W is the reference's operator in the new numbering */
+orc_label orc_isai_generate_pk(orc_label n, const orc_label *rowptr, const orc_label *cols,
+                               const orc_scalar *vals, int spd, int power, const orc_label *key,
+                               orc_label *w_rowptr, orc_label *w_cols, orc_scalar *w_vals);
 orc_label orc_isai_generate(orc_label n, const orc_label *rowptr, const orc_label *cols,
                             const orc_scalar *vals, int spd, orc_label *w_rowptr, orc_label *w_cols,
                             orc_scalar *w_vals);

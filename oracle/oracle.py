@@ -371,14 +371,33 @@ class _CPrecond(C.Structure):
     _fields_ = [("kind", C.c_int), ("inv_diag", _SP), ("n_blocks", C.c_int32),
                 ("block_ptrs", _LP), ("blocks", _SP), ("stride", C.c_int32),
                 ("w_rowptr", _LP), ("w_cols", _LP), ("w_vals", _SP),
-                ("wt_rowptr", _LP), ("wt_cols", _LP), ("wt_vals", _SP)]
+                ("wt_rowptr", _LP), ("wt_cols", _LP), ("wt_vals", _SP), ("block_rows", _LP)]
 
 
 class Precond:
     """Jacobi preconditioner object: scalar (maxBlockSize 1) or block (maxBlockSize k > 1)."""
 
-    def __init__(self, rowptr, cols, vals, max_block_size=1, isai=None, sparsity_power=1):
-        """isai: None (Jacobi), "spd" (keyword ISAI) or "general" (keyword GISAI)."""
+    def __init__(self, rowptr, cols, vals, max_block_size=1, isai=None, sparsity_power=1, caller=None):
+        """isai: None (Jacobi), "spd" (keyword ISAI) or "general" (keyword GISAI).
+        caller = (rowptr0, cols0, vals0, new_id): (rowptr, cols, vals) is the system the backend renumbered by
+        new_id (new_id[caller row] = row here) and the preconditioner is the one the reference generates on the
+        matrix OpenFOAM hands over (Preconditioner.H:91-105, :225-241), expressed in the new numbering: block-Jacobi
+        blocks are found and inverted on the caller's matrix and applied through new_id; ISAI(spd) takes the
+        triangle by the caller's index."""
+        if caller is not None and isai is None and int(max_block_size) > 1:
+            rp0, c0, v0, new_id = caller
+            base = Precond(rp0, c0, v0, max_block_size)
+            self.__dict__.update(base.__dict__)
+            self.block_rows, pbr = _l(new_id)
+            self.c = _CPrecond(2, None, base.c.n_blocks, self.block_ptrs.ctypes.data_as(_LP),
+                               self.blocks.ctypes.data_as(_SP), int(max_block_size), None, None, None, None, None,
+                               None, pbr)
+            return
+        key = None
+        if caller is not None and isai == "spd":
+            old_of = np.empty(len(caller[3]), label)
+            old_of[np.asarray(caller[3])] = np.arange(len(caller[3]), dtype=label)
+            self.tri_key, key = _l(old_of)
         rowptr, prp = _l(rowptr)
         cols, pc = _l(cols)
         vals, pv = _s(vals)
@@ -386,16 +405,16 @@ class Precond:
         self.max_block_size = int(max_block_size)
         if isai is not None:
             spd = C.c_int(isai == "spd")
-            lib().orc_isai_generate_p.restype = C.c_int32
+            lib().orc_isai_generate_pk.restype = C.c_int32
             pw = C.c_int(int(sparsity_power))
             self.w_rowptr = np.zeros(n + 1, label)
-            nnz = lib().orc_isai_generate_p(C.c_int32(n), prp, pc, pv, spd, pw,
-                                            self.w_rowptr.ctypes.data_as(_LP), None, None)
+            nnz = lib().orc_isai_generate_pk(C.c_int32(n), prp, pc, pv, spd, pw, key,
+                                             self.w_rowptr.ctypes.data_as(_LP), None, None)
             if nnz < 0:
                 raise ValueError("ISAI row wider than 64")
             self.w_cols, self.w_vals = np.zeros(max(1, nnz), label), np.zeros(max(1, nnz), scalar)
-            lib().orc_isai_generate_p(C.c_int32(n), prp, pc, pv, spd, pw, self.w_rowptr.ctypes.data_as(_LP),
-                                      self.w_cols.ctypes.data_as(_LP), self.w_vals.ctypes.data_as(_SP))
+            lib().orc_isai_generate_pk(C.c_int32(n), prp, pc, pv, spd, pw, key, self.w_rowptr.ctypes.data_as(_LP),
+                                       self.w_cols.ctypes.data_as(_LP), self.w_vals.ctypes.data_as(_SP))
             self.wt_rowptr = np.zeros(n + 1, label)
             self.wt_cols, self.wt_vals = np.zeros_like(self.w_cols), np.zeros_like(self.w_vals)
             lib().orc_csr_transpose(C.c_int32(n), self.w_rowptr.ctypes.data_as(_LP),
@@ -406,11 +425,11 @@ class Precond:
             self.c = _CPrecond(3 if isai == "spd" else 4, None, 0, None, None, 0,
                                self.w_rowptr.ctypes.data_as(_LP), self.w_cols.ctypes.data_as(_LP),
                                self.w_vals.ctypes.data_as(_SP), self.wt_rowptr.ctypes.data_as(_LP),
-                               self.wt_cols.ctypes.data_as(_LP), self.wt_vals.ctypes.data_as(_SP))
+                               self.wt_cols.ctypes.data_as(_LP), self.wt_vals.ctypes.data_as(_SP), None)
         elif self.max_block_size == 1:
             self.inv_diag = jacobi_generate_scalar(rowptr, cols, vals)
             self.c = _CPrecond(1, self.inv_diag.ctypes.data_as(_SP), 0, None, None, 0, None, None,
-                               None, None, None, None)
+                               None, None, None, None, None)
         else:
             k = self.max_block_size
             bp = np.zeros(n + 1, label)
@@ -423,7 +442,7 @@ class Precond:
                                              self.block_ptrs.ctypes.data_as(_LP), C.c_int32(k),
                                              self.blocks.ctypes.data_as(_SP))
             self.c = _CPrecond(2, None, nb, self.block_ptrs.ctypes.data_as(_LP),
-                               self.blocks.ctypes.data_as(_SP), k, None, None, None, None, None, None)
+                               self.blocks.ctypes.data_as(_SP), k, None, None, None, None, None, None, None)
 
 
 class DistMatrix:

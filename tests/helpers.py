@@ -53,3 +53,11 @@ def oracle_matrix_renumbered(oracle, case, new_id, **kw):
     rowptr, cols, vals = oracle_csr(oracle, case, **kw)
     rp, cc, vv, _ = oracle.permute_csr(rowptr, cols, vals, new_id)
     return oracle.DistMatrix(rp, cc, vv), (rp, cc, vv)
+
+
+def oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, max_block_size=1, isai=None, **kw):
+    """The reference's preconditioner -- generated on the matrix OpenFOAM hands over, i.e. in the CALLER's numbering
+    (Preconditioner.H:91-105, :225-241) -- expressed on the system (rp, cols, vals) the library renumbered by new_id:
+    block-Jacobi blocks are runs of consecutive CALLER rows, ISAI(spd) takes tril(A) by the caller's index."""
+    rp0, c0, v0 = oracle_csr(oracle, case, **kw)
+    return oracle.Precond(rp, cols, vals, max_block_size, isai=isai, caller=(rp0, c0, v0, new_id))

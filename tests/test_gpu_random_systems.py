@@ -6,7 +6,7 @@ import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 from ogl_amd import capi, synthetic
-from helpers import blocked, oracle_csr, oracle_matrix, oracle_matrix_renumbered, to_new
+from helpers import blocked, oracle_csr, oracle_matrix, oracle_matrix_renumbered, oracle_precond_renumbered, to_new
 
 pytestmark = pytest.mark.gpu
 
@@ -97,11 +97,14 @@ def test_random_systems_bit_identical(reg, oracle, sysdata, combo, krylov_dim, r
     # ISAI rows of up to 64 pattern entries (<= 32: one thread per row, wider: one wavefront per row);
     # the product refuses wider ones, the oracle too
     P, too_wide = None, False
+    # (a renumbered device copy keeps the preconditioner of the caller's numbering: blocks / triangle through new_id)
+    mk = (lambda *a, **kw_: oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, *a, **kw_)) if renumber \
+        else (lambda *a, **kw_: oracle.Precond(rp, cols, vals, *a, **kw_))
     if precond == "bj":
-        P = oracle.Precond(rp, cols, vals, k)
+        P = mk(k)
     elif precond != "none":
         try:
-            P = oracle.Precond(rp, cols, vals, isai="spd" if precond == "isai" else "general")
+            P = mk(isai="spd" if precond == "isai" else "general")
         except ValueError:
             too_wide = True
     try:
