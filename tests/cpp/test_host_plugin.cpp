@@ -1,4 +1,4 @@
-// test_host_plugin.cpp -- the C++ plug-in surface (ogl_amd/host/OGLAdapter.H over MiniFoam.H).
+// test_host_plugin.cpp -- the C++ plug-in surface (ogl_amd/host/OGLAdapter.H over tests/cpp/MiniFoam.H).
 //   ./test_host_plugin cpu   host logic, dictionary / selection-table behaviour, loud failure w/o GPU
 //   ./test_host_plugin gpu   GKOCG through lduMatrix::solver::New on the MI355X vs the oracle
 // The first three cases re-state the reference's gtest cases (unitTests/test_HostMatrix.C:8-107)

@@ -1,5 +1,5 @@
 """Runs the C++ plug-in surface tests (tests/cpp/test_host_plugin.cpp): the lduMatrix::solver
-classes GKOCG / GKOBiCGStab / GKOGMRES of ogl_amd/host/OGLAdapter.H over the MiniFoam stand-in."""
+classes GKOCG / GKOBiCGStab / GKOGMRES of ogl_amd/host/OGLAdapter.H over the MiniFoam stand-in (tests/cpp/MiniFoam.H: test infrastructure)."""
 import os
 import subprocess
 
@@ -45,7 +45,8 @@ def test_openfoam_translation_unit_parses_against_the_api_stub(flags):
     stub of the OpenFOAM declarations it uses (tests/cpp/foam_stub, on top of MiniFoam.H) lets `g++ -fsyntax-only`
     catch typos and signature slips in the adapter translation unit before a maintainer's wmake does."""
     p = subprocess.run(["g++", "-std=c++17", "-Wall", "-fsyntax-only", *flags,
-                        "-I", os.path.join(ROOT, "tests", "cpp", "foam_stub"), "-I", os.path.join(ROOT, "ogl_amd", "host"),
+                        "-I", os.path.join(ROOT, "tests", "cpp", "foam_stub"), "-I", os.path.join(ROOT, "tests", "cpp"),
+                        "-I", os.path.join(ROOT, "ogl_amd", "host"),
                         "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "ogl_amd", "foam", "GKOSolvers.C")],
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "error" not in p.stderr, p.stderr[-3000:]
