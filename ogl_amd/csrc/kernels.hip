@@ -718,6 +718,124 @@ __global__ __launch_bounds__(WAVE) void k_isai_generate_wide(int n_wide, const i
     }
 }
 
+// One HUGE row (MAX_ISAI_ROW < entries <= MAX_ISAI_HUGE_ROW) per workgroup: the dense system lives in global
+// scratch (row-major, leading dimension bs; it stays in L2), right-hand side and column list in LDS.  Elimination:
+// every element of the trailing block sees `a[i][j] -= (a[i][k] / a[k][k]) * a[k][j]` exactly as in the oracle's
+// solve_dense_wide (same factor expression, products and differences rounded separately); pivot = the first row
+// with the largest |a[r][k]|; back substitution column by column.
+__global__ __launch_bounds__(BLOCK) void k_isai_generate_huge(const int *__restrict__ huge_rows,
+                                                             const long long *__restrict__ scratch_off,
+                                                             double *__restrict__ scratch,
+                                                             const int *__restrict__ row_ptrs,
+                                                             const int *__restrict__ cols,
+                                                             const double *__restrict__ vals, int spd,
+                                                             const int *__restrict__ w_row_ptrs,
+                                                             const int *__restrict__ w_cols,
+                                                             double *__restrict__ w_vals)
+{
+    __shared__ int Js[MAX_ISAI_HUGE_ROW];
+    __shared__ double rhs[MAX_ISAI_HUGE_ROW];
+    __shared__ double red_v[N_WAVES];
+    __shared__ int red_i[N_WAVES];
+    __shared__ int piv_s;
+    const int i = huge_rows[blockIdx.x];
+    const int w0 = w_row_ptrs[i], bs = w_row_ptrs[i + 1] - w0;
+    double *a = scratch + scratch_off[blockIdx.x];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < bs; c += BLOCK) {
+        const int J = w_cols[w0 + c];
+        Js[c] = J;
+        rhs[c] = J == i ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < bs * bs; e += BLOCK) {
+        const int r = e / bs, c = e - r * bs;
+        a[e] = spd ? csr_entry(row_ptrs, cols, vals, Js[r], Js[c]) : csr_entry(row_ptrs, cols, vals, Js[c], Js[r]);
+    }
+    __syncthreads();
+    for (int k = 0; k < bs; ++k) {
+        // pivot: the first row >= k with the largest |a[r][k]|
+        double best = -1.0;
+        int bi = 0x7fffffff;
+        for (int r = k + tid; r < bs; r += BLOCK) {
+            const double v = fabs(a[(long)r * bs + k]);
+            if (v > best) {
+                best = v;
+                bi = r;
+            }
+        }
+#pragma unroll
+        for (int off = WAVE / 2; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(best, off, WAVE);
+            const int oi = __shfl_xor(bi, off, WAVE);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & (WAVE - 1)) == 0) {
+            red_v[tid / WAVE] = best;
+            red_i[tid / WAVE] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double bv = red_v[0];
+            int bidx = red_i[0];
+            for (int w = 1; w < N_WAVES; ++w)
+                if (red_v[w] > bv || (red_v[w] == bv && red_i[w] < bidx)) {
+                    bv = red_v[w];
+                    bidx = red_i[w];
+                }
+            piv_s = bidx;
+        }
+        __syncthreads();
+        const int piv = piv_s;
+        if (piv != k) {
+            for (int j = tid; j < bs; j += BLOCK) {
+                const double t = a[(long)k * bs + j];
+                a[(long)k * bs + j] = a[(long)piv * bs + j];
+                a[(long)piv * bs + j] = t;
+            }
+            if (tid == 0) {
+                const double t = rhs[k];
+                rhs[k] = rhs[piv];
+                rhs[piv] = t;
+            }
+            __syncthreads();
+        }
+        // trailing block + right-hand side: (m rows) x (m columns + 1)
+        const int m = bs - k - 1;
+        const double akk = a[(long)k * bs + k], rk = rhs[k];
+        for (int e = tid; e < m * (m + 1); e += BLOCK) {
+            const int ii = e / (m + 1), jj = e - ii * (m + 1);
+            const int r = k + 1 + ii;
+            const double f = a[(long)r * bs + k] / akk;
+            if (jj < m) {
+                const int c = k + 1 + jj;
+                a[(long)r * bs + c] -= f * a[(long)k * bs + c];
+            } else {
+                rhs[r] -= f * rk;
+            }
+        }
+        __syncthreads();
+    }
+    for (int r = bs - 1; r >= 0; --r) {  // column-wise back substitution
+        if (tid == 0) rhs[r] = rhs[r] / a[(long)r * bs + r];
+        __syncthreads();
+        const double xr = rhs[r];
+        for (int q = tid; q < r; q += BLOCK) rhs[q] -= a[(long)q * bs + r] * xr;
+        __syncthreads();
+    }
+    double scale = 1.0;
+    if (spd) {
+        int pos = 0;
+        for (int r = 0; r < bs; ++r)
+            if (Js[r] == i) pos = r;
+        scale = sqrt(rhs[pos]);
+    }
+    for (int c = tid; c < bs; c += BLOCK) w_vals[w0 + c] = spd ? rhs[c] / scale : rhs[c];
+}
+
 __global__ __launch_bounds__(BLOCK) void k_permute_scatter(int n, const int *__restrict__ new_id,
                                                            const double *__restrict__ in,
                                                            double *__restrict__ out)
@@ -3530,6 +3648,17 @@ void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_
     if (n_wide > 0)
         hipLaunchKernelGGL(k_isai_generate_wide, dim3(n_wide), dim3(WAVE), 0, st, n_wide, wide_rows,
                            A.row_ptrs, A.cols, A.vals, spd, w_row_ptrs, w_cols, w_vals);
+}
+
+void launch_isai_generate_huge(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
+                               const int32_t *w_cols, double *w_vals, const int32_t *huge_rows,
+                               const int64_t *scratch_off, int32_t first, int32_t count, double *scratch)
+{
+    if (count <= 0) return;
+    static_assert(sizeof(long long) == sizeof(int64_t), "scratch offsets");
+    hipLaunchKernelGGL(k_isai_generate_huge, dim3(count), dim3(BLOCK), 0, st, huge_rows + first,
+                       reinterpret_cast<const long long *>(scratch_off) + first, scratch, A.row_ptrs, A.cols, A.vals,
+                       spd, w_row_ptrs, w_cols, w_vals);
 }
 
 void launch_permute_scatter(hipStream_t st, int32_t n, const int32_t *new_id, const double *in, double *out)

@@ -210,13 +210,23 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
 // A(J,J)^T y = e_i, W(i,J) = y.  Rows of up to ISAI_THREAD_ROW entries: one thread per row (per-thread
 // arrays); longer ones, up to MAX_ISAI_ROW: one wavefront per row, the system in LDS, lane = column --
 // the same operations on every element in the same order, so both give the oracle's bits.
+// Rows beyond MAX_ISAI_ROW, up to MAX_ISAI_HUGE_ROW: one WORKGROUP per row, the system in global scratch
+// (bs x bs doubles per row), the same elimination, the back substitution column by column (the oracle's
+// solve_dense_wide: a row-wise walk would be one dependent chain of bs^2 / 2 operations).  [UPSTREAM] Ginkgo solves
+// rows beyond its in-kernel limit through an iterative "excess system" (GMRES to 1e-6): an approximation of this.
 constexpr int ISAI_THREAD_ROW = 32;
 constexpr int MAX_ISAI_ROW = 64;
+constexpr int MAX_ISAI_HUGE_ROW = 512;
 // max_row = longest row of W (selects the per-thread scratch size: 8, 16 or 32);
-// wide_rows[n_wide] = the rows longer than ISAI_THREAD_ROW
+// wide_rows[n_wide] = the rows with ISAI_THREAD_ROW < entries <= MAX_ISAI_ROW
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
                           const int32_t *w_cols, double *w_vals, int32_t max_row,
                           const int32_t *wide_rows, int32_t n_wide);
+// huge_rows[first .. first + count): rows wider than MAX_ISAI_ROW; scratch_off[k] = where row huge_rows[k]'s
+// system starts in `scratch` (doubles)
+void launch_isai_generate_huge(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
+                               const int32_t *w_cols, double *w_vals, const int32_t *huge_rows,
+                               const int64_t *scratch_off, int32_t first, int32_t count, double *scratch);
 
 // renumbering (keyword `renumber`): host vectors arrive in the caller's cell order
 //   scatter: out[new_id[i]] = in[i]   (b, x on upload)      gather: out[i] = in[new_id[i]]   (x on copy-back)

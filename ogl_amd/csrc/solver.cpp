@@ -1783,21 +1783,54 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             std::vector<int32_t> wrp, wc;
             ogl_label wide = -1;
             OGL_TRY(download_local_pattern(pat));
-            if (!isai_pattern(pat, spd, cfg.sparsity_power, MAX_ISAI_ROW, wrp, wc, wide))
+            if (!isai_pattern(pat, spd, cfg.sparsity_power, MAX_ISAI_HUGE_ROW, wrp, wc, wide))
                 return fail(OGL_ERR_UNSUPPORTED,
-                            "ISAI sparsityPower %d: row %d of the approximate inverse has more than %d "
-                            "pattern entries", cfg.sparsity_power, wide, MAX_ISAI_ROW);
+                            "preconditioner %s, sparsityPower %d: row %d of the approximate inverse has more than %d "
+                            "pattern entries (lower sparsityPower)", spd ? "ISAI" : "GISAI", cfg.sparsity_power, wide,
+                            MAX_ISAI_HUGE_ROW);
             int32_t max_row = 0;
-            std::vector<int32_t> wide_rows;  // rows solved by one wavefront each (the others: one thread)
+            // rows solved by one wavefront each (33 .. 64 entries) / by one workgroup each in global scratch
+            // (65 .. 512); the others: one thread
+            std::vector<int32_t> wide_rows, huge_rows;
+            std::vector<int64_t> huge_off;
+            P.huge_batches.assign(1, 0);
+            // scratch for the dense systems of the huge rows: batches of rows within a budget (property, bytes)
+            const int64_t budget = (int64_t)(prop("isaiScratchBytes", 2147483648.0) / sizeof(double));
+            int64_t used = 0, most = 0;
             for (int32_t r = 0; r < N; ++r) {
                 const int32_t len = wrp[(size_t)r + 1] - wrp[(size_t)r];
                 max_row = std::max(max_row, len);
-                if (len > ISAI_THREAD_ROW) wide_rows.push_back(r);
+                if (len > MAX_ISAI_ROW) {
+                    const int64_t need = (int64_t)len * len;
+                    if (used + need > budget && used > 0) {
+                        P.huge_batches.push_back((int32_t)huge_rows.size());
+                        used = 0;
+                    }
+                    huge_rows.push_back(r);
+                    huge_off.push_back(used);
+                    used += need;
+                    most = std::max(most, used);
+                } else if (len > ISAI_THREAD_ROW) {
+                    wide_rows.push_back(r);
+                }
             }
+            P.huge_batches.push_back((int32_t)huge_rows.size());
             P.n_wide_rows = (int32_t)wide_rows.size();
+            P.n_huge_rows = (int32_t)huge_rows.size();
             OGL_TRY(P.wide_rows.alloc(std::max<size_t>(1, wide_rows.size()), st));
             if (!wide_rows.empty())
                 OGL_TRY(reg->stager.h2d(P.wide_rows.p, wide_rows.data(), wide_rows.size() * sizeof(int32_t), st));
+            OGL_TRY(P.huge_rows.alloc(std::max<size_t>(1, huge_rows.size()), st));
+            OGL_TRY(P.huge_off.alloc(std::max<size_t>(1, huge_off.size()), st));
+            if (!huge_rows.empty()) {
+                OGL_TRY(reg->stager.h2d(P.huge_rows.p, huge_rows.data(), huge_rows.size() * sizeof(int32_t), st));
+                OGL_TRY(reg->stager.h2d(P.huge_off.p, huge_off.data(), huge_off.size() * sizeof(int64_t), st));
+                OGL_TRY(P.huge_scratch.alloc((size_t)most, st));
+            } else {
+                P.huge_scratch.release();
+            }
+            props["isaiWideRows"] = (double)wide_rows.size();
+            props["isaiHugeRows"] = (double)huge_rows.size();
             const size_t wn = wc.size();
             OGL_TRY(P.w_row_ptrs.alloc((size_t)N + 1, st));
             OGL_TRY(P.w_cols.alloc(wn + NNZ_PAD, st));
@@ -1836,6 +1869,10 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         }
         launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p,
                              P.w_max_row, P.wide_rows.p, P.n_wide_rows);
+        for (size_t bt = 0; bt + 1 < P.huge_batches.size(); ++bt)  // (stream order: a batch reuses the scratch)
+            launch_isai_generate_huge(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p, P.huge_rows.p,
+                                      P.huge_off.p, P.huge_batches[bt], P.huge_batches[bt + 1] - P.huge_batches[bt],
+                                      P.huge_scratch.p);
         if (spd) launch_gather_coeffs(st, P.w_nnz, P.wt_map.p, P.w_vals.p, P.wt_vals.p);
         P.w_sell.refresh(P.w_vals.p, st);
         if (spd) P.wt_sell.refresh(P.wt_vals.p, st);

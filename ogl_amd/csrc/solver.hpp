@@ -134,8 +134,16 @@ struct PrecondData {
     DevBuf<int32_t> w_row_ptrs, w_cols, wt_row_ptrs, wt_cols, wt_map;
     DevBuf<double> w_vals, wt_vals;
     int32_t w_nnz = 0, w_max_row = 0;
-    DevBuf<int32_t> wide_rows;  // rows of W with more than ISAI_THREAD_ROW entries (one wavefront each)
+    DevBuf<int32_t> wide_rows;  // rows of W with ISAI_THREAD_ROW < entries <= MAX_ISAI_ROW (one wavefront each)
     int32_t n_wide_rows = 0;
+    // rows of W with more than MAX_ISAI_ROW entries (one workgroup each, dense system in global scratch):
+    // huge_off[k] = start of row huge_rows[k]'s system in huge_scratch; huge_batches = runs of rows that share
+    // the scratch at one time
+    DevBuf<int32_t> huge_rows;
+    DevBuf<int64_t> huge_off;
+    DevBuf<double> huge_scratch;
+    std::vector<int32_t> huge_batches;
+    int32_t n_huge_rows = 0;
     SellDev w_sell, wt_sell;  // compressed copies the apply runs on when compress_indices is set
     // the pattern-only part (block pointers / W and W^T patterns) is kept for as long as it was
     // derived from the same sparsity pattern: only the values are regenerated per solve

@@ -809,10 +809,49 @@ static void solve_dense(orc_label bs, orc_scalar *a, orc_label ld, orc_scalar *r
     }
 }
 
+/* Rows wider than ORC_ISAI_NARROW_ROW (below): the same elimination, but the back substitution walks the COLUMNS
+ * from the last to the first -- x_r = rhs_r / a_rr, then rhs_i -= a_ir x_r for every i < r -- so that the updates of
+ * one step are independent of each other (the product solves such a row with a whole workgroup; the row-wise walk
+ * above is one dependent chain of bs^2 / 2 operations).  Same exact solve, the subtractions of a row in descending
+ * instead of ascending column order.  [UPSTREAM] Ginkgo hands rows beyond its in-kernel limit of 32 to an "excess
+ * system" solved ITERATIVELY (block-Jacobi-preconditioned GMRES to a residual reduction of 1e-6, isai.cpp
+ * excess_solver_factory / excess_solver_reduction): an approximation of the solution computed here. */
+static void solve_dense_wide(orc_label bs, orc_scalar *a, orc_label ld, orc_scalar *rhs) {
+    for (orc_label k = 0; k < bs; ++k) {
+        orc_label piv = k;
+        orc_scalar best = fabs(a[k * ld + k]);
+        for (orc_label i = k + 1; i < bs; ++i)
+            if (fabs(a[i * ld + k]) > best) {
+                best = fabs(a[i * ld + k]);
+                piv = i;
+            }
+        if (piv != k) {
+            for (orc_label j = 0; j < bs; ++j) {
+                const orc_scalar t = a[k * ld + j];
+                a[k * ld + j] = a[piv * ld + j];
+                a[piv * ld + j] = t;
+            }
+            const orc_scalar t = rhs[k];
+            rhs[k] = rhs[piv];
+            rhs[piv] = t;
+        }
+        for (orc_label i = k + 1; i < bs; ++i) {
+            const orc_scalar f = a[i * ld + k] / a[k * ld + k];
+            for (orc_label j = k + 1; j < bs; ++j) a[i * ld + j] -= f * a[k * ld + j];
+            rhs[i] -= f * rhs[k];
+        }
+    }
+    for (orc_label r = bs - 1; r >= 0; --r) {
+        rhs[r] = rhs[r] / a[r * ld + r];
+        for (orc_label i = 0; i < r; ++i) rhs[i] -= a[i * ld + r] * rhs[r];
+    }
+}
+
 /* Pattern of S^power, rows in ascending column order, S = tril(A) (spd) or A (general)
  * ([UPSTREAM] isai extend_sparsity; Preconditioner.H:227 `sparsityPower`).  Returns the number of
  * entries, -1 if a row gets more than ORC_ISAI_MAX_ROW of them; p_cols == NULL: sizes only. */
-#define ORC_ISAI_MAX_ROW 64
+#define ORC_ISAI_MAX_ROW 512   /* widest row of W handled at all */
+#define ORC_ISAI_NARROW_ROW 64 /* up to here: solve_dense (row-wise back substitution), above: solve_dense_wide */
 #define ISAI_IN_S(r, c) (!spd || (key ? key[c] <= key[r] : (c) <= (r)))
 static orc_label isai_pattern(orc_label n, const orc_label *rowptr, const orc_label *cols, int spd,
                               int power, const orc_label *key, orc_label *p_rowptr, orc_label *p_cols) {
@@ -881,13 +920,17 @@ orc_label orc_isai_generate_pk(orc_label n, const orc_label *rowptr, const orc_l
         orc_label pos = -1;
         for (orc_label r = 0; r < bs; ++r)
             if (J[r] == i) pos = r;
+        const orc_label ld = bs <= ORC_ISAI_NARROW_ROW ? ORC_ISAI_NARROW_ROW : LD; /* (storage only: same bits) */
         for (orc_label r = 0; r < bs; ++r) {
             for (orc_label c = 0; c < bs; ++c)
-                a[r * LD + c] = spd ? csr_entry(rowptr, cols, vals, J[r], J[c])
+                a[r * ld + c] = spd ? csr_entry(rowptr, cols, vals, J[r], J[c])
                                     : csr_entry(rowptr, cols, vals, J[c], J[r]);
             rhs[r] = (r == pos) ? 1.0 : 0.0;
         }
-        solve_dense(bs, a, LD, rhs);
+        if (bs <= ORC_ISAI_NARROW_ROW)
+            solve_dense(bs, a, ld, rhs);
+        else
+            solve_dense_wide(bs, a, ld, rhs);
         const orc_scalar scale = spd ? sqrt(rhs[pos]) : 1.0;
         for (orc_label r = 0; r < bs; ++r) w_vals[w_rowptr[i] + r] = spd ? rhs[r] / scale : rhs[r];
     }

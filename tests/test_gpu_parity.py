@@ -587,11 +587,17 @@ def test_isai(reg, oracle, chunk_rows, precond, kind, sym, solver):
     (capi.PRECOND_GISAI, "general", False, "bicgstab", 2, 25),   # A^2: 25 entries, one thread per row
     (capi.PRECOND_GISAI, "general", False, "bicgstab", 3, 63),   # A^3: 63 entries, one wavefront per row
     (capi.PRECOND_GISAI, "general", True, "cg", 3, 63),
-], ids=["ISAI-p2", "ISAI-p3", "GISAI-p2", "GISAI-p3-wide", "GISAI-p3-wide-cg"])
+    (capi.PRECOND_GISAI, "general", False, "bicgstab", 4, 129),  # A^4: 129 entries, one workgroup per row
+    (capi.PRECOND_GISAI, "general", False, "bicgstab", 5, 225),  # A^5: 225
+    (capi.PRECOND_ISAI, "spd", True, "cg", 6, 84),               # tril(A)^6: 84
+], ids=["ISAI-p2", "ISAI-p3", "GISAI-p2", "GISAI-p3-wide", "GISAI-p3-wide-cg", "GISAI-p4-huge", "GISAI-p5-huge",
+        "ISAI-p6-huge"])
 def test_isai_sparsity_power(reg, oracle, chunk_rows, precond, kind, sym, solver, power, widest):
     """Preconditioner.H:227 `sparsityPower`: W lives on the pattern of S^power.  Rows of up to 32 entries
-    are solved by one thread each, wider ones (up to 64) by one wavefront each with the system in LDS;
-    both must give the oracle's bits (same dense solve, same order of operations per element)."""
+    are solved by one thread each, wider ones (up to 64) by one wavefront each with the system in LDS, still
+    wider ones (up to 512; the reference hands rows beyond 32 to Ginkgo's iterative excess system) by one
+    workgroup each with the system in global scratch; all must give the oracle's bits (same dense solve, same
+    order of operations per element)."""
     case = synthetic.poisson_case(9, symmetric=sym)
     xs = synthetic.x_star(case.global_index, case.global_n)
     b = synthetic.apply_case(case, xs)
@@ -615,12 +621,51 @@ def test_isai_sparsity_power(reg, oracle, chunk_rows, precond, kind, sym, solver
     assert perf.n_iterations < perf1.n_iterations
 
 
-def test_isai_rows_wider_than_64_are_refused(reg):
+def test_isai_huge_rows_in_scratch_batches(reg, oracle, chunk_rows):
+    """Rows wider than 64: the dense systems share a scratch buffer in batches (property isaiScratchBytes) -- a
+    budget that holds a handful of rows at a time must give the same W.  A hub cell coupled to 150 others makes
+    ONE huge row (general: the hub's; spd: the hub is the last cell) among thread-sized ones."""
     case = synthetic.poisson_case(9)
-    s = reg.solver("isai_p4", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=4)).set_matrix(case)
-    with pytest.raises(capi.OglError) as e:                 # A^4 on the 7-point box: 129 entries per row
+    b = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
+    kw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=100)
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    P = oracle.Precond(rp, cols, vals, isai="general", sparsity_power=4)
+    with blocked(oracle, chunk_rows):
+        ref = oracle.cg(A, b, np.zeros_like(b), P, **kw)
+    for budget in (3 * 129 * 129 * 8, 1 << 31):
+        s = reg.solver(f"isai_batch_{budget}", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=4, **kw))
+        s.set_property("isaiScratchBytes", float(budget))
+        s.set_matrix(case)
+        x, perf = s.solve(b, np.zeros_like(b))
+        assert s.get_property("isaiHugeRows") > 100
+        np.testing.assert_array_equal(s.history(), ref.history)
+        np.testing.assert_array_equal(x, ref.x)
+    n = 400
+    rng = np.random.default_rng(SEED)
+    lower = np.concatenate([np.arange(n - 2, dtype=np.int32), np.arange(0, 300, 2, dtype=np.int32)])
+    upper = np.concatenate([np.arange(1, n - 1, dtype=np.int32), np.full(150, n - 1, np.int32)])
+    order = np.lexsort((upper, lower))
+    hub = synthetic.LduCase(n, lower[order], upper[order], rng.uniform(200, 201, n), rng.uniform(-1, 0, order.size), None)
+    bh = rng.uniform(-1, 1, n)
+    A, (rp, cols, vals) = oracle_matrix(oracle, hub)
+    for pk, kind in ((capi.PRECOND_GISAI, "general"), (capi.PRECOND_ISAI, "spd")):
+        P = oracle.Precond(rp, cols, vals, isai=kind)
+        assert int(np.diff(P.w_rowptr).max()) == 151
+        s = reg.solver(f"isai_hub_{kind}", cg_cfg(preconditioner=pk, **kw)).set_matrix(hub)
+        x, perf = s.solve(bh, np.zeros_like(bh))
+        assert s.get_property("isaiHugeRows") == 1.0
+        with blocked(oracle, chunk_rows):
+            ref = oracle.cg(A, bh, np.zeros_like(bh), P, **kw)
+        np.testing.assert_array_equal(s.history(), ref.history)
+        np.testing.assert_array_equal(x, ref.x)
+
+
+def test_isai_rows_wider_than_512_are_refused(reg):
+    case = synthetic.poisson_case(9)
+    s = reg.solver("isai_p8", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=8)).set_matrix(case)
+    with pytest.raises(capi.OglError) as e:                 # A^8 on the 9^3 box: rows of up to 729 entries
         s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
-    assert e.value.status == capi.ERR_UNSUPPORTED
+    assert e.value.status == capi.ERR_UNSUPPORTED and "sparsityPower 8" in str(e.value)
     s = reg.solver("isai_p0", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=0)).set_matrix(case)
     with pytest.raises(capi.OglError) as e:
         s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))

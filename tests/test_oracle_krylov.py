@@ -139,7 +139,7 @@ def test_adaptive_policy(oracle):
 
 
 @pytest.mark.parametrize("sym", [True, False])
-@pytest.mark.parametrize("power", [1, 2, 3])
+@pytest.mark.parametrize("power", [1, 2, 3, 5])       # 5: rows wider than 64 (general: 216 = the whole 6^3 box)
 def test_isai_defining_property_with_sparsity_power(oracle, sym, power):
     """Preconditioner.H:227 `sparsityPower`: W lives on the pattern of S^power (S = tril(A) for ISAI, A for
     GISAI).  General: (W A)(i, j) = delta_ij for every (i, j) of W's pattern -- the defining property of
@@ -163,8 +163,10 @@ def test_isai_defining_property_with_sparsity_power(oracle, sym, power):
     else:
         R = (W @ A - sp.identity(A.shape[0])).toarray()
         assert np.abs(R[(W != 0).toarray()]).max() < 1e-13
+    case9 = synthetic.poisson_case(9, symmetric=sym)
+    rp9, cols9, vals9 = oracle_csr(oracle, case9)
     with pytest.raises(ValueError):
-        oracle.Precond(rp, cols, vals, isai="general", sparsity_power=5)      # rows wider than 64
+        oracle.Precond(rp9, cols9, vals9, isai="general", sparsity_power=8)    # rows wider than 512
 
 
 def test_openmp_baseline_follows_the_sequential_oracle(oracle):
