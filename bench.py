@@ -820,6 +820,14 @@ def main():
             "first_set_matrix_s": t_first_matrix, "refresh_set_matrix_s": t_refresh_matrix,
             "solve_incl_pcie_s": t_e2e,
             "iters_per_sec_incl_pcie": (p_e2e.n_iterations - 1) / t_e2e,
+            # the legs of that one plug-in call as the library timed them (ogl_perf, lduLduBase.H:296-305's block):
+            # coefficients up (upper [+ lower] + diag through the pinned ring, then the gathers), b [+ x] up,
+            # the Krylov loop, x down
+            "update_matrix_ms": p_e2e.t_update_matrix_ms, "upload_ms": p_e2e.t_upload_ms,
+            "solve_ms": p_e2e.t_solve_ms, "copy_back_ms": p_e2e.t_copy_back_ms,
+            "h2d_GBps": 8.0 * (case.n_faces * (1 if case.lower is None else 2) + N) / 1e9 /
+                        max(1e-9, t_refresh_matrix),
+            "d2h_GBps": 8.0 * N / 1e6 / max(1e-9, p_e2e.t_copy_back_ms),
         },
     }
 
