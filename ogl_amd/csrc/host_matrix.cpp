@@ -118,7 +118,7 @@ void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *o
 }
 
 void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
-                        std::vector<ogl_label> &block_ptrs, std::vector<ogl_label> &row_block)
+                        std::vector<ogl_label> &block_ptrs, std::vector<ogl_label> &row_block, bool caller_numbering)
 {
     const ogl_label n = p.n_rows;
     block_ptrs.assign(1, 0);
@@ -127,7 +127,7 @@ void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
     // A renumbered pattern: the blocks are formed on the CALLER's numbering, position i there being row
     // p.new_id[i] here (two rows have the same column set in one numbering exactly when they have it in the other,
     // and both are stored in ascending order of THIS numbering)
-    const bool rn = p.renumbered();
+    const bool rn = p.renumbered() && caller_numbering;
     auto same_pattern = [&](ogl_label a, ogl_label b) {
         if (rn) {
             a = p.new_id[a];
@@ -424,7 +424,7 @@ int build_host_pattern(const ogl_ldu_view &ldu, HostPattern &p)
 }
 
 bool isai_pattern(const HostPattern &p, bool spd, int power, int max_row, std::vector<ogl_label> &w_row_ptrs,
-                  std::vector<ogl_label> &w_cols, ogl_label &first_wide_row)
+                  std::vector<ogl_label> &w_cols, ogl_label &first_wide_row, bool caller_numbering)
 {
     const ogl_label N = p.n_rows;
     w_row_ptrs.assign((size_t)N + 1, 0);
@@ -433,7 +433,7 @@ bool isai_pattern(const HostPattern &p, bool spd, int power, int max_row, std::v
     std::vector<ogl_label> seen((size_t)N, -1), row, next;
     // spd: tril(A) of the matrix OpenFOAM hands over (Preconditioner.H:225-241) -- on a renumbered pattern the
     // triangle is taken by the caller's index, i.e. W gets the pattern P tril(A) P^T
-    const bool rn = p.renumbered();
+    const bool rn = p.renumbered() && caller_numbering;
     auto in_s = [&](ogl_label r, ogl_label c) {
         return !spd || (rn ? p.old_of[(size_t)c] <= p.old_of[(size_t)r] : c <= r);
     };

@@ -75,8 +75,11 @@ bool same_counts(const ogl_ldu_view &ldu, const HostPattern &p);
 // Jacobi block pointers for maxBlockSize > 1 ([UPSTREAM] gko::preconditioner::Jacobi
 // find_blocks): natural blocks = runs of consecutive rows with identical column pattern (capped at
 // max_block_size), adjacent natural blocks agglomerated while the merged size <= max_block_size.
+// On a renumbered pattern the blocks are those of the CALLER's numbering (block_ptrs / row_block refer to positions
+// there, position i = row p.new_id[i] here) unless caller_numbering is false (an A/B switch: round-3 behaviour).
 void find_jacobi_blocks(const HostPattern &p, ogl_label max_block_size,
-                        std::vector<ogl_label> &block_ptrs, std::vector<ogl_label> &row_block);
+                        std::vector<ogl_label> &block_ptrs, std::vector<ogl_label> &row_block,
+                        bool caller_numbering = true);
 
 // Index-compressed chunked ELL of a row-major sorted pattern (SellChunk, common.hpp).  Returns false
 // (and leaves `out` unusable) when the pattern does not qualify; the CSR-stream kernel runs then.
@@ -209,8 +212,10 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
 // Pattern of the ISAI approximate inverse W (keyword sparsityPower, Preconditioner.H:227): rows of
 // S^power in ascending column order, S = tril(A) (spd = ISAI) or A (general = GISAI).  Returns false
 // (first_wide_row set) when a row would get more than `max_row` entries.
+// spd on a renumbered pattern: the triangle is taken by the caller's index (P tril(A) P^T) unless caller_numbering
+// is false.
 bool isai_pattern(const HostPattern &p, bool spd, int power, int max_row, std::vector<ogl_label> &w_row_ptrs,
-                  std::vector<ogl_label> &w_cols, ogl_label &first_wide_row);
+                  std::vector<ogl_label> &w_cols, ogl_label &first_wide_row, bool caller_numbering = true);
 
 // HostMatrix.C:180-207: concatenated bouCoeffs of the (non-)processor interfaces, times -1.
 void collect_interface_coeffs(const ogl_ldu_view &ldu, bool local, ogl_scalar *out);

@@ -553,12 +553,19 @@ __global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__r
             for (int j = 0; j < bs; ++j) a[i * LD + j] -= f * a[k * LD + j];
         }
     }
+    // block-major, `ld` doubles per block row -- except through a permutation, where member i's row of the inverse
+    // is stored at its DEVICE row (rows[r0 + i] * ld): the apply then reads it coalesced instead of from wherever
+    // the block sits in the caller's order
     double *out = blocks + (size_t)b * ld * ld;
-    for (int i = 0; i < ld * ld; ++i) out[i] = 0.0;
+    if (!rows)
+        for (int i = 0; i < ld * ld; ++i) out[i] = 0.0;
     double row[LD];
     for (int i = 0; i < bs; ++i) {
         for (int j = 0; j < bs; ++j) row[perm[j]] = a[i * LD + j];
-        for (int j = 0; j < bs; ++j) out[i * ld + j] = row[j];
+        double *o = rows ? blocks + (size_t)rows[r0 + i] * ld : out + (size_t)i * ld;
+        for (int j = 0; j < bs; ++j) o[j] = row[j];
+        if (rows)
+            for (int j = bs; j < ld; ++j) o[j] = 0.0;
     }
 }
 
@@ -974,7 +981,7 @@ __global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply(int n_rows,
             r0 = block_ptrs[b];
             bs = block_ptrs[b + 1] - r0;
         }
-        const double *a = blocks + (size_t)b * ld * ld + (size_t)(at - r0) * ld;
+        const double *a = rows ? blocks + (size_t)row * ld : blocks + (size_t)b * ld * ld + (size_t)(at - r0) * ld;
         if (rows)
             for (int j = 0; j < bs; ++j) sum += a[j] * in[rows[r0 + j]];
         else

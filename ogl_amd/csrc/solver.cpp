@@ -86,6 +86,8 @@ class ogl::CopyPool {
 public:
     explicit CopyPool(int n_threads) : n_(std::max(1, n_threads))
     {
+        // (binding the helpers to different L3 domains of the caller's socket was measured and changes nothing:
+        //  46 GB/s either way on the 2 x EPYC 9575F hosts -- the copy is not what limits a transfer any more)
         for (int t = 1; t < n_; ++t) helpers_.emplace_back([this, t] { run(t); });
     }
     ~CopyPool()
@@ -1771,6 +1773,12 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
 {
     hipStream_t st = reg->stream;
     const size_t n = (size_t)pat.n_rows;
+    // structures of a renumbered device copy (block-Jacobi blocks, ISAI(spd)'s triangle) in the CALLER's numbering:
+    // the reference's operator (property precondCallerNumbering 0 = the backend's numbering, for A/B)
+    const bool caller_numbering = prop("precondCallerNumbering", 1.0) != 0.0;
+    const bool through_perm = pat.renumbered() && caller_numbering;
+    if (P.struct_caller_numbering != caller_numbering) P.struct_pat_id = 0;  // (the switch was flipped: rebuild)
+    P.struct_caller_numbering = caller_numbering;
     if (cfg.preconditioner == OGL_PRECOND_ISAI || cfg.preconditioner == OGL_PRECOND_GISAI) {
         // Isai<spd|general> with sparsity_power 1 and skip_sorting (Preconditioner.H:225-258).
         // Pattern of W on the host (tril(A) for spd, A for general), its transpose + map for spd,
@@ -1783,7 +1791,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             std::vector<int32_t> wrp, wc;
             ogl_label wide = -1;
             OGL_TRY(download_local_pattern(pat));
-            if (!isai_pattern(pat, spd, cfg.sparsity_power, MAX_ISAI_HUGE_ROW, wrp, wc, wide))
+            if (!isai_pattern(pat, spd, cfg.sparsity_power, MAX_ISAI_HUGE_ROW, wrp, wc, wide, caller_numbering))
                 return fail(OGL_ERR_UNSUPPORTED,
                             "preconditioner %s, sparsityPower %d: row %d of the approximate inverse has more than %d "
                             "pattern entries (lower sparsityPower)", spd ? "ISAI" : "GISAI", cfg.sparsity_power, wide,
@@ -1863,6 +1871,8 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             if (cfg.compress_indices) OGL_TRY(P.w_sell.build(N, wrp.data(), wc.data(), reg->stager, st));
             P.w_nnz = (int32_t)wn;
             P.w_max_row = max_row;
+            props["isaiWCompressed"] = P.w_sell.ready ? 1.0 : 0.0;
+            props["isaiWtCompressed"] = P.wt_sell.ready ? 1.0 : 0.0;
             P.struct_pat_id = pat_id;
             P.struct_kind = kind;
             P.struct_stride = cfg.sparsity_power;
@@ -1890,7 +1900,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             P.struct_pat_id = 0;
             std::vector<int32_t> ptrs, row_block;
             OGL_TRY(download_local_pattern(pat));
-            find_jacobi_blocks(pat, cfg.max_block_size, ptrs, row_block);
+            find_jacobi_blocks(pat, cfg.max_block_size, ptrs, row_block, caller_numbering);
             P.n_blocks = (int32_t)ptrs.size() - 1;
             P.uniform_blocks = true;
             for (int32_t b = 0; b + 1 < P.n_blocks; ++b)
@@ -1914,10 +1924,12 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         J.block_ptrs = P.block_ptrs.p;
         J.row_block = P.row_block.p;
         J.blocks = P.values.p;
-        if (pat.renumbered()) {  // blocks of the caller's numbering, reached through the permutation
+        if (through_perm) {  // blocks of the caller's numbering, reached through the permutation
             J.rows = d_new_id.p;
             J.pos = d_old_of.p;
         }
+        P.through_perm = through_perm;
+        P.perm_pat_id = through_perm ? pat_id : 0;
         launch_bj_generate(st, csr(), J);
         P.kind = 2;
         P.stride = cfg.max_block_size;
@@ -1971,7 +1983,7 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
     J.row_block = precond_data->row_block.p;
     J.blocks = precond_data->values.p;
     J.uniform = precond_data->uniform_blocks ? 1 : 0;
-    if (pat.renumbered()) {
+    if (pat.renumbered() && precond_data->through_perm) {
         J.rows = d_new_id.p;
         J.pos = d_old_of.p;
     }
@@ -1999,7 +2011,10 @@ int ogl_solver::init_preconditioner()
     const int cache = (int)prop("preconditionerCaching", 0);
     const bool stored =
         reg->has_cached_precond && reg->cached_precond.matches(kind, (size_t)pat.n_rows, stride);
-    if (stored && cache > 0) {
+    // (a stored block Jacobi whose rows were laid out through ANOTHER pattern's permutation -- the store is shared by
+    //  all fields, Preconditioner.H:357 -- cannot be applied through this one's: generate for this solve instead)
+    const bool foreign = stored && reg->cached_precond.through_perm && reg->cached_precond.perm_pat_id != pat_id;
+    if (stored && cache > 0 && !foreign) {
         props["preconditionerCaching"] = cache - 1;
         precond_data = &reg->cached_precond;
     } else {

@@ -126,6 +126,8 @@ struct PrecondData {
     int stride = 0;  // block Jacobi: maxBlockSize
     int32_t n_blocks = 0;
     bool uniform_blocks = false;  // block Jacobi: every block but the last has exactly `stride` rows
+    bool through_perm = false;    // block Jacobi: block_ptrs / row_block are positions in the caller's numbering
+    uint64_t perm_pat_id = 0;     // ... and the block rows are stored at the device rows of THIS pattern's permutation
     DevBuf<double> values;  // inverse diagonal (n_rows + 2) or inverted blocks
     DevBuf<int32_t> block_ptrs, row_block;
     // ISAI (kind 3: spd, M^-1 = W^T W; kind 4: general, M^-1 = W): CSR arrays padded like the
@@ -149,6 +151,7 @@ struct PrecondData {
     // derived from the same sparsity pattern: only the values are regenerated per solve
     uint64_t struct_pat_id = 0;
     int struct_kind = 0, struct_stride = 0;
+    bool struct_caller_numbering = true;
     bool has_structure(uint64_t id, int k, int st) const
     {
         return id != 0 && struct_pat_id == id && struct_kind == k && struct_stride == st;
