@@ -55,9 +55,10 @@ def oracle_matrix_renumbered(oracle, case, new_id, **kw):
     return oracle.DistMatrix(rp, cc, vv), (rp, cc, vv)
 
 
-def oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, max_block_size=1, isai=None, **kw):
+def oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, max_block_size=1, isai=None, sparsity_power=1, **kw):
     """The reference's preconditioner -- generated on the matrix OpenFOAM hands over, i.e. in the CALLER's numbering
     (Preconditioner.H:91-105, :225-241) -- expressed on the system (rp, cols, vals) the library renumbered by new_id:
     block-Jacobi blocks are runs of consecutive CALLER rows, ISAI(spd) takes tril(A) by the caller's index."""
     rp0, c0, v0 = oracle_csr(oracle, case, **kw)
-    return oracle.Precond(rp, cols, vals, max_block_size, isai=isai, caller=(rp0, c0, v0, new_id))
+    return oracle.Precond(rp, cols, vals, max_block_size, isai=isai, sparsity_power=sparsity_power,
+                          caller=(rp0, c0, v0, new_id))
