@@ -267,3 +267,35 @@ def test_auto_renumbering_above_its_size_threshold_with_numbering_dependent_prec
           else oracle.Precond(rp0, cols0, vals0, isai="spd"))
     ref0 = oracle.cg(A0, b, np.zeros_like(b), P0, **skw)
     assert abs(perf.n_iterations - ref0.n_iterations) <= 1
+
+
+@pytest.mark.parametrize("name,kw", [("cg_bj4", dict(preconditioner=capi.PRECOND_BJ, max_block_size=4)),
+                                     ("cg_isai", dict(preconditioner=capi.PRECOND_ISAI))])
+def test_preconditioner_structures_in_the_backends_numbering_on_request(reg, oracle, chunk_rows, name, kw):
+    """Property precondCallerNumbering 0 (the A/B switch): blocks / triangle taken in the backend's
+    numbering -- the round-3 behaviour, another preconditioner of the same kind; bit-exact against the oracle that
+    builds its preconditioner on the permuted system.  Flipping the property on a live field rebuilds the structure."""
+    case = synthetic.renumber_case(synthetic.poisson_case(14), 700)
+    b = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
+    skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=300)
+    s = reg.solver("rnb_" + name, cfg(**kw, **skw))
+    s.set_property("precondCallerNumbering", 0.0)
+    s.set_matrix(case)
+    new_id = s.renumbering()
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    P_dev = (oracle.Precond(rp, cols, vals, kw["max_block_size"]) if kw["preconditioner"] == capi.PRECOND_BJ
+             else oracle.Precond(rp, cols, vals, isai="spd"))
+    P_caller = oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, kw.get("max_block_size", 1),
+                                         isai="spd" if kw["preconditioner"] == capi.PRECOND_ISAI else None)
+    with blocked(oracle, chunk_rows):
+        ref_dev = oracle.cg(A, to_new(b, new_id), np.zeros_like(b), P_dev, **skw)
+        ref_caller = oracle.cg(A, to_new(b, new_id), np.zeros_like(b), P_caller, **skw)
+    np.testing.assert_array_equal(s.history(), ref_dev.history)
+    np.testing.assert_array_equal(x, ref_dev.x[new_id])
+    assert not np.array_equal(ref_dev.history[:10], ref_caller.history[:10])      # really two operators
+    s.set_property("precondCallerNumbering", 1.0)                                 # back to the reference's operator
+    s.upload_solution(None)
+    x1, _ = s.solve(b, np.zeros_like(b))
+    np.testing.assert_array_equal(s.history(), ref_caller.history)
+    np.testing.assert_array_equal(x1, ref_caller.x[new_id])
