@@ -507,7 +507,8 @@ __global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__r
                                                     const int *__restrict__ cols,
                                                     const double *__restrict__ vals,
                                                     double *__restrict__ blocks, int ld,
-                                                    const int *__restrict__ rows, const int *__restrict__ pos)
+                                                    const int *__restrict__ rows, const int *__restrict__ pos,
+                                                    int by_device_row)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_blocks) return;
@@ -557,14 +558,15 @@ __global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__r
     // is stored at its DEVICE row (rows[r0 + i] * ld): the apply then reads it coalesced instead of from wherever
     // the block sits in the caller's order
     double *out = blocks + (size_t)b * ld * ld;
-    if (!rows)
+    const bool dev = rows && by_device_row;
+    if (!dev)
         for (int i = 0; i < ld * ld; ++i) out[i] = 0.0;
     double row[LD];
     for (int i = 0; i < bs; ++i) {
         for (int j = 0; j < bs; ++j) row[perm[j]] = a[i * LD + j];
-        double *o = rows ? blocks + (size_t)rows[r0 + i] * ld : out + (size_t)i * ld;
+        double *o = dev ? blocks + (size_t)rows[r0 + i] * ld : out + (size_t)i * ld;
         for (int j = 0; j < bs; ++j) o[j] = row[j];
-        if (rows)
+        if (dev)
             for (int j = bs; j < ld; ++j) o[j] = 0.0;
     }
 }
@@ -944,6 +946,41 @@ __device__ __forceinline__ void st2_stream(double *__restrict__ p, const RowPair
     }
 }
 static_assert(ROWS_PER_THREAD == 2, "vector kernels are written for two rows per thread");
+
+// Block Jacobi through a permutation, staged (launch_bj_apply_staged): the input once into the CALLER's order
+// (out[i] = in[idx[i]], one gather per row instead of one per block member), the contiguous apply there, and back:
+__global__ __launch_bounds__(BLOCK) void k_gather_gated(int n, const int *__restrict__ idx, const double *__restrict__ in,
+                                                        double *__restrict__ out, const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+// out[row] = src[idx[row]] for this chunk's rows, and (NDOT) the chunk's partial of sum_i w_i * out_i in the
+// canonical per-chunk tree (k_partials' bits)
+template <int NDOT>
+__global__ __launch_bounds__(BLOCK) void k_gather_back_dot(int n, const int *__restrict__ idx,
+                                                           const double *__restrict__ src, double *__restrict__ out,
+                                                           const double *__restrict__ w,
+                                                           double *__restrict__ dot_part, const DevScalars *gate)
+{
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 v;
+    v.x = rp.n > 0 ? src[idx[rp.row]] : 0.0;
+    v.y = rp.n > 1 ? src[idx[rp.row + 1]] : 0.0;
+    st2(out, rp, v);
+    if (NDOT) {
+        const double2 vw = ld2(w, rp);
+        double d = 0.0;
+        if (rp.n > 0) d += vw.x * v.x;
+        if (rp.n > 1) d += vw.y * v.y;
+        const double s = block_sum(d, slot);
+        if (threadIdx.x == 0) dot_part[chunk] = s;
+    }
+}
 
 // block-Jacobi apply (DevBlockJacobi): one row per thread, CHUNK_ROWS threads per workgroup (the
 // dependent index loads want many rows in flight).  NDOT = 1: also the chunk's partial of
@@ -3609,7 +3646,7 @@ void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J
     const dim3 grid((J.n_blocks + 63) / 64), block(64);
 #define OGL_BJ(LD)                                                                              \
     hipLaunchKernelGGL((k_bj_generate<LD>), grid, block, 0, st, J.n_blocks, J.block_ptrs,        \
-                       A.row_ptrs, A.cols, A.vals, J.blocks, J.stride, J.rows, J.pos)
+                       A.row_ptrs, A.cols, A.vals, J.blocks, J.stride, J.rows, J.pos, J.by_device_row)
     if (J.stride <= 2)
         OGL_BJ(2);
     else if (J.stride <= 4)
@@ -3634,6 +3671,21 @@ void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, 
     else
         hipLaunchKernelGGL((k_bj_apply<0>), grid, block, 0, st, J.n_rows, J.block_ptrs, J.row_block,
                            J.blocks, J.stride, J.uniform, in, out, dot_part, gate, J.rows, J.pos);
+}
+
+void launch_bj_apply_staged(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out, double *dot_part,
+                            const DevScalars *gate, double *tmp_in, double *tmp_out)
+{
+    if (J.n_rows == 0) return;
+    hipLaunchKernelGGL(k_gather_gated, dim3(blocks_for(J.n_rows)), dim3(BLOCK), 0, st, J.n_rows, J.rows, in, tmp_in, gate);
+    DevBlockJacobi C = J;  // the blocks as they lie in the caller's order
+    C.rows = C.pos = nullptr;
+    launch_bj_apply(st, C, tmp_in, tmp_out, nullptr, gate);
+    const dim3 grid((unsigned)n_chunks(J.n_rows)), block(BLOCK);
+    if (dot_part)
+        hipLaunchKernelGGL((k_gather_back_dot<1>), grid, block, 0, st, J.n_rows, J.pos, tmp_out, out, in, dot_part, gate);
+    else
+        hipLaunchKernelGGL((k_gather_back_dot<0>), grid, block, 0, st, J.n_rows, J.pos, tmp_out, out, in, dot_part, gate);
 }
 
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,

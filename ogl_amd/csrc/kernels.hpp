@@ -195,6 +195,9 @@ struct DevBlockJacobi {
     // the matrix OpenFOAM hands over) -- block_ptrs / row_block refer to positions there, rows[position] = device
     // row, pos[device row] = position.  nullptr: the device copy is in the caller's numbering.
     const int32_t *rows = nullptr, *pos = nullptr;
+    // ... and the block rows are stored at their device rows (rows[position] * stride; the direct apply) instead of
+    // block-major in the caller's order (the staged apply)
+    int32_t by_device_row = 0;
 };
 constexpr int MAX_JACOBI_BLOCK = 32;
 // blocks[b] = inverse of A(block b, block b) by Gauss-Jordan with partial pivoting
@@ -203,6 +206,11 @@ void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J
 // dot_part != nullptr: also the per-chunk partials of sum_i in_i * out_i
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,
                      double *dot_part, const DevScalars *gate);
+// the same through a permutation in three launches (J.rows / J.pos set, blocks block-major in the caller's order):
+// in -> caller's order (one gather per row), contiguous apply, back to the device order + the dot partials.
+// tmp_in / tmp_out: two scratch vectors of n_rows doubles
+void launch_bj_apply_staged(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out, double *dot_part,
+                            const DevScalars *gate, double *tmp_in, double *tmp_out);
 
 // ISAI / GISAI (Preconditioner.H:225-258): row i of the approximate inverse W lives on the pattern J of
 // row i of S^sparsityPower (S = tril(A) resp. A, built on the host) and solves a dense system over it by

@@ -127,7 +127,8 @@ struct PrecondData {
     int32_t n_blocks = 0;
     bool uniform_blocks = false;  // block Jacobi: every block but the last has exactly `stride` rows
     bool through_perm = false;    // block Jacobi: block_ptrs / row_block are positions in the caller's numbering
-    uint64_t perm_pat_id = 0;     // ... and the block rows are stored at the device rows of THIS pattern's permutation
+    uint64_t perm_pat_id = 0;     // ... of THIS pattern's permutation
+    bool by_device_row = false;   // block rows stored at their device rows (direct apply) instead of block-major (staged)
     DevBuf<double> values;  // inverse diagonal (n_rows + 2) or inverted blocks
     DevBuf<int32_t> block_ptrs, row_block;
     // ISAI (kind 3: spd, M^-1 = W^T W; kind 4: general, M^-1 = W): CSR arrays padded like the
@@ -368,6 +369,7 @@ struct ogl_solver {
     ogl::DevBuf<double> d_x, d_b, d_r, d_p, d_q, d_w, d_inv_diag;
     ogl::DevBuf<double> d_p2;  // second p buffer of the 2-launch turn (k_cg_turn_sym)
     ogl::DevBuf<double> d_p_halo;  // multi-rank merged turn: old / new p at the halo columns
+    ogl::DevBuf<double> d_bj_tmp0, d_bj_tmp1;  // block Jacobi through a permutation, staged apply: in / out in the caller's order
     ogl::DevBuf<double> d_v, d_s, d_t, d_y, d_z, d_rr;  // BiCGStab
     ogl::DevBuf<double> d_V, d_gm;                      // GMRES: Krylov bases, dense state
     ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T

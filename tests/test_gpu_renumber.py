@@ -299,3 +299,36 @@ def test_preconditioner_structures_in_the_backends_numbering_on_request(reg, ora
     x1, _ = s.solve(b, np.zeros_like(b))
     np.testing.assert_array_equal(s.history(), ref_caller.history)
     np.testing.assert_array_equal(x1, ref_caller.x[new_id])
+
+
+@pytest.mark.parametrize("staged", [1.0, 0.0], ids=["staged", "direct"])
+@pytest.mark.parametrize("k", [2, 4, 7])
+def test_block_jacobi_through_the_permutation_both_applies(reg, oracle, chunk_rows, staged, k):
+    """The caller's blocks on a renumbered copy: the staged apply (vectors carried into the caller's order and back,
+    blocks block-major there; default) and the direct one (block rows stored at their device rows, members gathered)
+    give the oracle's bits; block sizes that do not divide the row count."""
+    case = synthetic.renumber_case(synthetic.poisson_block(13, 11, 7), 300)
+    b = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
+    skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=200)
+    s = reg.solver(f"rnbj_{k}_{staged}", cfg(preconditioner=capi.PRECOND_BJ, max_block_size=k, **skw))
+    s.set_property("bjStagedApply", staged)
+    s.set_matrix(case)
+    new_id = s.renumbering()
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    P = oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, k)
+    with blocked(oracle, chunk_rows):
+        ref = oracle.cg(A, to_new(b, new_id), np.zeros_like(b), P, **skw)
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x[new_id])
+    # BiCGStab and GMRES use the apply without the fused dot
+    for solver, fn, extra in ((capi.SOLVER_BICGSTAB, oracle.bicgstab, {}), (capi.SOLVER_GMRES, oracle.gmres, dict(krylov_dim=10))):
+        s2 = reg.solver(f"rnbj_{k}_{staged}_{solver}", cfg(solver=solver, preconditioner=capi.PRECOND_BJ, max_block_size=k,
+                                                          krylov_dim=extra.get("krylov_dim", 0), **skw))
+        s2.set_property("bjStagedApply", staged)
+        s2.set_matrix(case)
+        x2, _ = s2.solve(b, np.zeros_like(b))
+        with blocked(oracle, chunk_rows):
+            ref2 = fn(A, to_new(b, new_id), np.zeros_like(b), P, **extra, **skw)
+        np.testing.assert_array_equal(s2.history(), ref2.history)
+        np.testing.assert_array_equal(x2, ref2.x[new_id])
