@@ -355,6 +355,20 @@ extern "C" int ogl_solver_spmv(ogl_solver *s, const ogl_scalar *x, ogl_scalar *y
     OGL_TRY(s->dist_spmv(SPMV_PLAIN, s->d_w.p, nullptr, s->d_q.p, SpmvDots{}, nullptr));
     OGL_TRY(s->download_rows(y, s->d_q.p));
     OGL_HIP_CHECK(hipGetLastError());
+    // a neighbour whose halo values did not arrive within the time-out leaves the LOCAL product behind and raises
+    // comm_error in the device scalars (kernels.hip halo_fused_add / k_halo_finish): never hand that out silently
+    if (s->pat.non_local_nnz > 0 && s->peer_halo) {
+        DevScalars sc;
+        OGL_HIP_CHECK(hipMemcpy(&sc, s->d_scal.p, sizeof(sc), hipMemcpyDeviceToHost));
+        if (sc.comm_error) {
+            sc.comm_error = 0;
+            sc.stop = 0;
+            OGL_HIP_CHECK(hipMemcpy(s->d_scal.p, &sc, sizeof(sc), hipMemcpyHostToDevice));
+            return fail(OGL_ERR_COMM, "halo exchange timed out: a neighbour's values did not arrive (ranks that share "
+                                      "one device can starve each other's put kernels: every waiting workgroup holds a "
+                                      "slot the producer needs)");
+        }
+    }
     return OGL_OK;
     OGL_GUARD_END
 }

@@ -87,10 +87,14 @@ def gather_global(case, x):
 
 
 def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
-    b = b_g[case.global_index]
-
     A, (rp, cols, vals), nl, comm = oracle_dist_matrix(
         case, allreduce_rank_order if args.mode == "gpu-peer" else allreduce)
+    if glob is None:
+        # --no-global (full-size decomposed configs): nothing of the assembled system is built -- b = A x* through the
+        # oracle's own distributed product (halo exchange over gloo), every check is rank-local or collective
+        b = A.apply(synthetic.x_star(case.global_index, case.global_n))
+    else:
+        b = b_g[case.global_index]
     inv = orc.jacobi_generate_scalar(rp, cols, vals) if args.precond else None
 
     # ---- product host logic per rank vs the oracle (pure host, no GPU) ----
@@ -104,10 +108,15 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
 
     # ---- distributed SpMV vs the global operator ----
     rng = np.random.default_rng(20241016)
-    xg = rng.uniform(-1, 1, glob.n_cells)
-    y = A.apply(xg[case.global_index])
-    np.testing.assert_allclose(gather_global(case, y), synthetic.apply_case(glob, xg), rtol=1e-13,
-                               atol=1e-13)
+    if glob is None:
+        x_loc = np.random.default_rng(20241016 + rank).uniform(-1, 1, case.n_cells)
+        y = A.apply(x_loc)
+    else:
+        xg = rng.uniform(-1, 1, glob.n_cells)
+        x_loc = xg[case.global_index]
+        y = A.apply(x_loc)
+        np.testing.assert_allclose(gather_global(case, y), synthetic.apply_case(glob, xg), rtol=1e-13,
+                                   atol=1e-13)
 
     solve = orc.bicgstab if args.asym else orc.cg
     if args.gmres:
@@ -188,10 +197,32 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
         np.testing.assert_array_equal(r_, nl[0])
         np.testing.assert_array_equal(c_, nl[1])
         np.testing.assert_array_equal(v_, nl[3])
+        if os.environ.get("OGL_DIST_DEBUG"):
+            import time
+            t0 = time.time()
+            yd = s.spmv(x_loc)
+            print(f"rank {rank}: first spmv took {time.time() - t0:.2f} s", flush=True)
+            bad = np.flatnonzero(yd != y)
+            y_local = orc.spmv(rp, cols, vals, x_loc)          # without the non-local part
+            nlr = np.asarray(nl[0])
+            print(f"rank {rank}: {bad.size} rows differ; of them {int(np.isin(bad, nlr).sum())} are boundary rows "
+                  f"(boundary rows: {np.unique(nlr).size}); equal to the LOCAL product on {int((yd[bad] == y_local[bad]).sum())}; "
+                  f"first bad rows {bad[:6].tolist()} last {bad[-3:].tolist()}", flush=True)
+            # which neighbour's block do the bad rows read?
+            ids, sizes = np.asarray(comm[0]), np.asarray(comm[1])
+            offs = np.concatenate([[0], np.cumsum(sizes)])
+            nlc = np.asarray(nl[1])
+            for i, nb in enumerate(ids):
+                rows_i = nlr[(nlc >= offs[i]) & (nlc < offs[i + 1])]
+                print(f"rank {rank}: neighbour {nb} block [{offs[i]}, {offs[i+1]}): {int(np.isin(rows_i, bad).sum())} of "
+                      f"{rows_i.size} rows bad", flush=True)
+            t0 = time.time()
+            yd2 = s.spmv(x_loc)
+            print(f"rank {rank}: second spmv: {int((yd2 != y).sum())} rows differ, took {time.time() - t0:.2f} s", flush=True)
         if args.renumber:
-            np.testing.assert_allclose(s.spmv(xg[case.global_index]), y, rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(s.spmv(x_loc), y, rtol=1e-13, atol=1e-13)
         else:
-            np.testing.assert_array_equal(s.spmv(xg[case.global_index]), y)
+            np.testing.assert_array_equal(s.spmv(x_loc), y)
         x, perf = s.solve(b, np.zeros_like(b))
         hist = s.history()
         if args.expect_merged >= 0:
@@ -212,7 +243,7 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
             m = min(hist.size, ref.history.size, 30)
             np.testing.assert_allclose(hist[:m], ref.history[:m], rtol=1e-10)
             np.testing.assert_allclose(x, ref.x, atol=1e-9, rtol=0)
-        if args.max_iter >= 300:
+        if args.max_iter >= 300 and glob is not None:
             np.testing.assert_allclose(gather_global(case, x), xs_g, atol=1e-8, rtol=0)
 
 
@@ -237,6 +268,12 @@ def main():
                     help="0 / 1: assert that the merged turn did not run / ran (fusedTurnInUse)")
     ap.add_argument("--max-iter", type=int, default=300,
                     help="below 300: a fixed number of turns (large systems), no convergence check")
+    ap.add_argument("--no-global", type=int, default=0,
+                    help="1: do not assemble the global system on every rank (full-size decomposed configs: 20 M / 50 M "
+                         "cells); b = A x* through the oracle's distributed product, rank-local and collective checks only")
+    ap.add_argument("--shuffle", type=int, default=0,
+                    help="W > 0: every rank's cells renamed at random inside windows of W cells (an unstructured numbering "
+                         "per rank; interfaces keep their face order)")
     ap.add_argument("--relabel", type=int, default=0,
                     help="1 (gpu modes): after the first solve the LAST rank alone renames its cells (same "
                          "counts, new addressing) and every rank calls set_matrix + solve again: the rebuild "
@@ -263,9 +300,11 @@ def main():
         if args.asym:
             kw.update(off_upper=-0.9, off_lower=-1.1)
         case = synthetic.poisson_block(gx, gy, gz, px, py, pz, rank, **kw)
-        glob = synthetic.poisson_block(gx, gy, gz, **kw)
-    xs_g = synthetic.x_star(glob.global_index, glob.global_n)
-    b_g = synthetic.apply_case(glob, xs_g)
+        glob = None if args.no_global else synthetic.poisson_block(gx, gy, gz, **kw)
+        if args.shuffle:
+            case = synthetic.renumber_case(case, args.shuffle, seed=20241016 + rank)
+    xs_g = None if glob is None else synthetic.x_star(glob.global_index, glob.global_n)
+    b_g = None if glob is None else synthetic.apply_case(glob, xs_g)
     skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=args.max_iter)
     cases = [case]
     if args.relabel:
