@@ -2053,7 +2053,8 @@ int ogl_solver::init_preconditioner()
 HaloPutFused ogl_solver::begin_halo_put()
 {
     HaloPutFused put;
-    if (!(pat.non_local_nnz > 0 && peer_halo) || prop("haloFused", 1.0) == 0.0) return put;
+    if (!(pat.non_local_nnz > 0 && peer_halo) || prop("haloFused", 1.0) == 0.0 || prop("peerSafeWait", 0.0) != 0.0)
+        return put;
     if (++halo_seq == 0) ++halo_seq;
     cur_halo = peer_halo_args(halo_seq);
     put.P = cur_halo;
@@ -2093,7 +2094,11 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     // peer-put transport: by default the non-local part is added inside the local kernel (HaloFused) -- a
     // distributed SpMV is then 2 launches (pack + put + signal | local + wait + non-local), 1 when the producer
     // of x has put the values itself; property haloFused 0 keeps the separate finish kernel (A/B)
-    const bool fuse = has_halo && peer_halo && prop("haloFused", 1.0) != 0.0;
+    // peerSafeWait 1 (ranks that SHARE a device): no workgroup of the SpMV waits -- ONE workgroup of a
+    // kernel of its own does, then the non-local part is added by kernels that find the values there.  Many waiting
+    // workgroups of several ranks on one device can hold every slot the producers' put kernels need.
+    const bool safe = has_halo && peer_halo && prop("peerSafeWait", 0.0) != 0.0;
+    const bool fuse = has_halo && peer_halo && !safe && prop("haloFused", 1.0) != 0.0;
     HaloFused hf;
     if (has_halo && peer_halo) {
         // peer-put: the values go straight into the neighbours' receive blocks over xGMI, then the
@@ -2134,7 +2139,16 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
         launch_spmv_sell(st, sell(), mode, x, b, y, dots, gate, hf);
     else
         launch_spmv(st, csr(), mode, x, b, y, dots, gate, hf);
-    if (has_halo && peer_halo && !fuse) {
+    if (safe) {
+        launch_halo_wait(st, ph, gate, d_scal.p);
+        launch_spmv_non_local(st, halo(), mode, recv, y, gate);
+        if (dots.part)
+            launch_partials_dot_chunks(st, pat.n_rows, dots.with, y, dots.part, gate, d_boundary_chunks.p,
+                                       n_boundary_chunks);
+        if (dots.part_yy)
+            launch_partials_dot_chunks(st, pat.n_rows, y, y, dots.part_yy, gate, d_boundary_chunks.p,
+                                       n_boundary_chunks);
+    } else if (has_halo && peer_halo && !fuse) {
         // wait for the neighbours' flags, add the non-local part, redo the touched chunks' partials
         launch_halo_finish(st, halo(), mode, pat.n_rows, d_boundary_chunks.p, d_boundary_chunk_ptr.p,
                            n_boundary_chunks, recv, y, dots, ph, gate, d_scal.p);
@@ -2240,7 +2254,9 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     const bool multi = reg->comm->multi();
     bool merged = !bicg && !gmres && !generic && nc >= 1 && use_sym() && cfg.matrix_format != OGL_FORMAT_ELL &&
                   (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
-    if (multi) merged = merged && peer_halo && prop("haloFused", 1.0) != 0.0 && prop("fusedTurnMulti", 1.0) != 0.0;
+    if (multi)
+        merged = merged && peer_halo && prop("haloFused", 1.0) != 0.0 && prop("fusedTurnMulti", 1.0) != 0.0 &&
+                 prop("peerSafeWait", 0.0) == 0.0;
     double n_global = (double)n;
     if (multi) {
         // global row count (Partition.H:118-121) and the agreement on the turn, through the device all-reduce

@@ -260,6 +260,16 @@ def test_gpu_config4_eight_way_50m_cells_gmres():
 
 
 @pytest.mark.gpu
+def test_gpu_config3_eight_way_20m_cells_peer_mesh_single_waiter():
+    # the same 8 x 136^3 through the PEER MESH (puts into the neighbours' receive blocks, mailbox all-reduces) with property
+    # peerSafeWait: one workgroup per rank waits for the flags instead of every boundary workgroup of the SpMV, so eight
+    # ranks on one device cannot starve each other -- three neighbours and 55,488 halo values per rank at full size
+    run_ranks(8, "--mode", "gpu-peer", "--shape", "272,272,272", "--procs", "2,2,2", "--precond", "1",
+              "--max-iter", "10", "--no-global", "1", "--peer-safe-wait", "1", "--expect-merged", "0", timeout=1500)
+    run_ranks(3, "--mode", "gpu-peer", "--random", "15", "--peer-safe-wait", "1", "--asym", "1")
+
+
+@pytest.mark.gpu
 def test_gpu_peer_starved_puts_fail_loudly():
     # the situation described above, provoked on purpose with a short time-out: the SpMV entry point must report
     # OGL_ERR_COMM instead of handing out the local product
