@@ -312,6 +312,24 @@ static void run_gkocg_case(bool periodic)
 }
 
 TEST(gpu_GKOCG_BJ_matches_oracle) { run_gkocg_case(false); }
+
+// the backend's switches as keywords of the solver dictionary (OGLAdapter.H)
+TEST(gpu_property_keywords_reach_the_backend)
+{
+    Case c;
+    build_poisson(c, 12, 10, 8, false, false);
+    scalarField source(c.n, 1.0), psi(c.n, 0.0);
+    dictionary d = cg_dict();
+    auto s1 = lduMatrix::solver::New("pk_default", *c.A, c.bou, c.intc, c.ifaces, d);
+    s1->solve(psi, source);
+    EXPECT_EQ(dynamic_cast<const GKOlduBaseSolver &>(*s1).backend_property("fusedFinalizersInUse"), 1.0);
+    d.add("fusedFinalizers", 0);
+    scalarField psi2(c.n, 0.0);
+    auto s2 = lduMatrix::solver::New("pk_off", *c.A, c.bou, c.intc, c.ifaces, d);
+    s2->solve(psi2, source);
+    EXPECT_EQ(dynamic_cast<const GKOlduBaseSolver &>(*s2).backend_property("fusedFinalizersInUse"), 0.0);
+    EXPECT_TRUE(std::memcmp(psi.cdata(), psi2.cdata(), sizeof(scalar) * c.n) == 0);   // same bits either way
+}
 TEST(gpu_GKOCG_BJ_cyclic_patches) { run_gkocg_case(true); }
 
 TEST(gpu_unsupported_coupled_patch_is_fatal)
