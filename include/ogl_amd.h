@@ -89,7 +89,7 @@ typedef struct ogl_config {
     int32_t force_host_buffer;  /* 0     ExecutorHandler.H:136-139               "forceHostBuffer"   */
     int32_t ranks_per_gpu;      /* 1     ExecutorHandler.H:135 (only 1 works)    "ranksPerGPU"       */
     int32_t krylov_dim;         /* 0 = Ginkgo default (100); GMRES only; NOT a reference keyword   */
-    int32_t sparsity_power;     /* 1     Preconditioner.H:227 (rows of W <= 512)  "sparsityPower"     */
+    int32_t sparsity_power;     /* 1     Preconditioner.H:227 (rows of W <= 2048)  "sparsityPower"     */
     int32_t profile_kernels;    /* 0; k > 0 = hipEvent-time the in-loop SpMV of every k-th turn
                                    (bench.py roofline leg)                                         */
     int32_t compress_indices;   /* 1; Coo/Csr formats: run the SpMV on the index-compressed chunked

@@ -218,13 +218,13 @@ void launch_bj_apply_staged(hipStream_t st, const DevBlockJacobi &J, const doubl
 // A(J,J)^T y = e_i, W(i,J) = y.  Rows of up to ISAI_THREAD_ROW entries: one thread per row (per-thread
 // arrays); longer ones, up to MAX_ISAI_ROW: one wavefront per row, the system in LDS, lane = column --
 // the same operations on every element in the same order, so both give the oracle's bits.
-// Rows beyond MAX_ISAI_ROW, up to MAX_ISAI_HUGE_ROW: one WORKGROUP per row, the system in global scratch
+// Rows beyond MAX_ISAI_ROW, up to MAX_ISAI_HUGE_ROW (2048: the square of a polyhedral mesh's pattern): one WORKGROUP per row, the system in global scratch
 // (bs x bs doubles per row), the same elimination, the back substitution column by column (the oracle's
 // solve_dense_wide: a row-wise walk would be one dependent chain of bs^2 / 2 operations).  [UPSTREAM] Ginkgo solves
 // rows beyond its in-kernel limit through an iterative "excess system" (GMRES to 1e-6): an approximation of this.
 constexpr int ISAI_THREAD_ROW = 32;
 constexpr int MAX_ISAI_ROW = 64;
-constexpr int MAX_ISAI_HUGE_ROW = 512;
+constexpr int MAX_ISAI_HUGE_ROW = 2048;
 // max_row = longest row of W (selects the per-thread scratch size: 8, 16 or 32);
 // wide_rows[n_wide] = the rows with ISAI_THREAD_ROW < entries <= MAX_ISAI_ROW
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,

@@ -850,7 +850,7 @@ static void solve_dense_wide(orc_label bs, orc_scalar *a, orc_label ld, orc_scal
 /* Pattern of S^power, rows in ascending column order, S = tril(A) (spd) or A (general)
  * ([UPSTREAM] isai extend_sparsity; Preconditioner.H:227 `sparsityPower`).  Returns the number of
  * entries, -1 if a row gets more than ORC_ISAI_MAX_ROW of them; p_cols == NULL: sizes only. */
-#define ORC_ISAI_MAX_ROW 512   /* widest row of W handled at all */
+#define ORC_ISAI_MAX_ROW 2048  /* widest row of W handled at all */
 #define ORC_ISAI_NARROW_ROW 64 /* up to here: solve_dense (row-wise back substitution), above: solve_dense_wide */
 #define ISAI_IN_S(r, c) (!spd || (key ? key[c] <= key[r] : (c) <= (r)))
 static orc_label isai_pattern(orc_label n, const orc_label *rowptr, const orc_label *cols, int spd,
@@ -920,7 +920,7 @@ orc_label orc_isai_generate_pk(orc_label n, const orc_label *rowptr, const orc_l
         orc_label pos = -1;
         for (orc_label r = 0; r < bs; ++r)
             if (J[r] == i) pos = r;
-        const orc_label ld = bs <= ORC_ISAI_NARROW_ROW ? ORC_ISAI_NARROW_ROW : LD; /* (storage only: same bits) */
+        const orc_label ld = bs <= ORC_ISAI_NARROW_ROW ? ORC_ISAI_NARROW_ROW : ((bs + 7) & ~7); /* (storage only: same bits) */
         for (orc_label r = 0; r < bs; ++r) {
             for (orc_label c = 0; c < bs; ++c)
                 a[r * ld + c] = spd ? csr_entry(rowptr, cols, vals, J[r], J[c])

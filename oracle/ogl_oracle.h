@@ -259,7 +259,7 @@ typedef struct {
  * of tril(A); row i solves A(J,J) y = e_i and stores y / sqrt(y_i) (FSAI), M^-1 = W^T W.
  * spd == 0 (GISAI): W has A's pattern; row i solves A(J,J)^T y = e_i, M^-1 = W.
  * Step 1 (vals == NULL): returns nnz(W) and fills w_rowptr[n+1]; step 2: fills w_cols / w_vals.
- * Rows of up to 64 pattern entries: one dense solve with the row-wise back substitution; up to 512: the same
+ * Rows of up to 64 pattern entries: one dense solve with the row-wise back substitution; up to 2048: the same
  * elimination with the column-wise back substitution (see solve_dense_wide); wider: returns -1. */
 /* the same on the pattern of S^power (keyword sparsityPower, Preconditioner.H:227) */
 orc_label orc_isai_generate_p(orc_label n, const orc_label *rowptr, const orc_label *cols,

@@ -411,7 +411,7 @@ class Precond:
             nnz = lib().orc_isai_generate_pk(C.c_int32(n), prp, pc, pv, spd, pw, key,
                                              self.w_rowptr.ctypes.data_as(_LP), None, None)
             if nnz < 0:
-                raise ValueError("ISAI row wider than 512")
+                raise ValueError("ISAI row wider than 2048")
             self.w_cols, self.w_vals = np.zeros(max(1, nnz), label), np.zeros(max(1, nnz), scalar)
             lib().orc_isai_generate_pk(C.c_int32(n), prp, pc, pv, spd, pw, key, self.w_rowptr.ctypes.data_as(_LP),
                                        self.w_cols.ctypes.data_as(_LP), self.w_vals.ctypes.data_as(_SP))

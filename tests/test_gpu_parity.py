@@ -595,8 +595,8 @@ def test_isai(reg, oracle, chunk_rows, precond, kind, sym, solver):
 def test_isai_sparsity_power(reg, oracle, chunk_rows, precond, kind, sym, solver, power, widest):
     """Preconditioner.H:227 `sparsityPower`: W lives on the pattern of S^power.  Rows of up to 32 entries
     are solved by one thread each, wider ones (up to 64) by one wavefront each with the system in LDS, still
-    wider ones (up to 512; the reference hands rows beyond 32 to Ginkgo's iterative excess system) by one
-    workgroup each with the system in global scratch; all must give the oracle's bits (same dense solve, same
+    wider ones (the reference hands rows beyond 32 to Ginkgo's iterative excess system) by one
+    workgroup each (up to 2048) with the system in global scratch; all must give the oracle's bits (same dense solve, same
     order of operations per element)."""
     case = synthetic.poisson_case(9, symmetric=sym)
     xs = synthetic.x_star(case.global_index, case.global_n)
@@ -660,12 +660,46 @@ def test_isai_huge_rows_in_scratch_batches(reg, oracle, chunk_rows):
         np.testing.assert_array_equal(x, ref.x)
 
 
-def test_isai_rows_wider_than_512_are_refused(reg):
+def _hub_case(m, seed=SEED):
+    """A chain of 2 m + 50 cells whose LAST cell is coupled to m others: one row of m + 1 entries (GISAI: the hub's;
+    ISAI: the hub is the last cell, so tril(A) keeps the row)."""
+    n = 2 * m + 50
+    rng = np.random.default_rng(seed)
+    lower = np.concatenate([np.arange(n - 2, dtype=np.int32), np.arange(0, 2 * m, 2, dtype=np.int32)])
+    upper = np.concatenate([np.arange(1, n - 1, dtype=np.int32), np.full(m, n - 1, np.int32)])
+    order = np.lexsort((upper, lower))
+    return synthetic.LduCase(n, lower[order], upper[order], rng.uniform(3 * m, 3 * m + 1, n),
+                             rng.uniform(-1, 0, order.size), None)
+
+
+def test_isai_row_of_701_entries(reg, oracle, chunk_rows):
+    hub = _hub_case(700)
+    kw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=60)
+    A, (rp, cols, vals) = oracle_matrix(oracle, hub)
+    bh = np.random.default_rng(SEED).uniform(-1, 1, hub.n_cells)
+    for pk, kind in ((capi.PRECOND_GISAI, "general"), (capi.PRECOND_ISAI, "spd")):
+        P = oracle.Precond(rp, cols, vals, isai=kind)
+        assert int(np.diff(P.w_rowptr).max()) == 701
+        s = reg.solver(f"isai_hub701_{kind}", cg_cfg(preconditioner=pk, **kw)).set_matrix(hub)
+        x, perf = s.solve(bh, np.zeros_like(bh))
+        assert s.get_property("isaiHugeRows") == 1.0
+        with blocked(oracle, chunk_rows):
+            ref = oracle.cg(A, bh, np.zeros_like(bh), P, **kw)
+        np.testing.assert_array_equal(s.history(), ref.history)
+        np.testing.assert_array_equal(x, ref.x)
+
+
+def test_isai_rows_wider_than_2048_are_refused(reg):
+    hub = _hub_case(2100)                                   # one row of 2101 entries
+    s = reg.solver("isai_hub2101", cg_cfg(preconditioner=capi.PRECOND_GISAI)).set_matrix(hub)
+    with pytest.raises(capi.OglError) as e:
+        s.solve(np.ones(hub.n_cells), np.zeros(hub.n_cells))
+    assert e.value.status == capi.ERR_UNSUPPORTED and "GISAI" in str(e.value) and "sparsityPower 1" in str(e.value)
+    # ... and a 7-point stencil stays below the limit for every admissible sparsityPower (8: 729 = the whole 9^3 box)
     case = synthetic.poisson_case(9)
-    s = reg.solver("isai_p8", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=8)).set_matrix(case)
-    with pytest.raises(capi.OglError) as e:                 # A^8 on the 9^3 box: rows of up to 729 entries
-        s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
-    assert e.value.status == capi.ERR_UNSUPPORTED and "sparsityPower 8" in str(e.value)
+    s = reg.solver("isai_p8", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=8, max_iter=3)).set_matrix(case)
+    s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))
+    assert s.get_property("isaiHugeRows") == case.n_cells
     s = reg.solver("isai_p0", cg_cfg(preconditioner=capi.PRECOND_GISAI, sparsity_power=0)).set_matrix(case)
     with pytest.raises(capi.OglError) as e:
         s.solve(np.ones(case.n_cells), np.zeros(case.n_cells))

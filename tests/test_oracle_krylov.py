@@ -163,10 +163,14 @@ def test_isai_defining_property_with_sparsity_power(oracle, sym, power):
     else:
         R = (W @ A - sp.identity(A.shape[0])).toarray()
         assert np.abs(R[(W != 0).toarray()]).max() < 1e-13
-    case9 = synthetic.poisson_case(9, symmetric=sym)
-    rp9, cols9, vals9 = oracle_csr(oracle, case9)
+    n = 4300                                                    # a hub cell coupled to 2100 others: a row of 2101 entries
+    lower = np.concatenate([np.arange(n - 2), np.arange(0, 4200, 2)]).astype(np.int32)
+    upper = np.concatenate([np.arange(1, n - 1), np.full(2100, n - 1)]).astype(np.int32)
+    order = np.lexsort((upper, lower))
+    hub = synthetic.LduCase(n, lower[order], upper[order], np.full(n, 6300.0), np.full(order.size, -1.0), None)
+    rph, colsh, valsh = oracle_csr(oracle, hub)
     with pytest.raises(ValueError):
-        oracle.Precond(rp9, cols9, vals9, isai="general", sparsity_power=8)    # rows wider than 512
+        oracle.Precond(rph, colsh, valsh, isai="general")                      # rows wider than 2048
 
 
 def test_openmp_baseline_follows_the_sequential_oracle(oracle):

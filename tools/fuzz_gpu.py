@@ -157,11 +157,11 @@ def main():
                 try:
                     P = mk(isai="spd" if pc == "isai" else "general", sparsity_power=cfgkw["sparsity_power"])
                 except ValueError:
-                    too_wide = True       # a row of W wider than 512: both sides refuse
+                    too_wide = True       # a row of W wider than 2048: both sides refuse
             if too_wide and not dry:
                 try:
                     s.solve(b, x.copy())
-                    raise AssertionError("a W row wider than 512 was accepted")
+                    raise AssertionError("a W row wider than 2048 was accepted")
                 except capi.OglError as e:
                     assert e.status == capi.ERR_UNSUPPORTED, e
                 continue
