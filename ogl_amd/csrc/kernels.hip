@@ -757,10 +757,10 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_huge(const int *__restr
         rhs[c] = J == i ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int e = tid; e < bs * bs; e += BLOCK) {
-        const int r = e / bs, c = e - r * bs;
-        a[e] = spd ? csr_entry(row_ptrs, cols, vals, Js[r], Js[c]) : csr_entry(row_ptrs, cols, vals, Js[c], Js[r]);
-    }
+    for (int r = tid / WAVE; r < bs; r += N_WAVES)
+        for (int c = tid & (WAVE - 1); c < bs; c += WAVE)
+            a[(long)r * bs + c] =
+                spd ? csr_entry(row_ptrs, cols, vals, Js[r], Js[c]) : csr_entry(row_ptrs, cols, vals, Js[c], Js[r]);
     __syncthreads();
     for (int k = 0; k < bs; ++k) {
         // pivot: the first row >= k with the largest |a[r][k]|
@@ -812,19 +812,14 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_huge(const int *__restr
             }
             __syncthreads();
         }
-        // trailing block + right-hand side: (m rows) x (m columns + 1)
-        const int m = bs - k - 1;
+        // trailing block + right-hand side: a wavefront per row (lanes along the row: coalesced, no index division),
+        // the row's factor formed once per lane from the same expression
         const double akk = a[(long)k * bs + k], rk = rhs[k];
-        for (int e = tid; e < m * (m + 1); e += BLOCK) {
-            const int ii = e / (m + 1), jj = e - ii * (m + 1);
-            const int r = k + 1 + ii;
+        const int lane = tid & (WAVE - 1);
+        for (int r = k + 1 + tid / WAVE; r < bs; r += N_WAVES) {
             const double f = a[(long)r * bs + k] / akk;
-            if (jj < m) {
-                const int c = k + 1 + jj;
-                a[(long)r * bs + c] -= f * a[(long)k * bs + c];
-            } else {
-                rhs[r] -= f * rk;
-            }
+            for (int c = k + 1 + lane; c < bs; c += WAVE) a[(long)r * bs + c] -= f * a[(long)k * bs + c];
+            if (lane == 0) rhs[r] -= f * rk;
         }
         __syncthreads();
     }
