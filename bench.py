@@ -394,10 +394,22 @@ def main():
         rep = {"edge": e, "ok": False}
         hist, x = None, None
         try:
+            # both multi-rank GKOCG turns go through the transport: the merged 4-launch one (what a share of this size
+            # runs by default with the peer mesh: z put by step_2r) and the 5-launch one (p put by step_1x: what the
+            # timed 216^3 shares run) -- same bits required
+            sv5 = reg.solver("selfcheck5", c)
+            sv5.set_property("fusedTurnMulti", 0.0)
+            sv5.set_matrix(sc)
+            x5, _ = sv5.solve(sb, np.zeros_like(sb))
             sv = reg.solver("selfcheck", c).set_matrix(sc)
             x, perf = sv.solve(sb, np.zeros_like(sb))
             hist = sv.history()
             rep["peer_halo"] = sv.get_property("peerHalo") == 1.0
+            rep["merged_turn_checked"] = sv.get_property("fusedTurnInUse") == 1.0
+            rep["five_launch_turn_bit_identical"] = bool(np.array_equal(sv5.history(), hist) and np.array_equal(x5, x))
+            if not rep["five_launch_turn_bit_identical"]:
+                hist = None
+                rep["error"] = "the 4- and the 5-launch turn disagree"
         except capi.OglError as ex:
             rep["error"] = str(ex)
         if not all_ok(hist is not None):
