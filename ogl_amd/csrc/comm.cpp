@@ -179,7 +179,10 @@ int RcclComm::self_test(hipStream_t st)
         double *p;
         ~Free() { (void)hipFree(p); }
     } guard{d};
-    // all-reduce: sum of (rank + 1) and of (rank + 1) / 2 over the ranks
+    // Both stages run on EVERY rank whatever the first one gave: a rank that left after a wrong all-reduce would leave
+    // the others waiting in the ring (ncclSend / ncclRecv have no time-out).  The verdict is agreed afterwards by a
+    // third collective, so all ranks return the same status and step down (or carry on) together.
+    // stage 1, all-reduce: sum of (rank + 1) and of (rank + 1) / 2 over the ranks
     const double mine[2] = {rank + 1.0, 0.5 * (rank + 1.0)};
     OGL_HIP_TRY(hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, st));
     if (int rc = allreduce(d, 2, st)) return rc;
@@ -187,10 +190,8 @@ int RcclComm::self_test(hipStream_t st)
     OGL_HIP_TRY(hipMemcpyAsync(got, d, sizeof(got), hipMemcpyDeviceToHost, st));
     OGL_HIP_TRY(hipStreamSynchronize(st));
     const double tri = 0.5 * n_ranks * (n_ranks + 1.0);
-    if (got[0] != tri || got[1] != 0.5 * tri)
-        return fail(OGL_ERR_COMM_SELFTEST, "RCCL self-test: all-reduce over %d ranks gave %g, %g (expected %g, %g)", n_ranks,
-                    got[0], got[1], tri, 0.5 * tri);
-    // ring: every rank sends 1000 * rank + destination to its two ring neighbours and expects theirs
+    const bool bad_sum = got[0] != tri || got[1] != 0.5 * tri;
+    // stage 2, ring: every rank sends 1000 * rank + destination to its two ring neighbours and expects theirs
     const int prev = (rank + n_ranks - 1) % n_ranks, next = (rank + 1) % n_ranks;
     std::vector<int> nb, cnt;
     if (prev == next) {
@@ -208,10 +209,27 @@ int RcclComm::self_test(hipStream_t st)
     if (int rc = exchange(d + 2, d + 4, nb, cnt, st)) return rc;
     OGL_HIP_TRY(hipMemcpyAsync(recv, d + 4, sizeof(recv), hipMemcpyDeviceToHost, st));
     OGL_HIP_TRY(hipStreamSynchronize(st));
+    int bad_ring = -1;
     for (size_t i = 0; i < nb.size(); ++i)
-        if (recv[i] != want[i])
-            return fail(OGL_ERR_COMM_SELFTEST, "RCCL self-test: send/recv with rank %d gave %g (expected %g)", nb[i], recv[i],
-                        want[i]);
+        if (recv[i] != want[i] && bad_ring < 0) bad_ring = (int)i;
+    // stage 3, the verdict: number of ranks that saw a wrong all-reduce / a wrong ring value.  (A broken all-reduce may
+    // garble this sum too: anything but exactly 0, 0 counts as a failure, and a rank that saw a failure itself fails
+    // whatever the sum says.)
+    const double verdict[2] = {bad_sum ? 1.0 : 0.0, bad_ring >= 0 ? 1.0 : 0.0};
+    double all[2] = {-1, -1};
+    OGL_HIP_TRY(hipMemcpyAsync(d + 6, verdict, sizeof(verdict), hipMemcpyHostToDevice, st));
+    if (int rc = allreduce(d + 6, 2, st)) return rc;
+    OGL_HIP_TRY(hipMemcpyAsync(all, d + 6, sizeof(all), hipMemcpyDeviceToHost, st));
+    OGL_HIP_TRY(hipStreamSynchronize(st));
+    if (bad_sum)
+        return fail(OGL_ERR_COMM_SELFTEST, "RCCL self-test: all-reduce over %d ranks gave %g, %g (expected %g, %g)", n_ranks,
+                    got[0], got[1], tri, 0.5 * tri);
+    if (bad_ring >= 0)
+        return fail(OGL_ERR_COMM_SELFTEST, "RCCL self-test: send/recv with rank %d gave %g (expected %g)", nb[bad_ring],
+                    recv[bad_ring], want[bad_ring]);
+    if (all[0] != 0.0 || all[1] != 0.0)
+        return fail(OGL_ERR_COMM_SELFTEST, "RCCL self-test: %g rank(s) saw a wrong all-reduce, %g a wrong send/recv", all[0],
+                    all[1]);
     return OGL_OK;
 }
 

@@ -795,7 +795,9 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_huge(const int *__restr
                     bv = red_v[w];
                     bidx = red_i[w];
                 }
-            piv_s = bidx;
+            // (a column of NaNs -- diverged coefficients, a zero pivot earlier -- wins no comparison: keep row k, as the
+            //  oracle's search does, and let the NaN propagate into W instead of indexing outside the scratch)
+            piv_s = (bidx >= k && bidx < bs) ? bidx : k;
         }
         __syncthreads();
         const int piv = piv_s;
@@ -2388,15 +2390,20 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      const double *__restrict__ w,
                                                      double *__restrict__ dot_partials,
                                                      double *__restrict__ dot2_partials,
-                                                     const DevScalars *gate, int xgroup, HaloFused hf)
+                                                     const DevScalars *gate, int xgroup, HaloFused hf,
+                                                     const uint16_t *__restrict__ rmap)
 {
     __shared__ double slot[N_WAVES];
     __shared__ int stab[SELL_TABLE_INTS];
+    static_assert(SELL_TABLE_INTS * sizeof(int) >= CHUNK_ROWS * sizeof(double), "the table doubles as the row-sum exchange");
     if (gate && gate->stop) return;
     const int chunk = xcd_chunk(blockIdx.x, xgroup);
     if (chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
+    // (DevSell::rmap: whose rows this thread's two slot rows hold -- asked for now, needed at the very end)
+    unsigned own = 0;
+    if (rmap) own = *reinterpret_cast<const unsigned *>(rmap + (long)chunk * CHUNK_ROWS + t * ROWS_PER_THREAD);
     // spill (the tails of this chunk's long rows): which row this thread will finish and where its
     // tail sits -- asked for now, so that the answers arrive while the planes are being worked on
     int sp0 = 0, sp1 = 0, s_row = 0, s_k0 = 0, s_k1 = 0;
@@ -2416,7 +2423,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
     const int row = chunk * CHUNK_ROWS + t * ROWS_PER_THREAD;
     double2 acc;
     acc.x = acc.y = 0.0;
-    if (MODE == SPMV_RESIDUAL) acc = ld2(b, rp);
+    if (MODE == SPMV_RESIDUAL) {
+        if (rmap) {  // (b of the rows the slot rows hold)
+            const int ra = chunk * CHUNK_ROWS + (int)(own & 0xffffu), rb = chunk * CHUNK_ROWS + (int)(own >> 16);
+            acc.x = ra < n_rows ? b[ra] : 0.0;
+            acc.y = rb < n_rows ? b[rb] : 0.0;
+        } else {
+            acc = ld2(b, rp);
+        }
+    }
     const double *v = vals + h.val_off + t * ROWS_PER_THREAD;
     // this wavefront runs to the longest of ITS rows: the planes beyond (padding up to the chunk's
     // longest row) are never touched.  Wave-uniform, so the loops below do not diverge.
@@ -2657,6 +2672,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
             }
             ys[li] = a;
         }
+        __syncthreads();
+        acc.x = ys[ROWS_PER_THREAD * t];
+        acc.y = ys[ROWS_PER_THREAD * t + 1];
+    }
+    if (rmap) {  // the sums go to the rows they belong to (workgroup-uniform branch)
+        double *ys = reinterpret_cast<double *>(stab);  // the table is not needed any more
+        __syncthreads();
+        ys[own & 0xffffu] = acc.x;
+        ys[own >> 16] = acc.y;
         __syncthreads();
         acc.x = ys[ROWS_PER_THREAD * t];
         acc.y = ys[ROWS_PER_THREAD * t + 1];
@@ -3464,7 +3488,8 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
 #define OGL_SELL_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
                        A.dict, A.codes, A.vals, A.spill_chunk_ptr, A.spill_rows, A.spill_ptrs,          \
-                       A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf)
+                       A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf, \
+                       A.rmap)
 #define OGL_SELL(MODE, NDOT)               \
     do {                                   \
         if (A.stream)                      \

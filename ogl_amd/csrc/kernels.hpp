@@ -122,6 +122,11 @@ struct DevSell {
     const double *spill_vals = nullptr;
     bool stream = false;  // as DevCsr::stream, for the value planes and the 16 / 32-bit code words
     int32_t xcd_group = 0;  // as DevCsr::xcd_group
+    // rows of a wavefront's window stored in an order of their own (longest first: SellDev::build, sort_windows):
+    // rmap[chunk * CHUNK_ROWS + slot row] = the row of the chunk whose entries the slot row holds.  The workgroup
+    // hands the sums back to the rows' owners through LDS before y and the dot partials are formed, so y, the
+    // per-row order of the products and the partials are those of the plain layout.  PLAIN mode, no spill, no halo.
+    const uint16_t *rmap = nullptr;
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
                       double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});

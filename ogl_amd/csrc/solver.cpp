@@ -1109,11 +1109,49 @@ int ogl_solver::build_sym_on_device(const HostPattern &np, SymDistances *sd_out,
 }
 
 int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, Stager &stager,
-                   hipStream_t st)
+                   hipStream_t st, bool sort_windows)
 {
     ready = false;
+    sorted = false;
+    rmap.release();
     SellLayout L;
-    if (n_rows == 0 || !build_sell_layout(n_rows, row_ptrs, cols, L, /*allow_spill*/ false)) return OGL_OK;
+    if (n_rows == 0) return OGL_OK;
+    if (!sort_windows) {
+        if (!build_sell_layout(n_rows, row_ptrs, cols, L, /*allow_spill*/ false)) return OGL_OK;
+    } else {
+        // The rows of every wavefront's window (SELL_WAVE_ROWS rows) longest first, in a copy of the pattern that only
+        // this layout sees: what choose_numbering does for the system matrix through the numbering itself is done here
+        // with a slot order of the layout's own, undone by the kernel (DevSell::rmap) -- W in the CALLER's triangle on a
+        // renumbered copy has rows of 1 .. 7 entries next to each other and does not qualify otherwise.
+        const int64_t nc = n_chunks(n_rows);
+        std::vector<ogl_label> order((size_t)nc * CHUNK_ROWS);
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (ogl_label)i;
+        auto len = [&](ogl_label r) { return row_ptrs[r + 1] - row_ptrs[r]; };
+        bool moved = false;
+        for (ogl_label k0 = 0; k0 < n_rows; k0 += SELL_WAVE_ROWS) {
+            const auto b = order.begin() + k0, e = order.begin() + std::min<int64_t>(n_rows, (int64_t)k0 + SELL_WAVE_ROWS);
+            std::stable_sort(b, e, [&](ogl_label x, ogl_label y) { return len(x) > len(y); });
+            for (auto it = b; it != e && !moved; ++it) moved = *it != k0 + (ogl_label)(it - b);
+        }
+        if (!moved) return OGL_OK;
+        std::vector<ogl_label> prp((size_t)n_rows + 1, 0), pc((size_t)row_ptrs[n_rows]), at((size_t)row_ptrs[n_rows]);
+        for (ogl_label sr = 0; sr < n_rows; ++sr) prp[(size_t)sr + 1] = prp[(size_t)sr] + len(order[(size_t)sr]);
+        for (ogl_label sr = 0; sr < n_rows; ++sr) {
+            const ogl_label r = order[(size_t)sr];
+            for (ogl_label k = row_ptrs[r], q = prp[(size_t)sr]; k < row_ptrs[r + 1]; ++k, ++q) {
+                pc[(size_t)q] = cols[k];
+                at[(size_t)q] = k;
+            }
+        }
+        if (!build_sell_layout(n_rows, prp.data(), pc.data(), L, /*allow_spill*/ false)) return OGL_OK;
+        for (auto &m : L.map)
+            if (m >= 0) m = at[(size_t)m];  // (values are gathered from the CSR values of the pattern itself)
+        std::vector<uint16_t> rm(order.size());
+        for (size_t i = 0; i < order.size(); ++i) rm[i] = (uint16_t)(order[i] - (ogl_label)(i / CHUNK_ROWS * CHUNK_ROWS));
+        OGL_TRY(rmap.alloc(rm.size(), st));
+        OGL_TRY(stager.h2d(rmap.p, rm.data(), rm.size() * sizeof(uint16_t), st));
+        sorted = true;
+    }
     OGL_TRY(chunks.alloc(L.chunks.size(), st));
     OGL_TRY(dict.alloc(L.dict.size(), st));
     OGL_TRY(codes.alloc(L.codes.size(), st));
@@ -1124,6 +1162,7 @@ int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label 
     OGL_TRY(stager.h2d(codes.p, L.codes.data(), L.codes.size(), st));
     OGL_TRY(stager.h2d(map.p, L.map.data(), L.map.size() * sizeof(int32_t), st));
     slots = L.n_slots;
+    read_slots = L.read_slots;
     ready = true;
     return OGL_OK;
 }
@@ -1840,6 +1879,8 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             props["isaiWideRows"] = (double)wide_rows.size();
             props["isaiHugeRows"] = (double)huge_rows.size();
             const size_t wn = wc.size();
+            // (property isaiSortRows 0: W / W^T on the compressed layout only where their own row order qualifies, A/B)
+            const bool sort_w = prop("isaiSortRows", 1.0) != 0.0;
             OGL_TRY(P.w_row_ptrs.alloc((size_t)N + 1, st));
             OGL_TRY(P.w_cols.alloc(wn + NNZ_PAD, st));
             OGL_TRY(P.w_vals.alloc(wn + NNZ_PAD, st));
@@ -1863,12 +1904,19 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
                 OGL_TRY(reg->stager.h2d(P.wt_row_ptrs.p, trp.data(), trp.size() * sizeof(int32_t), st));
                 OGL_TRY(reg->stager.h2d(P.wt_cols.p, tc.data(), wn * sizeof(int32_t), st));
                 OGL_TRY(reg->stager.h2d(P.wt_map.p, tmap.data(), wn * sizeof(int32_t), st));
-                if (cfg.compress_indices)
+                if (cfg.compress_indices) {
                     OGL_TRY(P.wt_sell.build(N, trp.data(), tc.data(), reg->stager, st));
+                    if (!P.wt_sell.ready && sort_w) OGL_TRY(P.wt_sell.build(N, trp.data(), tc.data(), reg->stager, st, true));
+                }
             }
             if (!spd || !cfg.compress_indices) P.wt_sell.ready = false;
             P.w_sell.ready = false;
-            if (cfg.compress_indices) OGL_TRY(P.w_sell.build(N, wrp.data(), wc.data(), reg->stager, st));
+            if (cfg.compress_indices) {
+                OGL_TRY(P.w_sell.build(N, wrp.data(), wc.data(), reg->stager, st));
+                if (!P.w_sell.ready && sort_w) OGL_TRY(P.w_sell.build(N, wrp.data(), wc.data(), reg->stager, st, true));
+            }
+            props["isaiWSorted"] = P.w_sell.sorted ? 1.0 : 0.0;
+            props["isaiWtSorted"] = P.wt_sell.sorted ? 1.0 : 0.0;
             P.w_nnz = (int32_t)wn;
             P.w_max_row = max_row;
             props["isaiWCompressed"] = P.w_sell.ready ? 1.0 : 0.0;
@@ -1941,6 +1989,9 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         P.stride = cfg.max_block_size;
     }
     P.n_rows = n;
+    P.gen_pat_id = pat_id;
+    P.gen_device_numbering =
+        pat.renumbered() && !(P.kind == 2 && P.through_perm && !P.by_device_row);  // (see PrecondData::foreign_to)
     return OGL_OK;
 }
 
@@ -1989,7 +2040,9 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
     J.row_block = precond_data->row_block.p;
     J.blocks = precond_data->values.p;
     J.uniform = precond_data->uniform_blocks ? 1 : 0;
-    if (pat.renumbered() && precond_data->through_perm) {
+    // (blocks kept in the caller's order -- also a stored object that a field WITHOUT a numbering of its own generated --
+    //  are reached through this solver's permutation)
+    if (pat.renumbered() && (precond_data->through_perm || precond_data->caller_order_blocks())) {
         J.rows = d_new_id.p;
         J.pos = d_old_of.p;
         J.by_device_row = precond_data->by_device_row ? 1 : 0;
@@ -2022,11 +2075,11 @@ int ogl_solver::init_preconditioner()
     const int cache = (int)prop("preconditionerCaching", 0);
     const bool stored =
         reg->has_cached_precond && reg->cached_precond.matches(kind, (size_t)pat.n_rows, stride);
-    // (a stored block Jacobi whose rows were laid out through ANOTHER pattern's permutation -- the store is shared by
-    //  all fields, Preconditioner.H:357 -- cannot be applied through this one's when its block rows were stored by
-    //  device row (the direct apply): generate for this solve instead; the staged layout is in the caller's order)
-    const bool foreign = stored && reg->cached_precond.through_perm && reg->cached_precond.by_device_row &&
-                         reg->cached_precond.perm_pat_id != pat_id;
+    // (the store is shared by all fields, Preconditioner.H:357: a stored object whose values live in ANOTHER pattern's
+    //  device numbering -- inverse diagonal, W / W^T, block rows stored by device row, the backend's own blocks -- would be
+    //  a silently permuted operator here: generate for this solve instead.  Blocks kept block-major in the caller's
+    //  order are applied through this solver's permutation.)
+    const bool foreign = stored && reg->cached_precond.foreign_to(pat_id, pat.renumbered());
     if (stored && cache > 0 && !foreign) {
         props["preconditionerCaching"] = cache - 1;
         precond_data = &reg->cached_precond;
@@ -2038,7 +2091,8 @@ int ogl_solver::init_preconditioner()
         precond_data = &P;
     }
     if (precond_data->kind == 1) precond = precond_data->values.p;
-    if (precond_data->kind == 2 && precond_data->through_perm && !precond_data->by_device_row && pat.renumbered()) {
+    if (pat.renumbered() && precond_data->kind == 2 && !precond_data->by_device_row &&
+        (precond_data->through_perm || precond_data->caller_order_blocks())) {
         // (the staged apply's two vectors in the caller's order; also for a stored object another field generated)
         OGL_TRY(d_bj_tmp0.alloc((size_t)pat.n_rows + 2, reg->stream));
         OGL_TRY(d_bj_tmp1.alloc((size_t)pat.n_rows + 2, reg->stream));

@@ -98,10 +98,13 @@ struct SellDev {
     DevBuf<int32_t> dict, map;
     DevBuf<uint8_t> codes;
     DevBuf<double> vals;
-    int64_t slots = 0;
+    int64_t slots = 0, read_slots = 0;
     bool ready = false;  // false: the pattern does not qualify (or build was never called)
+    // rows of each wavefront's window stored longest first (sort_windows; the kernel undoes it: DevSell::rmap)
+    DevBuf<uint16_t> rmap;
+    bool sorted = false;
     int build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, Stager &stager,
-              hipStream_t st);
+              hipStream_t st, bool sort_windows = false);
     void refresh(const double *csr_vals, hipStream_t st)
     {
         if (ready) launch_gather_sell(st, (int32_t)chunks.n, chunks.p, map.p, csr_vals, vals.p);
@@ -114,6 +117,7 @@ struct SellDev {
         S.dict = dict.p;
         S.codes = codes.p;
         S.vals = vals.p;
+        S.rmap = sorted ? rmap.p : nullptr;
         S.stream = 9.0 * (double)slots + 40.0 * (double)n_rows > ogl::STREAM_MATRIX_ABOVE_BYTES;
         return S;
     }
@@ -158,6 +162,19 @@ struct PrecondData {
         return id != 0 && struct_pat_id == id && struct_kind == k && struct_stride == st;
     }
     bool matches(int k, size_t n, int st) const { return kind == k && n_rows == n && stride == st; }
+    // Which numbering the VALUES are laid out in.  The store is shared by all fields (Preconditioner.H:357), so the
+    // object may be applied by a solver other than the one that generated it: that is sound when both see the caller's
+    // numbering, or when the object is a block Jacobi kept block-major in the caller's order (the applying solver carries
+    // the vectors through ITS permutation); everything else -- inverse diagonal, W / W^T, block rows stored by device
+    // row, the backend's own blocks -- belongs to the generating pattern's device numbering.
+    uint64_t gen_pat_id = 0;
+    bool gen_device_numbering = false;
+    bool caller_order_blocks() const { return kind == 2 && !by_device_row && !gen_device_numbering; }
+    bool foreign_to(uint64_t id, bool renumbered) const
+    {
+        if (gen_pat_id == id) return false;
+        return gen_device_numbering || (renumbered && !caller_order_blocks());
+    }
 };
 
 }  // namespace ogl

@@ -15,6 +15,11 @@ plus a stated bound against the oracle in the reference executor's left-to-right
       ogl_solver_set_matrix -> ogl_solver_get_local_matrix, i.e. through the DEVICE set-up kernels, compared with the
       JSON directly
 
+  (f) BASELINE configs[2]'s keyword pair at its size: GKOBiCGStab + ISAI and + GISAI on ~2 M unstructured cells (128^3
+      cells shuffled in windows of 65536 -- `renumber auto` renumbers, ISAI(spd)'s W keeps the CALLER's triangle and runs
+      on the compressed layout with its rows sorted by length inside the wavefront windows -- and a three-block
+      blockMesh of 2.06 M cells), first 10 turns: history, x, iteration count bit-equal on the reported numbering
+
 The oracle needs 0.3-0.4 s per CG turn at 10 M rows on one host core; the whole file runs in about three minutes.
 Reference: StoppingCriterion/StoppingCriterion.C:71-151 (what a history entry is), lduLduBase/lduLduBase.H:189-308.
 """
@@ -22,7 +27,8 @@ import numpy as np
 import pytest
 
 from ogl_amd import capi, synthetic
-from helpers import blocked, oracle_csr, oracle_matrix, oracle_matrix_renumbered, rel_dev, to_new
+from helpers import (blocked, oracle_csr, oracle_matrix, oracle_matrix_renumbered, oracle_precond_renumbered, rel_dev,
+                     to_new)
 
 pytestmark = pytest.mark.gpu
 
@@ -275,3 +281,49 @@ def test_gtest_non_symmetric_update_through_the_device(reg, golden):
     rp, cols, mp, vals = s.local_matrix()
     assert mp.tolist() == g["permute"]
     assert vals.tolist() == [float(v) for v in g["expected"]]
+
+
+# ------------------------------------------------------------------------------------------ (f)
+
+def _config2_mesh(which):
+    import dataclasses
+    if which == "shuffled128":
+        return synthetic.renumber_case(synthetic.poisson_case(128, symmetric=False), 65536)      # 2,097,152 rows
+    case = synthetic.multi_block_case([60, 90, 40], 104, 104)                                     # 2,055,040 rows
+    return dataclasses.replace(case, upper=np.full(case.n_faces, -0.9), lower=np.full(case.n_faces, -1.1))
+
+
+@pytest.mark.parametrize("which", ["shuffled128", "blocks3"])
+@pytest.mark.parametrize("pc,isai", [(capi.PRECOND_ISAI, "spd"), (capi.PRECOND_GISAI, "general")], ids=["ISAI", "GISAI"])
+def test_config2_bicgstab_isai_at_size_bit_equal(reg, oracle, chunk_rows, which, pc, isai):
+    """configs[2]: GKOBiCGStab + ISAI / GISAI on ~2 M unstructured cells, 10 turns (Preconditioner/Preconditioner.H:225-241,
+    Solver/BiCGStab/GKOBiCGStab.H:49-67)."""
+    turns = 10
+    case = _config2_mesh(which)
+    kw = dict(tolerance=0.0, rel_tol=0.0, max_iter=turns)
+    s = reg.solver(f"U_{which}_{isai}", cfg(solver=capi.SOLVER_BICGSTAB, preconditioner=pc, max_iter=turns)).set_matrix(case)
+    new_id = s.renumbering()
+    assert (new_id is not None) == (which == "shuffled128")
+    if new_id is None:
+        new_id = np.arange(case.n_cells, dtype=np.int32)
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    d_rp, d_cols, _, d_vals = s.local_matrix()
+    np.testing.assert_array_equal(d_rp, rp)
+    np.testing.assert_array_equal(d_cols, cols)
+    np.testing.assert_array_equal(d_vals, vals)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = oracle.spmv(rp, cols, vals, to_new(xs, new_id))[new_id]                 # caller's order
+    x, perf = s.solve(b, np.zeros_like(b))
+    # W runs on the compressed layout in every one of these cases; on the renumbered copy ISAI(spd)'s triangle is the
+    # CALLER's (rows of 1 .. 7 entries side by side), which qualifies through the length sort inside the windows
+    assert s.get_property("isaiWCompressed") == 1.0
+    if which == "shuffled128" and isai == "spd":
+        assert s.get_property("isaiWSorted") == 1.0 and s.get_property("isaiWtCompressed") == 1.0
+    P = oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, isai=isai)
+    with blocked(oracle, chunk_rows):
+        ref = oracle.bicgstab(A, to_new(b, new_id), np.zeros_like(b), P, **kw)
+    assert perf.n_iterations == ref.n_iterations // 2                  # GKOBiCGStab.H:114
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x[new_id])
+    assert perf.norm_factor == ref.norm_factor
+    assert np.isfinite(s.history()).all() and s.history().size == 2 * turns + 1
