@@ -122,6 +122,18 @@ __device__ __forceinline__ void reduce_partials(const double *const (&part)[2], 
 // new p of a halo column is recomputed here from it and the OLD p of that column, which this rank keeps
 // (p_new = z + tmp p_old: the expression, scalars and operands of the owner's own update, hence its bits), and left
 // behind in the other of two halo-p buffers for the next turn.
+// wait accounting (DevScalars::halo_wait_ticks): the waiting lanes leave their wait in *longest (LDS, zeroed before),
+// one thread adds the workgroup's figure to the solve's counters afterwards
+__device__ __forceinline__ void note_wait(unsigned *longest, long long t0)
+{
+    atomicMax(longest, (unsigned)min((long long)0xffffffffll, wall_clock64() - t0));
+}
+__device__ __forceinline__ void add_halo_wait(DevScalars *s, unsigned longest)
+{
+    atomicAdd(&s->halo_wait_ticks, (unsigned long long)longest);
+    atomicAdd(&s->halo_waits, 1u);
+}
+
 template <int MODE, bool TURN = false>
 __device__ __forceinline__ void halo_fused_add(const HaloFused &H, int chunk, double &acc0, double &acc1, double *ys,
                                                double tmp = 0.0, const double *__restrict__ ph_in = nullptr,
@@ -130,7 +142,11 @@ __device__ __forceinline__ void halo_fused_add(const HaloFused &H, int chunk, do
     const int b0 = H.chunk_bptr[chunk], b1 = H.chunk_bptr[chunk + 1];
     if (b0 == b1) return;
     __shared__ int halo_timed_out;
-    if (threadIdx.x == 0) halo_timed_out = 0;
+    __shared__ unsigned halo_waited;
+    if (threadIdx.x == 0) {
+        halo_timed_out = 0;
+        halo_waited = 0;
+    }
     __syncthreads();
     if ((int)threadIdx.x < H.n_neigh) {
         const long long t0 = wall_clock64();
@@ -144,10 +160,12 @@ __device__ __forceinline__ void halo_fused_add(const HaloFused &H, int chunk, do
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        note_wait(&halo_waited, t0);
     }
     ys[ROWS_PER_THREAD * threadIdx.x] = acc0;
     ys[ROWS_PER_THREAD * threadIdx.x + 1] = acc1;
     __syncthreads();
+    if (threadIdx.x == 0) add_halo_wait(H.s, halo_waited);
     if (halo_timed_out) {  // a neighbour is gone: end the solve (y stays the local product)
         if (threadIdx.x == 0) {
             H.s->comm_error = 1;
@@ -3028,15 +3046,17 @@ __device__ __forceinline__ size_t peer_word(int slot, int src, int e)
 {
     return ((size_t)slot * PEER_MAX_RANKS + src) * PEER_ELEMS + e;
 }
-__device__ bool peer_allreduce2(const PeerArgs &pa, double &v0, double &v1)
+__device__ bool peer_allreduce2(const PeerArgs &pa, double &v0, double &v1, unsigned *waited_out = nullptr)
 {
     __shared__ unsigned halves[PEER_MAX_RANKS * PEER_ELEMS];
     __shared__ double mine[2];
     __shared__ int timed_out;
+    __shared__ unsigned waited;  // the longest mailbox wait of this all-reduce (DevScalars::reduce_wait_ticks)
     if (threadIdx.x == 0) {
         mine[0] = v0;
         mine[1] = v1;
         timed_out = 0;
+        waited = 0;
     }
     __syncthreads();
     const int t = threadIdx.x;
@@ -3060,10 +3080,12 @@ __device__ bool peer_allreduce2(const PeerArgs &pa, double &v0, double &v1)
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        note_wait(&waited, t0);
         halves[q * PEER_ELEMS + e] = (unsigned)w;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (waited_out) *waited_out = waited;
         double s0 = 0.0, s1 = 0.0;
         for (int q = 0; q < pa.world; ++q) {
             const unsigned *h = halves + q * PEER_ELEMS;
@@ -3152,8 +3174,12 @@ __global__ __launch_bounds__(BLOCK) void k_halo_finish(int n_rows,
 {
     __shared__ double slot[N_WAVES];
     __shared__ int timed_out;
+    __shared__ unsigned waited;
     if (gate && gate->stop) return;
-    if (threadIdx.x == 0) timed_out = 0;
+    if (threadIdx.x == 0) {
+        timed_out = 0;
+        waited = 0;
+    }
     __syncthreads();
     if ((int)threadIdx.x < P.n_neigh) {
         const long long t0 = wall_clock64();
@@ -3167,8 +3193,10 @@ __global__ __launch_bounds__(BLOCK) void k_halo_finish(int n_rows,
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        note_wait(&waited, t0);
     }
     __syncthreads();
+    if (threadIdx.x == 0) add_halo_wait(s, waited);
     if (timed_out) {  // a neighbour is gone: end the solve (y stays the local product)
         if (threadIdx.x == 0) {
             s->comm_error = 1;
@@ -3221,8 +3249,12 @@ __global__ __launch_bounds__(64) void k_halo_signal(PeerHalo P, const DevScalars
 __global__ __launch_bounds__(64) void k_halo_wait(PeerHalo P, const DevScalars *gate, DevScalars *s)
 {
     __shared__ int timed_out;
+    __shared__ unsigned waited;
     if (gate && gate->stop) return;
-    if (threadIdx.x == 0) timed_out = 0;
+    if (threadIdx.x == 0) {
+        timed_out = 0;
+        waited = 0;
+    }
     __syncthreads();
     const int i = threadIdx.x;
     if (i < P.n_neigh) {
@@ -3237,8 +3269,10 @@ __global__ __launch_bounds__(64) void k_halo_wait(PeerHalo P, const DevScalars *
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        note_wait(&waited, t0);
     }
     __syncthreads();
+    if (threadIdx.x == 0) add_halo_wait(s, waited);
     if (threadIdx.x == 0 && timed_out) {  // a neighbour is gone: end the solve
         s->comm_error = 1;
         s->stop = 1;
@@ -3297,8 +3331,14 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
         }
     }
     bool comm_ok = true;
-    if (a.peer.world > 1 && a.do_reduce && a.do_logic) comm_ok = peer_allreduce2(a.peer, v0, v1);
+    unsigned reduce_waited = 0;
+    const bool peer_reduce = a.peer.world > 1 && a.do_reduce && a.do_logic;
+    if (peer_reduce) comm_ok = peer_allreduce2(a.peer, v0, v1, &reduce_waited);
     if (!a.do_logic || threadIdx.x != 0) return;
+    if (peer_reduce) {
+        L.reduce_wait_ticks += reduce_waited;
+        L.reduce_waits += 1;
+    }
     if (!comm_ok) {  // a rank is gone: end the solve, the host reports OGL_ERR_COMM
         L.comm_error = 1;
         L.stop = 1;

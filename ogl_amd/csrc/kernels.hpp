@@ -32,7 +32,14 @@ struct DevScalars {
     double stale_norm;                  // GMRES: sum|r| of the last restart (what the criterion sees)
     DevCriterion crit;                  // this solve's criterion (kernel arguments stay solve-independent)
     int32_t x_pending;                  // GKOCG: step_2r's x update is still to be applied by a step_1x
-    int32_t pad_;
+    // Where a multi-rank turn waits (per solve; wall_clock64 ticks of 10 ns): halo_wait_ticks = sum over the workgroups
+    // that waited for the neighbours' puts of the longest of their flag waits (halo_waits of them: boundary workgroups
+    // of the SpMV, or the single waiter of peerSafeWait / the separate finish kernel); reduce_wait_ticks = sum over
+    // the in-finaliser all-reduces of the longest mailbox wait (reduce_waits of them).  bench.py reports both per turn
+    // and rank, so that a scaling curve below DESIGN.md section 6's table can be attributed.
+    uint32_t halo_waits;
+    unsigned long long halo_wait_ticks, reduce_wait_ticks;
+    uint32_t reduce_waits, pad_;
 };
 
 // Persistent device CSR ("<field>_matrix", CsrMatrixWrapper.H:163-210) + halo part.

@@ -348,6 +348,33 @@ int ogl_registry::peer_connect(int rank, int n_ranks, const void *handles)
         if (sum != (double)n_ranks) return fail(OGL_ERR_COMM, "peer put self-test: closing all-reduce gave %g", sum);
         // (the records stay where they are: a pattern handshake compares epochs, which count up from 1)
     }
+    // Do two ranks sit on ONE device?  (ranksPerGPU > 1 is not a supported deployment, but it is what every multi-rank run
+    // on a 1-GPU box does.)  Waiting workgroups of several ranks' SpMVs can then hold every slot the producers' put
+    // kernels need: such a mesh runs with a single waiting workgroup per rank (peerSafeWait) without
+    // being asked.  The ranks' PCI bus ids are gathered through the all-reduce that was just tested.
+    peer_shared_device = false;
+    if (n_ranks > 1) {
+        char bus[64] = {0};
+        OGL_HIP_CHECK(hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device));
+        unsigned long long id = 0;  // domain:bus:device.function -> its hex digits, at most 9 of them (exact in a double)
+        for (const char *c = bus; *c; ++c) {
+            const int v = (*c >= '0' && *c <= '9') ? *c - '0' : (*c >= 'a' && *c <= 'f') ? *c - 'a' + 10
+                          : (*c >= 'A' && *c <= 'F') ? *c - 'A' + 10 : -1;
+            if (v >= 0) id = id * 16 + (unsigned long long)v;
+        }
+        id = (id & 0xFFFFFFFFFFFull) + 1;
+        DevBuf<double> ids;
+        OGL_TRY(ids.alloc((size_t)n_ranks + 1, stream));
+        std::vector<double> mine((size_t)n_ranks + 1, 0.0), all((size_t)n_ranks + 1, 0.0);
+        mine[(size_t)rank] = (double)id;
+        OGL_HIP_CHECK(hipMemcpyAsync(ids.p, mine.data(), mine.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        for (int i = 0; i < n_ranks; i += 2)
+            launch_peer_allreduce(stream, peer_next(), ids.p + i, std::min(2, n_ranks - i), peer_error);
+        OGL_HIP_CHECK(hipMemcpyAsync(all.data(), ids.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        OGL_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int a = 0; a < n_ranks; ++a)
+            for (int b = a + 1; b < n_ranks; ++b) peer_shared_device = peer_shared_device || all[(size_t)a] == all[(size_t)b];
+    }
     peer_ready = true;
     return OGL_OK;
 }
@@ -471,6 +498,13 @@ double *ogl_solver::peer_recv(uint32_t seq) const
     const size_t nn = neighbours.size();
     return reinterpret_cast<double *>(reg->peer_local + PEER_ARENA_OFF + peer_block + 2 * nn +
                                       (size_t)(seq & 1u) * (size_t)pat.non_local_nnz);
+}
+
+// one waiting workgroup per rank instead of every boundary workgroup of the SpMV: asked for (property), or because
+// peer_connect found two ranks on one device
+bool ogl_solver::peer_safe_wait() const
+{
+    return prop("peerSafeWait", reg->peer_shared_device ? 1.0 : 0.0) != 0.0;
 }
 
 int ogl_registry::allreduce(double *dev, int n)
@@ -2107,7 +2141,7 @@ int ogl_solver::init_preconditioner()
 HaloPutFused ogl_solver::begin_halo_put()
 {
     HaloPutFused put;
-    if (!(pat.non_local_nnz > 0 && peer_halo) || prop("haloFused", 1.0) == 0.0 || prop("peerSafeWait", 0.0) != 0.0)
+    if (!(pat.non_local_nnz > 0 && peer_halo) || prop("haloFused", 1.0) == 0.0 || peer_safe_wait())
         return put;
     if (++halo_seq == 0) ++halo_seq;
     cur_halo = peer_halo_args(halo_seq);
@@ -2148,10 +2182,11 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
     // peer-put transport: by default the non-local part is added inside the local kernel (HaloFused) -- a
     // distributed SpMV is then 2 launches (pack + put + signal | local + wait + non-local), 1 when the producer
     // of x has put the values itself; property haloFused 0 keeps the separate finish kernel (A/B)
-    // peerSafeWait 1 (ranks that SHARE a device): no workgroup of the SpMV waits -- ONE workgroup of a
+    // peerSafeWait 1 (ranks that SHARE a device; switched on by peer_connect itself when two ranks
+    // report the same PCI bus id): no workgroup of the SpMV waits -- ONE workgroup of a
     // kernel of its own does, then the non-local part is added by kernels that find the values there.  Many waiting
     // workgroups of several ranks on one device can hold every slot the producers' put kernels need.
-    const bool safe = has_halo && peer_halo && prop("peerSafeWait", 0.0) != 0.0;
+    const bool safe = has_halo && peer_halo && peer_safe_wait();
     const bool fuse = has_halo && peer_halo && !safe && prop("haloFused", 1.0) != 0.0;
     HaloFused hf;
     if (has_halo && peer_halo) {
@@ -2310,7 +2345,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                   (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
     if (multi)
         merged = merged && peer_halo && prop("haloFused", 1.0) != 0.0 && prop("fusedTurnMulti", 1.0) != 0.0 &&
-                 prop("peerSafeWait", 0.0) == 0.0;
+                 !peer_safe_wait();
     double n_global = (double)n;
     if (multi) {
         // global row count (Partition.H:118-121) and the agreement on the turn, through the device all-reduce
@@ -2759,6 +2794,13 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     float chk_ms = 0.f;
     OGL_HIP_CHECK(hipEventElapsedTime(&chk_ms, ev_chk[0], ev_chk[1]));
 
+    // where the multi-rank turns of this solve waited (DevScalars, kernels.hpp; wall_clock64 counts 10 ns)
+    props["haloWaits"] = (double)fin.halo_waits;
+    props["haloWaitUs"] = (double)fin.halo_wait_ticks / 100.0;
+    props["allreduceWaits"] = (double)fin.reduce_waits;
+    props["allreduceWaitUs"] = (double)fin.reduce_wait_ticks / 100.0;
+    props["peerSafeWaitInUse"] = (pat.non_local_nnz > 0 && peer_halo && peer_safe_wait()) ? 1.0 : 0.0;
+    props["peerSharedDevice"] = reg->peer_shared_device ? 1.0 : 0.0;
     perf->initial_residual = fin.init_res;                  // lduLduBase.H:283
     perf->final_residual = fin.res;                         // :284
     perf->n_iterations = bicg ? fin.iter / 2 : fin.iter;    // :285, GKOCG.H:105-108, GKOBiCGStab.H:114

@@ -204,6 +204,7 @@ struct ogl_registry {
     ogl::PeerArgs peer{};                         // world/rank/box[]; seq is stamped per call
     uint32_t peer_seq = 0;
     bool peer_ready = false;
+    bool peer_shared_device = false;  // two ranks of the mesh report the same PCI bus id (peer_connect)
     // peer-put halo arena behind the mailbox in the same IPC allocation (PeerHalo, kernels.hpp):
     // solvers take blocks at pattern-build time; every rank builds patterns in the same order, so
     // `halo_epoch` names the same handshake on all ranks
@@ -433,6 +434,7 @@ struct ogl_solver {
     ogl::DevCsr csr() const;
     ogl::DevHalo halo() const;
     double prop(const std::string &key, double dflt) const;
+    bool peer_safe_wait() const;
     double stream_above_bytes() const;
     int32_t xcd_group() const;
     int32_t pat_xcd_group = 0;  // chosen per pattern (0 = the built-in group of 4 chunks)

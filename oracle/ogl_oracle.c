@@ -383,8 +383,47 @@ void orc_rowptr_from_rows(orc_label nrows, orc_label nnz, const orc_label *rows,
     for (orc_label r = 0; r < nrows; ++r) rowptr[r + 1] += rowptr[r];
 }
 
+static int g_reduce_mode = ORC_REDUCE_SEQUENTIAL;
+static orc_label g_chunk_rows = 512;
+
+/* ORC_REDUCE_EXACT: every sum of products / sum of terms is carried as an unevaluated pair (hi, lo) with error-free
+ * transformations -- TwoSum (Knuth) for the additions, TwoProduct (Dekker) for the products -- and rounded to
+ * double once at the end (Ogita, Rump, Oishi: "Accurate sum and dot product", SIAM J. Sci. Comput. 26 (2005), Sum2 /
+ * Dot2: the result is as accurate as if computed in twice the working precision, i.e. the correctly rounded exact
+ * sum unless the condition number exceeds ~1e16).  The arbiter between two summation orders: NOT a reference
+ * semantic, NOT what the device computes. */
+typedef struct {
+    orc_scalar hi, lo;
+} acc2;
+static inline void acc2_add(acc2 *a, orc_scalar v) { /* TwoSum(hi, v) */
+    const orc_scalar s = a->hi + v;
+    const orc_scalar bb = s - a->hi;
+    const orc_scalar e = (a->hi - (s - bb)) + (v - bb);
+    a->hi = s;
+    a->lo += e;
+}
+static inline void acc2_add_prod(acc2 *a, orc_scalar x, orc_scalar y) { /* TwoProduct, then TwoSum */
+    /* TwoProduct after Dekker / Veltkamp (split at 27 bits): p + pe = x * y exactly, barring over- / underflow; no
+     * fma(), which a baseline x86-64 build would take from libm one call per entry */
+    const orc_scalar p = x * y;
+    const orc_scalar cx = 134217729.0 * x, xh = cx - (cx - x), xl = x - xh;
+    const orc_scalar cy = 134217729.0 * y, yh = cy - (cy - y), yl = y - yh;
+    const orc_scalar pe = xl * yl - (((p - xh * yh) - xl * yh) - xh * yl);
+    acc2_add(a, p);
+    a->lo += pe;
+}
+static inline orc_scalar acc2_value(const acc2 *a) { return a->hi + a->lo; }
+
 void orc_spmv(orc_label n, const orc_label *rowptr, const orc_label *cols, const orc_scalar *vals,
               const orc_scalar *x, orc_scalar *y) {
+    if (g_reduce_mode == ORC_REDUCE_EXACT) {
+        for (orc_label row = 0; row < n; ++row) {
+            acc2 a = {0.0, 0.0};
+            for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) acc2_add_prod(&a, vals[k], x[cols[k]]);
+            y[row] = acc2_value(&a);
+        }
+        return;
+    }
     for (orc_label row = 0; row < n; ++row) {
         orc_scalar sum = 0.0;
         for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) sum += vals[k] * x[cols[k]];
@@ -395,6 +434,15 @@ void orc_spmv(orc_label n, const orc_label *rowptr, const orc_label *cols, const
 void orc_spmv_adv(orc_label n, const orc_label *rowptr, const orc_label *cols,
                   const orc_scalar *vals, orc_scalar alpha, const orc_scalar *x, orc_scalar beta,
                   orc_scalar *y) {
+    if (g_reduce_mode == ORC_REDUCE_EXACT) { /* (alpha = +-1, beta = 1 at every call site: alpha * val is exact) */
+        for (orc_label row = 0; row < n; ++row) {
+            acc2 a = {0.0, 0.0};
+            acc2_add_prod(&a, y[row], beta);
+            for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k) acc2_add_prod(&a, alpha * vals[k], x[cols[k]]);
+            y[row] = acc2_value(&a);
+        }
+        return;
+    }
     for (orc_label row = 0; row < n; ++row) {
         orc_scalar sum = y[row] * beta;
         for (orc_label k = rowptr[row]; k < rowptr[row + 1]; ++k)
@@ -402,9 +450,6 @@ void orc_spmv_adv(orc_label n, const orc_label *rowptr, const orc_label *cols,
         y[row] = sum;
     }
 }
-
-static int g_reduce_mode = ORC_REDUCE_SEQUENTIAL;
-static orc_label g_chunk_rows = 512;
 
 void orc_set_reduction(int mode, orc_label chunk_rows) {
     g_reduce_mode = mode;
@@ -470,6 +515,14 @@ static orc_scalar reduce_blocked_partials(orc_label m, const orc_scalar *part) {
 }
 
 static orc_scalar reduce_terms(orc_label n, const orc_scalar *a, const orc_scalar *b, term_fn f) {
+    if (g_reduce_mode == ORC_REDUCE_EXACT) {
+        acc2 s = {0.0, 0.0};
+        if (f == term_dot)
+            for (orc_label i = 0; i < n; ++i) acc2_add_prod(&s, a[i], b[i]);
+        else
+            for (orc_label i = 0; i < n; ++i) acc2_add(&s, f(a, b, i));
+        return acc2_value(&s);
+    }
     if (g_reduce_mode == ORC_REDUCE_SEQUENTIAL) {
         orc_scalar s = 0.0;
         for (orc_label i = 0; i < n; ++i) s += f(a, b, i);

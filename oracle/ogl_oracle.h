@@ -150,8 +150,11 @@ void orc_spmv_adv(orc_label n, const orc_label *rowptr, const orc_label *cols,
 
 /* Reduction order.  SEQUENTIAL = reference executor (left to right).  BLOCKED = the fixed
  * tree the HIP kernels use (chunks of `chunk_rows` rows, 256 threads, 64-lane xor tree), so
- * that a HIP result can be checked bit-for-bit; it is NOT a reference semantic. */
-enum { ORC_REDUCE_SEQUENTIAL = 0, ORC_REDUCE_BLOCKED = 1 };
+ * that a HIP result can be checked bit-for-bit; it is NOT a reference semantic.  EXACT = every dot / norm1 / sum and
+ * every SpMV row sum accumulated with error-free transformations (TwoSum, TwoProduct) and rounded once: the arbiter
+ * that says which of two summation orders is closer to the exact result (tests/test_gpu_exact_arbiter.py); neither a
+ * reference semantic nor the device's. */
+enum { ORC_REDUCE_SEQUENTIAL = 0, ORC_REDUCE_BLOCKED = 1, ORC_REDUCE_EXACT = 2 };
 void orc_set_reduction(int mode, orc_label chunk_rows);
 
 orc_scalar orc_dot(orc_label n, const orc_scalar *a, const orc_scalar *b);

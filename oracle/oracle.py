@@ -23,6 +23,7 @@ IFACE_PROCESSOR = 0
 IFACE_CYCLIC = 1
 REDUCE_SEQUENTIAL = 0
 REDUCE_BLOCKED = 1
+REDUCE_EXACT = 2
 
 
 def build(force=False):

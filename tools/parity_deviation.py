@@ -87,7 +87,39 @@ def main():
             print(f"   {label:60s} {v:.3e}")
         print("   per check:", " ".join(f"{v:.1e}" for v in dev))
         print(f"   max |x_gpu - x_oracle| = {np.abs(x - ref.x).max():.3e}")
+        arbiter(f"cg_{precond}_{edge}, 50 turns", hist, ref.history, A, b, inv, kw)
+    # ---- 64^3 to convergence under the arbiter
+    case = synthetic.poisson_case(64)
+    b, xs = synthetic.rhs_for_x_star(case)
+    kw = dict(tolerance=1e-9, rel_tol=0.0, max_iter=2000)
+    x, perf, hist = gpu_solve(reg, "arb64", case, b, "cg", "bj", {}, **kw)
+    rp, cols, vals = oracle_csr(orc, case)
+    A = orc.DistMatrix(rp, cols, vals)
+    inv = orc.jacobi_generate_scalar(rp, cols, vals)
+    ref = orc.cg(A, b, np.zeros_like(b), inv, **kw)
+    arbiter("cg_bj_64 to 1e-9", hist, ref.history, A, b, inv, kw)
     reg.close()
+
+
+def arbiter(label, h_gpu, h_seq, A, b, inv, kw):
+    """Both orders against the oracle's EXACT mode (error-free transformations, rounded once): which one is closer to the
+    exact history (tests/test_gpu_exact_arbiter.py asserts what is printed here)."""
+    orc.set_reduction(orc.REDUCE_EXACT)
+    try:
+        ex = orc.cg(A, b, np.zeros_like(b), inv, **kw).history
+    finally:
+        orc.set_reduction(orc.REDUCE_SEQUENTIAL)
+    m = min(ex.size, h_gpu.size, h_seq.size)
+    d_gpu = np.abs(h_gpu[:m] - ex[:m]) / ex[:m]
+    d_seq = np.abs(h_seq[:m] - ex[:m]) / ex[:m]
+    print(f"\n== arbiter, {label}: |history - exact| / exact per check ({m} checks; exact = TwoSum / TwoProduct accumulation)")
+    print("   check  residual/start   sequential (reference executor's order)   device tree")
+    step = max(1, m // 25)
+    for k in list(range(0, m, step)) + [m - 1]:
+        print(f"   {k:5d}  {ex[k] / ex[0]:.3e}      {d_seq[k]:.3e}                                {d_gpu[k]:.3e}")
+    early = ex[:m] / ex[0] > 1e-3
+    print(f"   running maxima: residual above 1e-3 of its start ({int(early.sum())} checks): sequential {d_seq[early].max():.3e}, "
+          f"device {d_gpu[early].max():.3e}; all checks: sequential {d_seq.max():.3e}, device {d_gpu.max():.3e}")
 
 
 if __name__ == "__main__":
