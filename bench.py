@@ -132,6 +132,19 @@ def parse():
                          "auto: the default headline run at N = 1 when rocprofv3 is there and this process is not "
                          "itself profiled; otherwise (and whenever a pass fails) the committed summary of the same "
                          "kernels is quoted")
+    ap.add_argument("--config", type=int, default=0, choices=[0, 3, 4],
+                    help="the 8-way configurations as BASELINE.json states them, STRONG scaling (the global system is "
+                         "fixed, `value` = global solver turns per second): 3 = channel-flow proxy of 20 M cells "
+                         "(272^3 box) cut into N blocks (8: 2 x 2 x 2), GKOCG + BJ; 4 = 50 M-cell unstructured proxy "
+                         "(368^3 box, every rank's cells shuffled in windows of 65536) cut the same way, "
+                         "GKOGMRES(30) + BJ, --format Csr | Ell.  0 = the headline workload (216^3 per GPU, weak scaling)")
+    ap.add_argument("--no-rung-probes", dest="rung_probes", action="store_false",
+                    help="N > 1: do not collect evidence for the transport rungs the timed run did not use (by default "
+                         "every rung of the ladder -- peer mesh over RCCL, peer mesh over the host bootstrap, RCCL alone, "
+                         "host buffers alone -- is brought up once in child processes after the timed region, self-checked "
+                         "and timed for a few steps: config.transport.rungs)")
+    ap.add_argument("--rung-timeout", type=float, default=150.0,
+                    help="seconds a rung probe may take before its child processes are ended")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not event-time the in-loop SpMV (roofline then comes from a "
                          "separate back-to-back SpMV loop)")
@@ -251,7 +264,8 @@ def main():
         import datetime
         # gloo is the control plane only (agreeing on transports, the final MAX over ranks); a rank that dies
         # must not leave the others waiting for the default 30 minutes
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=8))
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(
+            seconds=float(os.environ.get("OGL_BENCH_GLOO_TIMEOUT_S", "480"))))
 
     def barrier():
         torch.cuda.synchronize()
@@ -259,7 +273,21 @@ def main():
             dist.barrier()
 
     n = args.n
-    if args.asym:
+    procs = (1, 1, world)                       # the headline: z-slabs of n^3 cells each
+    if args.config:
+        # BASELINE.json configs[3] / configs[4]: one global box for every N, cut as cubically as N allows
+        n = args.n = {3: 272, 4: 368}[args.config]
+        procs = {1: (1, 1, 1), 2: (1, 1, 2), 4: (1, 2, 2), 8: (2, 2, 2)}.get(world)
+        if procs is None:
+            raise SystemExit("--config 3 | 4 runs on 1, 2, 4 or 8 ranks")
+        if args.config == 4:
+            args.solver, args.precond = "GKOGMRES", "BJ"
+        else:
+            args.solver, args.precond = "GKOCG", "BJ"
+        case = synthetic.poisson_block(n, n, n, procs[0], procs[1], procs[2], rank)
+        if args.config == 4:                    # an unstructured numbering per rank (interfaces keep their face order)
+            case = synthetic.renumber_case(case, 65536, seed=20241016 + rank)
+    elif args.asym:
         case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank, symmetric=False,
                                        off_upper=-0.9, off_lower=-1.1)
     else:
@@ -386,7 +414,7 @@ def main():
         every rank and agree with a single-GPU solve of the assembled system (rank 0) to 1e-11; the
         solution slices to 1e-12."""
         e = args.selfcheck_edge
-        sc = synthetic.poisson_block(e, e, e * world, pz=world, rank=rank)
+        sc = synthetic.poisson_block(e * procs[0], e * procs[1], e * procs[2], procs[0], procs[1], procs[2], rank)
         sb, _ = synthetic.rhs_for_x_star(sc)
         c = capi.default_config(solver=capi.SOLVER_CG, preconditioner=capi.PRECOND_BJ, tolerance=0.0,
                                 rel_tol=0.0, max_iter=20, export_res=1, adapt_min_iter=0,
@@ -423,7 +451,7 @@ def main():
         xref = torch.zeros(glob_n, dtype=torch.float64)
         if rank == 0:
             r1 = capi.Registry(device_id=local_rank)
-            g = synthetic.poisson_block(e, e, e * world)
+            g = synthetic.poisson_block(e * procs[0], e * procs[1], e * procs[2])
             gb, _ = synthetic.rhs_for_x_star(g)
             s1 = r1.solver("selfcheck_global", c).set_matrix(g)
             gx, _ = s1.solve(gb, np.zeros_like(gb))
@@ -472,9 +500,13 @@ def main():
         ladder = [r for r in ladder if r[0] == want]
     if os.environ.get("OGL_BENCH_PEER", "1") != "1":
         ladder = [r for r in ladder if not r[1]]
+    full_ladder = [("rccl", True), ("host", True), ("rccl", False), ("host", False)]
+    rung_name = lambda r: r[0] + ("+peer" if r[1] else "")
+    if os.environ.get("OGL_BENCH_RUNG"):     # a rung probe (child of a bench.py run): exactly this rung or nothing
+        ladder = [r for r in full_ladder if rung_name(r) == os.environ["OGL_BENCH_RUNG"]]
     if world == 1:
         ladder = [("none", False)]
-    state, selfcheck_report, tried = None, None, []
+    state, selfcheck_report, tried, chosen_rung = None, None, [], None
     for kind, use_peer in ladder:
         got = connect(kind, use_peer)
         if got is None:
@@ -506,6 +538,7 @@ def main():
                 reg.close()
                 continue
             state = (reg, s, transport, t_first_matrix, t_refresh_matrix)
+            chosen_rung = rung_name((kind, use_peer))
             break
         except Exception:
             reg.close()
@@ -514,6 +547,62 @@ def main():
         raise SystemExit(f"bench.py: rank {rank}: no transport survived: {tried}")
     reg, s, transport, t_first_matrix, t_refresh_matrix = state
     comm_info = reg.comm_info()
+
+    def probe_rungs(timed_rung, timed_us_per_turn):
+        """Evidence for the rungs the timed run did not use (RCCL with more than one rank must not
+        need the peer mesh to fail before it is ever exercised).  Each remaining rung: every rank starts ONE child
+        process -- this script, restricted to that rung (OGL_BENCH_RUNG), own gloo rendezvous on a port of its own --
+        which connects, runs the cross-rank self-check and two short timed steps of this workload.  Children are
+        ordinary child processes (nothing is exec'ed in place), watched with a time limit and ended by PID when it
+        passes: a rung that hangs costs its time limit, not the run."""
+        import subprocess
+        res = []
+        base_port = int(os.environ.get("MASTER_PORT", "29500"))
+        for idx, r in enumerate(full_ladder):
+            name = rung_name(r)
+            if name == timed_rung:
+                res.append({"rung": name, "ok": True, "timed_run": True, "us_per_turn": timed_us_per_turn,
+                            "selfcheck_ok": None if not selfcheck_report else bool(selfcheck_report.get("ok"))})
+                continue
+            env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
+            env.update({"MASTER_PORT": str(base_port + 31 + idx), "OGL_BENCH_RUNG": name, "OGL_BENCH_CHILD": "1",
+                        "OGL_BENCH_GLOO_TIMEOUT_S": str(int(args.rung_timeout))})
+            cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                   "--iters", str(min(args.iters, 50)), "--edge", str(n), "--precond", args.precond, "--solver", args.solver,
+                   "--block-size", str(args.block_size), "--krylov-dim", str(args.krylov_dim), "--format", args.format,
+                   "--cpu-iters", "0", "--no-general-legs", "--no-rung-probes", "--live-pmc", "off",
+                   "--selfcheck-edge", str(args.selfcheck_edge)] + (["--asym"] if args.asym else []) + \
+                  (["--config", str(args.config)] if getattr(args, "config", 0) else []) + \
+                  sum((["--prop", kv] for kv in args.prop), [])
+            t0 = time.perf_counter()
+            rec = {"rung": name, "ok": False, "timed_run": False}
+            p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            try:
+                so, se = p.communicate(timeout=args.rung_timeout)
+                rec["rc"] = p.returncode
+                if p.returncode == 0 and rank == 0:
+                    d = json.loads(so.strip().splitlines()[-1])
+                    sc = d["config"].get("selfcheck") or {}
+                    rec.update({"ok": bool(sc.get("ok", False)) if args.selfcheck else True,
+                                "selfcheck_ok": sc.get("ok"), "us_per_turn": 1e3 * d["solver_turn"]["ms"],
+                                "value": d["value"], "transport": d["config"]["parallelism"],
+                                "rccl_ranks_seen": d["config"]["transport"]["rccl_ranks_seen"],
+                                "wait_us": d["config"]["transport"]["wait_us"]})
+                elif p.returncode != 0:
+                    rec["error"] = se.strip().splitlines()[-1][-400:] if se.strip() else "child failed"
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.communicate()
+                rec["error"] = f"no result within {args.rung_timeout:.0f} s: children ended"
+            rec["seconds"] = time.perf_counter() - t0
+            # every rank's child has ended before the next rung starts (the children of one rung talk to each other)
+            every = [None] * world
+            dist.all_gather_object(every, rec.get("rc", -9))
+            rec["child_rc_by_rank"] = every
+            if any(c != 0 for c in every):
+                rec["ok"] = False
+            res.append(rec)
+        return res
 
     def step():
         s.upload_solution(None)              # x0 = 0, device memset
@@ -534,7 +623,8 @@ def main():
     iters = sum(p.n_iterations - (0 if bicg else 1) for p in perfs)
     expect = args.iters if bicg else args.iters + 1
     assert all(p.n_iterations == expect for p in perfs), [p.n_iterations for p in perfs]
-    value = world * iters / elapsed
+    # headline: weak scaling, 10 M-row block iterations of all ranks; --config 3 | 4: ONE global system, global turns
+    value = iters / elapsed if args.config else world * iters / elapsed
 
     # ---- roofline of the dominant kernel: the in-loop SpMV -----------------------------------
     def prop_or(sv, name, default):
@@ -689,7 +779,7 @@ def main():
     # region: full storage (pattern-coded compressed copy), plain CSR-stream, cells shuffled (irregular
     # numbering: the library renumbers its device copy itself) -- each a short run of its own solver
     general = None
-    if world == 1 and args.general_legs and plain_box and not args.shuffle and args.format == "Csr" \
+    if world == 1 and args.general_legs and plain_box and not args.shuffle and args.format == "Csr" and not args.config \
             and not (args.full_storage or args.no_compress or args.force_compress) and cg_headline \
             and not args.no_profile:
         general = []
@@ -742,14 +832,47 @@ def main():
             general.append(r)
             del sv
 
+    # ---- N > 1: where the turns waited, and evidence for EVERY rung of the transport ladder ------------------
+    waits, rungs = None, None
+    if world > 1:
+        turns = max(1, perfs[-1].n_iterations - (0 if bicg else 1))
+        mine = {"rank": rank,
+                # halo: sum over the workgroups that waited for the neighbours' puts (boundary workgroups of the SpMV; ONE
+                # with the single waiter) of their longest flag wait; all-reduce: the finaliser's longest mailbox wait,
+                # summed over the turn's all-reduces -- device clock, last timed step, per turn (DevScalars, kernels.hpp)
+                "halo_wait_us_per_turn": prop_or(s, "haloWaitUs", 0.0) / turns,
+                "halo_waiting_workgroups_per_turn": prop_or(s, "haloWaits", 0.0) / turns,
+                "allreduce_wait_us_per_turn": prop_or(s, "allreduceWaitUs", 0.0) / turns,
+                "allreduces_per_turn": prop_or(s, "allreduceWaits", 0.0) / turns,
+                "single_waiter": prop_or(s, "peerSafeWaitInUse", 0.0) == 1.0,
+                "shares_its_device": prop_or(s, "peerSharedDevice", 0.0) == 1.0}
+        waits = [None] * world
+        dist.all_gather_object(waits, mine)
+        if args.rung_probes and not os.environ.get("OGL_BENCH_RUNG"):
+            rungs = probe_rungs(chosen_rung, 1e3 * elapsed / max(1, iters) * 1e3)
+
+    if general:
+        # north_star's graded figure -- the in-loop CSR SpMV on SURVEY.md 8(d)'s bytes (12 nnz + 20 N + 4) -- where the
+        # record's reader looks for it: the `no_compress` leg's kernel (k_spmv_stream, the kernel north_star sketches)
+        g = next(x for x in general if x["leg"] == "no_compress")
+        roofline["csr"] = {k: g[k] for k in ("kernel", "frac", "achieved", "avg_kernel_ms", "bytes_per_launch", "traffic",
+                                              "traffic_over_model", "traffic_measured_in_this_run", "cg_iters_per_sec")}
+        roofline["csr"]["what"] = ("compressIndices false on the same system, 5 steps after the timed region: the plain CSR "
+                                   "arrays through k_spmv_stream; bytes_per_launch = SURVEY.md 8(d)'s 12 nnz + 20 N + 4")
+
     out = {
         "metric": "cg_iters_per_sec", "value": value, "unit": "iter/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / max(1, args.steps),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if args.config else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": (f"Voronoi mesh of {args.voronoi} random points (polyhedral cells, random numbering) lduMatrix"
+            "workload": ({3: f"BASELINE.json configs[3]: channel-flow proxy, {n}^3 = {n ** 3:,} cells cut into "
+                             f"{procs[0]} x {procs[1]} x {procs[2]} blocks (strong scaling), ",
+                          4: f"BASELINE.json configs[4]: unstructured proxy, {n}^3 = {n ** 3:,} cells cut into "
+                             f"{procs[0]} x {procs[1]} x {procs[2]} blocks, every rank's cells shuffled in windows of 65536 "
+                             f"(strong scaling), matrixFormat {args.format}, "}.get(args.config, "")) +
+                        (f"Voronoi mesh of {args.voronoi} random points (polyhedral cells, random numbering) lduMatrix"
                          if args.voronoi else
                          f"octree mesh: {n}^3 hexahedra, those within {args.octree} cells of a sphere split 2x2x2"
                          f"{' (children appended to the cell list)' if args.octree_append else ''} lduMatrix"
@@ -774,7 +897,8 @@ def main():
                                     "16-byte word (CSR-stream SpMV)",
                            "ell": "fp64/int32 ELL copy of the persistent device CSR"}[layout]
                         + (", device copy renumbered by the library (RCM)" if renumbered else "")
-                        + (" (BASELINE.json configs[1])" if not (args.voronoi or args.shuffle or args.drop_faces
+                        + ("" if args.config else
+                           " (BASELINE.json configs[1])" if not (args.voronoi or args.shuffle or args.drop_faces
                                                                 or args.long_rows or args.octree or args.blocks)
                            else " (proxy of a multi-block / unstructured mesh)"),
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
@@ -788,11 +912,16 @@ def main():
             "spilled_entries": prop_or(s, "sellSpilledEntries", 0.0) if layout == "sell" else 0.0,
             "gather_sectors_per_entry": {"as_given": s.get_property("gatherSectorRatioNatural"),
                                          "in_use": s.get_property("gatherSectorRatio")},
-            "parallelism": f"rows sharded into {world} z-slab(s), {transport}"
-                           if world > 1 else "single GPU",
+            "parallelism": (f"rows sharded into {procs[0]} x {procs[1]} x {procs[2]} blocks, {transport}" if args.config else
+                            f"rows sharded into {world} z-slab(s), {transport}") if world > 1 else "single GPU",
             "transport": {"kind": {0: "none", 1: "host-buffer", 2: "rccl"}[comm_info.transport],
                           "rccl_ranks_seen": comm_info.ranks_seen if comm_info.transport == 2 else None,
-                          "peer_mesh": bool(comm_info.peer_mesh), "stepped_down_from": tried},
+                          "peer_mesh": bool(comm_info.peer_mesh), "stepped_down_from": tried,
+                          "timed_rung": chosen_rung,
+                          # every rung of the ladder brought up once (the ones the timed run did not use: in child
+                          # processes after the timed region), self-checked and timed on this workload
+                          "rungs": rungs,
+                          "wait_us": waits},
             "selfcheck": selfcheck_report,
         },
         "roofline": dict(roofline, note=(
@@ -846,7 +975,7 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the oracle on the same matrix ----------------------
     headline = (args.solver == "GKOCG" and args.precond in ("BJ", "none") and args.block_size == 1
                 and not args.asym)
-    if rank == 0 and world == 1 and args.cpu_iters != 0 and headline and not args.shuffle:
+    if rank == 0 and world == 1 and args.cpu_iters != 0 and headline and not args.shuffle and not args.config:
         # a child process: thread placement must be fixed before an OpenMP runtime loads (this process
         # already carries torch's), and the oracle shares nothing with the GPU run
         import subprocess

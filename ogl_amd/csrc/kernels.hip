@@ -2892,6 +2892,276 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_step3(int n, double *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// GKOBiCGStab on small systems (<= FUSED_FIN_MAX_CHUNKS chunks, one rank): the three single-workgroup finalisers of
+// a turn folded into the step kernels that consume their results, as for GKOCG (k_cg_step1x_fin): every workgroup
+// reduces the per-chunk partials itself -- 256 threads walking the 1024-thread tree of k_finalize, same bits -- and runs
+// the scalar logic on its own copy of the scalars; workgroup 0 stores them.  The scalars ping-pong between two slots
+// (a kernel reads `sin`, writes `sout`).  Turn:
+//   [check of the previous turn + step_1] -> (M^-1) -> SpMV -> [alpha + step_2] -> (M^-1) -> SpMV
+//   -> [mid-turn check + omega + step_3 (or bicgstab::finalize when that check stops the solve)]
+// 5 launches instead of 8 (+ the preconditioner's own).  A kernel that reads partials never writes the arrays it
+// reads -- another workgroup may still be reducing them -- so the turn uses six partial arrays.
+// ------------------------------------------------------------------------------------------
+// FIN_CG_CHECK + step_1.  The closing check of a solve is one more launch of this kernel (the step it then takes on
+// p is harmless: the solve has stopped, or fails with "did not stop").
+__global__ __launch_bounds__(BLOCK) void k_bicg_fold1(int n, double *__restrict__ p, const double *__restrict__ r,
+                                                      const double *__restrict__ v,
+                                                      const double *__restrict__ inv_diag, double *__restrict__ y,
+                                                      const DevScalars *sin, DevScalars *sout,
+                                                      const double *__restrict__ part_rho,
+                                                      const double *__restrict__ part_norm, int n_part,
+                                                      double *history)
+{
+    __shared__ double red[2 * FIN_WAVES];
+    __shared__ double sh[2];
+    __shared__ int sh_stop;
+    // (everything asked for at once, the scalars field by field: see k_cg_step1x_fin)
+    const int stopped = sin->stop;
+    const double s_rho = sin->rho, alpha = sin->alpha, omega = sin->omega, s_nf = sin->norm_factor,
+                 s_init = sin->init_res;
+    const int s_iter = sin->iter, s_evals = sin->n_evals;
+    const double c_tol = sin->crit.tolerance, c_rel = sin->crit.rel_tol;
+    const int c_min = sin->crit.min_iter, c_max = sin->crit.max_iter, c_freq = sin->crit.frequency,
+              c_exp = sin->crit.export_res;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevScalars) / 8)  // fields this kernel leaves alone
+        reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
+            reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
+    const RowPair rp = my_rows(blockIdx.x, n);
+    const double2 vr = ld2_stream(r, rp);
+    const double2 po = ld2_stream(p, rp), vv = ld2_stream(v, rp);
+    double2 vi;
+    vi.x = vi.y = 1.0;
+    if (inv_diag) vi = ld2_stream(inv_diag, rp);
+    double pv[2][FIN_VT];
+    load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
+    if (stopped) return;
+    double vsum[2];
+    reduce_partials_as_finaliser<2>(pv, n_part, red, vsum);
+    if (threadIdx.x == 0) {
+        // FIN_CG_CHECK: swap(prev_rho, rho) of the previous turn, then criterion_check (StoppingCriterion.C:71-151)
+        const double prev_rho = s_rho, rho = vsum[0];
+        int iter = s_iter, n_evals = s_evals, stop = 0;
+        double init_res = s_init, res = 0.0;
+        bool evaluated = false;
+        if (iter > 0 && iter < c_min) {           // :77-81
+            iter += 1;
+        } else if (iter % c_freq != 0) {          // :84-87
+            iter += 1;
+        } else {
+            evaluated = true;
+            n_evals += 1;
+            res = vsum[1];
+            if (iter == 0) init_res = res / s_nf;  // :102-111
+            res /= s_nf;                           // :113
+            if (c_exp && history && blockIdx.x == 0) history[iter] = res;  // :115-117
+            if (iter >= c_max) stop = 1;                                   // :124
+            if (res < c_tol) stop = 1;                                     // :128
+            if (c_rel > 0 && res < c_rel * init_res) stop = 1;             // :132-136
+            iter += 1;                                                     // :143
+        }
+        sh[0] = prev_rho;
+        sh[1] = rho;
+        sh_stop = stop;
+        if (blockIdx.x == 0) {
+            sout->prev_rho = prev_rho;
+            sout->rho = rho;
+            sout->iter = iter;
+            sout->x_pending = 0;
+            if (evaluated) {
+                sout->n_evals = n_evals;
+                sout->init_res = init_res;
+                sout->res = res;
+            }
+            if (stop) sout->stop = 1;
+        }
+    }
+    __syncthreads();
+    if (sh_stop) return;
+    const double prev = sh[0], rho = sh[1];
+    double2 vp = vr;
+    if (prev * omega != 0.0) {  // step_1 (k_bicg_step1)
+        const double tmp = rho / prev * alpha / omega;
+        vp.x = vr.x + tmp * (po.x - omega * vv.x);
+        vp.y = vr.y + tmp * (po.y - omega * vv.y);
+    }
+    if (inv_diag) st2_stream(p, rp, vp); else st2(p, rp, vp);
+    if (inv_diag) {
+        double2 vy;
+        vy.x = vp.x * vi.x;
+        vy.y = vp.y * vi.y;
+        st2(y, rp, vy);
+    }
+}
+
+// FIN_BICG_ALPHA + step_2
+__global__ __launch_bounds__(BLOCK) void k_bicg_fold2(int n, const double *__restrict__ r,
+                                                      const double *__restrict__ v, double *__restrict__ sv,
+                                                      const double *__restrict__ inv_diag, double *__restrict__ z,
+                                                      double *__restrict__ part_norm_out, const DevScalars *sin,
+                                                      DevScalars *sout, const double *__restrict__ part_beta,
+                                                      int n_part)
+{
+    __shared__ double red[2 * FIN_WAVES];
+    __shared__ double sh[2];
+    __shared__ double slot[N_WAVES];
+    const int stopped = sin->stop;
+    const double s_rho = sin->rho;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevScalars) / 8)
+        reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
+            reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vs = ld2_stream(r, rp);
+    const double2 vv = ld2_stream(v, rp);
+    double2 vi;
+    vi.x = vi.y = 1.0;
+    if (inv_diag) vi = ld2_stream(inv_diag, rp);
+    double pv[2][FIN_VT];
+    load_partials_as_finaliser<1>(part_beta, nullptr, n_part, pv);
+    if (stopped) return;
+    double vsum[2];
+    reduce_partials_as_finaliser<1>(pv, n_part, red, vsum);
+    if (threadIdx.x == 0) {  // beta = rr.v ; alpha = rho / beta (0 when beta == 0)
+        const double beta = vsum[0], alpha = (beta != 0.0) ? s_rho / beta : 0.0;
+        sh[0] = alpha;
+        sh[1] = beta;
+        if (blockIdx.x == 0) {
+            sout->beta = beta;
+            sout->alpha = alpha;
+        }
+    }
+    __syncthreads();
+    const double alpha = sh[0], beta = sh[1];
+    if (beta != 0.0) {  // step_2 (k_bicg_step2)
+        vs.x = vs.x - alpha * vv.x;
+        vs.y = vs.y - alpha * vv.y;
+    }
+    st2(sv, rp, vs);
+    if (inv_diag) {
+        double2 vz;
+        vz.x = vs.x * vi.x;
+        vz.y = vs.y * vi.y;
+        st2(z, rp, vz);
+    }
+    double a = 0.0;
+    if (rp.n > 0) a += fabs(vs.x);
+    if (rp.n > 1) a += fabs(vs.y);
+    const double s1 = block_sum(a, slot);
+    if (threadIdx.x == 0) part_norm_out[chunk] = s1;
+}
+
+// FIN_BICG_CHECK2_OMEGA + step_3 (bicgstab::finalize, x += alpha y, when the mid-turn check stops the solve)
+__global__ __launch_bounds__(BLOCK) void k_bicg_fold3(int n, double *__restrict__ x, double *__restrict__ r,
+                                                      const double *__restrict__ sv, const double *__restrict__ t,
+                                                      const double *__restrict__ y, const double *__restrict__ z,
+                                                      const double *__restrict__ rr,
+                                                      double *__restrict__ part_rho_out,
+                                                      double *__restrict__ part_norm_out, const DevScalars *sin,
+                                                      DevScalars *sout, const double *__restrict__ part_gamma,
+                                                      const double *__restrict__ part_tt,
+                                                      const double *__restrict__ part_snorm, int n_part,
+                                                      double *history, int turn)
+{
+    __shared__ double red[2 * FIN_WAVES];
+    __shared__ double sh[1];
+    __shared__ int sh_stop;
+    __shared__ double slot[2 * N_WAVES];
+    const int stopped = sin->stop;
+    const double alpha = sin->alpha, s_nf = sin->norm_factor, s_init = sin->init_res;
+    const int s_iter = sin->iter, s_evals = sin->n_evals;
+    const double c_tol = sin->crit.tolerance, c_rel = sin->crit.rel_tol;
+    const int c_min = sin->crit.min_iter, c_max = sin->crit.max_iter, c_freq = sin->crit.frequency,
+              c_exp = sin->crit.export_res;
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(DevScalars) / 8)
+        reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
+            reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vx = ld2_stream(x, rp);
+    const double2 vy = ld2_stream(y, rp), vz = ld2_stream(z, rp), vs = ld2_stream(sv, rp), vt = ld2_stream(t, rp),
+                  vrr = ld2_stream(rr, rp);
+    double pv[2][FIN_VT], pn[2][FIN_VT];
+    load_partials_as_finaliser<2>(part_gamma, part_tt, n_part, pv);
+    load_partials_as_finaliser<1>(part_snorm, nullptr, n_part, pn);
+    if (stopped) return;
+    double vsum[2], vnorm[2];
+    reduce_partials_as_finaliser<2>(pv, n_part, red, vsum);
+    reduce_partials_as_finaliser<1>(pn, n_part, red, vnorm);
+    if (threadIdx.x == 0) {
+        // the mid-turn check on s (criterion_check, StoppingCriterion.C:71-151), then gamma = s.t, beta = t.t,
+        // omega = gamma / beta unless it stopped
+        int iter = s_iter, n_evals = s_evals, stop = 0;
+        double init_res = s_init, res = 0.0;
+        bool evaluated = false;
+        if (iter > 0 && iter < c_min) {
+            iter += 1;
+        } else if (iter % c_freq != 0) {
+            iter += 1;
+        } else {
+            evaluated = true;
+            n_evals += 1;
+            res = vnorm[0];
+            if (iter == 0) init_res = res / s_nf;
+            res /= s_nf;
+            if (c_exp && history && blockIdx.x == 0) history[iter] = res;
+            if (iter >= c_max) stop = 1;
+            if (res < c_tol) stop = 1;
+            if (c_rel > 0 && res < c_rel * init_res) stop = 1;
+            iter += 1;
+        }
+        const double omega = (vsum[1] != 0.0) ? vsum[0] / vsum[1] : 0.0;
+        sh[0] = omega;
+        sh_stop = stop;
+        if (blockIdx.x == 0) {
+            sout->iter = iter;
+            if (evaluated) {
+                sout->n_evals = n_evals;
+                sout->init_res = init_res;
+                sout->res = res;
+            }
+            if (stop) {
+                sout->stop = 1;
+                sout->stop_phase = 1;
+                sout->stop_turn = turn;
+            } else {
+                sout->gamma = vsum[0];
+                sout->beta = vsum[1];
+                sout->omega = omega;
+            }
+        }
+    }
+    __syncthreads();
+    if (sh_stop) {  // bicgstab::finalize: x += alpha y
+        vx.x += alpha * vy.x;
+        vx.y += alpha * vy.y;
+        st2(x, rp, vx);
+        return;
+    }
+    const double omega = sh[0];
+    vx.x += alpha * vy.x + omega * vz.x;  // step_3 (k_bicg_step3)
+    vx.y += alpha * vy.y + omega * vz.y;
+    double2 vr;
+    vr.x = vs.x - omega * vt.x;
+    vr.y = vs.y - omega * vt.y;
+    st2_stream(x, rp, vx);
+    st2(r, rp, vr);
+    double d = 0.0, a = 0.0;
+    if (rp.n > 0) {
+        d += vrr.x * vr.x;
+        a += fabs(vr.x);
+    }
+    if (rp.n > 1) {
+        d += vrr.y * vr.y;
+        a += fabs(vr.y);
+    }
+    block_sum2(d, a, slot);
+    if (threadIdx.x == 0) {
+        part_rho_out[chunk] = d;
+        part_norm_out[chunk] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // GMRES vector kernels
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_gmres_scale(int n, double *__restrict__ out,
@@ -4018,6 +4288,37 @@ void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const do
     if (nc == 0) return;
     hipLaunchKernelGGL(k_bicg_step3, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr,
                        part_rho, part_norm, s, turn);
+}
+
+void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,
+                       double *y, const DevScalars *sin, DevScalars *sout, const double *part_rho,
+                       const double *part_norm, double *history)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_bicg_fold1, dim3(nc), dim3(BLOCK), 0, st, n, p, r, v, inv_diag, y, sin, sout, part_rho,
+                       part_norm, nc, history);
+}
+
+void launch_bicg_fold2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv, const double *inv_diag,
+                       double *z, double *part_norm_out, const DevScalars *sin, DevScalars *sout,
+                       const double *part_beta)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_bicg_fold2, dim3(nc), dim3(BLOCK), 0, st, n, r, v, sv, inv_diag, z, part_norm_out, sin, sout,
+                       part_beta, nc);
+}
+
+void launch_bicg_fold3(hipStream_t st, int32_t n, double *x, double *r, const double *sv, const double *t,
+                       const double *y, const double *z, const double *rr, double *part_rho_out, double *part_norm_out,
+                       const DevScalars *sin, DevScalars *sout, const double *part_gamma, const double *part_tt,
+                       const double *part_snorm, double *history, int turn)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_bicg_fold3, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr, part_rho_out,
+                       part_norm_out, sin, sout, part_gamma, part_tt, part_snorm, nc, history, turn);
 }
 
 void launch_gmres_scale(hipStream_t st, int32_t n, double *out, const double *in,

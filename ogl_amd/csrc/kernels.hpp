@@ -324,6 +324,18 @@ void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in,
                             double *p_halo_out = nullptr);
 
 // --- BiCGStab steps ([UPSTREAM] bicgstab::step_1/2/3, finalize) ---
+// GKOBiCGStab with the finalisers folded into the step kernels (<= FUSED_FIN_MAX_CHUNKS chunks, one rank; kernels.hip):
+// scalars go sin -> sout; a kernel never writes a partial array it reads
+void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,
+                       double *y, const DevScalars *sin, DevScalars *sout, const double *part_rho,
+                       const double *part_norm, double *history);
+void launch_bicg_fold2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv, const double *inv_diag,
+                       double *z, double *part_norm_out, const DevScalars *sin, DevScalars *sout,
+                       const double *part_beta);
+void launch_bicg_fold3(hipStream_t st, int32_t n, double *x, double *r, const double *sv, const double *t,
+                       const double *y, const double *z, const double *rr, double *part_rho_out, double *part_norm_out,
+                       const DevScalars *sin, DevScalars *sout, const double *part_gamma, const double *part_tt,
+                       const double *part_snorm, double *history, int turn);
 void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,
                        const double *inv_diag, double *y, const DevScalars *s);
 void launch_bicg_step2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv,

@@ -551,6 +551,26 @@ double ogl_solver::stream_above_bytes() const
     return prop("streamAboveBytes", env_default);
 }
 
+// What a turn of this solver touches BESIDES the system matrix and GKOCG's five vectors (which the built-in threshold
+// was measured with): the preconditioner's own matrices (ISAI: W and W^T, GISAI: W; block Jacobi: its blocks) and the
+// further vectors of GKOBiCGStab / the Krylov basis of GKOGMRES.  All of it passes through the Infinity Cache once per
+// turn, so it counts when the question is "does the turn's working set still live there" (property streamTurnSet 0:
+// the matrix alone decides, as before round 5).
+double ogl_solver::turn_extra_bytes() const
+{
+    if (prop("streamTurnSet", 1.0) == 0.0) return 0.0;
+    const double N = (double)pat.n_rows, nnz = (double)pat.local_nnz;
+    double extra = 0.0;
+    if (cfg.preconditioner == OGL_PRECOND_ISAI) extra += 10.0 * (nnz + N);      // tril(A) twice, ~10 bytes per entry
+    if (cfg.preconditioner == OGL_PRECOND_GISAI) extra += 10.0 * nnz;
+    if (cfg.preconditioner == OGL_PRECOND_BJ && cfg.max_block_size > 1) extra += 8.0 * cfg.max_block_size * N;
+    if (cfg.preconditioner != OGL_PRECOND_NONE && !(cfg.preconditioner == OGL_PRECOND_BJ && cfg.max_block_size == 1))
+        extra += 16.0 * N;                                                      // materialised z (and the ISAI temporary)
+    if (cfg.solver == OGL_SOLVER_BICGSTAB) extra += 32.0 * N;
+    if (cfg.solver == OGL_SOLVER_GMRES) extra += 8.0 * N * ((cfg.krylov_dim > 0 ? cfg.krylov_dim : 100) + 1 - 3);
+    return extra;
+}
+
 // chunks per XCD group of the CSR-stream / compressed SpMV (DevCsr::xcd_group): property `xcdGroup`, else the
 // environment's OGL_XCD_GROUP, else what the pattern's set-up chose (0 = the kernels' built-in 4)
 int32_t ogl_solver::xcd_group() const
@@ -571,7 +591,7 @@ DevCsr ogl_solver::csr() const
     A.row_ptrs = d_row_ptrs.p;
     A.cols = d_cols.p;
     A.vals = d_vals.p;
-    A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows > stream_above_bytes();
+    A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     A.xcd_group = xcd_group();
     if (s21_use && s21_state == 1) {
         A.chunks21 = d_s21_chunks.p;
@@ -631,7 +651,7 @@ DevEll ogl_solver::ell() const
     E.stride = ell_stride;
     E.cols = d_ell_cols.p;
     E.vals = d_ell_vals.p;
-    E.stream = 12.0 * (double)ell_width * (double)ell_stride + 40.0 * (double)pat.n_rows > stream_above_bytes();
+    E.stream = 12.0 * (double)ell_width * (double)ell_stride + 40.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     return E;
 }
 
@@ -672,7 +692,7 @@ DevSell ogl_solver::sell() const
     S.dict = d_sell_dict.p;
     S.codes = d_sell_codes.p;
     S.vals = d_sell_vals.p;
-    S.stream = sell_bytes + 40.0 * (double)pat.n_rows > stream_above_bytes();
+    S.stream = sell_bytes + 40.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     S.xcd_group = xcd_group();
     if (n_spill) {
         S.spill_chunk_ptr = d_spill_chunks.p;
@@ -692,7 +712,7 @@ DevSym ogl_solver::sym() const
     for (int j = 0; j < 4; ++j) S.d[j] = sym_d[j];
     S.mask = d_sym_mask.p;
     S.planes = d_sym_planes.p;
-    S.stream = 8.0 * (double)d_sym_planes.n + 41.0 * (double)pat.n_rows > stream_above_bytes();
+    S.stream = 8.0 * (double)d_sym_planes.n + 41.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     if (d_sym_order.n && !band_order_off) {
         S.block_order = d_sym_order.p;
         S.n_blocks = (int32_t)d_sym_order.n;
@@ -710,7 +730,7 @@ DevSymx ogl_solver::symx() const
     S.ex_rowptr = d_symx_ex_rowptr.p;
     S.ex_cols = d_symx_ex_cols.p;
     S.ex_vals = d_symx_ex_vals.p;
-    S.stream = symx_bytes + 41.0 * (double)pat.n_rows > stream_above_bytes();
+    S.stream = symx_bytes + 41.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     S.fast = symx_fast;
     S.n_blocks = (int32_t)d_symx_chunks.n;
     S.chunks_general = d_symx_chunks_general.p;
@@ -2049,8 +2069,11 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
         const bool w_sell = cfg.compress_indices && precond_data->w_sell.ready;
         const bool general = precond_data->kind == 4;
         double *w_out = general ? out : d_isai_tmp.p;
+        // (W / W^T are streamed past the caches exactly when the system matrix is: one working set, one policy)
+        const bool stream_w = props.count("spmvStream") && props.at("spmvStream") == 1.0;
+        W.stream = stream_w;
         if (w_sell)
-            launch_spmv_sell(st, precond_data->w_sell.view(pat.n_rows), SPMV_PLAIN, in, nullptr, w_out,
+            launch_spmv_sell(st, precond_data->w_sell.view(pat.n_rows, stream_w), SPMV_PLAIN, in, nullptr, w_out,
                              general ? last : SpmvDots{}, gate);
         else
             launch_spmv(st, W, SPMV_PLAIN, in, nullptr, w_out, general ? last : SpmvDots{}, gate);
@@ -2060,7 +2083,7 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
         WT.cols = precond_data->wt_cols.p;
         WT.vals = precond_data->wt_vals.p;
         if (cfg.compress_indices && precond_data->wt_sell.ready)
-            launch_spmv_sell(st, precond_data->wt_sell.view(pat.n_rows), SPMV_PLAIN, d_isai_tmp.p,
+            launch_spmv_sell(st, precond_data->wt_sell.view(pat.n_rows, stream_w), SPMV_PLAIN, d_isai_tmp.p,
                              nullptr, out, last, gate);
         else
             launch_spmv(st, WT, SPMV_PLAIN, d_isai_tmp.p, nullptr, out, last, gate);
@@ -2328,7 +2351,14 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                        nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
                        prop("fusedFinalizers", 1.0) != 0.0;
     DevScalars *s2 = s + 1;
-    props["fusedFinalizersInUse"] = fused ? 1.0 : 0.0;
+    // ... and the same for small single-rank GKOBiCGStab systems: three finalisers folded into step_1 / step_2 / step_3
+    // (k_bicg_fold1/2/3: 5 launches per turn instead of 8, plus the preconditioner's own)
+    const bool bicg_fold = bicg && !reg->comm->multi() && nc >= 1 &&
+                           nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
+                           prop("fusedFinalizers", 1.0) != 0.0 && prop("bicgFold", 1.0) != 0.0;
+    DevScalars *slot_s[2] = {s, s2};
+    int cur = 0;  // the slot that holds the scalars after everything enqueued so far (bicg_fold only)
+    props["fusedFinalizersInUse"] = (fused || bicg_fold) ? 1.0 : 0.0;
     // ... and on half storage step_1x(_fin) and the SpMV are one kernel (k_cg_turn_sym, k_cg_turn_sym_big): 2 launches
     // per turn for small systems, 4 for larger ones, p alternating between two buffers (single rank: with halos the
     // put and the wait for the neighbours' puts would sit in one kernel)
@@ -2392,6 +2422,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     OGL_TRY(d_history.alloc((size_t)max_checks + 4, st));
     if (cfg.export_res)
         OGL_HIP_CHECK(hipMemsetAsync(d_history.p, 0, d_history.n * sizeof(double), st));
+    if (bicg_fold) {  // (a folded kernel never writes a partial array it reads: six of them per turn)
+        OGL_TRY(d_part3.alloc((size_t)nc, st));
+        OGL_TRY(d_part4.alloc((size_t)nc, st));
+        OGL_TRY(d_part5.alloc((size_t)nc, st));
+    }
     if (bicg) {
         const size_t nv = (size_t)n + 2;
         OGL_TRY(d_v.alloc(nv, st));
@@ -2511,7 +2546,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     chk.n_part = nc;
     chk.n_sums = 2;
     chk.history = d_history.p;
-    if (!gmres && !fused) {  // (fused: this check opens the first step_1x_fin)
+    if (!gmres && !fused && !bicg_fold) {  // (fused / bicg_fold: this check opens the first folded kernel)
         OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
         OGL_TRY(finalize(FIN_CG_CHECK, chk));
         OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
@@ -2640,6 +2675,26 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s);
                 chk.turn = 1;  // this check leaves an x update pending for the next step_1x
                 OGL_TRY(finalize(FIN_CG_CHECK, chk));
+            } else if (bicg_fold) {
+                // [check + step_1] | M^-1 | SpMV | [alpha + step_2] | M^-1 | SpMV | [mid-turn check + omega + step_3];
+                // partials: rho, sum|r| in part0 / part1; rr.v in part2; sum|s| in part3; s.t, t.t in part4 / part5
+                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
+                launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, y, slot_s[cur], slot_s[cur ^ 1], d_part0.p,
+                                  d_part1.p, d_history.p);
+                cur ^= 1;
+                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+                if (generic) apply_preconditioner(d_p.p, y, slot_s[cur]);
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+                OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p, SpmvDots{d_rr.p, d_part2.p, nullptr}, slot_s[cur]));
+                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+                launch_bicg_fold2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part3.p, slot_s[cur], slot_s[cur ^ 1],
+                                  d_part2.p);
+                cur ^= 1;
+                if (generic) apply_preconditioner(d_s.p, z, slot_s[cur]);
+                OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p, SpmvDots{d_s.p, d_part4.p, d_part5.p}, slot_s[cur]));
+                launch_bicg_fold3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p, d_part1.p, slot_s[cur],
+                                  slot_s[cur ^ 1], d_part4.p, d_part5.p, d_part3.p, d_history.p, enq);
+                cur ^= 1;
             } else {
                 launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
                 if (generic) apply_preconditioner(d_p.p, y, s);
@@ -2677,7 +2732,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         return OGL_OK;
     };
     auto poll_record = [&](int slot) -> int {
-        OGL_HIP_CHECK(hipMemcpyAsync(&h_scal[slot], s, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipMemcpyAsync(&h_scal[slot], bicg_fold ? slot_s[cur] : s, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
         OGL_HIP_CHECK(hipEventRecord(poll_ev[slot], st));
         return OGL_OK;
     };
@@ -2756,16 +2811,21 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         }
         OGL_HIP_CHECK(hipEventSynchronize(poll_ev[k & 1]));
         if (h_scal[k & 1].stop) break;
-        if (!more && fused) break;  // (the check of the last enqueued turn is still to come: below)
+        if (!more && (fused || bicg_fold)) break;  // (the check of the last enqueued turn is still to come: below)
         if (!more) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
     }
     if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
         launch_cg_step1x_fin(st, n, p_of_turn(enq), d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0);
+    if (bicg_fold) {  // the check that closes the last turn run so far (a plain copy of the scalars when the solve has stopped)
+        launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, y, slot_s[cur], slot_s[cur ^ 1], d_part0.p, d_part1.p,
+                          d_history.p);
+        cur ^= 1;
+    }
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
     DevScalars fin;
-    OGL_HIP_CHECK(hipMemcpy(&fin, fused ? s2 : s, sizeof(fin), hipMemcpyDeviceToHost));
-    if (fused && !fin.stop) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
+    OGL_HIP_CHECK(hipMemcpy(&fin, bicg_fold ? slot_s[cur] : (fused ? s2 : s), sizeof(fin), hipMemcpyDeviceToHost));
+    if ((fused || bicg_fold) && !fin.stop) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
     if (fin.comm_error)
         return fail(OGL_ERR_COMM, "peer all-reduce timed out: a rank did not take part (check %d)",
                     fin.iter);

@@ -109,7 +109,7 @@ struct SellDev {
     {
         if (ready) launch_gather_sell(st, (int32_t)chunks.n, chunks.p, map.p, csr_vals, vals.p);
     }
-    DevSell view(int32_t n_rows) const
+    DevSell view(int32_t n_rows, bool stream) const
     {
         DevSell S;
         S.n_rows = n_rows;
@@ -118,7 +118,7 @@ struct SellDev {
         S.codes = codes.p;
         S.vals = vals.p;
         S.rmap = sorted ? rmap.p : nullptr;
-        S.stream = 9.0 * (double)slots + 40.0 * (double)n_rows > ogl::STREAM_MATRIX_ABOVE_BYTES;
+        S.stream = stream;
         return S;
     }
 };
@@ -392,6 +392,7 @@ struct ogl_solver {
     ogl::DevBuf<double> d_V, d_gm;                      // GMRES: Krylov bases, dense state
     ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T
     ogl::DevBuf<double> d_part0, d_part1, d_part2;  // (part2: beta partials of the fused-finaliser turn)
+    ogl::DevBuf<double> d_part3, d_part4, d_part5;  // (the folded GKOBiCGStab turn: sum|s|, s.t, t.t)
     ogl::DevBuf<ogl::DevScalars> d_scal;
     ogl::DevBuf<double> d_history;
     ogl::DevScalars *h_scal = nullptr;  // pinned, 2 slots
@@ -436,6 +437,7 @@ struct ogl_solver {
     double prop(const std::string &key, double dflt) const;
     bool peer_safe_wait() const;
     double stream_above_bytes() const;
+    double turn_extra_bytes() const;
     int32_t xcd_group() const;
     int32_t pat_xcd_group = 0;  // chosen per pattern (0 = the built-in group of 4 chunks)
 };

@@ -1,4 +1,20 @@
 export OGL_CASE_CACHE_DIR=/tmp/cc HSA_ENABLE_IPC_MODE_LEGACY=0; mkdir -p /tmp/cc gpurun_out
-timeout 900 python -m pytest tests/test_gpu_exact_arbiter.py -q -x -s 2>&1 | tail -8
-timeout 1200 python tools/parity_deviation.py > gpurun_out/r05_parity_deviation.txt 2> gpurun_out/r05_parity_deviation.err; tail -5 gpurun_out/r05_parity_deviation.txt
-bash tools/gpu_pass.sh r05c prof:--iters+100+--edge+128+--shuffle+65536+--solver+GKOBiCGStab+--asym+--precond+ISAI+--prop+streamAboveBytes=100000000
+B="--steps 3 --warmup 2 --cpu-iters 0 --no-general-legs"
+run() { T=$1; shift
+  python bench.py $B "$@" > gpurun_out/r05d.json 2> gpurun_out/r05d.err || { echo "$T FAILED"; tail -3 gpurun_out/r05d.err; return; }
+  python - "$T" <<'PY'
+import json,sys
+d=json.load(open("gpurun_out/r05d.json")); r=d["roofline"]; t=d["solver_turn"]
+print("%-34s turns/s=%8.1f us/turn=%6.1f spmv_us=%5.1f frac %.3f turn frac %.3f %s" % (sys.argv[1], d["value"], 1e3*t["ms"], 1e3*r["avg_kernel_ms"], r["frac"], t["frac_of_peak"], r["kernel"]))
+PY
+}
+for rep in 1 2; do
+for V in "" "--prop streamTurnSet=0"; do
+run "c3_bicg_isai_128s $V"   --iters 100 --edge 128 --shuffle 65536 --solver GKOBiCGStab --asym --precond ISAI $V
+run "bicg_bj_128a $V"        --iters 100 --solver GKOBiCGStab --asym --edge 128 $V
+run "bicg_gisai_128a $V"     --iters 100 --solver GKOBiCGStab --asym --edge 128 --precond GISAI $V
+run "c5_gmres_csr_184s $V"   --iters 60 --edge 184 --shuffle 65536 --solver GKOGMRES --krylov-dim 30 $V
+run "gmres30_bj_128 $V"      --iters 60 --edge 128 --solver GKOGMRES --krylov-dim 30 $V
+run "cg_bj4_128s $V"         --iters 100 --edge 128 --shuffle 65536 --block-size 4 $V
+run "cg_isai_136 $V"         --iters 100 --edge 136 --precond ISAI $V
+done; done
