@@ -3205,6 +3205,47 @@ __global__ __launch_bounds__(BLOCK) void k_gmres_mgs(int n, double *__restrict__
     if (threadIdx.x == 0) part[chunk] = s0;
 }
 
+// Small single-rank systems (<= FUSED_FIN_MAX_CHUNKS chunks): the finaliser between two Gram-Schmidt links (FIN_GMRES_H:
+// H(k, it) = sum of the link's partials) folded into the next link's kernel -- every workgroup reduces the partials
+// itself in the finaliser's order (same bits), workgroup 0 stores H(k, it).  One launch per link instead of two; the
+// link reads `part_in` and writes `part_out` (never the same array: another workgroup may still be reducing).
+__global__ __launch_bounds__(BLOCK) void k_gmres_mgs_fold(int n, double *__restrict__ w,
+                                                          const double *__restrict__ vprev,
+                                                          double *__restrict__ h_out,
+                                                          const double *__restrict__ vdot,
+                                                          const double *__restrict__ part_in, int n_part,
+                                                          double *__restrict__ part_out, const DevScalars *gate)
+{
+    __shared__ double red[2 * FIN_WAVES];
+    __shared__ double sh_h;
+    __shared__ double slot[N_WAVES];
+    if (gate && gate->stop) return;
+    const int chunk = blockIdx.x;
+    const RowPair rp = my_rows(chunk, n);
+    double2 vw = ld2(w, rp);
+    if (vprev) {
+        const double2 vp = ld2(vprev, rp);
+        double pv[2][FIN_VT], v[2];
+        load_partials_as_finaliser<1>(part_in, nullptr, n_part, pv);
+        reduce_partials_as_finaliser<1>(pv, n_part, red, v);
+        if (threadIdx.x == 0) {
+            sh_h = v[0];
+            if (blockIdx.x == 0) *h_out = v[0];  // FIN_GMRES_H
+        }
+        __syncthreads();
+        const double h = sh_h;
+        vw.x -= h * vp.x;
+        vw.y -= h * vp.y;
+        st2(w, rp, vw);
+    }
+    const double2 vd = vdot ? ld2(vdot, rp) : vw;
+    double d = 0.0;
+    if (rp.n > 0) d += vw.x * vd.x;
+    if (rp.n > 1) d += vw.y * vd.y;
+    const double s0 = block_sum(d, slot);
+    if (threadIdx.x == 0) part_out[chunk] = s0;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_gmres_update_x(int n, const double *__restrict__ V,
                                                           long ld, const double *__restrict__ y,
                                                           int it, const double *__restrict__ inv_diag,
@@ -4288,6 +4329,15 @@ void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const do
     if (nc == 0) return;
     hipLaunchKernelGGL(k_bicg_step3, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr,
                        part_rho, part_norm, s, turn);
+}
+
+void launch_gmres_mgs_fold(hipStream_t st, int32_t n, double *w, const double *vprev, double *h_out, const double *vdot,
+                           const double *part_in, double *part_out, const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_gmres_mgs_fold, dim3(nc), dim3(BLOCK), 0, st, n, w, vprev, h_out, vdot, part_in, nc, part_out,
+                       gate);
 }
 
 void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,

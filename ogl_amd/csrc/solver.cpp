@@ -2356,9 +2356,14 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     const bool bicg_fold = bicg && !reg->comm->multi() && nc >= 1 &&
                            nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
                            prop("fusedFinalizers", 1.0) != 0.0 && prop("bicgFold", 1.0) != 0.0;
+    // ... and for small single-rank GKOGMRES systems the finaliser between two Gram-Schmidt links is folded into the next
+    // link's kernel (k_gmres_mgs_fold: one launch per link instead of two)
+    const bool gmres_fold = gmres && !reg->comm->multi() && nc >= 1 &&
+                            nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
+                            prop("fusedFinalizers", 1.0) != 0.0 && prop("gmresFold", 1.0) != 0.0;
     DevScalars *slot_s[2] = {s, s2};
     int cur = 0;  // the slot that holds the scalars after everything enqueued so far (bicg_fold only)
-    props["fusedFinalizersInUse"] = (fused || bicg_fold) ? 1.0 : 0.0;
+    props["fusedFinalizersInUse"] = (fused || bicg_fold || gmres_fold) ? 1.0 : 0.0;
     // ... and on half storage step_1x(_fin) and the SpMV are one kernel (k_cg_turn_sym, k_cg_turn_sym_big): 2 launches
     // per turn for small systems, 4 for larger ones, p alternating between two buffers (single rank: with halos the
     // put and the wait for the neighbours' puts would sit in one kernel)
@@ -2600,6 +2605,20 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                 // finish_arnoldi (modified Gram-Schmidt): H(k,it) = nx.V_k ; nx -= H(k,it) V_k
                 fg.turn = it;
                 fg.n_sums = 1;
+                if (gmres_fold) {
+                    double *pin = d_part1.p, *pout = d_part0.p;  // (a link reads the partials of the one before it)
+                    for (int k = 0; k <= it; ++k) {
+                        launch_gmres_mgs_fold(st, n, nx, k > 0 ? d_V.p + (size_t)(k - 1) * ldv : nullptr,
+                                              k > 0 ? gm_h(k - 1, it) : nullptr, d_V.p + (size_t)k * ldv, pin, pout, s);
+                        std::swap(pin, pout);
+                    }
+                    launch_gmres_mgs_fold(st, n, nx, v_it, gm_h(it, it), nullptr, pin, pout, s);
+                    fg.part[0] = pout;
+                    OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
+                    fg.part[0] = d_part0.p;
+                    launch_gmres_scale(st, n, nx, nx, beta_ptr, s);
+                    continue;
+                }
                 for (int k = 0; k <= it; ++k) {
                     launch_gmres_mgs(st, n, nx, k > 0 ? d_V.p + (size_t)(k - 1) * ldv : nullptr,
                                      k > 0 ? gm_h(k - 1, it) : nullptr, d_V.p + (size_t)k * ldv,

@@ -131,3 +131,42 @@ def test_folded_turn_same_bits_as_the_eight_launch_turn(reg, oracle, shape):
         np.testing.assert_array_equal(out[0][1], out[1][1], err_msg=str((shape, kw)))
         np.testing.assert_array_equal(out[0][0], out[1][0], err_msg=str((shape, kw)))
         assert out[0][2:] == out[1][2:], (shape, kw, out[0][2:], out[1][2:])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GKOGMRES: the finaliser between two Gram-Schmidt links folded into the next link's kernel (k_gmres_mgs_fold):
+# one launch per link instead of two.  Solver/GMRES/GKOGMRES.H:13-113.
+# ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape,sym", [((16, 16, 16), True), ((33, 31, 29), False), ((64, 64, 64), True),
+                                       ((80, 81, 80), True), ((1, 1, 1), True), ((700, 1, 1), False)])
+def test_gmres_folded_links_same_bits(reg, oracle, shape, sym):
+    kw_case = {} if sym else dict(symmetric=False, off_upper=-0.9, off_lower=-1.1)
+    case = synthetic.poisson_block(*shape, **kw_case)
+    xs = synthetic.x_star(case.global_index, case.global_n)
+    b = synthetic.apply_case(case, xs)
+    n_chunks = -(-case.n_cells // capi.lib().ogl_reduction_chunk_rows())
+    A, (rp, cols, vals) = oracle_matrix(oracle, case)
+    variants = [dict(tolerance=1e-9, rel_tol=0.0, max_iter=45, krylov_dim=10, preconditioner=capi.PRECOND_BJ),
+                dict(tolerance=0.0, rel_tol=0.0, max_iter=23, krylov_dim=30, preconditioner=capi.PRECOND_NONE),
+                dict(tolerance=1e-8, rel_tol=0.0, max_iter=40, krylov_dim=7, preconditioner=capi.PRECOND_BJ, max_block_size=4)]
+    for i, kw in enumerate(variants):
+        out = []
+        for fold in (1.0, 0.0):
+            s = reg.solver(f"gf_{i}_{int(fold)}", capi.default_config(
+                solver=capi.SOLVER_GMRES, export_res=1, adapt_min_iter=0, update_init_guess=1, **kw)).set_matrix(case)
+            s.set_property("gmresFold", fold)
+            x, perf = s.solve(b, np.zeros_like(b))
+            assert s.get_property("fusedFinalizersInUse") == (fold if n_chunks <= 1024 else 0.0)
+            out.append((x, s.history().copy(), perf.n_iterations, perf.n_norm_evals, perf.initial_residual,
+                        perf.final_residual))
+        np.testing.assert_array_equal(out[0][1], out[1][1], err_msg=str((shape, kw)))
+        np.testing.assert_array_equal(out[0][0], out[1][0], err_msg=str((shape, kw)))
+        assert out[0][2:] == out[1][2:], (shape, kw)
+        if i < 2 and case.n_cells <= 40000:          # ... and the oracle's bits
+            P = precond_of(oracle, (rp, cols, vals), kw["preconditioner"])
+            okw = {k: v for k, v in kw.items() if k in ("tolerance", "rel_tol", "max_iter", "krylov_dim")}
+            with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+                ref = oracle.gmres(A, b, np.zeros_like(b), P, **okw)
+            np.testing.assert_array_equal(out[0][1], ref.history)
+            np.testing.assert_array_equal(out[0][0], ref.x)
