@@ -775,6 +775,25 @@ def main():
     _, p_e2e = s.solve(b, psi_io, inplace=True)
     t_e2e = time.perf_counter() - t0
 
+    # Momentum components (ogl_solver_set_matrix_like): three solvers on ONE set of host arrays, as solveSegregated
+    # builds them for Ux, Uy, Uz -- the second and third take the first one's device copy of upper / lower
+    components = None
+    if world == 1 and not args.config and not os.environ.get("OGL_BENCH_CHILD"):
+        cs = [reg.solver("U" + c, cfg) for c in "xyz"]
+        for k, c in enumerate(cs):                       # (patterns: not timed)
+            c.set_matrix(ldu_arrays, like=cs[k - 1] if k else None)
+        torch.cuda.synchronize()
+        ms, reused = [], []
+        for k, c in enumerate(cs):
+            t0 = time.perf_counter()
+            c.set_matrix(ldu_arrays, like=cs[k - 1] if k else None)
+            ms.append(1e3 * (time.perf_counter() - t0))
+            reused.append(c.get_property("offDiagReused") == 1.0)
+        components = {"refresh_ms": ms, "off_diagonals_taken_from_the_sibling": reused,
+                      "what": "values-only set_matrix of Ux, Uy, Uz on one lduMatrix (same upper / lower host arrays): "
+                              "Uy and Uz upload their diagonal only and copy upper / lower device to device"}
+        del cs
+
     # ---- the general layouts on the same system (N = 1, the plain benchmark box only), outside the timed
     # region: full storage (pattern-coded compressed copy), plain CSR-stream, cells shuffled (irregular
     # numbering: the library renumbers its device copy itself) -- each a short run of its own solver
@@ -969,6 +988,7 @@ def main():
             "h2d_GBps": 8.0 * (case.n_faces * (1 if case.lower is None else 2) + N) / 1e9 /
                         max(1e-9, t_refresh_matrix),
             "d2h_GBps": 8.0 * N / 1e6 / max(1e-9, p_e2e.t_copy_back_ms),
+            "momentum_components": components,
         },
     }
 

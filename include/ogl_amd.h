@@ -250,6 +250,18 @@ int ogl_solver_get_or_create(ogl_registry *reg, const char *field_name, const og
  * CsrMatrixWrapper.H:74-136). */
 int ogl_solver_set_matrix(ogl_solver *s, const ogl_ldu_view *ldu);
 
+/* The components of a vector field: fvMatrix::solveSegregated constructs the solvers of Ux, Uy, Uz on ONE lduMatrix --
+ * the same upper() / lower() storage with the same values, only diag() and the interface coefficients differ per
+ * component -- and the reference uploads all of it three times (HostMatrix.C:644-682 runs once per solver object,
+ * lduLduBase.H:224-237).  Like ogl_solver_set_matrix, but the off-diagonal coefficients are taken from `donor`'s device
+ * copy (a device-to-device copy) instead of crossing PCIe again, when ALL of this holds: same registry, same face
+ * addressing (fingerprint of lowerAddr / upperAddr / interfaces), ldu->upper / ldu->lower are the very host arrays
+ * `donor` uploaded from (pointer identity), a checksum over 8192 sampled entries of them still equals what `donor`
+ * recorded, and neither solver reorders on the host.  Otherwise it IS ogl_solver_set_matrix.  The caller vouches that
+ * nothing wrote to those arrays in between (the plug-in asks for this only for the sibling component solved
+ * immediately before, in the same time step: OGLAdapter.H).  Property offDiagReused tells what happened. */
+int ogl_solver_set_matrix_like(ogl_solver *s, const ogl_ldu_view *ldu, ogl_solver *donor);
+
 /* lduMatrix::solver::solve(psi, source, cmpt) (GKOCG.H:149-153 -> lduLduBase.H:189-308):
  * upload source (updateRHS) and psi (first call / updateInitGuess), scale the RHS, (re)generate
  * the preconditioner, run the Krylov loop, copy x back into psi, fill `perf`. */

@@ -81,7 +81,7 @@ EXPORTED_SYMBOLS = [
     "ogl_last_error", "ogl_abi_version", "ogl_config_default", "ogl_registry_create",
     "ogl_registry_destroy", "ogl_registry_set_host_comm", "ogl_rccl_unique_id",
     "ogl_registry_rccl_ready", "ogl_registry_init_rccl", "ogl_registry_peer_handle", "ogl_registry_peer_connect",
-    "ogl_registry_peer_disable", "ogl_solver_get_or_create", "ogl_solver_set_matrix",
+    "ogl_registry_peer_disable", "ogl_solver_get_or_create", "ogl_solver_set_matrix", "ogl_solver_set_matrix_like",
     "ogl_solver_solve", "ogl_solver_history", "ogl_solver_export_system",
     "ogl_solver_get_property",
     "ogl_solver_set_property", "ogl_solver_apply_resident", "ogl_solver_upload_solution",
@@ -265,9 +265,15 @@ class Solver:
                                               C.byref(self._h)))
         self._ldu = None
 
-    def set_matrix(self, case):
+    def set_matrix(self, case, like=None):
+        """like: another Solver of this registry whose device copy of upper / lower may be taken instead of uploading
+        them again (ogl_solver_set_matrix_like: momentum components; `case` must then be LduArrays built on the very
+        host arrays `like` uploaded from)."""
         self._ldu = case if isinstance(case, LduArrays) else LduArrays(case)
-        _check(lib().ogl_solver_set_matrix(self._h, C.byref(self._ldu.view)))
+        if like is None:
+            _check(lib().ogl_solver_set_matrix(self._h, C.byref(self._ldu.view)))
+        else:
+            _check(lib().ogl_solver_set_matrix_like(self._h, C.byref(self._ldu.view), like._h))
         return self
 
     def solve(self, source, psi, inplace=False):

@@ -189,6 +189,17 @@ extern "C" int ogl_solver_set_matrix(ogl_solver *s, const ogl_ldu_view *ldu)
     OGL_GUARD_END
 }
 
+extern "C" int ogl_solver_set_matrix_like(ogl_solver *s, const ogl_ldu_view *ldu, ogl_solver *donor)
+{
+    OGL_GUARD_BEGIN
+    if (!s || !ldu) return fail(OGL_ERR_INVALID, "NULL argument");
+    s->share_from = (donor && donor != s && donor->reg == s->reg) ? donor : nullptr;
+    const int rc = s->set_matrix(*ldu);
+    s->share_from = nullptr;
+    return rc;
+    OGL_GUARD_END
+}
+
 extern "C" int ogl_solver_solve(ogl_solver *s, const ogl_scalar *source, ogl_scalar *psi,
                                 ogl_perf *perf)
 {

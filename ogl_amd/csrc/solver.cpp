@@ -1410,6 +1410,27 @@ int ogl_solver::ensure_vectors()
     return OGL_OK;
 }
 
+// checksum over (at most) 4096 evenly spaced entries of each off-diagonal array plus their last ones (bit patterns):
+// what ogl_solver_set_matrix_like compares before it trusts a donor's device copy
+static uint64_t offdiag_sample(const double *upper, const double *lower, int64_t F)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const double *a, int64_t i) {
+        uint64_t w;
+        std::memcpy(&w, a + i, sizeof(w));
+        h = (h ^ w) * 1099511628211ull;
+    };
+    if (F <= 0 || !upper) return h;
+    const int64_t step = std::max<int64_t>(1, F / 4096);
+    for (int64_t i = 0; i < F; i += step) {
+        mix(upper, i);
+        if (lower) mix(lower, i);
+    }
+    mix(upper, F - 1);
+    if (lower) mix(lower, F - 1);
+    return h;
+}
+
 // ------------------------------------------------------------------------------------------
 // HostMatrixWrapper: pattern once, coefficients every call (HostMatrix.C:15-96)
 // ------------------------------------------------------------------------------------------
@@ -1433,6 +1454,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             collect_interface_coeffs(ldu, true, iface.data());
         }
         if (cfg.reorder_on_host) {  // :608-633, scaling applied by the host update functions
+            offdiag_valid = false;  // (d_source is not filled on this path: nothing for a sibling to take)
+            props["offDiagReused"] = 0.0;
             OGL_TRY(download_local_pattern(pat));
             std::vector<double> sorted(nnz);
             if (pat.local_iface_nnz) {
@@ -1454,9 +1477,26 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             OGL_TRY(reg->stager.h2d(d_vals.p, sorted.data(), nnz * sizeof(double), st));
         } else {  // :634-704 -- H2D into the unsorted slots, then the device permutation (K9)
             double *src = d_source.p;
-            OGL_TRY(reg->stager.h2d(src, ldu.upper, (size_t)F * sizeof(double), st));          // :644-650
-            if (!pat.symmetric)
-                OGL_TRY(reg->stager.h2d(src + F, ldu.lower, (size_t)F * sizeof(double), st));  // :653-660
+            // (ogl_solver_set_matrix_like: a sibling component's device copy of the same upper / lower arrays)
+            const ogl_solver *d = share_from;
+            const uint64_t sum = offdiag_sample(ldu.upper, pat.symmetric ? nullptr : ldu.lower, F);
+            const bool reuse = d && d->offdiag_valid && d->matrix_set && !d->cfg.reorder_on_host && d->have_pattern &&
+                               d->pat.fingerprint == pat.fingerprint && d->pat.upper_nnz == F && d->pat.n_rows == N &&
+                               d->pat.symmetric == pat.symmetric && d->offdiag_upper == ldu.upper &&
+                               (pat.symmetric || d->offdiag_lower == ldu.lower) && d->offdiag_sum == sum && F > 0;
+            if (reuse) {
+                OGL_HIP_CHECK(hipMemcpyAsync(src, d->d_source.p, (size_t)F * (pat.symmetric ? 1 : 2) * sizeof(double),
+                                             hipMemcpyDeviceToDevice, st));
+            } else {
+                OGL_TRY(reg->stager.h2d(src, ldu.upper, (size_t)F * sizeof(double), st));          // :644-650
+                if (!pat.symmetric)
+                    OGL_TRY(reg->stager.h2d(src + F, ldu.lower, (size_t)F * sizeof(double), st));  // :653-660
+            }
+            offdiag_upper = ldu.upper;
+            offdiag_lower = pat.symmetric ? nullptr : ldu.lower;
+            offdiag_sum = sum;
+            offdiag_valid = true;
+            props["offDiagReused"] = reuse ? 1.0 : 0.0;
             OGL_TRY(reg->stager.h2d(src + pat.diag_start(), ldu.diag, (size_t)N * sizeof(double),
                                     st));                                                     // :663-669
             if (pat.local_iface_nnz)

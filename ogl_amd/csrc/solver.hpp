@@ -435,6 +435,12 @@ struct ogl_solver {
     ogl::DevCsr csr() const;
     ogl::DevHalo halo() const;
     double prop(const std::string &key, double dflt) const;
+    // ogl_solver_set_matrix_like: the solver whose device copy of upper / lower this set_matrix may take (only during
+    // that call), and what THIS solver's copy was uploaded from (host arrays + sampled checksum) for a later taker
+    const ogl_solver *share_from = nullptr;
+    const double *offdiag_upper = nullptr, *offdiag_lower = nullptr;
+    uint64_t offdiag_sum = 0;
+    bool offdiag_valid = false;
     bool peer_safe_wait() const;
     double stream_above_bytes() const;
     double turn_extra_bytes() const;

@@ -159,6 +159,16 @@ static dictionary cg_dict()
     return d;
 }
 
+// ------------------------------------------------------------------ momentum components (cpu)
+TEST(cpu_component_sibling_names)
+{
+    EXPECT_TRUE(componentSiblings("Ux", "Uy") && componentSiblings("Uz", "Ux") && componentSiblings("Rxx", "Rxy"));
+    EXPECT_TRUE(componentSiblings("Rxy", "Ryz") && componentSiblings("U.waterx", "U.watery"));
+    EXPECT_TRUE(!componentSiblings("Ux", "Ux") && !componentSiblings("Ux", "p") && !componentSiblings("x", "y"));
+    EXPECT_TRUE(!componentSiblings("Ux", "Vx") && !componentSiblings("Ux", "Uxx") && !componentSiblings("k", "p"));
+    EXPECT_TRUE(!componentSiblings("Ua", "Ub") && !componentSiblings("", ""));
+}
+
 // ------------------------------------------------------------------ dictionary / selection (cpu)
 TEST(cpu_config_defaults_and_keywords)
 {
@@ -331,6 +341,63 @@ TEST(gpu_property_keywords_reach_the_backend)
     EXPECT_TRUE(std::memcmp(psi.cdata(), psi2.cdata(), sizeof(scalar) * c.n) == 0);   // same bits either way
 }
 TEST(gpu_GKOCG_BJ_cyclic_patches) { run_gkocg_case(true); }
+
+// fvMatrix<vector>::solveSegregated: ONE lduMatrix, the solvers of Ux, Uy, Uz built one after the other, diag() changed in
+// between.  The second and third component take the first one's device copy of upper / lower (offDiagReused) and give
+// the bits of a full upload; a new time step, a field that is no sibling, or off-diagonals written to in between: full upload.
+TEST(gpu_momentum_components_share_the_off_diagonals)
+{
+    Case c;
+    build_poisson(c, 14, 11, 9, false, true);
+    dictionary pc;
+    pc.add("preconditioner", "BJ").add("maxBlockSize", 1);
+    dictionary d;
+    d.add("solver", "GKOBiCGStab").add("preconditioner", pc).add("tolerance", 1e-10).add("relTol", 0.0);
+    d.add("maxIter", 300).add("export", "true").add("matrixFormat", "Csr").add("executor", "hip").add("adaptMinIter", "false");
+    dictionary d_off = d;
+    d_off.add("componentCoeffsReuse", "false");
+    const scalarField diag0(c.A->diag());
+    auto component = [&](const char *name, int cmpt, const dictionary &dict, scalarField &psi, double &reused) {
+        for (label i = 0; i < c.n; ++i) c.A->diag()[i] = diag0[i] + 0.01 * cmpt * (1 + i % 5);   // (addBoundaryDiag)
+        scalarField source(c.n);
+        for (label i = 0; i < c.n; ++i) source[i] = std::sin(0.37 * i + cmpt) + 0.25;
+        auto solver = lduMatrix::solver::New(name, *c.A, c.bou, c.intc, c.ifaces, dict);
+        const solverPerformance perf = solver->solve(psi, source, (direction)cmpt);
+        reused = dynamic_cast<const GKOlduBaseSolver &>(*solver).backend_property("offDiagReused");
+        return perf;
+    };
+    Foam::Time::index() = 7;
+    double r[3], q[3];
+    std::vector<scalarField> x(3, scalarField(c.n, 0.0)), y(3, scalarField(c.n, 0.0));
+    const char *names[3] = {"Ux", "Uy", "Uz"}, *names_off[3] = {"Vx", "Vy", "Vz"};
+    solverPerformance px[3], py[3];
+    for (int k = 0; k < 3; ++k) px[k] = component(names[k], k, d, x[k], r[k]);
+    EXPECT_TRUE(r[0] == 0.0 && r[1] == 1.0 && r[2] == 1.0);
+    for (int k = 0; k < 3; ++k) py[k] = component(names_off[k], k, d_off, y[k], q[k]);       // every component uploads all
+    EXPECT_TRUE(q[0] == 0.0 && q[1] == 0.0 && q[2] == 0.0);
+    for (int k = 0; k < 3; ++k) {
+        EXPECT_EQ(px[k].nIterations(), py[k].nIterations());
+        EXPECT_EQ(px[k].finalResidual(), py[k].finalResidual());
+        EXPECT_TRUE(std::memcmp(x[k].cdata(), y[k].cdata(), sizeof(scalar) * c.n) == 0);
+    }
+    // the next time step: Ux uploads again (the previous object was Vz: no sibling), then a time-index change between
+    // two siblings, then off-diagonals written to in between (the sampled checksum sees entry 0 change)
+    Foam::Time::index() = 8;
+    double rr;
+    scalarField z(c.n, 0.0);
+    component("Ux", 0, d, z, rr);
+    EXPECT_EQ(rr, 0.0);
+    Foam::Time::index() = 9;
+    component("Uy", 1, d, z, rr);
+    EXPECT_EQ(rr, 0.0);
+    component("Uz", 2, d, z, rr);
+    EXPECT_EQ(rr, 1.0);
+    c.A->upper()[0] *= 1.5;
+    component("Ux", 0, d, z, rr);
+    EXPECT_EQ(rr, 0.0);
+    component("p", 0, d, z, rr);   // (no sibling of Ux)
+    EXPECT_EQ(rr, 0.0);
+}
 
 TEST(gpu_unsupported_coupled_patch_is_fatal)
 {
