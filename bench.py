@@ -89,6 +89,9 @@ def parse():
                     help="instead of the box: the Voronoi cells of this many random points (a polyhedral mesh, "
                          "15.5 faces per cell on average, random numbering); single rank only; scipy Delaunay "
                          "takes about a minute per million points")
+    ap.add_argument("--no-centres", action="store_true",
+                    help="with --voronoi: do not hand the cell centres over (reverse Cuthill-McKee is then the only "
+                         "candidate for the library's own numbering; with them the Hilbert order through the centres competes)")
     ap.add_argument("--blocks", default="",
                     help="instead of the plain box: a multi-block structured mesh -- comma-separated block lengths along "
                          "x (e.g. 120,96), each block n x n in y and z, numbered block after block as blockMesh does; "
@@ -294,7 +297,8 @@ def main():
         case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
     if args.voronoi:
         assert world == 1, "--voronoi is a single-rank option"
-        case = synthetic.voronoi_case(args.voronoi)
+        # (the generating points stand in for mesh.C(): the plug-in passes the cell centres, ogl_ldu_view::cell_centres)
+        case = synthetic.voronoi_case(args.voronoi, with_centres=not args.no_centres)
     if args.blocks:
         assert world == 1 and not args.voronoi and not args.asym, "--blocks is a single-rank, symmetric option"
         case = synthetic.multi_block_case([int(v) for v in args.blocks.split(",")], n, n)
@@ -589,7 +593,9 @@ def main():
                                 "rccl_ranks_seen": d["config"]["transport"]["rccl_ranks_seen"],
                                 "wait_us": d["config"]["transport"]["wait_us"]})
                 elif p.returncode != 0:
-                    rec["error"] = se.strip().splitlines()[-1][-400:] if se.strip() else "child failed"
+                    said = [ln for ln in se.splitlines() if ln.startswith("bench.py:")]
+                    rec["error"] = " | ".join(dict.fromkeys(ln[-300:] for ln in said[-3:])) if said else \
+                        (se.strip().splitlines()[-1][-400:] if se.strip() else "child failed")
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.communicate()
@@ -923,6 +929,9 @@ def main():
             "rows_per_gpu": N, "nnz_per_gpu": nnz, "cg_iters_per_step": args.iters,
             "renumber": args.renumber, "renumbered": renumbered,
             "rows_sorted_by_length": prop_or(s, "rowsSortedByLength", 0.0) == 1.0,
+            "numbering": {"along_hilbert_curve": prop_or(s, "renumberedAlongCurve", 0.0) == 1.0,
+                          "gather_sectors_rcm": prop_or(s, "gatherSectorRatioRcm", None),
+                          "gather_sectors_curve": prop_or(s, "gatherSectorRatioCurve", None)},
             # irregular patterns: both SpMV kernels timed once per pattern at set_matrix, the faster one runs
             "layout_tuned_us": ({"csr": prop_or(s, "spmvTunedCsrUs", None), "sell": prop_or(s, "spmvTunedSellUs", None),
                                  "csr21": prop_or(s, "spmvTunedCsr21Us", None), "symx": prop_or(s, "spmvTunedSymxUs", None)}

@@ -149,6 +149,12 @@ typedef struct ogl_ldu_view {
     const ogl_scalar *lower;       /* matrix.lower(); NULL <=> matrix.symmetric() HostMatrix.C:473  */
     ogl_label n_interfaces;
     const ogl_interface *interfaces;
+    /* Optional (NULL = not given; this build's addition, the reference reads no geometry): the cell centres,
+     * mesh.C() -- x, y, z per cell, 3 n_cells doubles.  With `renumber auto | on` the library then has a second
+     * candidate for the numbering of its device copy next to reverse Cuthill-McKee: the cells along a Hilbert curve
+     * through their centres, which on polyhedral meshes gathers x from fewer cache lines (host_matrix.hpp
+     * NumberingHooks).  Read during the ogl_solver_set_matrix call that builds the pattern only. */
+    const ogl_scalar *cell_centres;
 } ogl_ldu_view;
 
 /* solverPerformance fields the reference fills (lduLduBase.H:283-285) + its statistics block
@@ -372,6 +378,9 @@ int ogl_host_pattern(const ogl_ldu_view *ldu, ogl_matrix_dims *dims, ogl_label *
  * followed by the policy of config `renumber` (mode) -- same outputs in the chosen numbering plus
  * new_id[n_cells] (identity when the caller's numbering was kept); returns 1 if renumbered. */
 int ogl_host_rcm(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, ogl_label *new_id);
+/* ... and the second candidate when ogl_ldu_view::cell_centres is given: new_id[old] = position of cell `old` along the
+ * Hilbert curve (16 bits per axis over the bounding box) through the centres; ties keep the caller's order. */
+int ogl_host_hilbert_order(ogl_label n_cells, const ogl_scalar *centres, ogl_label *new_id);
 double ogl_host_gather_sector_ratio(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols,
                                     const ogl_label *new_id);
 int ogl_host_pattern_renumbered(const ogl_ldu_view *ldu, int32_t mode, int32_t compress_indices,

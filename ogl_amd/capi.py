@@ -51,7 +51,7 @@ class Interface(C.Structure):
 class LduView(C.Structure):
     _fields_ = [("n_cells", C.c_int32), ("n_faces", C.c_int32), ("lower_addr", _LP),
                 ("upper_addr", _LP), ("diag", _SP), ("upper", _SP), ("lower", _SP),
-                ("n_interfaces", C.c_int32), ("interfaces", C.POINTER(Interface))]
+                ("n_interfaces", C.c_int32), ("interfaces", C.POINTER(Interface)), ("cell_centres", _SP)]
 
 
 class Perf(C.Structure):
@@ -91,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "ogl_solver_get_comm_pattern", "ogl_host_init_local_sparsity", "ogl_host_symmetric_update",
     "ogl_host_symmetric_update_w_interface", "ogl_host_non_symmetric_update_w_interface",
     "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
-    "ogl_host_sell_check", "ogl_host_sym_check", "ogl_host_symx_check", "ogl_solver_get_renumbering", "ogl_host_rcm",
+    "ogl_host_sell_check", "ogl_host_sym_check", "ogl_host_symx_check", "ogl_solver_get_renumbering", "ogl_host_rcm", "ogl_host_hilbert_order",
     "ogl_host_gather_sector_ratio", "ogl_host_pattern_renumbered",
     "ogl_host_addressing_fingerprint", "ogl_registry_comm_info",
 ]
@@ -172,10 +172,12 @@ class LduArrays:
         for i, (fc, bc, f) in enumerate(self.ifaces):
             self.c_ifaces[i] = Interface(f.kind, f.neighb_proc, f.neighb_patch, fc.size, _pl(fc),
                                          _ps(bc))
+        centres = getattr(case, "centres", None)
+        self.centres = None if centres is None else _s(np.asarray(centres).reshape(case.n_cells, 3))
         self.view = LduView(case.n_cells, self.upper_addr.size, _pl(self.lower_addr),
                             _pl(self.upper_addr), _ps(self.diag), _ps(self.upper),
                             None if self.lower is None else _ps(self.lower), len(self.ifaces),
-                            self.c_ifaces)
+                            self.c_ifaces, None if self.centres is None else _ps(self.centres))
 
 
 class Registry:
@@ -474,6 +476,14 @@ def host_rcm(row_ptrs, cols):
     rp, cc = _l(row_ptrs), _l(cols)
     new_id = np.zeros(len(rp) - 1, np.int32)
     _check(lib().ogl_host_rcm(C.c_int32(len(rp) - 1), _pl(rp), _pl(cc), _pl(new_id)))
+    return new_id
+
+
+def host_hilbert_order(centres):
+    """Cells along the Hilbert curve through their centres: new_id[old] = new."""
+    c = _s(np.asarray(centres).reshape(-1, 3))
+    new_id = np.zeros(c.shape[0], np.int32)
+    _check(lib().ogl_host_hilbert_order(C.c_int32(c.shape[0]), _ps(c), _pl(new_id)))
     return new_id
 
 

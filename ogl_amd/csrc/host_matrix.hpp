@@ -180,7 +180,13 @@ struct NumberingHooks {
     std::function<bool(const HostPattern &p, std::vector<ogl_label> &new_id)> rcm;
     // p.row_ptrs / p.cols / p.ldu_mapping rewritten into the numbering new_id (p.rows is left alone)
     std::function<bool(HostPattern &p, const std::vector<ogl_label> &new_id)> renumber_local;
+    // cell centres (x, y, z per cell; ogl_ldu_view::cell_centres), nullptr = not given: a second candidate for the
+    // order at large -- the cells along a Hilbert curve through their centres -- next to reverse Cuthill-McKee
+    const double *centres = nullptr;
 };
+// new_id[old] = position of cell `old` along the Hilbert curve (16 bits per axis over the bounding box) through the
+// cell centres; ties keep the caller's order
+void hilbert_order(ogl_label n, const double *centres, std::vector<ogl_label> &new_id);
 // Rewrites `p` (built by build_host_pattern in the caller's numbering) into the numbering new_id.
 // Rows keep their entries; within a row the entries are ordered by NEW column (stable).
 void renumber_pattern(HostPattern &p, std::vector<ogl_label> new_id, const NumberingHooks *hooks = nullptr);
@@ -193,6 +199,8 @@ struct RenumberReport {
     bool sorted_by_length = false;  // rows of a wavefront reordered longest first (compressed layout)
     bool sell_natural = false, sell_used = false;  // compressed layout qualifies (only when tried)
     double ratio_natural = 0.0, ratio_used = 0.0;  // gather_sector_ratio before / after
+    double ratio_rcm = -1.0, ratio_curve = -1.0;    // ... of the two candidates (-1: not formed)
+    bool curve_used = false;                        // the Hilbert order through the cell centres was taken
     double slot_ratio = 0.0;  // slot_gather_sector_ratio of the numbering at large (0: not needed)
 };
 // mode 0: keep the caller's numbering; 1: always RCM; 2 (default, "auto"): keep it when the

@@ -1611,15 +1611,18 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             OGL_TRY(download_local_pattern(np));
             // with the pattern on the device the two heavy steps of a renumbering run there (same results)
             NumberingHooks hooks;
-            hooks.rcm = [&](const HostPattern &hp, std::vector<ogl_label> &nid) {
-                return rcm_on_device(hp, nid) == OGL_OK && !nid.empty();
-            };
-            hooks.renumber_local = [&](HostPattern &hp, const std::vector<ogl_label> &nid) {
-                renumbered_on_device = renumber_on_device(hp, nid) == OGL_OK;
-                return renumbered_on_device;
-            };
-            OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep,
-                                     built_on_device ? &hooks : nullptr));
+            if (built_on_device) {
+                hooks.rcm = [&](const HostPattern &hp, std::vector<ogl_label> &nid) {
+                    return rcm_on_device(hp, nid) == OGL_OK && !nid.empty();
+                };
+                hooks.renumber_local = [&](HostPattern &hp, const std::vector<ogl_label> &nid) {
+                    renumbered_on_device = renumber_on_device(hp, nid) == OGL_OK;
+                    return renumbered_on_device;
+                };
+            }
+            // (cell centres, when the caller passes them: the Hilbert-curve candidate; property renumberCurve 0 = RCM only)
+            if (ldu.cell_centres && prop("renumberCurve", 1.0) != 0.0) hooks.centres = ldu.cell_centres;
+            OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep, &hooks));
         }
         pat_renumber_mode = cfg.renumber;
         pat_try_sell = try_sell;
@@ -1629,6 +1632,9 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         props["renumbered"] = rep.applied ? 1.0 : 0.0;
         props["gatherSectorRatioNatural"] = rep.ratio_natural;
         props["gatherSectorRatio"] = rep.ratio_used;
+        props["gatherSectorRatioRcm"] = rep.ratio_rcm;
+        props["gatherSectorRatioCurve"] = rep.ratio_curve;
+        props["renumberedAlongCurve"] = rep.curve_used ? 1.0 : 0.0;
         np.fingerprint = fp_new.get();
         pat = std::move(np);
         have_pattern = true;

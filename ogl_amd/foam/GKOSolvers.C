@@ -24,6 +24,13 @@
 #define OGL_EXPORT_NOW(db) ((db).time().writeTime())
 #define OGL_EXPORT_DIR(db) (Foam::mkDir((db).time().timePath()), std::string((db).time().timePath()))
 
+// mesh.C() for ogl_ldu_view::cell_centres (three contiguous doubles per cell): with `renumber auto | on` the cells along
+// a Hilbert curve through their centres compete with reverse Cuthill-McKee for the numbering of the device copy
+#define OGL_CELL_CENTRES(m)                                                                                     \
+    (Foam::isA<Foam::fvMesh>((m).mesh())                                                                        \
+         ? reinterpret_cast<const double *>(Foam::refCast<const Foam::fvMesh>((m).mesh()).C().primitiveField().cdata()) \
+         : nullptr)
+
 #include "OGLAdapter.H"
 
 namespace Foam {

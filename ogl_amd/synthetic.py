@@ -42,6 +42,7 @@ class LduCase:
     interfaces: List[Interface] = field(default_factory=list)
     global_index: Optional[np.ndarray] = None   # int64 [N] global cell id of each local cell
     global_n: int = 0
+    centres: Optional[np.ndarray] = None        # float64 [N, 3] cell centres (mesh.C()), optional
 
     @property
     def symmetric(self):
@@ -200,8 +201,12 @@ def permute_case(case: LduCase, new_id) -> LduCase:
         gi[new_id] = case.global_index
     ifaces = [Interface(f.kind, new_id[f.face_cells].astype(np.int32), f.bou_coeffs, f.neighb_proc,
                         f.neighb_patch, f.neighb_global) for f in case.interfaces]
+    centres = None
+    if case.centres is not None:
+        centres = np.empty_like(case.centres)
+        centres[new_id] = case.centres
     return LduCase(n, lo[order].astype(np.int32), up[order].astype(np.int32), diag, upper[order], lower,
-                   ifaces, gi, case.global_n)
+                   ifaces, gi, case.global_n, centres)
 
 
 def renumber_case(case: LduCase, window: int, seed: int = 20241016) -> LduCase:
@@ -259,7 +264,7 @@ def long_rows_case(case: LduCase, fraction: float, nx: int, seed: int = 20241016
                    None if low is None else low[order], [], case.global_index, case.global_n)
 
 
-def voronoi_case(n_points: int, seed: int = 20241016) -> LduCase:
+def voronoi_case(n_points: int, seed: int = 20241016, with_centres: bool = False) -> LduCase:
     """A genuinely unstructured finite-volume pattern: the cells are the Voronoi cells of `n_points`
     random points in the unit cube, two cells share a face when their points share a Delaunay edge
     (scipy.spatial.Delaunay) -- a polyhedral mesh with 15.5 faces per cell on average (5 ... ~60), numbered
@@ -286,7 +291,9 @@ def voronoi_case(n_points: int, seed: int = 20241016) -> LduCase:
             np.savez(path, lo=lo, up=up, n_faces=n_faces)
     gi = np.arange(n_points, dtype=np.int64)
     diag = n_faces.astype(np.float64) + _delta(gi)
-    return LduCase(n_points, lo, up, diag, np.full(lo.size, -1.0), None, [], gi, n_points)
+    # (the generating points stand in for the cell centres: same seed, same first draw as the triangulation's)
+    centres = np.random.default_rng(seed).random((n_points, 3)) if with_centres else None
+    return LduCase(n_points, lo, up, diag, np.full(lo.size, -1.0), None, [], gi, n_points, centres)
 
 
 def octree_case(n: int, band: float = 1.5, append_children: bool = False) -> LduCase:

@@ -36,12 +36,15 @@ def proxy(name):
                 synthetic.drop_faces_case(synthetic.poisson_case(40), 0.3), 4096),
             "shuffled": lambda: synthetic.renumber_case(synthetic.poisson_case(44), 65536),
             "voronoi": lambda: synthetic.voronoi_case(110000),
+            # the same mesh handed over WITH its cell centres (ogl_ldu_view::cell_centres): the Hilbert order through
+            # them competes with reverse Cuthill-McKee for the numbering of the device copy, and wins here
+            "voronoi_centres": lambda: synthetic.voronoi_case(110000, with_centres=True),
         }[name]()
     return _cache[name]
 
 
 PROXIES = ["octree", "octree_append", "long_rows", "long_rows_shuffled", "drop_faces", "drop_faces_shuffled",
-           "shuffled", "voronoi"]
+           "shuffled", "voronoi", "voronoi_centres"]
 # compressIndices: 1 = the default policy (irregular patterns: both kernels timed once, the faster runs),
 # 2 = force the compressed layout when it qualifies, 0 = plain CSR-stream
 MODES = {"auto": 1, "force": 2, "csr": 0}
@@ -94,8 +97,11 @@ def test_the_mechanisms_are_really_in_play(reg):
             except capi.OglError:      # (layout properties exist only once that layout was built)
                 return 0.0
         got[name] = {k: prop(k) for k in ("renumbered", "rowsSortedByLength", "sellSpilledEntries",
-                                          "sellChunksDelta16", "sellChunksCol32", "spmvLayout")}
+                                          "sellChunksDelta16", "sellChunksCol32", "spmvLayout", "renumberedAlongCurve",
+                                          "gatherSectorRatio")}
     assert got["voronoi"]["renumbered"] == 1.0 and got["shuffled"]["renumbered"] == 1.0, got
+    assert got["voronoi"]["renumberedAlongCurve"] == 0.0 and got["voronoi_centres"]["renumberedAlongCurve"] == 1.0, got
+    assert got["voronoi_centres"]["gatherSectorRatio"] < 0.8 * got["voronoi"]["gatherSectorRatio"], got
     assert got["shuffled"]["spmvLayout"] == 2.0 and got["octree"]["spmvLayout"] == 2.0, got
     assert got["long_rows"]["sellSpilledEntries"] > 0 or got["long_rows_shuffled"]["sellSpilledEntries"] > 0, got
     assert any(g["rowsSortedByLength"] == 1.0 for g in got.values()), got
