@@ -233,13 +233,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ b,
     double *__restrict__ y, const double *__restrict__ w, double *__restrict__ dot_partials,
-    double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup, HaloFused hf)
+    double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup, HaloFused hf,
+    const int *__restrict__ block_order)
 {
     __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
     __shared__ double slot[N_WAVES];
     if (gate && gate->stop) return;
-    const int chunk = xcd_chunk(blockIdx.x, xgroup);
-    if (chunk >= n_chunks) return;
+    // (banded patterns: the chunks of rows r and r +- band on one XCD, band_block_order -- as the half-storage kernels)
+    const int chunk = block_order ? block_order[blockIdx.x] : xcd_chunk(blockIdx.x, xgroup);
+    if (chunk < 0 || chunk >= n_chunks) return;
     const int tid = threadIdx.x;
     const int r0 = chunk * CHUNK_ROWS;
     const int r1 = min(r0 + CHUNK_ROWS, n_rows);
@@ -2409,14 +2411,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_sell(int n_rows, int n_chunks,
                                                      double *__restrict__ dot_partials,
                                                      double *__restrict__ dot2_partials,
                                                      const DevScalars *gate, int xgroup, HaloFused hf,
-                                                     const uint16_t *__restrict__ rmap)
+                                                     const uint16_t *__restrict__ rmap,
+                                                     const int *__restrict__ block_order)
 {
     __shared__ double slot[N_WAVES];
     __shared__ int stab[SELL_TABLE_INTS];
     static_assert(SELL_TABLE_INTS * sizeof(int) >= CHUNK_ROWS * sizeof(double), "the table doubles as the row-sum exchange");
     if (gate && gate->stop) return;
-    const int chunk = xcd_chunk(blockIdx.x, xgroup);
-    if (chunk >= n_chunks) return;
+    const int chunk = block_order ? block_order[blockIdx.x] : xcd_chunk(blockIdx.x, xgroup);
+    if (chunk < 0 || chunk >= n_chunks) return;
     const SellChunk h = chunks[chunk];
     const int t = threadIdx.x;
     // (DevSell::rmap: whose rows this thread's two slot rows hold -- asked for now, needed at the very end)
@@ -3768,10 +3771,11 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
-    const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
+    const bool ordered = A.block_order && !A.codes21;
+    const dim3 grid(ordered ? A.n_blocks : xcd_grid(nc, xg)), block(BLOCK);
 #define OGL_SPMV_K(MODE, NDOT, STREAM)                                                                     \
     hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
-                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf)
+                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf, A.block_order)
 #define OGL_SPMV21_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_stream21<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs, \
                        A.chunks21, A.codes21, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf)
@@ -3835,12 +3839,12 @@ void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
-    const dim3 grid(xcd_grid(nc, xg)), block(BLOCK);
+    const dim3 grid(A.block_order ? A.n_blocks : xcd_grid(nc, xg)), block(BLOCK);
 #define OGL_SELL_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_sell<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.chunks,    \
                        A.dict, A.codes, A.vals, A.spill_chunk_ptr, A.spill_rows, A.spill_ptrs,          \
                        A.spill_cols, A.spill_vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf, \
-                       A.rmap)
+                       A.rmap, A.block_order)
 #define OGL_SELL(MODE, NDOT)               \
     do {                                   \
         if (A.stream)                      \

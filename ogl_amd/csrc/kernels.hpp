@@ -58,6 +58,10 @@ struct DevCsr {
     // packed columns (Stream21Chunk, common.hpp): when set, the kernel reads these instead of `cols`
     const Stream21Chunk *chunks21 = nullptr;
     const uint4 *codes21 = nullptr;
+    // banded patterns: the order in which the workgroups take the chunks (band_block_order, host_matrix.hpp: the
+    // chunks of rows r and r +- band on one XCD; -1 = no chunk), n_blocks entries; nullptr = the XCD groups above
+    const int32_t *block_order = nullptr;
+    int32_t n_blocks = 0;
 };
 
 // Rows that own non-local entries, for "y += A_non_local * recv" (distributed::Matrix::apply).
@@ -134,6 +138,8 @@ struct DevSell {
     // hands the sums back to the rows' owners through LDS before y and the dot partials are formed, so y, the
     // per-row order of the products and the partials are those of the plain layout.  PLAIN mode, no spill, no halo.
     const uint16_t *rmap = nullptr;
+    const int32_t *block_order = nullptr;  // as DevCsr::block_order
+    int32_t n_blocks = 0;
 };
 void launch_spmv_sell(hipStream_t st, const DevSell &A, int mode, const double *x, const double *b,
                       double *y, const SpmvDots &dots, const DevScalars *gate, const HaloFused &hf = HaloFused{});

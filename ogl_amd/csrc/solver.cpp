@@ -593,6 +593,10 @@ DevCsr ogl_solver::csr() const
     A.vals = d_vals.p;
     A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     A.xcd_group = xcd_group();
+    if (d_band_order.n) {
+        A.block_order = d_band_order.p;
+        A.n_blocks = (int32_t)d_band_order.n;
+    }
     if (s21_use && s21_state == 1) {
         A.chunks21 = d_s21_chunks.p;
         A.codes21 = d_s21_codes.p;
@@ -694,6 +698,10 @@ DevSell ogl_solver::sell() const
     S.vals = d_sell_vals.p;
     S.stream = sell_bytes + 40.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     S.xcd_group = xcd_group();
+    if (d_band_order.n) {
+        S.block_order = d_band_order.p;
+        S.n_blocks = (int32_t)d_band_order.n;
+    }
     if (n_spill) {
         S.spill_chunk_ptr = d_spill_chunks.p;
         S.spill_rows = d_spill_rows.p;
@@ -1382,6 +1390,8 @@ int ogl_solver::tune_spmv_layout()
     if (have[2] && !s21_use) {
         d_s21_chunks.release();
         d_s21_codes.release();
+        d_band_order.release();
+        band_order_rows = 0;
         s21_state = -1;
     }
     return OGL_OK;
@@ -1870,6 +1880,22 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
     // (2 also for the half storage of a symmetric matrix: property symmetricHalf tells them apart)
     // 3: CSR-stream with packed columns
+    {   // Band-aware workgroup order of the CSR-stream / compressed kernels (property spmvBandRows = the band in rows,
+        // 0 = off: an experiment switch -- the half-storage kernels take their order from their own distances).  The
+        // chunks of rows r and r +- band run on one XCD, so a strip of x is fetched into one L2 instead of three.
+        const int64_t band = (int64_t)prop("spmvBandRows", 0.0);
+        if (band != band_order_rows) {
+            d_band_order.release();
+            band_order_rows = band;
+            std::vector<int32_t> order;
+            if (band > 0) band_block_order(pat.n_rows, band, order);
+            if (!order.empty()) {
+                OGL_TRY(d_band_order.alloc(order.size(), st));
+                OGL_TRY(reg->stager.h2d(d_band_order.p, order.data(), order.size() * sizeof(int32_t), st));
+            }
+            drop_cg_graph();
+        }
+    }
     const bool on_csr = cfg.matrix_format != OGL_FORMAT_ELL && !use_sell() && !use_sym() && !use_symx();
     if (!cfg.compress_indices) s21_use = false;
     props["spmvLayout"] = cfg.matrix_format == OGL_FORMAT_ELL ? 1.0 : (!on_csr ? 2.0 : (s21_use && s21_state == 1 ? 3.0 : 0.0));
@@ -2357,18 +2383,11 @@ int ogl_solver::finalize(int phase, FinArgs &a)
 }
 
 // ------------------------------------------------------------------------------------------
-// GKOCG: gko::solver::Cg step order ([UPSTREAM], SURVEY.md §8 a19) with the OpenFOAM criterion
-// evaluated on the device.  Per turn:
-//   (z = M^-1 r, rho = r.z, sum|r|)  -> check -> p = z + (rho/prev_rho) p -> q = A p, beta = p.q
-//   -> x += (rho/beta) p, r -= (rho/beta) q
-// The host only enqueues; it looks at the stop flag one batch late, and kernels enqueued after
-// the stop are no-ops, so x, r and the counters are exactly those of the stopping turn.
+// The Krylov drivers
 // ------------------------------------------------------------------------------------------
-int ogl_solver::run_cg(ogl_perf *perf) { return run_krylov(perf); }
-int ogl_solver::run_bicgstab(ogl_perf *perf) { return run_krylov(perf); }
-
-// One driver for GKOCG and GKOBiCGStab: criterion set-up, initial residual + norm factor, the
-// solver-specific turn, the batched enqueue / late stop-poll, result collection.
+// One driver for GKOCG, GKOBiCGStab and GKOGMRES: plan (which turn shape) -> prepare (criterion, buffers, norm factor,
+// initial residual, the sums of turn 0) -> batches of turns with the stop flag polled one batch late -> finish (x,
+// history, perf).  One member function per solver x turn shape (turn_*); what they share per solve lives in KrylovRun.
 //
 // GKOBiCGStab ([UPSTREAM] gko::solver::Bicgstab), per turn:
 //   rho = rr.r, sum|r| -> check#1 -> p = r + (rho/prev_rho * alpha/omega)(p - omega v) -> y = M^-1 p
@@ -2377,39 +2396,82 @@ int ogl_solver::run_bicgstab(ogl_perf *perf) { return run_krylov(perf); }
 //   x += alpha y + omega z, r = s - omega t.
 // Two checks per turn: maxIter is doubled (StoppingCriterion.H:188) and the reported count halved
 // (GKOBiCGStab.H:114).
+struct ogl_solver::KrylovRun {
+    hipStream_t st = nullptr;
+    int n = 0, nc = 0;
+    DevScalars *s = nullptr, *s2 = nullptr;
+    DevScalars *slot_s[2] = {nullptr, nullptr};
+    int cur = 0;  // the slot that holds the scalars after everything enqueued so far (folded GKOBiCGStab turn only)
+    bool bicg = false, gmres = false, generic = false, multi = false;
+    // turn shapes (see plan)
+    bool fused = false, fused2 = false, merged = false, merged_halo = false, bicg_fold = false, gmres_fold = false;
+    int m = 0;        // Krylov dimension of GKOGMRES
+    int64_t ldv = 0;  // leading dimension of the Krylov bases
+    double n_global = 0.0;
+    size_t n_halo = 0;
+    double *p0 = nullptr, *p1 = nullptr, *ph = nullptr;  // p of even / odd turns (merged turn), old p at the halo columns
+    double *z_kept = nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
+    DevCriterion crit{};
+    bool is_final = false;
+    int max_checks = 0, max_turns = 0;
+    int prof_stride = 0, prof_cap = 0;
+    EventPair ev_chk;
+    double t_start = 0.0;
+    FinArgs fg{}, chk{}, f1{}, f2{};  // GMRES finaliser arguments; the head-of-turn check; one / two partial arrays
+    const double *beta_ptr = nullptr;
+    double *gm = nullptr, *gm_y = nullptr;
+    double *y = nullptr, *z = nullptr;  // BiCGStab: identity preconditioner -> y aliases p, z aliases s
+    int enq = 0;                        // turns enqueued so far
+    double *gm_h(int i, int j) const { return gm + (size_t)j * (m + 1) + i; }
+    double *p_of_turn(int turn) const { return (merged && (turn & 1)) ? p1 : p0; }  // p that turn `turn` reads
+    double *p_halo_of_turn(int turn) const { return ph + (size_t)(turn & 1) * n_halo; }
+    bool folded() const { return fused || bicg_fold; }  // the check of a turn runs at the head of the next kernel
+};
+
+int ogl_solver::run_cg(ogl_perf *perf) { return run_krylov(perf); }
+int ogl_solver::run_bicgstab(ogl_perf *perf) { return run_krylov(perf); }
+
 int ogl_solver::run_krylov(ogl_perf *perf)
 {
-    hipStream_t st = reg->stream;
-    const int n = pat.n_rows;
-    DevScalars *s = d_scal.p;
-    const int nc = (int)n_chunks(n);
-    const bool bicg = cfg.solver == OGL_SOLVER_BICGSTAB;
-    const bool gmres = cfg.solver == OGL_SOLVER_GMRES;
+    KrylovRun k;
+    OGL_TRY(krylov_plan(k));
+    OGL_TRY(krylov_prepare(k));
+    OGL_TRY(krylov_loop(k));
+    return krylov_finish(k, perf);
+}
+
+// Which solver, which turn shape.
+int ogl_solver::krylov_plan(KrylovRun &k)
+{
+    hipStream_t st = k.st = reg->stream;
+    const int n = k.n = pat.n_rows;
+    DevScalars *s = k.s = d_scal.p;
+    const int nc = k.nc = (int)n_chunks(n);
+    const bool bicg = k.bicg = cfg.solver == OGL_SOLVER_BICGSTAB;
+    const bool gmres = k.gmres = cfg.solver == OGL_SOLVER_GMRES;
     // Ginkgo's default Krylov dimension is 100; the reference has no keyword for it
     // (GKOGMRES.H:46-63), `krylovDim` is this build's addition
-    const int m = cfg.krylov_dim > 0 ? cfg.krylov_dim : 100;
-    const int64_t ldv = (int64_t)n + 2;  // leading dimension of the Krylov bases
+    k.m = cfg.krylov_dim > 0 ? cfg.krylov_dim : 100;
+    k.ldv = (int64_t)n + 2;
     // block Jacobi (maxBlockSize > 1): z = M^-1 r is materialised by its own kernel; the scalar
     // case stays fused into the step kernels
-    const bool generic = precond_data && precond_data->kind >= 2;  // block Jacobi, ISAI, GISAI
-    // small single-rank GKOCG systems: finalisers folded into the step kernels, 3 launches per turn (kernels.hip)
-    const bool fused = !bicg && !gmres && !generic && !reg->comm->multi() && nc >= 1 &&
+    const bool generic = k.generic = precond_data && precond_data->kind >= 2;  // block Jacobi, ISAI, GISAI
+    const bool multi = k.multi = reg->comm->multi();
+    const bool small = !multi && nc >= 1 &&
                        nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
                        prop("fusedFinalizers", 1.0) != 0.0;
-    DevScalars *s2 = s + 1;
+    // small single-rank GKOCG systems: finalisers folded into the step kernels, 3 launches per turn (kernels.hip)
+    const bool fused = k.fused = !bicg && !gmres && !generic && small;
+    k.s2 = s + 1;
     // ... and the same for small single-rank GKOBiCGStab systems: three finalisers folded into step_1 / step_2 / step_3
     // (k_bicg_fold1/2/3: 5 launches per turn instead of 8, plus the preconditioner's own)
-    const bool bicg_fold = bicg && !reg->comm->multi() && nc >= 1 &&
-                           nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
-                           prop("fusedFinalizers", 1.0) != 0.0 && prop("bicgFold", 1.0) != 0.0;
+    k.bicg_fold = bicg && small && prop("bicgFold", 1.0) != 0.0;
     // ... and for small single-rank GKOGMRES systems the finaliser between two Gram-Schmidt links is folded into the next
     // link's kernel (k_gmres_mgs_fold: one launch per link instead of two)
-    const bool gmres_fold = gmres && !reg->comm->multi() && nc >= 1 &&
-                            nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
-                            prop("fusedFinalizers", 1.0) != 0.0 && prop("gmresFold", 1.0) != 0.0;
-    DevScalars *slot_s[2] = {s, s2};
-    int cur = 0;  // the slot that holds the scalars after everything enqueued so far (bicg_fold only)
-    props["fusedFinalizersInUse"] = (fused || bicg_fold || gmres_fold) ? 1.0 : 0.0;
+    k.gmres_fold = gmres && small && prop("gmresFold", 1.0) != 0.0;
+    k.slot_s[0] = s;
+    k.slot_s[1] = k.s2;
+    props["fusedFinalizersInUse"] = (fused || k.bicg_fold || k.gmres_fold) ? 1.0 : 0.0;
     // ... and on half storage step_1x(_fin) and the SpMV are one kernel (k_cg_turn_sym, k_cg_turn_sym_big): 2 launches
     // per turn for small systems, 4 for larger ones, p alternating between two buffers (single rank: with halos the
     // put and the wait for the neighbours' puts would sit in one kernel)
@@ -2421,13 +2483,12 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // columns and forms p_new there itself (kernels.hip, k_cg_turn_sym_big<.., HALO>), so the merged kernel has
     // nothing to put and only waits for a put of the PREVIOUS launch.  Every rank must run the same turn (what the
     // neighbours put differs): agreed below together with the global row count.
-    const bool multi = reg->comm->multi();
     bool merged = !bicg && !gmres && !generic && nc >= 1 && use_sym() && cfg.matrix_format != OGL_FORMAT_ELL &&
                   (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
     if (multi)
         merged = merged && peer_halo && prop("haloFused", 1.0) != 0.0 && prop("fusedTurnMulti", 1.0) != 0.0 &&
                  !peer_safe_wait();
-    double n_global = (double)n;
+    k.n_global = (double)n;
     if (multi) {
         // global row count (Partition.H:118-121) and the agreement on the turn, through the device all-reduce
         const double mine[2] = {(double)n, merged ? 0.0 : 1.0};
@@ -2437,28 +2498,40 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         OGL_TRY(reg->allreduce(sums_ptr(s), 2));
         OGL_HIP_CHECK(hipMemcpyAsync(got, sums_ptr(s), sizeof(got), hipMemcpyDeviceToHost, st));
         OGL_HIP_CHECK(hipStreamSynchronize(st));
-        n_global = got[0];
+        k.n_global = got[0];
         merged = got[1] == 0.0;
     }
-    const bool fused2 = fused && merged;
-    const bool merged_halo = merged && multi && pat.non_local_nnz > 0;  // (a rank without neighbours: the single-rank kernel)
+    k.merged = merged;
+    k.fused2 = fused && merged;
+    k.merged_halo = merged && multi && pat.non_local_nnz > 0;  // (a rank without neighbours: the single-rank kernel)
     props["fusedTurnInUse"] = merged ? 1.0 : 0.0;
+    return OGL_OK;
+}
+
+// Buffers, the stopping criterion, the norm factor, r = b - A x, and the sums the first check needs.
+int ogl_solver::krylov_prepare(KrylovRun &k)
+{
+    hipStream_t st = k.st;
+    const int n = k.n, nc = k.nc, m = k.m;
+    DevScalars *s = k.s;
+    const bool bicg = k.bicg, gmres = k.gmres, generic = k.generic, merged = k.merged;
     if (merged) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
     if (merged && precond) OGL_TRY(d_z.alloc((size_t)n + 2, st));
-    const size_t n_halo = (size_t)pat.non_local_nnz;
-    if (merged_halo) {  // old p at the halo columns, two buffers like p itself; p = 0 before the first turn
-        OGL_TRY(d_p_halo.alloc(2 * n_halo + 2, st));
+    k.n_halo = (size_t)pat.non_local_nnz;
+    if (k.merged_halo) {  // old p at the halo columns, two buffers like p itself; p = 0 before the first turn
+        OGL_TRY(d_p_halo.alloc(2 * k.n_halo + 2, st));
         OGL_HIP_CHECK(hipMemsetAsync(d_p_halo.p, 0, d_p_halo.n * sizeof(double), st));
     }
-    auto p_halo_of_turn = [&](int turn) { return d_p_halo.p + (size_t)(turn & 1) * n_halo; };
-    auto p_of_turn = [&](int turn) { return (merged && (turn & 1)) ? d_p2.p : d_p.p; };  // p that turn `turn` reads
-    double *z_kept = merged && precond ? d_z.p : nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
+    k.p0 = d_p.p;
+    k.p1 = d_p2.p;
+    k.ph = d_p_halo.p;
+    k.z_kept = merged && precond ? d_z.p : nullptr;
 
     // StoppingCriterion ctor + build_dist_stopping_criterion (StoppingCriterion.H:164-234)
-    const bool is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
-    const int prev_iters = (int)prop(is_final ? "prevSolveIters_final" : "prevSolveIters", 1);
+    k.is_final = cfg.rel_tol == 0.0;  // get_is_final, :242
+    const int prev_iters = (int)prop(k.is_final ? "prevSolveIters_final" : "prevSolveIters", 1);
     const double prev_cost = prop("_prev_solve", 0.0);
-    DevCriterion crit{};
+    DevCriterion &crit = k.crit;
     crit.tolerance = cfg.tolerance;
     crit.rel_tol = cfg.rel_tol;
     crit.max_iter = bicg ? 2 * cfg.max_iter : cfg.max_iter;  // :188
@@ -2468,12 +2541,12 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // the criterion stops at the first evaluated check at or after max(maxIter, minIter): checks
     // below minIter are skipped without a verdict (StoppingCriterion.C:77-81), so a minIter above
     // maxIter keeps the loop going, as in the reference
-    const int max_checks = std::max(crit.max_iter, crit.min_iter) + crit.frequency + 1;
-    const int max_turns = bicg ? max_checks / 2 + 1 : max_checks;  // CG and GMRES: one check per turn
-    OGL_TRY(d_history.alloc((size_t)max_checks + 4, st));
+    k.max_checks = std::max(crit.max_iter, crit.min_iter) + crit.frequency + 1;
+    k.max_turns = bicg ? k.max_checks / 2 + 1 : k.max_checks;  // CG and GMRES: one check per turn
+    OGL_TRY(d_history.alloc((size_t)k.max_checks + 4, st));
     if (cfg.export_res)
         OGL_HIP_CHECK(hipMemsetAsync(d_history.p, 0, d_history.n * sizeof(double), st));
-    if (bicg_fold) {  // (a folded kernel never writes a partial array it reads: six of them per turn)
+    if (k.bicg_fold) {  // (a folded kernel never writes a partial array it reads: six of them per turn)
         OGL_TRY(d_part3.alloc((size_t)nc, st));
         OGL_TRY(d_part4.alloc((size_t)nc, st));
         OGL_TRY(d_part5.alloc((size_t)nc, st));
@@ -2489,7 +2562,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             OGL_TRY(d_z.alloc(nv, st));
         }
     } else if (gmres) {
-        OGL_TRY(d_V.alloc((size_t)(m + 1) * (size_t)ldv, st));
+        OGL_TRY(d_V.alloc((size_t)(m + 1) * (size_t)k.ldv, st));
         OGL_TRY(d_gm.alloc(gmres_state_len(m), st));
         OGL_HIP_CHECK(hipMemsetAsync(d_gm.p, 0, gmres_state_len(m) * sizeof(double), st));
         if (generic) OGL_TRY(d_z.alloc((size_t)n + 2, st));
@@ -2497,20 +2570,18 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         OGL_TRY(d_z.alloc((size_t)n + 2, st));
     }
 
-    // profile_kernels: one event pair per in-loop SpMV (the first of a BiCGStab turn)
-    // profile_kernels = k > 0: every k-th turn's SpMV is bracketed by an event pair (k = 1: all)
-    const int prof_stride = std::max(0, cfg.profile_kernels);
-    const int prof_cap = prof_stride ? std::min((max_turns + prof_stride - 1) / prof_stride, 4096) : 0;
-    while ((int)prof_ev.size() < 2 * prof_cap) {
+    // profile_kernels = k > 0: every k-th turn's in-loop SpMV (the first of a BiCGStab turn) is bracketed by an event pair
+    k.prof_stride = std::max(0, cfg.profile_kernels);
+    k.prof_cap = k.prof_stride ? std::min((k.max_turns + k.prof_stride - 1) / k.prof_stride, 4096) : 0;
+    while ((int)prof_ev.size() < 2 * k.prof_cap) {
         hipEvent_t e;
         OGL_HIP_CHECK(hipEventCreate(&e));
         prof_ev.push_back(e);
     }
-    EventPair ev_chk;
-    OGL_HIP_CHECK(hipEventCreate(&ev_chk[0]));
-    OGL_HIP_CHECK(hipEventCreate(&ev_chk[1]));
+    OGL_HIP_CHECK(hipEventCreate(&k.ev_chk[0]));
+    OGL_HIP_CHECK(hipEventCreate(&k.ev_chk[1]));
 
-    const double t_start = now_ms();
+    k.t_start = now_ms();
     launch_reset_scalars(st, s, crit);
 
     FinArgs fa;
@@ -2521,7 +2592,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     fa.n_part = nc;
     fa.n_sums = 1;
     fa.n_local = (double)n;
-    fa.n_global = n_global;  // (all-reduced above)
+    fa.n_global = k.n_global;  // (all-reduced in plan)
     OGL_TRY(finalize(FIN_MEAN, fa));
     // Axref = A * (xbar 1) (:24-29) into q
     launch_fill_xbar(st, n, d_w.p, s);
@@ -2539,44 +2610,20 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // solver initialisation + turn 0: rho, sum|r|, check (timed once as "time per residual norm
     // calculation", lduLduBase.H:287)
     OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, (size_t)n * sizeof(double), st));
-    FinArgs fg{};  // GMRES finaliser arguments
-    fg.part[0] = d_part0.p;
-    fg.part[1] = d_part1.p;
-    fg.n_part = nc;
-    fg.history = d_history.p;
-    fg.gm = d_gm.p;
-    fg.m = m;
-    const double *beta_ptr =
-        reinterpret_cast<const double *>(reinterpret_cast<const char *>(s) + offsetof(DevScalars, beta));
-    auto gm_h = [&](int i, int j) { return d_gm.p + (size_t)j * (m + 1) + i; };
-    double *gm_y = d_gm.p + (size_t)(m + 1) * m + 2 * (size_t)m + (m + 1);
-    // gmres::restart: rn = ||r||, rnc[0] = rn, V_0 = r / rn; the criterion keeps sum|r| of this r
-    auto gmres_restart = [&](const DevScalars *gate) -> int {
-        launch_cg_rho_norm(st, n, d_r.p, nullptr, d_part0.p, d_part1.p, gate);  // r.r and sum|r|
-        fg.n_sums = 2;
-        OGL_TRY(finalize(FIN_GMRES_RESTART, fg));
-        launch_gmres_scale(st, n, d_V.p, d_r.p, beta_ptr, gate);
-        return OGL_OK;
-    };
-    // solve_krylov + x += M^-1 (V y) over `cols` columns of the cycle
-    auto gmres_update_x = [&](int cols, const DevScalars *gate) -> int {
-        if (cols <= 0) return OGL_OK;
-        fg.n_sums = 0;
-        fg.turn = cols;
-        OGL_TRY(finalize(FIN_GMRES_SOLVE, fg));
-        if (generic) {
-            launch_gmres_update_x(st, n, d_V.p, ldv, gm_y, cols, nullptr, d_x.p, d_w.p, gate);
-            apply_preconditioner(d_w.p, d_z.p, gate);
-            launch_add(st, n, d_x.p, d_z.p, gate);
-        } else {
-            launch_gmres_update_x(st, n, d_V.p, ldv, gm_y, cols, precond, d_x.p, nullptr, gate);
-        }
-        return OGL_OK;
-    };
+    k.fg = FinArgs{};
+    k.fg.part[0] = d_part0.p;
+    k.fg.part[1] = d_part1.p;
+    k.fg.n_part = nc;
+    k.fg.history = d_history.p;
+    k.fg.gm = d_gm.p;
+    k.fg.m = m;
+    k.beta_ptr = reinterpret_cast<const double *>(reinterpret_cast<const char *>(s) + offsetof(DevScalars, beta));
+    k.gm = d_gm.p;
+    k.gm_y = d_gm.p + (size_t)(m + 1) * m + 2 * (size_t)m + (m + 1);
     if (gmres) {
-        OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
-        OGL_TRY(gmres_restart(nullptr));
-        OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+        OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
+        OGL_TRY(gmres_restart(k, nullptr));
+        OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     } else if (bicg) {
         // rr = r ; p = v = 0 ([UPSTREAM] bicgstab::initialize); rho = rr.r = r.r
         OGL_HIP_CHECK(hipMemcpyAsync(d_rr.p, d_r.p, (size_t)n * sizeof(double),
@@ -2586,226 +2633,348 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     } else {
         // p = q = 0 ([UPSTREAM] cg::initialize); z is never materialised (z = r * inv_diag on the fly)
         launch_cg_rho_norm(st, n, d_r.p, precond, d_part0.p, d_part1.p, s);
-        if (z_kept) launch_mul(st, n, z_kept, d_r.p, precond, nullptr);  // (the z of the first k_cg_turn_sym)
+        if (k.z_kept) launch_mul(st, n, k.z_kept, d_r.p, precond, nullptr);  // (the z of the first k_cg_turn_sym)
         if (generic) {  // rho = r . (M^-1 r) with the block preconditioner
             apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);
         }
     }
-    FinArgs chk{};
-    chk.part[0] = d_part0.p;
-    chk.part[1] = d_part1.p;
-    chk.n_part = nc;
-    chk.n_sums = 2;
-    chk.history = d_history.p;
-    if (!gmres && !fused && !bicg_fold) {  // (fused / bicg_fold: this check opens the first folded kernel)
-        OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
-        OGL_TRY(finalize(FIN_CG_CHECK, chk));
-        OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
+    k.chk = FinArgs{};
+    k.chk.part[0] = d_part0.p;
+    k.chk.part[1] = d_part1.p;
+    k.chk.n_part = nc;
+    k.chk.n_sums = 2;
+    k.chk.history = d_history.p;
+    if (!gmres && !k.folded()) {  // (folded turns: this check opens the first folded kernel)
+        OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
+        OGL_TRY(finalize(FIN_CG_CHECK, k.chk));
+        OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     }
-    if (merged_halo) {  // the z of the first merged turn (later ones: put by step_2r)
+    if (k.merged_halo) {  // the z of the first merged turn (later ones: put by step_2r)
         if (++halo_seq == 0) ++halo_seq;
         cur_halo = peer_halo_args(halo_seq);
-        launch_pack_put_signal(st, halo(), cur_halo, z_kept ? z_kept : d_r.p, s, d_ticket.p);
+        launch_pack_put_signal(st, halo(), cur_halo, k.z_kept ? k.z_kept : d_r.p, s, d_ticket.p);
     }
 
-    FinArgs f1{};  // one partial array
-    f1.part[0] = d_part0.p;
-    f1.n_part = nc;
-    f1.n_sums = 1;
-    f1.history = d_history.p;
-    FinArgs f2 = f1;  // two partial arrays
-    f2.part[1] = d_part1.p;
-    f2.n_sums = 2;
+    k.f1 = FinArgs{};  // one partial array
+    k.f1.part[0] = d_part0.p;
+    k.f1.n_part = nc;
+    k.f1.n_sums = 1;
+    k.f1.history = d_history.p;
+    k.f2 = k.f1;  // two partial arrays
+    k.f2.part[1] = d_part1.p;
+    k.f2.n_sums = 2;
 
-    double *y = (precond || generic) ? d_y.p : d_p.p;  // identity: y aliases p, z aliases s
-    double *z = (precond || generic) ? d_z.p : d_s.p;
+    k.y = (precond || generic) ? d_y.p : d_p.p;  // identity: y aliases p, z aliases s
+    k.z = (precond || generic) ? d_z.p : d_s.p;
+    k.enq = 0;
+    return OGL_OK;
+}
 
-    int enq = 0;
-    auto enqueue_direct = [&](int count) -> int {
-        for (int i = 0; i < count; ++i, ++enq) {
-            const bool prof = prof_stride && enq % prof_stride == 0 && enq / prof_stride < prof_cap;
-            const int pe = prof ? enq / prof_stride : 0;  // event pair of this turn
-            if (gmres) {
-                // [UPSTREAM] Gmres loop: check (on the residual of the last restart), restart
-                // when the cycle is full, then one Arnoldi step
-                fg.n_sums = 0;
-                OGL_TRY(finalize(FIN_GMRES_CHECK, fg));
-                if (enq > 0 && enq % m == 0) {
-                    OGL_TRY(gmres_update_x(m, s));
-                    OGL_TRY(dist_spmv(SPMV_RESIDUAL, d_x.p, d_b.p, d_r.p, SpmvDots{}, s));
-                    OGL_TRY(gmres_restart(s));
-                }
-                const int it = enq % m;
-                double *v_it = d_V.p + (size_t)it * ldv, *nx = d_V.p + (size_t)(it + 1) * ldv;
-                const double *w = v_it;  // identity preconditioner: w aliases V_it
-                if (generic) {
-                    apply_preconditioner(v_it, d_w.p, s);
-                    w = d_w.p;
-                } else if (precond) {
-                    launch_mul(st, n, d_w.p, v_it, precond, s);
-                    w = d_w.p;
-                }
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                OGL_TRY(dist_spmv(SPMV_PLAIN, w, nullptr, nx, SpmvDots{}, s));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                // finish_arnoldi (modified Gram-Schmidt): H(k,it) = nx.V_k ; nx -= H(k,it) V_k
-                fg.turn = it;
-                fg.n_sums = 1;
-                if (gmres_fold) {
-                    double *pin = d_part1.p, *pout = d_part0.p;  // (a link reads the partials of the one before it)
-                    for (int k = 0; k <= it; ++k) {
-                        launch_gmres_mgs_fold(st, n, nx, k > 0 ? d_V.p + (size_t)(k - 1) * ldv : nullptr,
-                                              k > 0 ? gm_h(k - 1, it) : nullptr, d_V.p + (size_t)k * ldv, pin, pout, s);
-                        std::swap(pin, pout);
-                    }
-                    launch_gmres_mgs_fold(st, n, nx, v_it, gm_h(it, it), nullptr, pin, pout, s);
-                    fg.part[0] = pout;
-                    OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
-                    fg.part[0] = d_part0.p;
-                    launch_gmres_scale(st, n, nx, nx, beta_ptr, s);
-                    continue;
-                }
-                for (int k = 0; k <= it; ++k) {
-                    launch_gmres_mgs(st, n, nx, k > 0 ? d_V.p + (size_t)(k - 1) * ldv : nullptr,
-                                     k > 0 ? gm_h(k - 1, it) : nullptr, d_V.p + (size_t)k * ldv,
-                                     d_part0.p, s);
-                    fg.k = k;
-                    OGL_TRY(finalize(FIN_GMRES_H, fg));
-                }
-                launch_gmres_mgs(st, n, nx, v_it, gm_h(it, it), nullptr, d_part0.p, s);
-                OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
-                launch_gmres_scale(st, n, nx, nx, beta_ptr, s);
-            } else if (!bicg && generic) {
-                launch_cg_step1(st, n, d_p.p, d_z.p, nullptr, s);  // p = z + (rho/prev_rho) p
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
-                                  SpmvDots{d_p.p, d_part0.p, nullptr}, s));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                OGL_TRY(finalize(FIN_BETA, f1));
-                launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, nullptr, d_part0.p, d_part1.p, s);
-                apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);  // z = M^-1 r and the partials of r.z
-                OGL_TRY(finalize(FIN_CG_CHECK, chk));
-            } else if (!bicg && fused2) {
-                // [check of the previous turn + pending x update + step_1 + SpMV] | beta + step_2r
-                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                launch_cg_turn_sym(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p, z_kept ? z_kept : d_r.p,
-                                   d_q.p, d_part2.p, s, s2, d_part0.p, d_part1.p, d_history.p, enq == 0 ? 1 : 0);
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
-                launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s2, s, d_part2.p, z_kept);
-            } else if (!bicg && fused) {
-                // check of the previous turn (or of the initial residual) + pending x update + step_1 | SpMV |
-                // beta + step_2r: the scalars go s -> s2 -> s
-                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
-                launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p,
-                                     enq == 0 ? 1 : 0);
-                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, s2));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s2, s, d_part2.p);
-            } else if (!bicg && merged) {
-                // [pending x update + step_1 + SpMV] | beta | step_2r (keeps z) | check
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                if (merged_halo) {
-                    // (waits for the z the neighbours put one kernel -- or, before turn 0, one launch -- earlier)
-                    launch_cg_turn_sym_big(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p,
-                                           z_kept ? z_kept : d_r.p, d_q.p, d_part0.p, s,
-                                           halo_fused_args(cur_halo), p_halo_of_turn(enq), p_halo_of_turn(enq + 1));
-                } else {
-                    launch_cg_turn_sym_big(st, sym(), p_of_turn(enq), p_of_turn(enq + 1), d_x.p,
-                                           z_kept ? z_kept : d_r.p, d_q.p, d_part0.p, s);
-                }
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                OGL_TRY(finalize(FIN_BETA, f1));
-                if (merged_halo) {
-                    const HaloPutFused put = begin_halo_put();  // z of the next turn
-                    launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, z_kept, &put);
-                } else {
-                    launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, z_kept);
-                }
-                chk.turn = 1;  // this check leaves an x update pending for the next turn's kernel
-                OGL_TRY(finalize(FIN_CG_CHECK, chk));
-            } else if (!bicg) {
-                // x += t p is deferred into the next turn's step_1x (kernels.hip): p is read once
-                // (peer-put transport: the halo values of the SpMV are put by step_1x itself)
-                const HaloPutFused put = begin_halo_put();
-                launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s, &put);
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
-                                  SpmvDots{d_p.p, d_part0.p, nullptr}, s, put.chunk_sptr != nullptr));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                OGL_TRY(finalize(FIN_BETA, f1));
-                launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s);
-                chk.turn = 1;  // this check leaves an x update pending for the next step_1x
-                OGL_TRY(finalize(FIN_CG_CHECK, chk));
-            } else if (bicg_fold) {
-                // [check + step_1] | M^-1 | SpMV | [alpha + step_2] | M^-1 | SpMV | [mid-turn check + omega + step_3];
-                // partials: rho, sum|r| in part0 / part1; rr.v in part2; sum|s| in part3; s.t, t.t in part4 / part5
-                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[0], st));
-                launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, y, slot_s[cur], slot_s[cur ^ 1], d_part0.p,
-                                  d_part1.p, d_history.p);
-                cur ^= 1;
-                if (enq == 0) OGL_HIP_CHECK(hipEventRecord(ev_chk[1], st));
-                if (generic) apply_preconditioner(d_p.p, y, slot_s[cur]);
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p, SpmvDots{d_rr.p, d_part2.p, nullptr}, slot_s[cur]));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                launch_bicg_fold2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part3.p, slot_s[cur], slot_s[cur ^ 1],
-                                  d_part2.p);
-                cur ^= 1;
-                if (generic) apply_preconditioner(d_s.p, z, slot_s[cur]);
-                OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p, SpmvDots{d_s.p, d_part4.p, d_part5.p}, slot_s[cur]));
-                launch_bicg_fold3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p, d_part1.p, slot_s[cur],
-                                  slot_s[cur ^ 1], d_part4.p, d_part5.p, d_part3.p, d_history.p, enq);
-                cur ^= 1;
-            } else {
-                launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
-                if (generic) apply_preconditioner(d_p.p, y, s);
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-                OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p,
-                                  SpmvDots{d_rr.p, d_part0.p, nullptr}, s));
-                if (prof) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-                OGL_TRY(finalize(FIN_BICG_ALPHA, f1));
-                if (!reg->comm->multi() && prop("bicgMergedCheck", 1.0) != 0.0) {
-                    // single rank: the mid-turn check moves behind the second SpMV and shares its finaliser (8 launches
-                    // per turn instead of 9; when it stops the solve that SpMV ran for nothing)
-                    launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part2.p, s);
-                    if (generic) apply_preconditioner(d_s.p, z, s);
-                    OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
-                                      SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
-                    FinArgs f3 = f2;
-                    f3.part_extra = d_part2.p;
-                    f3.n_sums = 3;
-                    f3.turn = enq;
-                    OGL_TRY(finalize(FIN_BICG_CHECK2_OMEGA, f3));
-                } else {
-                    launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part0.p, s);
-                    if (generic) apply_preconditioner(d_s.p, z, s);
-                    f1.turn = enq;
-                    OGL_TRY(finalize(FIN_BICG_CHECK2, f1));
-                    OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
-                                      SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
-                    OGL_TRY(finalize(FIN_BICG_OMEGA, f2));
-                }
-                launch_bicg_step3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p,
-                                  d_part1.p, s, enq);
-                OGL_TRY(finalize(FIN_CG_CHECK, chk));
-            }
+// gmres::restart: rn = ||r||, rnc[0] = rn, V_0 = r / rn; the criterion keeps sum|r| of this r
+int ogl_solver::gmres_restart(KrylovRun &k, const DevScalars *gate)
+{
+    launch_cg_rho_norm(k.st, k.n, d_r.p, nullptr, d_part0.p, d_part1.p, gate);  // r.r and sum|r|
+    k.fg.n_sums = 2;
+    OGL_TRY(finalize(FIN_GMRES_RESTART, k.fg));
+    launch_gmres_scale(k.st, k.n, d_V.p, d_r.p, k.beta_ptr, gate);
+    return OGL_OK;
+}
+
+// solve_krylov + x += M^-1 (V y) over `cols` columns of the cycle
+int ogl_solver::gmres_update_x(KrylovRun &k, int cols, const DevScalars *gate)
+{
+    if (cols <= 0) return OGL_OK;
+    k.fg.n_sums = 0;
+    k.fg.turn = cols;
+    OGL_TRY(finalize(FIN_GMRES_SOLVE, k.fg));
+    if (k.generic) {
+        launch_gmres_update_x(k.st, k.n, d_V.p, k.ldv, k.gm_y, cols, nullptr, d_x.p, d_w.p, gate);
+        apply_preconditioner(d_w.p, d_z.p, gate);
+        launch_add(k.st, k.n, d_x.p, d_z.p, gate);
+    } else {
+        launch_gmres_update_x(k.st, k.n, d_V.p, k.ldv, k.gm_y, cols, precond, d_x.p, nullptr, gate);
+    }
+    return OGL_OK;
+}
+
+// ---- one turn of every solver x turn shape.  enq = index of the turn; pe >= 0: the event pair that brackets the turn's
+// in-loop SpMV (profile_kernels), -1: none.  Kernels enqueued after the stop are no-ops (gated on the device scalars).
+
+// GKOGMRES ([UPSTREAM] Gmres loop): check (on the residual of the last restart), restart when the cycle is full, then one
+// Arnoldi step; gmres_fold: the finaliser between two Gram-Schmidt links runs inside the next link's kernel
+int ogl_solver::turn_gmres(KrylovRun &k, int enq, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n, m = k.m;
+    const int64_t ldv = k.ldv;
+    DevScalars *s = k.s;
+    FinArgs &fg = k.fg;
+    fg.n_sums = 0;
+    OGL_TRY(finalize(FIN_GMRES_CHECK, fg));
+    if (enq > 0 && enq % m == 0) {
+        OGL_TRY(gmres_update_x(k, m, s));
+        OGL_TRY(dist_spmv(SPMV_RESIDUAL, d_x.p, d_b.p, d_r.p, SpmvDots{}, s));
+        OGL_TRY(gmres_restart(k, s));
+    }
+    const int it = enq % m;
+    double *v_it = d_V.p + (size_t)it * ldv, *nx = d_V.p + (size_t)(it + 1) * ldv;
+    const double *w = v_it;  // identity preconditioner: w aliases V_it
+    if (k.generic) {
+        apply_preconditioner(v_it, d_w.p, s);
+        w = d_w.p;
+    } else if (precond) {
+        launch_mul(st, n, d_w.p, v_it, precond, s);
+        w = d_w.p;
+    }
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, w, nullptr, nx, SpmvDots{}, s));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    // finish_arnoldi (modified Gram-Schmidt): H(k,it) = nx.V_k ; nx -= H(k,it) V_k
+    fg.turn = it;
+    fg.n_sums = 1;
+    if (k.gmres_fold) {
+        double *pin = d_part1.p, *pout = d_part0.p;  // (a link reads the partials of the one before it)
+        for (int j = 0; j <= it; ++j) {
+            launch_gmres_mgs_fold(st, n, nx, j > 0 ? d_V.p + (size_t)(j - 1) * ldv : nullptr,
+                                  j > 0 ? k.gm_h(j - 1, it) : nullptr, d_V.p + (size_t)j * ldv, pin, pout, s);
+            std::swap(pin, pout);
         }
-        return OGL_OK;
-    };
+        launch_gmres_mgs_fold(st, n, nx, v_it, k.gm_h(it, it), nullptr, pin, pout, s);
+        fg.part[0] = pout;
+        OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
+        fg.part[0] = d_part0.p;
+    } else {
+        for (int j = 0; j <= it; ++j) {
+            launch_gmres_mgs(st, n, nx, j > 0 ? d_V.p + (size_t)(j - 1) * ldv : nullptr,
+                             j > 0 ? k.gm_h(j - 1, it) : nullptr, d_V.p + (size_t)j * ldv,
+                             d_part0.p, s);
+            fg.k = j;
+            OGL_TRY(finalize(FIN_GMRES_H, fg));
+        }
+        launch_gmres_mgs(st, n, nx, v_it, k.gm_h(it, it), nullptr, d_part0.p, s);
+        OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
+    }
+    launch_gmres_scale(st, n, nx, nx, k.beta_ptr, s);
+    return OGL_OK;
+}
+
+// GKOCG with a materialised z = M^-1 r (block Jacobi, ISAI): step_1 | SpMV | beta | step_2 | M^-1 | check
+int ogl_solver::turn_cg_generic(KrylovRun &k, int, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n;
+    DevScalars *s = k.s;
+    launch_cg_step1(st, n, d_p.p, d_z.p, nullptr, s);  // p = z + (rho/prev_rho) p
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part0.p, nullptr}, s));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    OGL_TRY(finalize(FIN_BETA, k.f1));
+    launch_cg_step2(st, n, d_x.p, d_r.p, d_p.p, d_q.p, nullptr, d_part0.p, d_part1.p, s);
+    apply_preconditioner(d_r.p, d_z.p, s, d_part0.p);  // z = M^-1 r and the partials of r.z
+    OGL_TRY(finalize(FIN_CG_CHECK, k.chk));
+    return OGL_OK;
+}
+
+// small single-rank GKOCG on half storage, 2 launches: [check of the previous turn + pending x update + step_1 + SpMV] |
+// beta + step_2r
+int ogl_solver::turn_cg_two_launch(KrylovRun &k, int enq, int pe)
+{
+    hipStream_t st = k.st;
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    launch_cg_turn_sym(st, sym(), k.p_of_turn(enq), k.p_of_turn(enq + 1), d_x.p, k.z_kept ? k.z_kept : d_r.p,
+                       d_q.p, d_part2.p, k.s, k.s2, d_part0.p, d_part1.p, d_history.p, enq == 0 ? 1 : 0);
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
+    launch_cg_step2r_fin(st, k.n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p, k.z_kept);
+    return OGL_OK;
+}
+
+// small single-rank GKOCG, 3 launches: check of the previous turn (or of the initial residual) + pending x update +
+// step_1 | SpMV | beta + step_2r: the scalars go s -> s2 -> s
+int ogl_solver::turn_cg_three_launch(KrylovRun &k, int enq, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n;
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
+    launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_r.p, precond, k.s, k.s2, d_part0.p, d_part1.p, d_history.p,
+                         enq == 0 ? 1 : 0);
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, k.s2));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p);
+    return OGL_OK;
+}
+
+// GKOCG on half storage between the single-workgroup finalisers, 4 launches: [pending x update + step_1 + SpMV] | beta |
+// step_2r (keeps z) | check; several ranks: the neighbours' step_2r has put z, p_new is formed at the halo columns here
+int ogl_solver::turn_cg_merged(KrylovRun &k, int enq, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n;
+    DevScalars *s = k.s;
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    if (k.merged_halo) {
+        // (waits for the z the neighbours put one kernel -- or, before turn 0, one launch -- earlier)
+        launch_cg_turn_sym_big(st, sym(), k.p_of_turn(enq), k.p_of_turn(enq + 1), d_x.p,
+                               k.z_kept ? k.z_kept : d_r.p, d_q.p, d_part0.p, s,
+                               halo_fused_args(cur_halo), k.p_halo_of_turn(enq), k.p_halo_of_turn(enq + 1));
+    } else {
+        launch_cg_turn_sym_big(st, sym(), k.p_of_turn(enq), k.p_of_turn(enq + 1), d_x.p,
+                               k.z_kept ? k.z_kept : d_r.p, d_q.p, d_part0.p, s);
+    }
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    OGL_TRY(finalize(FIN_BETA, k.f1));
+    if (k.merged_halo) {
+        const HaloPutFused put = begin_halo_put();  // z of the next turn
+        launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, k.z_kept, &put);
+    } else {
+        launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s, k.z_kept);
+    }
+    k.chk.turn = 1;  // this check leaves an x update pending for the next turn's kernel
+    OGL_TRY(finalize(FIN_CG_CHECK, k.chk));
+    return OGL_OK;
+}
+
+// GKOCG, 5 launches (the headline's turn): step_1x | SpMV | beta | step_2r | check.  x += t p is deferred into the next
+// turn's step_1x (kernels.hip): p is read once (peer-put transport: the halo values of the SpMV are put by step_1x itself)
+int ogl_solver::turn_cg_five_launch(KrylovRun &k, int, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n;
+    DevScalars *s = k.s;
+    const HaloPutFused put = begin_halo_put();
+    launch_cg_step1x(st, n, d_p.p, d_x.p, d_r.p, precond, s, &put);
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p,
+                      SpmvDots{d_p.p, d_part0.p, nullptr}, s, put.chunk_sptr != nullptr));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    OGL_TRY(finalize(FIN_BETA, k.f1));
+    launch_cg_step2r(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, s);
+    k.chk.turn = 1;  // this check leaves an x update pending for the next step_1x
+    OGL_TRY(finalize(FIN_CG_CHECK, k.chk));
+    return OGL_OK;
+}
+
+// small single-rank GKOBiCGStab, 5 launches + the preconditioner's own: [check + step_1] | M^-1 | SpMV | [alpha + step_2] |
+// M^-1 | SpMV | [mid-turn check + omega + step_3]; partials: rho, sum|r| in part0 / part1; rr.v in part2; sum|s| in
+// part3; s.t, t.t in part4 / part5; the scalars alternate between the two slots (k.cur)
+int ogl_solver::turn_bicg_folded(KrylovRun &k, int enq, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n;
+    DevScalars **slot_s = k.slot_s;
+    int &cur = k.cur;
+    double *y = k.y, *z = k.z;
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
+    launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, y, slot_s[cur], slot_s[cur ^ 1], d_part0.p,
+                      d_part1.p, d_history.p);
+    cur ^= 1;
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
+    if (k.generic) apply_preconditioner(d_p.p, y, slot_s[cur]);
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p, SpmvDots{d_rr.p, d_part2.p, nullptr}, slot_s[cur]));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    launch_bicg_fold2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part3.p, slot_s[cur], slot_s[cur ^ 1],
+                      d_part2.p);
+    cur ^= 1;
+    if (k.generic) apply_preconditioner(d_s.p, z, slot_s[cur]);
+    OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p, SpmvDots{d_s.p, d_part4.p, d_part5.p}, slot_s[cur]));
+    launch_bicg_fold3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p, d_part1.p, slot_s[cur],
+                      slot_s[cur ^ 1], d_part4.p, d_part5.p, d_part3.p, d_history.p, enq);
+    cur ^= 1;
+    return OGL_OK;
+}
+
+// GKOBiCGStab, 8 launches + the preconditioner's own (9 with several ranks: the mid-turn check keeps its own finaliser)
+int ogl_solver::turn_bicg(KrylovRun &k, int enq, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n;
+    DevScalars *s = k.s;
+    double *y = k.y, *z = k.z;
+    FinArgs &f1 = k.f1, &f2 = k.f2;
+    launch_bicg_step1(st, n, d_p.p, d_r.p, d_v.p, precond, y, s);
+    if (k.generic) apply_preconditioner(d_p.p, y, s);
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p,
+                      SpmvDots{d_rr.p, d_part0.p, nullptr}, s));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    OGL_TRY(finalize(FIN_BICG_ALPHA, f1));
+    if (!k.multi && prop("bicgMergedCheck", 1.0) != 0.0) {
+        // single rank: the mid-turn check moves behind the second SpMV and shares its finaliser (8 launches
+        // per turn instead of 9; when it stops the solve that SpMV ran for nothing)
+        launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part2.p, s);
+        if (k.generic) apply_preconditioner(d_s.p, z, s);
+        OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
+                          SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
+        FinArgs f3 = f2;
+        f3.part_extra = d_part2.p;
+        f3.n_sums = 3;
+        f3.turn = enq;
+        OGL_TRY(finalize(FIN_BICG_CHECK2_OMEGA, f3));
+    } else {
+        launch_bicg_step2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part0.p, s);
+        if (k.generic) apply_preconditioner(d_s.p, z, s);
+        f1.turn = enq;
+        OGL_TRY(finalize(FIN_BICG_CHECK2, f1));
+        OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p,
+                          SpmvDots{d_s.p, d_part0.p, d_part1.p}, s));
+        OGL_TRY(finalize(FIN_BICG_OMEGA, f2));
+    }
+    launch_bicg_step3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p,
+                      d_part1.p, s, enq);
+    OGL_TRY(finalize(FIN_CG_CHECK, k.chk));
+    return OGL_OK;
+}
+
+// `count` turns into the stream, each in its solver's / system's shape
+int ogl_solver::krylov_enqueue(KrylovRun &k, int count)
+{
+    for (int i = 0; i < count; ++i, ++k.enq) {
+        const int enq = k.enq;
+        const bool prof = k.prof_stride && enq % k.prof_stride == 0 && enq / k.prof_stride < k.prof_cap;
+        const int pe = prof ? enq / k.prof_stride : -1;  // event pair of this turn
+        if (k.gmres)
+            OGL_TRY(turn_gmres(k, enq, pe));
+        else if (k.bicg)
+            OGL_TRY(k.bicg_fold ? turn_bicg_folded(k, enq, pe) : turn_bicg(k, enq, pe));
+        else if (k.generic)
+            OGL_TRY(turn_cg_generic(k, enq, pe));
+        else if (k.fused2)
+            OGL_TRY(turn_cg_two_launch(k, enq, pe));
+        else if (k.fused)
+            OGL_TRY(turn_cg_three_launch(k, enq, pe));
+        else if (k.merged)
+            OGL_TRY(turn_cg_merged(k, enq, pe));
+        else
+            OGL_TRY(turn_cg_five_launch(k, enq, pe));
+    }
+    return OGL_OK;
+}
+
+// GKOCG: gko::solver::Cg step order ([UPSTREAM], SURVEY.md §8 a19) with the OpenFOAM criterion
+// evaluated on the device.  Per turn:
+//   (z = M^-1 r, rho = r.z, sum|r|)  -> check -> p = z + (rho/prev_rho) p -> q = A p, beta = p.q
+//   -> x += (rho/beta) p, r -= (rho/beta) q
+// The host only enqueues; it looks at the stop flag one batch late, and kernels enqueued after
+// the stop are no-ops, so x, r and the counters are exactly those of the stopping turn.
+int ogl_solver::krylov_loop(KrylovRun &k)
+{
+    hipStream_t st = k.st;
+    const bool fused = k.fused;
     auto poll_record = [&](int slot) -> int {
-        OGL_HIP_CHECK(hipMemcpyAsync(&h_scal[slot], bicg_fold ? slot_s[cur] : s, sizeof(DevScalars), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipMemcpyAsync(&h_scal[slot], k.bicg_fold ? k.slot_s[k.cur] : k.s, sizeof(DevScalars),
+                                     hipMemcpyDeviceToHost, st));
         OGL_HIP_CHECK(hipEventRecord(poll_ev[slot], st));
         return OGL_OK;
     };
 
-    // The host never waits for the turn it has just enqueued: it looks at the stop flag of batch k
-    // only after batch k+1 is in the queue.  Every rank sees the same flags (the norms are
+    // The host never waits for the turn it has just enqueued: it looks at the stop flag of batch j
+    // only after batch j+1 is in the queue.  Every rank sees the same flags (the norms are
     // all-reduced), hence enqueues the same number of batches and of RCCL calls.
-    const int batch = bicg ? 8 : 16;
+    const int batch = k.bicg ? 8 : 16;
 
     // hipGraph replay of a full batch of single-rank GKOCG turns (property "hipGraph").  Nothing in the
     // captured launches depends on the turn or on the solve (criterion and flags live in the device
@@ -2813,24 +2982,24 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     // MI355X / ROCm 7.2 (23.7 us per turn with plain stream launches against 24.2 us replayed at 262k rows,
     // 286.1 against 285.3 us at 10M rows: the gap between two dependent kernels is the device's dispatch
     // latency, not host launch cost) and stays off by default.
-    const bool graphable = !gmres && !bicg && !generic && !reg->comm->multi() && prof_cap == 0 &&
+    const bool graphable = !k.gmres && !k.bicg && !k.generic && !k.multi && k.prof_cap == 0 &&
                            prop("hipGraph", fused ? 1.0 : 0.0) != 0.0;
     // (on by default for the folded 2- / 3-launch turns of small systems, where the host's launch rate shows: 32^3
     //  15.1 -> 13.0 us per 3-launch turn, 64^3 17.3 -> 16.7; the 5-launch turn of larger systems measures the same either way;
     //  a batch of 16 turns leaves the two p buffers of the 2-launch turn where it found them)
     auto enqueue_turns = [&](int count) -> int {
         // (the fused-finaliser turn: its first step_1x_fin differs from the later ones -- the first batch runs direct)
-        if (!graphable || count != batch || (fused && enq == 0)) return enqueue_direct(count);
+        if (!graphable || count != batch || (fused && k.enq == 0)) return krylov_enqueue(k, count);
         const std::vector<uintptr_t> key{
-            (uintptr_t)n, (uintptr_t)batch, (uintptr_t)cfg.matrix_format, (uintptr_t)use_sell(),
+            (uintptr_t)k.n, (uintptr_t)batch, (uintptr_t)cfg.matrix_format, (uintptr_t)use_sell(),
             (uintptr_t)d_p.p, (uintptr_t)d_x.p, (uintptr_t)d_r.p, (uintptr_t)d_q.p, (uintptr_t)precond,
-            (uintptr_t)d_part0.p, (uintptr_t)d_part1.p, (uintptr_t)s, (uintptr_t)d_history.p,
+            (uintptr_t)d_part0.p, (uintptr_t)d_part1.p, (uintptr_t)k.s, (uintptr_t)d_history.p,
             (uintptr_t)d_row_ptrs.p, (uintptr_t)d_cols.p, (uintptr_t)d_vals.p,
             (uintptr_t)d_sell_chunks.p, (uintptr_t)d_sell_dict.p, (uintptr_t)d_sell_codes.p,
             (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
             (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
             (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p,
-            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)merged, (uintptr_t)d_p2.p, (uintptr_t)z_kept,
+            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)k.merged, (uintptr_t)d_p2.p, (uintptr_t)k.z_kept,
             // what the captured kernels take BY VALUE: the pattern the layouts belong to, the distances / mask / order
             // of the half storage, the cache policy and the workgroup order (a rebuild with the same sizes usually
             // gets the same pointers back: 32x64x32 -> 64x32x32)
@@ -2840,14 +3009,15 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             (uintptr_t)d_s21_chunks.p, (uintptr_t)d_symx_chunks.p, (uintptr_t)d_symx_chunks.n,
             (uintptr_t)d_symx_chunks_general.p, (uintptr_t)d_symx_chunks_general.n, (uintptr_t)d_symx_mask.p,
             (uintptr_t)d_symx_ex_rowptr.p, (uintptr_t)d_symx_ex_cols.p, (uintptr_t)d_symx_ex_vals.p,
-            (uintptr_t)d_symx_ex_lrow.p, (uintptr_t)symx_fast, (uintptr_t)d_spill_chunks.p, (uintptr_t)d_z.p};
+            (uintptr_t)d_symx_ex_lrow.p, (uintptr_t)symx_fast, (uintptr_t)d_spill_chunks.p, (uintptr_t)d_z.p,
+            (uintptr_t)d_band_order.p, (uintptr_t)d_band_order.n};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
             cg_graph = nullptr;
             OGL_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            const int before = enq;
-            const int rc = enqueue_direct(batch);
-            enq = before;  // captured, not run
+            const int before = k.enq;
+            const int rc = krylov_enqueue(k, batch);
+            k.enq = before;  // captured, not run
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(st, &g);
             if (rc != OGL_OK || e != hipSuccess) {
@@ -2863,41 +3033,52 @@ int ogl_solver::run_krylov(ogl_perf *perf)
             cg_graph_key = key;
         }
         OGL_HIP_CHECK(hipGraphLaunch(cg_graph, st));
-        enq += batch;
+        k.enq += batch;
         return OGL_OK;
     };
-    OGL_TRY(enqueue_turns(std::min(batch, max_turns - enq)));
+    OGL_TRY(enqueue_turns(std::min(batch, k.max_turns - k.enq)));
     OGL_TRY(poll_record(0));
-    for (int k = 0;; ++k) {
-        const bool more = enq < max_turns;
+    for (int j = 0;; ++j) {
+        const bool more = k.enq < k.max_turns;
         if (more) {
-            OGL_TRY(enqueue_turns(std::min(batch, max_turns - enq)));
-            OGL_TRY(poll_record((k + 1) & 1));
+            OGL_TRY(enqueue_turns(std::min(batch, k.max_turns - k.enq)));
+            OGL_TRY(poll_record((j + 1) & 1));
         }
-        OGL_HIP_CHECK(hipEventSynchronize(poll_ev[k & 1]));
-        if (h_scal[k & 1].stop) break;
-        if (!more && (fused || bicg_fold)) break;  // (the check of the last enqueued turn is still to come: below)
+        OGL_HIP_CHECK(hipEventSynchronize(poll_ev[j & 1]));
+        if (h_scal[j & 1].stop) break;
+        if (!more && k.folded()) break;  // (the check of the last enqueued turn is still to come: krylov_finish)
         if (!more) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
     }
+    return OGL_OK;
+}
+
+// The closing check of the folded turns, the pending x update, GMRES' final solve_krylov; history, perf, the
+// properties the adaptive criterion of the next solve reads.
+int ogl_solver::krylov_finish(KrylovRun &k, ogl_perf *perf)
+{
+    hipStream_t st = k.st;
+    const int n = k.n, m = k.m;
+    DevScalars *s = k.s, *s2 = k.s2;
+    const bool bicg = k.bicg, gmres = k.gmres, fused = k.fused, bicg_fold = k.bicg_fold;
     if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
-        launch_cg_step1x_fin(st, n, p_of_turn(enq), d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0);
+        launch_cg_step1x_fin(st, n, k.p_of_turn(k.enq), d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0);
     if (bicg_fold) {  // the check that closes the last turn run so far (a plain copy of the scalars when the solve has stopped)
-        launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, y, slot_s[cur], slot_s[cur ^ 1], d_part0.p, d_part1.p,
-                          d_history.p);
-        cur ^= 1;
+        launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, k.y, k.slot_s[k.cur], k.slot_s[k.cur ^ 1], d_part0.p,
+                          d_part1.p, d_history.p);
+        k.cur ^= 1;
     }
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
     DevScalars fin;
-    OGL_HIP_CHECK(hipMemcpy(&fin, bicg_fold ? slot_s[cur] : (fused ? s2 : s), sizeof(fin), hipMemcpyDeviceToHost));
-    if ((fused || bicg_fold) && !fin.stop) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
+    OGL_HIP_CHECK(hipMemcpy(&fin, bicg_fold ? k.slot_s[k.cur] : (fused ? s2 : s), sizeof(fin), hipMemcpyDeviceToHost));
+    if (k.folded() && !fin.stop) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
     if (fin.comm_error)
         return fail(OGL_ERR_COMM, "peer all-reduce timed out: a rank did not take part (check %d)",
                     fin.iter);
     if (fin.x_pending) {
         // the stop came with the check of the last enqueued turn: no step_1x followed to apply
         // that turn's x update
-        launch_cg_step1x(st, n, p_of_turn(enq), d_x.p, d_r.p, precond, s);
+        launch_cg_step1x(st, n, k.p_of_turn(k.enq), d_x.p, d_r.p, precond, s);
         OGL_HIP_CHECK(hipStreamSynchronize(st));
         OGL_HIP_CHECK(hipGetLastError());
     }
@@ -2905,11 +3086,11 @@ int ogl_solver::run_krylov(ogl_perf *perf)
         // final solve_krylov on the (partial) cycle: Arnoldi steps done since the last restart
         const int steps = fin.iter - 1;
         const int cols = steps <= 0 ? 0 : (steps - 1) % m + 1;
-        OGL_TRY(gmres_update_x(cols, nullptr));
+        OGL_TRY(gmres_update_x(k, cols, nullptr));
         OGL_HIP_CHECK(hipStreamSynchronize(st));
         OGL_HIP_CHECK(hipGetLastError());
     }
-    const double t_solve = now_ms() - t_start;
+    const double t_solve = now_ms() - k.t_start;
     history.clear();
     if (cfg.export_res) {
         history.resize(fin.iter);
@@ -2917,7 +3098,7 @@ int ogl_solver::run_krylov(ogl_perf *perf)
                                 hipMemcpyDeviceToHost));
     }
     float chk_ms = 0.f;
-    OGL_HIP_CHECK(hipEventElapsedTime(&chk_ms, ev_chk[0], ev_chk[1]));
+    OGL_HIP_CHECK(hipEventElapsedTime(&chk_ms, k.ev_chk[0], k.ev_chk[1]));
 
     // where the multi-rank turns of this solve waited (DevScalars, kernels.hpp; wall_clock64 counts 10 ns)
     props["haloWaits"] = (double)fin.halo_waits;
@@ -2935,22 +3116,22 @@ int ogl_solver::run_krylov(ogl_perf *perf)
     const int turns_done = bicg ? fin.iter / 2 : std::max(0, fin.iter - 1);
     perf->spmv_avg_ms = 0;
     perf->spmv_launches = 0;
-    if (prof_cap) {
+    if (k.prof_cap) {
         double acc = 0;
-        const int m = std::min((turns_done + prof_stride - 1) / prof_stride, prof_cap);
-        for (int i = 0; i < m; ++i) {
+        const int cnt = std::min((turns_done + k.prof_stride - 1) / k.prof_stride, k.prof_cap);
+        for (int i = 0; i < cnt; ++i) {
             float ms = 0.f;
             OGL_HIP_CHECK(hipEventElapsedTime(&ms, prof_ev[2 * i], prof_ev[2 * i + 1]));
             acc += ms;
         }
-        perf->spmv_launches = m;
-        perf->spmv_avg_ms = m ? acc / m : 0.0;
+        perf->spmv_launches = cnt;
+        perf->spmv_avg_ms = cnt ? acc / cnt : 0.0;
     }
 
     // store_number_of_iterations + relative residual-evaluation cost (lduLduBase.H:286-293);
     // both are stored as labels, i.e. truncated (common.C:75-76,117-123).  The stored count is the
     // raw number of checks for every solver (GKOBiCGStab.H:98-103).
-    props[is_final ? "prevSolveIters_final" : "prevSolveIters"] = fin.iter;
+    props[k.is_final ? "prevSolveIters_final" : "prevSolveIters"] = fin.iter;
     const double time_per_iter = t_solve * 1e3 / std::max(perf->n_iterations, 1);
     const double res_norm_time = std::max(1e-3, (double)chk_ms * 1e3);
     double rel_cost = time_per_iter / res_norm_time;

@@ -392,6 +392,8 @@ struct ogl_solver {
     ogl::DevBuf<double> d_V, d_gm;                      // GMRES: Krylov bases, dense state
     ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T
     ogl::DevBuf<double> d_part0, d_part1, d_part2;  // (part2: beta partials of the fused-finaliser turn)
+    int64_t band_order_rows = 0;
+    ogl::DevBuf<int32_t> d_band_order;  // band-aware workgroup order of the CSR-stream / compressed kernels (property spmvBandRows)
     ogl::DevBuf<double> d_part3, d_part4, d_part5;  // (the folded GKOBiCGStab turn: sum|s|, s.t, t.t)
     ogl::DevBuf<ogl::DevScalars> d_scal;
     ogl::DevBuf<double> d_history;
@@ -431,6 +433,23 @@ struct ogl_solver {
     int run_cg(ogl_perf *perf);
     int run_bicgstab(ogl_perf *perf);
     int run_krylov(ogl_perf *perf);
+    // run_krylov = plan -> prepare -> loop -> finish; one function per solver x turn shape (solver.cpp)
+    struct KrylovRun;
+    int krylov_plan(KrylovRun &k);
+    int krylov_prepare(KrylovRun &k);
+    int krylov_loop(KrylovRun &k);
+    int krylov_enqueue(KrylovRun &k, int count);
+    int krylov_finish(KrylovRun &k, ogl_perf *perf);
+    int gmres_restart(KrylovRun &k, const ogl::DevScalars *gate);
+    int gmres_update_x(KrylovRun &k, int cols, const ogl::DevScalars *gate);
+    int turn_gmres(KrylovRun &k, int enq, int pe);
+    int turn_cg_generic(KrylovRun &k, int enq, int pe);
+    int turn_cg_two_launch(KrylovRun &k, int enq, int pe);
+    int turn_cg_three_launch(KrylovRun &k, int enq, int pe);
+    int turn_cg_merged(KrylovRun &k, int enq, int pe);
+    int turn_cg_five_launch(KrylovRun &k, int enq, int pe);
+    int turn_bicg_folded(KrylovRun &k, int enq, int pe);
+    int turn_bicg(KrylovRun &k, int enq, int pe);
     int time_spmv(int repeats, double *avg_ms);
     ogl::DevCsr csr() const;
     ogl::DevHalo halo() const;
