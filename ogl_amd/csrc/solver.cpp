@@ -11,7 +11,10 @@
 #include <cstddef>
 #include <cstring>
 #include <future>
+#if defined(__x86_64__)
 #include <immintrin.h>
+#endif
+#include <sched.h>
 #include <mutex>
 #include <thread>
 
@@ -47,8 +50,9 @@ struct EventPair {  // destroyed on every return path
 // ------------------------------------------------------------------------------------------
 // ---- the host side of a transfer: [caller's pageable array] <-> [pinned buffer], split over helper threads ----
 namespace {
+#if defined(__x86_64__)
 // 32-byte non-temporal stores (AVX2, checked at run time: the library travels as generic x86-64 code); head and
-// tail, or the whole range without AVX2, by memcpy
+// tail, or the whole range without AVX2 (and on any other host architecture), by memcpy
 __attribute__((target("avx2"))) void stream_copy_avx2(char *d, const char *s, size_t len)
 {
     const size_t head = std::min(len, (size_t)(-(uintptr_t)d & 31));
@@ -70,13 +74,17 @@ __attribute__((target("avx2"))) void stream_copy_avx2(char *d, const char *s, si
     _mm_sfence();
     if (i < len) std::memcpy(d + i, s + i, len - i);
 }
+#endif
 void stream_copy(void *d, const void *s, size_t len)
 {
+#if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2") && std::getenv("OGL_STAGE_PLAIN_STORES") == nullptr;
-    if (avx2 && len >= 4096)
+    if (avx2 && len >= 4096) {
         stream_copy_avx2(static_cast<char *>(d), static_cast<const char *>(s), len);
-    else
-        std::memcpy(d, s, len);
+        return;
+    }
+#endif
+    std::memcpy(d, s, len);
 }
 }  // namespace
 
@@ -170,7 +178,12 @@ int Stager::init(size_t chunk_bytes)
     chunk_ = chunk_bytes;
     const char *e = std::getenv("OGL_STAGE_THREADS");
     int n_threads = std::max(1, std::min(32, e ? atoi(e) : 8));
-    n_threads = std::min(n_threads, std::max(1, (int)std::thread::hardware_concurrency()));
+    // ... but no more than the CPUs this thread may run on: an MPI rank bound to one core (mpirun --bind-to core) hands
+    // its one-CPU mask on to the helpers, and eight of them time-slicing that core copy no faster than the caller alone
+    int allowed = (int)std::thread::hardware_concurrency();
+    cpu_set_t mask;
+    if (sched_getaffinity(0, sizeof(mask), &mask) == 0) allowed = CPU_COUNT(&mask);
+    n_threads = std::min(n_threads, std::max(1, allowed));
     pool_ = new CopyPool(n_threads);
     return OGL_OK;
 }
@@ -1963,7 +1976,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
                             MAX_ISAI_HUGE_ROW);
             int32_t max_row = 0;
             // rows solved by one wavefront each (33 .. 64 entries) / by one workgroup each in global scratch
-            // (65 .. 512); the others: one thread
+            // (65 .. 2048 = MAX_ISAI_HUGE_ROW); the others: one thread
             std::vector<int32_t> wide_rows, huge_rows;
             std::vector<int64_t> huge_off;
             P.huge_batches.assign(1, 0);
@@ -1998,10 +2011,9 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             if (!huge_rows.empty()) {
                 OGL_TRY(reg->stager.h2d(P.huge_rows.p, huge_rows.data(), huge_rows.size() * sizeof(int32_t), st));
                 OGL_TRY(reg->stager.h2d(P.huge_off.p, huge_off.data(), huge_off.size() * sizeof(int64_t), st));
-                OGL_TRY(P.huge_scratch.alloc((size_t)most, st));
-            } else {
-                P.huge_scratch.release();
             }
+            P.huge_scratch_len = most;
+            P.huge_scratch.release();
             props["isaiWideRows"] = (double)wide_rows.size();
             props["isaiHugeRows"] = (double)huge_rows.size();
             const size_t wn = wc.size();
@@ -2053,10 +2065,18 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         }
         launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p,
                              P.w_max_row, P.wide_rows.p, P.n_wide_rows);
+        // the dense systems of the huge rows live in a scratch of up to isaiScratchBytes that only this generation
+        // needs: allocated here, released below (a field's own preconditioner plus the registry-wide cached one would
+        // otherwise sit on 2 GiB each for the whole run)
+        if (P.n_huge_rows > 0) OGL_TRY(P.huge_scratch.alloc((size_t)P.huge_scratch_len, st));
         for (size_t bt = 0; bt + 1 < P.huge_batches.size(); ++bt)  // (stream order: a batch reuses the scratch)
             launch_isai_generate_huge(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p, P.huge_rows.p,
                                       P.huge_off.p, P.huge_batches[bt], P.huge_batches[bt + 1] - P.huge_batches[bt],
                                       P.huge_scratch.p);
+        if (P.n_huge_rows > 0 && prop("isaiKeepScratch", 0.0) == 0.0) {
+            OGL_HIP_CHECK(hipStreamSynchronize(st));
+            P.huge_scratch.release();
+        }
         if (spd) launch_gather_coeffs(st, P.w_nnz, P.wt_map.p, P.w_vals.p, P.wt_vals.p);
         P.w_sell.refresh(P.w_vals.p, st);
         if (spd) P.wt_sell.refresh(P.wt_vals.p, st);

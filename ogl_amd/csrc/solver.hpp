@@ -148,7 +148,8 @@ struct PrecondData {
     // the scratch at one time
     DevBuf<int32_t> huge_rows;
     DevBuf<int64_t> huge_off;
-    DevBuf<double> huge_scratch;
+    DevBuf<double> huge_scratch;  // allocated for a generation, released after it
+    int64_t huge_scratch_len = 0;
     std::vector<int32_t> huge_batches;
     int32_t n_huge_rows = 0;
     SellDev w_sell, wt_sell;  // compressed copies the apply runs on when compress_indices is set

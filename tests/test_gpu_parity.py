@@ -660,6 +660,26 @@ def test_isai_huge_rows_in_scratch_batches(reg, oracle, chunk_rows):
         np.testing.assert_array_equal(x, ref.x)
 
 
+def test_isai_huge_row_with_nan_coefficients_does_not_fault(reg):
+    """a column of NaNs in the dense system of a huge row (diverged coefficients) won no comparison of the
+    pivot search and the row swap indexed far outside the scratch -- a GPU memory fault that took the process down.  Now
+    the pivot stays at row k, as in the oracle's search, and the NaN propagates into W and the criterion: the solve ends
+    (maxIter) with a NaN residual and the process lives on."""
+    hub = _hub_case(150)
+    hub.diag[-1] = np.nan                      # the hub's own diagonal: every entry of its system's last column
+    b = np.ones(hub.n_cells)
+    for pk in (capi.PRECOND_GISAI, capi.PRECOND_ISAI):
+        s = reg.solver(f"isai_nan_{pk}", cg_cfg(preconditioner=pk, tolerance=1e-11, rel_tol=0.0, max_iter=5)).set_matrix(hub)
+        x, perf = s.solve(b, np.zeros_like(b))
+        assert s.get_property("isaiHugeRows") == 1.0
+        assert np.isnan(s.history()).any() and np.isnan(x).any()
+    # ... and the next solve on a sane matrix is fine (the device is alive)
+    ok = _hub_case(150)
+    s = reg.solver("isai_nan_after", cg_cfg(preconditioner=capi.PRECOND_GISAI, tolerance=1e-11, rel_tol=0.0, max_iter=50)).set_matrix(ok)
+    x, perf = s.solve(b, np.zeros_like(b))
+    assert np.isfinite(x).all() and perf.final_residual < 1e-8
+
+
 def _hub_case(m, seed=SEED):
     """A chain of 2 m + 50 cells whose LAST cell is coupled to m others: one row of m + 1 entries (GISAI: the hub's;
     ISAI: the hub is the last cell, so tril(A) keeps the row)."""
