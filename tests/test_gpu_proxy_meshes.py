@@ -102,6 +102,7 @@ def test_the_mechanisms_are_really_in_play(reg):
     assert got["voronoi"]["renumbered"] == 1.0 and got["shuffled"]["renumbered"] == 1.0, got
     assert got["voronoi"]["renumberedAlongCurve"] == 0.0 and got["voronoi_centres"]["renumberedAlongCurve"] == 1.0, got
     assert got["voronoi_centres"]["gatherSectorRatio"] < 0.8 * got["voronoi"]["gatherSectorRatio"], got
+    assert got["voronoi_centres"]["rowsSortedByLength"] == 0.0, got      # (the curve's order is kept as it is)
     assert got["shuffled"]["spmvLayout"] == 2.0 and got["octree"]["spmvLayout"] == 2.0, got
     assert got["long_rows"]["sellSpilledEntries"] > 0 or got["long_rows_shuffled"]["sellSpilledEntries"] > 0, got
     assert any(g["rowsSortedByLength"] == 1.0 for g in got.values()), got
