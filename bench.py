@@ -300,8 +300,11 @@ def main():
         # (the generating points stand in for mesh.C(): the plug-in passes the cell centres, ogl_ldu_view::cell_centres)
         case = synthetic.voronoi_case(args.voronoi, with_centres=not args.no_centres)
     if args.blocks:
-        assert world == 1 and not args.voronoi and not args.asym, "--blocks is a single-rank, symmetric option"
+        assert world == 1 and not args.voronoi, "--blocks is a single-rank option"
         case = synthetic.multi_block_case([int(v) for v in args.blocks.split(",")], n, n)
+        if args.asym:       # (momentum-like coefficients on the same addressing, as tests/test_gpu_fullsize_configs.py)
+            import dataclasses
+            case = dataclasses.replace(case, upper=np.full(case.n_faces, -0.9), lower=np.full(case.n_faces, -1.1))
     if args.octree:
         assert world == 1 and not args.voronoi and not args.asym, "--octree is a single-rank, symmetric option"
         case = synthetic.octree_case(n, args.octree, args.octree_append)

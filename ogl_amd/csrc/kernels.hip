@@ -1063,6 +1063,48 @@ __global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply(int n_rows,
     }
 }
 
+// Block Jacobi through a permutation in ONE pass over the blocks (launch_bj_apply_staged, fused form): a workgroup takes
+// CHUNK_ROWS consecutive positions of the CALLER's order, every thread gathers the input of its own position once
+// (in[rows[position]]; the blocks' members are far apart on the device, so this is the one scattered read per row
+// the staged form also pays) into LDS together with the MAX_JACOBI_BLOCK - 1 positions either side that a block
+// straddling the workgroup's range may need, applies its block row from there (same products, same left-to-right
+// sum as k_bj_apply) and stores the result at its device row.  The dot partials of the device order follow in a
+// pass of their own (k_partials): 2 launches and 52 + 16 bytes per row (block size 4) instead of 3 launches and 100.
+__global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply_perm(int n_rows, const int *__restrict__ block_ptrs,
+                                                              const int *__restrict__ row_block,
+                                                              const double *__restrict__ blocks, int ld, int uniform,
+                                                              const double *__restrict__ in, double *__restrict__ out,
+                                                              const DevScalars *gate, const int *__restrict__ rows)
+{
+    constexpr int HALO = MAX_JACOBI_BLOCK - 1;
+    __shared__ double v[CHUNK_ROWS + 2 * HALO];
+    if (gate && gate->stop) return;
+    const int c0 = blockIdx.x * CHUNK_ROWS, at = c0 + (int)threadIdx.x;
+    const int dev = at < n_rows ? rows[at] : -1;
+    v[HALO + threadIdx.x] = dev >= 0 ? in[dev] : 0.0;
+    if (threadIdx.x < 2 * HALO) {  // the positions before and behind the range
+        const int h = threadIdx.x < HALO ? c0 - HALO + (int)threadIdx.x : c0 + CHUNK_ROWS + (int)threadIdx.x - HALO;
+        v[threadIdx.x < HALO ? threadIdx.x : CHUNK_ROWS + threadIdx.x] = (h >= 0 && h < n_rows) ? in[rows[h]] : 0.0;
+    }
+    __syncthreads();
+    if (dev < 0) return;
+    int b, r0, bs;
+    if (uniform) {  // blocks of exactly `ld` rows (the last one may be shorter)
+        b = at / ld;
+        r0 = b * ld;
+        bs = min(ld, n_rows - r0);
+    } else {
+        b = row_block[at];
+        r0 = block_ptrs[b];
+        bs = block_ptrs[b + 1] - r0;
+    }
+    const double *a = blocks + (size_t)b * ld * ld + (size_t)(at - r0) * ld;
+    const double *x = v + HALO + (r0 - c0);
+    double sum = 0.0;
+    for (int j = 0; j < bs; ++j) sum += a[j] * x[j];
+    out[dev] = sum;
+}
+
 enum PartialOp { P_SUM = 0, P_DOT = 1, P_NORM1 = 2 };
 template <int OP>
 __global__ __launch_bounds__(BLOCK) void k_partials(int n, int n_chunks,
@@ -4052,6 +4094,12 @@ void launch_bj_apply_staged(hipStream_t st, const DevBlockJacobi &J, const doubl
                             const DevScalars *gate, double *tmp_in, double *tmp_out)
 {
     if (J.n_rows == 0) return;
+    if (!tmp_in) {  // the fused form: one pass over the blocks in the caller's order, then the dot partials
+        hipLaunchKernelGGL(k_bj_apply_perm, dim3((unsigned)n_chunks(J.n_rows)), dim3(CHUNK_ROWS), 0, st, J.n_rows,
+                           J.block_ptrs, J.row_block, J.blocks, J.stride, J.uniform, in, out, gate, J.rows);
+        if (dot_part) launch_partials_dot(st, J.n_rows, in, out, dot_part, gate);
+        return;
+    }
     hipLaunchKernelGGL(k_gather_gated, dim3(blocks_for(J.n_rows)), dim3(BLOCK), 0, st, J.n_rows, J.rows, in, tmp_in, gate);
     DevBlockJacobi C = J;  // the blocks as they lie in the caller's order
     C.rows = C.pos = nullptr;

@@ -2196,7 +2196,10 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
         J.pos = d_old_of.p;
         J.by_device_row = precond_data->by_device_row ? 1 : 0;
         if (!precond_data->by_device_row) {
-            launch_bj_apply_staged(st, J, in, out, dot_part, gate, d_bj_tmp0.p, d_bj_tmp1.p);
+            // (property bjFusedPerm 0: the three-launch form with two staging vectors, for A/B)
+            const bool fused_perm = prop("bjFusedPerm", 1.0) != 0.0 && in != out;
+            launch_bj_apply_staged(st, J, in, out, dot_part, gate, fused_perm ? nullptr : d_bj_tmp0.p,
+                                   fused_perm ? nullptr : d_bj_tmp1.p);
             return;
         }
     }

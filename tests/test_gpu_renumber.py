@@ -301,17 +301,20 @@ def test_preconditioner_structures_in_the_backends_numbering_on_request(reg, ora
     np.testing.assert_array_equal(x1, ref_caller.x[new_id])
 
 
-@pytest.mark.parametrize("staged", [1.0, 0.0], ids=["staged", "direct"])
-@pytest.mark.parametrize("k", [2, 4, 7])
+@pytest.mark.parametrize("staged", [1.0, 2.0, 0.0], ids=["one_pass", "staged", "direct"])
+@pytest.mark.parametrize("k", [2, 4, 7, 32])
 def test_block_jacobi_through_the_permutation_both_applies(reg, oracle, chunk_rows, staged, k):
-    """The caller's blocks on a renumbered copy: the staged apply (vectors carried into the caller's order and back,
-    blocks block-major there; default) and the direct one (block rows stored at their device rows, members gathered)
-    give the oracle's bits; block sizes that do not divide the row count."""
-    case = synthetic.renumber_case(synthetic.poisson_block(13, 11, 7), 300)
+    """The caller's blocks on a renumbered copy: the one-pass apply over the blocks in the caller's order (every
+    workgroup gathers its positions' inputs once into LDS, blocks that straddle its range included; default), the
+    staged one (vectors carried into the caller's order and back by kernels of their own, bjFusedPerm 0) and the
+    direct one (block rows stored at their device rows, members gathered) give the oracle's bits; block sizes that do
+    not divide the row count, up to the largest (32: the widest halo of the one-pass form)."""
+    case = synthetic.renumber_case(synthetic.poisson_block(13, 11, 7 if k < 32 else 19), 300)
     b = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
     skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=200)
     s = reg.solver(f"rnbj_{k}_{staged}", cfg(preconditioner=capi.PRECOND_BJ, max_block_size=k, **skw))
-    s.set_property("bjStagedApply", staged)
+    s.set_property("bjStagedApply", 1.0 if staged else 0.0)
+    s.set_property("bjFusedPerm", 1.0 if staged == 1.0 else 0.0)
     s.set_matrix(case)
     new_id = s.renumbering()
     x, perf = s.solve(b, np.zeros_like(b))
@@ -325,7 +328,8 @@ def test_block_jacobi_through_the_permutation_both_applies(reg, oracle, chunk_ro
     for solver, fn, extra in ((capi.SOLVER_BICGSTAB, oracle.bicgstab, {}), (capi.SOLVER_GMRES, oracle.gmres, dict(krylov_dim=10))):
         s2 = reg.solver(f"rnbj_{k}_{staged}_{solver}", cfg(solver=solver, preconditioner=capi.PRECOND_BJ, max_block_size=k,
                                                           krylov_dim=extra.get("krylov_dim", 0), **skw))
-        s2.set_property("bjStagedApply", staged)
+        s2.set_property("bjStagedApply", 1.0 if staged else 0.0)
+        s2.set_property("bjFusedPerm", 1.0 if staged == 1.0 else 0.0)
         s2.set_matrix(case)
         x2, _ = s2.solve(b, np.zeros_like(b))
         with blocked(oracle, chunk_rows):

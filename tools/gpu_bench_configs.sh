@@ -1,7 +1,7 @@
 #!/bin/bash
 # Single-GPU measurements of the other BASELINE.json configs' solver / preconditioner pairs, each against
 # the byte model of one solver turn (bench.py turn_model).  Writes gpurun_out/${TAG}_configs.txt
-TAG=${1:-r02}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 OUT=gpurun_out/${TAG}_configs.txt
 echo "# tools/gpu_bench_configs.sh on one MI355X (bench.py --steps 3 --warmup 2, HBM-resident, fixed turn count)" > $OUT
@@ -32,6 +32,9 @@ run cg_bj_368        --iters 50 --edge 368
 # proxies of the unstructured configs (cells renumbered at random in windows of 65536; the backend renumbers itself)
 run c3_cg_bj_128s     --iters 100 --edge 128 --shuffle 65536
 run c3_bicg_isai_128s --iters 100 --edge 128 --shuffle 65536 --solver GKOBiCGStab --asym --precond ISAI
+# ... and on the kind of mesh pitzDaily is (three blockMesh blocks of 60 / 90 / 40 x 104 x 104 cells, 2.06 M, numbered block by block)
+run c3_cg_bj_blocks3     --iters 100 --edge 104 --blocks 60,90,40
+run c3_bicg_isai_blocks3 --iters 100 --edge 104 --blocks 60,90,40 --solver GKOBiCGStab --asym --precond ISAI
 run c4_cg_bj_136      --iters 100 --edge 136
 run c5_gmres_csr_184s --iters 60 --edge 184 --shuffle 65536 --solver GKOGMRES --krylov-dim 30
 run c5_gmres_ell_184s --iters 60 --edge 184 --shuffle 65536 --solver GKOGMRES --krylov-dim 30 --format Ell
