@@ -146,7 +146,7 @@ def parse():
                          "every rung of the ladder -- peer mesh over RCCL, peer mesh over the host bootstrap, RCCL alone, "
                          "host buffers alone -- is brought up once in child processes after the timed region, self-checked "
                          "and timed for a few steps: config.transport.rungs)")
-    ap.add_argument("--rung-timeout", type=float, default=150.0,
+    ap.add_argument("--rung-timeout", type=float, default=120.0,
                     help="seconds a rung probe may take before its child processes are ended")
     ap.add_argument("--no-profile", action="store_true",
                     help="do not event-time the in-loop SpMV (roofline then comes from a "

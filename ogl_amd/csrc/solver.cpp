@@ -1287,6 +1287,12 @@ int ogl_solver::build_sell(SellLayout *pre, bool pre_qualifies)
     sell_slots = L.n_slots;
     sell_state = 1;
     sell_irregular = L.n_delta16 + L.n_col32 > 0;
+    // a banded pattern (1-byte codes throughout: a structured mesh): the largest offset any chunk's table holds = the
+    // band the workgroup order below is built for
+    sell_band_rows = 0;
+    if (!sell_irregular)
+        for (int32_t d : L.dict)
+            if (d != SELL_PAD_OFFSET) sell_band_rows = std::max<int64_t>(sell_band_rows, std::abs((int64_t)d));
     sell_tuned = 0;
     // bytes one SpMV reads of this layout (bench.py's moved-bytes model): the value planes and codes
     // up to every wavefront's own width (planes beyond it are allocated, not read), headers, tables
@@ -1893,10 +1899,14 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     // which layout the in-loop SpMV runs on: 0 CSR-stream, 1 ELL, 2 index-compressed chunked ELL
     // (2 also for the half storage of a symmetric matrix: property symmetricHalf tells them apart)
     // 3: CSR-stream with packed columns
-    {   // Band-aware workgroup order of the CSR-stream / compressed kernels (property spmvBandRows = the band in rows,
-        // 0 = off: an experiment switch -- the half-storage kernels take their order from their own distances).  The
-        // chunks of rows r and r +- band run on one XCD, so a strip of x is fetched into one L2 instead of three.
-        const int64_t band = (int64_t)prop("spmvBandRows", 0.0);
+    {   // Band-aware workgroup order of the compressed / CSR-stream kernels (the half-storage kernels take theirs from
+        // their own distances): the chunks of rows r and r +- band run on one XCD, so a strip of x is fetched into one L2
+        // instead of three.  Full storage of the 216^3 box, STREAM instantiation: 128.2 -> 124.6 us (0.718 -> 0.739 of
+        // peak); the plain CSR-stream kernel measures the same either way (195.7 / 195.8 us) and is left alone.  Property
+        // spmvBandRows: the band in rows, 0 = off, -1 (default) = the compressed layout's own largest offset on a
+        // banded pattern.
+        int64_t band = (int64_t)prop("spmvBandRows", -1.0);
+        if (band < 0) band = (cfg.matrix_format != OGL_FORMAT_ELL && use_sell() && !use_sym() && !use_symx()) ? sell_band_rows : 0;
         if (band != band_order_rows) {
             d_band_order.release();
             band_order_rows = band;
