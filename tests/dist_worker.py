@@ -171,7 +171,8 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
         s = reg.solver("p", cfg)
         s.set_property("haloFused", float(args.halo_fused))
         s.set_property("fusedTurnMulti", float(args.fused_turn_multi))
-        s.set_property("peerSafeWait", float(args.peer_safe_wait))
+        if args.peer_safe_wait >= 0:        # (-1: the library decides -- it finds ranks that share a device by itself)
+            s.set_property("peerSafeWait", float(args.peer_safe_wait))
         s.set_matrix(case)
         new_id = s.renumbering()
         assert (new_id is not None) == bool(args.renumber and case.n_cells >= 2)
@@ -266,7 +267,9 @@ def main():
                     help="0: property fusedTurnMulti off -- the 5-launch multi-rank GKOCG turn (p put by step_1x) "
                          "instead of the merged 4-launch one (z put by step_2r)")
     ap.add_argument("--peer-safe-wait", type=int, default=0,
-                    help="1: property peerSafeWait -- one workgroup waits for the neighbours' puts instead of every boundary "
+                    help="0 (default here: the fused waits are what these tests are for, and slab cuts do not starve): forced "
+                         "off; -1: left to the library (peer_connect switches it on when two ranks report one PCI bus "
+                         "id); 1: property peerSafeWait -- one workgroup waits for the neighbours' puts instead of every boundary "
                          "workgroup of the SpMV (ranks sharing a device with a cut that puts boundary rows into every chunk)")
     ap.add_argument("--expect-merged", type=int, default=-1,
                     help="0 / 1: assert that the merged turn did not run / ran (fusedTurnInUse)")

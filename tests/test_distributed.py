@@ -270,9 +270,20 @@ def test_gpu_config3_eight_way_20m_cells_peer_mesh_single_waiter():
 
 
 @pytest.mark.gpu
+def test_gpu_peer_ranks_sharing_a_device_are_found_and_get_the_single_waiter():
+    """peer_connect gathers the ranks' PCI bus ids through the mesh's all-reduce; when two ranks sit on
+    one device the single waiter is switched on without the property -- the 2 x 2 x 2 cut of 8 x 96^3 that starves with
+    fused waits (next test) passes bit-equal to the distributed oracle as it is."""
+    if _n_devices() >= 8:
+        pytest.skip("a device per rank: nothing is shared")
+    run_ranks(8, "--mode", "gpu-peer", "--shape", "192,192,192", "--procs", "2,2,2", "--max-iter", "5", "--no-global", "1",
+              "--peer-safe-wait", "-1", "--expect-merged", "0", timeout=900)
+
+
+@pytest.mark.gpu
 def test_gpu_peer_starved_puts_fail_loudly():
-    # the situation described above, provoked on purpose with a short time-out: the SpMV entry point must report
-    # OGL_ERR_COMM instead of handing out the local product
+    # the situation described above, provoked on purpose (dist_worker.py forces the single waiter OFF unless told otherwise)
+    # with a short time-out: the SpMV entry point must report OGL_ERR_COMM instead of handing out the local product
     env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OGL_PEER_TIMEOUT_S="3")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
