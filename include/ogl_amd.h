@@ -263,7 +263,9 @@ int ogl_solver_set_matrix(ogl_solver *s, const ogl_ldu_view *ldu);
  * copy (a device-to-device copy) instead of crossing PCIe again, when ALL of this holds: same registry, same face
  * addressing (fingerprint of lowerAddr / upperAddr / interfaces), ldu->upper / ldu->lower are the very host arrays
  * `donor` uploaded from (pointer identity), a checksum over 8192 sampled entries of them still equals what `donor`
- * recorded, and neither solver reorders on the host.  Otherwise it IS ogl_solver_set_matrix.  The caller vouches that
+ * recorded, and neither solver reorders on the host.  Otherwise it IS ogl_solver_set_matrix.  (When, in addition, the
+ * addressing arrays are the very ones `donor` was handed -- same pointers, same counts -- their hash is taken over from
+ * `donor` instead of reading them again.)  The caller vouches that
  * nothing wrote to those arrays in between (the plug-in asks for this only for the sibling component solved
  * immediately before, in the same time step: OGLAdapter.H).  Property offDiagReused tells what happened. */
 int ogl_solver_set_matrix_like(ogl_solver *s, const ogl_ldu_view *ldu, ogl_solver *donor);

@@ -1439,6 +1439,18 @@ int ogl_solver::ensure_vectors()
     return OGL_OK;
 }
 
+bool ogl_solver::saw_addressing(const ogl_ldu_view &ldu) const
+{
+    if (seen_lower_addr != ldu.lower_addr || seen_upper_addr != ldu.upper_addr || seen_faces != ldu.n_faces ||
+        (ogl_label)seen_iface_cells.size() != ldu.n_interfaces)
+        return false;
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i)
+        if (seen_iface_cells[(size_t)i].first != ldu.interfaces[i].face_cells ||
+            seen_iface_cells[(size_t)i].second != ldu.interfaces[i].size)
+            return false;
+    return true;
+}
+
 // checksum over (at most) 4096 evenly spaced entries of each off-diagonal array plus their last ones (bit patterns):
 // what ogl_solver_set_matrix_like compares before it trusts a donor's device copy
 static uint64_t offdiag_sample(const double *upper, const double *lower, int64_t F)
@@ -1559,7 +1571,14 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     bool first = true, coefficients_done = false;
     int upload_rc = OGL_OK;  // (a failed speculative upload is reported after the ranks have agreed below)
     if (config_same && same_counts(ldu, pat)) {
-        auto fp = std::async(std::launch::async, [&ldu] { return addressing_fingerprint(ldu); });
+        // (ogl_solver_set_matrix_like: the sibling hashed these very addressing arrays a moment ago -- same pointers, same
+        //  counts -- and this field's pattern carries the fingerprint it found: the 240 MB are not read a second and
+        //  third time per time step)
+        const bool hashed_by_sibling = share_from && share_from->have_pattern &&
+                                       share_from->pat.fingerprint == pat.fingerprint && share_from->saw_addressing(ldu);
+        const uint64_t known = pat.fingerprint;
+        auto fp = hashed_by_sibling ? std::async(std::launch::deferred, [known] { return known; })
+                                    : std::async(std::launch::async, [&ldu] { return addressing_fingerprint(ldu); });
         int rc = OGL_OK;
         if (!matrix_set || cfg.update_sys_matrix || cfg.regenerate) {
             rc = upload_coefficients();
@@ -1945,6 +1964,14 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     }
     OGL_HIP_CHECK(hipStreamSynchronize(st));
     OGL_HIP_CHECK(hipGetLastError());
+    // what this call's addressing arrays were (ogl_solver_set_matrix_like: a sibling built on the same arrays right after
+    // need not hash them again)
+    seen_lower_addr = ldu.lower_addr;
+    seen_upper_addr = ldu.upper_addr;
+    seen_faces = ldu.n_faces;
+    seen_iface_cells.clear();
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i)
+        seen_iface_cells.emplace_back(ldu.interfaces[i].face_cells, ldu.interfaces[i].size);
     t_update_matrix_ms = now_ms() - t0;
     return OGL_OK;
 }

@@ -461,6 +461,11 @@ struct ogl_solver {
     const double *offdiag_upper = nullptr, *offdiag_lower = nullptr;
     uint64_t offdiag_sum = 0;
     bool offdiag_valid = false;
+    // the addressing arrays of the last set_matrix (a sibling on the same arrays need not hash them again)
+    const ogl_label *seen_lower_addr = nullptr, *seen_upper_addr = nullptr;
+    ogl_label seen_faces = -1;
+    std::vector<std::pair<const ogl_label *, ogl_label>> seen_iface_cells;
+    bool saw_addressing(const ogl_ldu_view &ldu) const;
     bool peer_safe_wait() const;
     double stream_above_bytes() const;
     double turn_extra_bytes() const;
