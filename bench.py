@@ -89,6 +89,9 @@ def parse():
                     help="instead of the box: the Voronoi cells of this many random points (a polyhedral mesh, "
                          "15.5 faces per cell on average, random numbering); single rank only; scipy Delaunay "
                          "takes about a minute per million points")
+    ap.add_argument("--centres", action="store_true",
+                    help="box cases: hand the cell centres over too (mesh.C(); with --shuffle the Hilbert order through them "
+                         "then competes with reverse Cuthill-McKee for the library's own numbering); single rank only")
     ap.add_argument("--no-centres", action="store_true",
                     help="with --voronoi: do not hand the cell centres over (reverse Cuthill-McKee is then the only "
                          "candidate for the library's own numbering; with them the Hilbert order through the centres competes)")
@@ -292,9 +295,9 @@ def main():
             case = synthetic.renumber_case(case, 65536, seed=20241016 + rank)
     elif args.asym:
         case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank, symmetric=False,
-                                       off_upper=-0.9, off_lower=-1.1)
+                                       off_upper=-0.9, off_lower=-1.1, with_centres=args.centres)
     else:
-        case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank)
+        case = synthetic.poisson_block(n, n, n * world, pz=world, rank=rank, with_centres=args.centres)
     if args.voronoi:
         assert world == 1, "--voronoi is a single-rank option"
         # (the generating points stand in for mesh.C(): the plug-in passes the cell centres, ogl_ldu_view::cell_centres)

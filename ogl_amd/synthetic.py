@@ -75,7 +75,7 @@ def _delta(gi):
 
 
 def poisson_block(gx, gy, gz, px=1, py=1, pz=1, rank=0, symmetric=True, periodic_x=False,
-                  off_upper=-1.0, off_lower=-1.0):
+                  off_upper=-1.0, off_lower=-1.0, with_centres=False):
     """Rank `rank`'s share of a gx*gy*gz Poisson box cut into px*py*pz equal blocks.
 
     rank = bx + px*(by + py*bz).  periodic_x adds a cyclic patch pair (only with px == 1).
@@ -137,7 +137,8 @@ def poisson_block(gx, gy, gz, px=1, py=1, pz=1, rank=0, symmetric=True, periodic
         ifaces.append(Interface(IFACE_CYCLIC, right,
                                 np.full(right.size, -(off_upper if symmetric else off_lower)), -1,
                                 p0))
-    return LduCase(n, lower_addr, upper_addr, diag, upper, lower, ifaces, gi, gx * gy * gz)
+    centres = np.stack([gI + 0.5, gJ + 0.5, gK + 0.5], axis=1).astype(np.float64) if with_centres else None
+    return LduCase(n, lower_addr, upper_addr, diag, upper, lower, ifaces, gi, gx * gy * gz, centres)
 
 
 def poisson_case(n, symmetric=True, **kw):
