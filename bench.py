@@ -790,7 +790,8 @@ def main():
     # Momentum components (ogl_solver_set_matrix_like): three solvers on ONE set of host arrays, as solveSegregated
     # builds them for Ux, Uy, Uz -- the second and third take the first one's device copy of upper / lower
     components = None
-    if world == 1 and not args.config and not os.environ.get("OGL_BENCH_CHILD"):
+    if world == 1 and not args.config and not os.environ.get("OGL_BENCH_CHILD") and plain_box and not args.shuffle \
+            and cg_headline:
         cs = [reg.solver("U" + c, cfg) for c in "xyz"]
         for k, c in enumerate(cs):                       # (patterns: not timed)
             c.set_matrix(ldu_arrays, like=cs[k - 1] if k else None)
