@@ -1409,8 +1409,6 @@ int ogl_solver::tune_spmv_layout()
     if (have[2] && !s21_use) {
         d_s21_chunks.release();
         d_s21_codes.release();
-        d_band_order.release();
-        band_order_rows = 0;
         s21_state = -1;
     }
     return OGL_OK;
@@ -1698,6 +1696,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         layout_tuned = false;
         d_s21_chunks.release();
         d_s21_codes.release();
+        d_band_order.release();  // (the band-aware workgroup order belongs to the pattern it was built for)
+        band_order_rows = 0;
         x_resident = b_resident = false;
         props["renumberedOnDevice"] = renumbered_on_device ? 1.0 : 0.0;
         if (!built_on_device || (rep.applied && !renumbered_on_device)) {  // the device does not hold the pattern (in this numbering) yet

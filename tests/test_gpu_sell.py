@@ -237,6 +237,30 @@ def test_pattern_change_rebuilds_the_layout(reg, oracle):
         np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
 
 
+def test_band_aware_workgroup_order_follows_a_pattern_rebuild(reg, oracle):
+    """Round 5: on a banded pattern the workgroups of the compressed kernel take the chunks in the band-aware order (the
+    chunks of rows r and r +- band on one XCD).  The order belongs to the pattern: a rebuild with the SAME band and MORE
+    rows (80 x 80 x 80 -> 80 x 80 x 100 cells, band 6400) must not run the new matrix on the old order, which would
+    leave its last chunks out; the product does not depend on the order (property spmvBandRows 0)."""
+    s = reg.solver("sell_band_rebuild", cfg(1, solver=capi.SOLVER_BICGSTAB))
+    for gz in (80, 100):
+        case = synthetic.poisson_block(80, 80, gz, symmetric=False, off_upper=-0.9, off_lower=-1.1)
+        s.set_matrix(case)
+        assert s.get_property("spmvLayout") == LAYOUT_SELL and s.get_property("symmetricHalf") == 0.0
+        rp, cols, vals = oracle_csr(oracle, case)
+        x = np.random.default_rng(gz).uniform(-1, 1, case.n_cells)
+        np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+    s0 = reg.solver("sell_band_off", cfg(1, solver=capi.SOLVER_BICGSTAB))
+    s0.set_property("spmvBandRows", 0.0)
+    s0.set_matrix(case)
+    np.testing.assert_array_equal(s0.spmv(x), s.spmv(x))
+    b = oracle.spmv(rp, cols, vals, synthetic.x_star(case.global_index, case.global_n))
+    xa, pa = s.solve(b, np.zeros_like(b))
+    xb, pb = s0.solve(b, np.zeros_like(b))
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(s.history(), s0.history())
+
+
 def test_offset_mode_when_a_chunk_has_too_many_row_patterns(reg, oracle):
     # every row couples to a pseudo-random 90 % of the 20 following rows: hundreds of distinct row
     # patterns per chunk but only 41 distinct offsets -> the chunks use one byte per (row, slot)
