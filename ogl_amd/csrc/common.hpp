@@ -18,6 +18,11 @@ int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)))
 // Geometry of the deterministic reduction tree and of the CSR-stream SpMV (kernels.hip).
 // One workgroup = BLOCK threads = one chunk of CHUNK_ROWS consecutive rows; thread t owns the
 // ROWS_PER_THREAD consecutive rows starting at chunk_start + t * ROWS_PER_THREAD.
+#if defined(__HIPCC__)
+#define OGL_HD_FWD __host__ __device__
+#else
+#define OGL_HD_FWD
+#endif
 constexpr int N_XCD = 8;  // MI355X: 8 XCDs, workgroup b is observed on XCD b % 8 (speed only)
 constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
@@ -28,14 +33,29 @@ constexpr int SPMV_TILE = 4096;
 // CSR-stream with packed columns (DevCsr::codes21; irregular patterns whose rows are too long / too uneven for the
 // chunked ELL, e.g. polyhedral meshes): the values stay the plain CSR array, the columns of a chunk are kept as
 // 21-bit offsets from the chunk's smallest column, six to a 16-byte word, in the order the lanes of the kernel
-// consume them -- 10.67 instead of 12 bytes per entry.  Needs every chunk's columns within a window of 2^21.
+// consume them -- 10.67 instead of 12 bytes per entry.  A chunk whose columns span 2^21 or more (a numbering along a
+// space-filling curve above 2 M rows: most neighbours in the chunk's own blob, a few in blobs anywhere) takes a window of
+// 2^21 columns around its own rows; the few entries outside it ("far") are coded as offset 0 and listed per chunk with
+// their entry index and column -- the kernel's workgroup overwrites their products before the rows are summed.
 constexpr int STREAM21_TILE = 3072;                 // entries per pass: 256 lanes x 2 groups x 6 entries
 constexpr int STREAM21_GROUPS = STREAM21_TILE / (BLOCK * 6);
 constexpr int STREAM21_BITS = 21;
-struct Stream21Chunk {  // per chunk
-    int32_t base;       // smallest column of the chunk
+struct Stream21Chunk {  // per chunk (16 bytes: one scalar load)
+    int32_t base;       // smallest column of the chunk / first column of its window
     int32_t word_off;   // first 16-byte code word of the chunk
+    int32_t far_off;    // first entry of the chunk in the far lists
+    int32_t far_n;      // entries of the chunk outside [base, base + 2^21)
 };
+// where a chunk's window starts when its columns span 2^21 or more: 2^20 columns before its first row, inside [0, n)
+OGL_HD_FWD inline int32_t stream21_window_base(int32_t first_row, int32_t n_rows)
+{
+    const int64_t top = (int64_t)n_rows - ((int64_t)1 << STREAM21_BITS);
+    int64_t b = (int64_t)first_row - ((int64_t)1 << (STREAM21_BITS - 1));
+    if (b > top) b = top;
+    if (b < 0) b = 0;
+    return (int32_t)b;
+}
+constexpr double STREAM21_MAX_FAR = 0.02;  // ... and the layout is given up when more than this share of the entries is far
 // Vector loads read up to 3 entries past a tile end: value/column arrays carry this much padding.
 constexpr int NNZ_PAD = 8;
 

@@ -901,15 +901,17 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
             for (ogl_label c = 0; c < N; ++c) curve_old[(size_t)curve[(size_t)c]] = c;
             rep.ratio_curve = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), curve.data(), curve_old.data());
             // ... unless it would cost the packed columns: along the curve most of a chunk's neighbours sit in the chunk's
-            // own blob, but a few sit in blobs anywhere in the numbering, and the CSR-stream kernel packs its columns as
-            // 21-bit offsets from the chunk's smallest one.  Above 2^21 rows a chunk's span can exceed that, the plain
-            // 12-byte CSR-stream kernel would run, and that loses more than the curve gains (Voronoi 3 M cells: 151 us
-            // against 133 in RCM order with packed columns; 1 M cells, packed either way: 43.5 against 51).
+            // own blob, but a few sit in blobs anywhere in the numbering.  The CSR-stream kernel packs its columns as 21-bit
+            // offsets into a window of 2^21 columns around the chunk's rows and lists the entries outside it ("far") apart;
+            // beyond STREAM21_MAX_FAR of the entries it gives the packing up, and the plain 12-byte CSR-stream kernel
+            // loses more than the curve gains (Voronoi 3 M cells: 151 us against 133 in RCM order with packed columns).
             bool packable = true;
             if ((int64_t)N > ((int64_t)1 << STREAM21_BITS)) {
-                for (ogl_label k0 = 0; k0 < N && packable; k0 += CHUNK_ROWS) {
+                int64_t far = 0;
+                for (ogl_label k0 = 0; k0 < N; k0 += CHUNK_ROWS) {
                     ogl_label lo = N, hi = 0;
-                    for (ogl_label k = k0; k < std::min<int64_t>(N, (int64_t)k0 + CHUNK_ROWS); ++k) {
+                    const ogl_label k1 = (ogl_label)std::min<int64_t>(N, (int64_t)k0 + CHUNK_ROWS);
+                    for (ogl_label k = k0; k < k1; ++k) {
                         const ogl_label row = curve_old[(size_t)k];
                         for (ogl_label e = p.row_ptrs[row]; e < p.row_ptrs[row + 1]; ++e) {
                             const ogl_label c = curve[(size_t)p.cols[e]];
@@ -917,8 +919,18 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
                             hi = std::max(hi, c);
                         }
                     }
-                    packable = hi < lo || (int64_t)hi - lo < ((int64_t)1 << STREAM21_BITS);
+                    if (hi < lo || (int64_t)hi - lo < ((int64_t)1 << STREAM21_BITS)) continue;
+                    const int64_t base = stream21_window_base(k0, N);
+                    for (ogl_label k = k0; k < k1; ++k) {
+                        const ogl_label row = curve_old[(size_t)k];
+                        for (ogl_label e = p.row_ptrs[row]; e < p.row_ptrs[row + 1]; ++e) {
+                            const int64_t d = (int64_t)curve[(size_t)p.cols[e]] - base;
+                            far += (d < 0 || d >= ((int64_t)1 << STREAM21_BITS)) ? 1 : 0;
+                        }
+                    }
                 }
+                packable = (double)far <= STREAM21_MAX_FAR * (double)p.row_ptrs[N];
+                rep.curve_far_entries = far;
             }
             rep.curve_packable = packable;
             if (rep.ratio_curve < r && packable) {

@@ -201,7 +201,8 @@ struct RenumberReport {
     double ratio_natural = 0.0, ratio_used = 0.0;  // gather_sector_ratio before / after
     double ratio_rcm = -1.0, ratio_curve = -1.0;    // ... of the two candidates (-1: not formed)
     bool curve_used = false;                        // the Hilbert order through the cell centres was taken
-    bool curve_packable = true;                     // ... every chunk's columns still span < 2^21 along the curve
+    bool curve_packable = true;                     // ... the packed columns of the CSR-stream kernel stay possible along the curve
+    int64_t curve_far_entries = 0;                  // entries outside their chunk's 2^21-column window along the curve
     double slot_ratio = 0.0;  // slot_gather_sector_ratio of the numbering at large (0: not needed)
 };
 // mode 0: keep the caller's numbering; 1: always RCM; 2 (default, "auto"): keep it when the

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream21(
     const uint4 *__restrict__ codes, const double *__restrict__ vals, const double *__restrict__ x,
     const double *__restrict__ b, double *__restrict__ y, const double *__restrict__ w,
     double *__restrict__ dot_partials, double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup,
-    HaloFused hf)
+    HaloFused hf, const int *__restrict__ far_idx, const int *__restrict__ far_col)
 {
     __shared__ __attribute__((aligned(16))) double prod[STREAM21_TILE];
     __shared__ double slot[N_WAVES];
@@ -398,6 +398,13 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream21(
         }
         __syncthreads();
         const int t1 = t0 + STREAM21_TILE;
+        if (ck.far_n) {  // the chunk's far entries (coded as offset 0 above): their products put right (workgroup-uniform)
+            for (int i = tid; i < ck.far_n; i += BLOCK) {
+                const int e = far_idx[ck.far_off + i];
+                if (e >= t0 && e < t1) prod[e - t0] = vals[e] * x[far_col[ck.far_off + i]];
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < ROWS_PER_THREAD; ++j) {
             const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
@@ -3820,7 +3827,8 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
                        A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf, A.block_order)
 #define OGL_SPMV21_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_stream21<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs, \
-                       A.chunks21, A.codes21, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf)
+                       A.chunks21, A.codes21, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf, \
+                       A.far_idx21, A.far_col21)
 #define OGL_SPMV(MODE, NDOT)                 \
     do {                                     \
         if (A.codes21 && A.stream)           \

@@ -58,6 +58,7 @@ struct DevCsr {
     // packed columns (Stream21Chunk, common.hpp): when set, the kernel reads these instead of `cols`
     const Stream21Chunk *chunks21 = nullptr;
     const uint4 *codes21 = nullptr;
+    const int32_t *far_idx21 = nullptr, *far_col21 = nullptr;  // the chunks' far entries (Stream21Chunk::far_off / far_n)
     // banded patterns: the order in which the workgroups take the chunks (band_block_order, host_matrix.hpp: the
     // chunks of rows r and r +- band on one XCD; -1 = no chunk), n_blocks entries; nullptr = the XCD groups above
     const int32_t *block_order = nullptr;

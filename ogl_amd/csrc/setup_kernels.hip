@@ -386,7 +386,8 @@ __global__ __launch_bounds__(BLOCK) void k_renumber_fill(RenumberWork w)
 // ---- packed columns for the CSR-stream kernel ----
 __global__ __launch_bounds__(BLOCK) void k_s21_plan(Stream21Build b, int n_chunks_)
 {
-    __shared__ int smin[BLOCK / WAVE], smax[BLOCK / WAVE];
+    __shared__ int smin[BLOCK / WAVE], smax[BLOCK / WAVE], sfar[BLOCK / WAVE];
+    __shared__ int s_base;
     const int c = blockIdx.x;
     if (c >= n_chunks_) return;
     const int r0 = c * CHUNK_ROWS, r1 = min(r0 + CHUNK_ROWS, b.n_rows);
@@ -413,22 +414,43 @@ __global__ __launch_bounds__(BLOCK) void k_s21_plan(Stream21Build b, int n_chunk
             hi = max(hi, smax[w]);
         }
         if (nz1 == nz0) lo = hi = 0;
-        if ((long)hi - (long)lo >= (1L << STREAM21_BITS)) b.flags[0] = 1;
-        b.chunks[c].base = lo;
+        // all columns within 2^21 of the smallest: that one is the base; else a window around the chunk's own rows
+        s_base = ((long)hi - (long)lo < (1L << STREAM21_BITS)) ? lo : stream21_window_base(r0, b.n_rows);
+    }
+    __syncthreads();
+    const int base = s_base;
+    int far = 0;
+    for (int e = nz0 + threadIdx.x; e < nz1; e += BLOCK) {
+        const long d = (long)b.cols[e] - base;
+        far += (d < 0 || d >= (1L << STREAM21_BITS)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = WAVE / 2; off >= 1; off >>= 1) far += __shfl_xor(far, off, WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) sfar[threadIdx.x / WAVE] = far;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLOCK / WAVE; ++w) far += sfar[w];
+        b.chunks[c].base = base;
+        b.chunks[c].far_n = 0;  // (counted up again by the fill)
+        b.far[c] = far;
         const int t0 = nz0 & ~3;
         const int tiles = nz1 > nz0 ? (nz1 - t0 + STREAM21_TILE - 1) / STREAM21_TILE : 0;
         b.words[c] = tiles * STREAM21_GROUPS * BLOCK;
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_s21_fill(Stream21Build b, int n_chunks_, uint4 *__restrict__ codes)
+__global__ __launch_bounds__(BLOCK) void k_s21_fill(Stream21Build b, int n_chunks_, uint4 *__restrict__ codes,
+                                                     int *__restrict__ far_idx, int *__restrict__ far_col)
 {
     const int c = blockIdx.x;
     if (c >= n_chunks_) return;
     const int r0 = c * CHUNK_ROWS, r1 = min(r0 + CHUNK_ROWS, b.n_rows);
     const int nz0 = b.row_ptrs[r0], nz1 = b.row_ptrs[r1];
-    const int base = b.chunks[c].base, word_off = b.words[c];
-    if (threadIdx.x == 0) b.chunks[c].word_off = word_off;
+    const int base = b.chunks[c].base, word_off = b.words[c], far_off = b.far[c];
+    if (threadIdx.x == 0) {
+        b.chunks[c].word_off = word_off;
+        b.chunks[c].far_off = far_off;
+    }
     const int tid = threadIdx.x;
     int tile = 0;
     for (int t0 = nz0 & ~3; t0 < nz1; t0 += STREAM21_TILE, ++tile)
@@ -437,7 +459,21 @@ __global__ __launch_bounds__(BLOCK) void k_s21_fill(Stream21Build b, int n_chunk
             for (int k = 0; k < 3; ++k)
                 for (int j = 0; j < 2; ++j) {
                     const int e = t0 + ((g * 3 + k) * BLOCK + tid) * 2 + j;
-                    code[2 * k + j] = (e >= nz0 && e < nz1) ? (unsigned long long)(b.cols[e] - base) : 0ull;
+                    unsigned long long cd = 0ull;
+                    if (e >= nz0 && e < nz1) {
+                        const int col = b.cols[e];
+                        const long d = (long)col - base;
+                        if (d < 0 || d >= (1L << STREAM21_BITS)) {
+                            // far: coded as offset 0 (a valid column), listed with its entry and column -- the order
+                            // within the chunk's list does not matter, every entry is put right on its own
+                            const int at = far_off + atomicAdd(&b.chunks[c].far_n, 1);
+                            far_idx[at] = e;
+                            far_col[at] = col;
+                        } else {
+                            cd = (unsigned long long)d;
+                        }
+                    }
+                    code[2 * k + j] = cd;
                 }
             const unsigned long long lo = code[0] | (code[1] << 21) | (code[2] << 42) | (code[3] << 63);
             const unsigned long long hi = (code[3] >> 1) | (code[4] << 20) | (code[5] << 41);
@@ -560,13 +596,14 @@ void launch_stream21_plan(hipStream_t st, const Stream21Build &b)
     if (nc == 0) return;
     hipLaunchKernelGGL(k_s21_plan, dim3(nc), dim3(BLOCK), 0, st, b, nc);
     launch_exclusive_scan(st, b.words, b.words, nc, b.scan_tmp);
+    launch_exclusive_scan(st, b.far, b.far, nc, b.scan_tmp);
 }
 
-void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes)
+void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes, int32_t *far_idx, int32_t *far_col)
 {
     const int nc = (int)n_chunks(b.n_rows);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_s21_fill, dim3(nc), dim3(BLOCK), 0, st, b, nc, codes);
+    hipLaunchKernelGGL(k_s21_fill, dim3(nc), dim3(BLOCK), 0, st, b, nc, codes, far_idx, far_col);
 }
 
 }  // namespace ogl

@@ -109,10 +109,13 @@ struct Stream21Build {
     Stream21Chunk *chunks = nullptr;  // [n_chunks] out
     int32_t *words = nullptr;         // [n_chunks + 1] scratch: code words per chunk, then their offsets; [n_chunks] = total
     int32_t *scan_tmp = nullptr;      // [scan_tmp_len(n_chunks)]
-    int32_t *flags = nullptr;         // [1] zeroed by the caller; set when a chunk's columns span 2^21 or more
+    int32_t *flags = nullptr;         // [1] zeroed by the caller (unused since the far lists: kept for the launch signature)
+    int32_t *far = nullptr;           // [n_chunks + 1] scratch: far entries per chunk, then their offsets; [n_chunks] = total
 };
-// per chunk: smallest column, code words needed; offsets by a scan (read words[n_chunks] and flags[0] afterwards)
+// per chunk: window base, code words needed, far entries; offsets by two scans (read words[n_chunks] and
+// far[n_chunks] afterwards)
 void launch_stream21_plan(hipStream_t st, const Stream21Build &b);
-void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes);
+// codes and the far lists (far_idx / far_col: far[n_chunks] entries each; may be nullptr when that is 0)
+void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes, int32_t *far_idx, int32_t *far_col);
 
 }  // namespace ogl

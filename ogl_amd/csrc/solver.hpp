@@ -326,6 +326,7 @@ struct ogl_solver {
     // (it won the one-off timing, or compress_indices = force and the chunked ELL does not qualify)
     ogl::DevBuf<ogl::Stream21Chunk> d_s21_chunks;
     ogl::DevBuf<uint4> d_s21_codes;
+    ogl::DevBuf<int32_t> d_s21_far_idx, d_s21_far_col;  // the chunks' entries outside their 2^21-column windows
     int s21_state = 0;  // 0 not tried for this pattern, 1 built, -1 a chunk's columns span 2^21 or more
     bool s21_use = false;
     int build_stream21();

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from ogl_amd import capi, synthetic
-from helpers import blocked, oracle_csr, oracle_matrix_renumbered, to_new
+from helpers import oracle_matrix, blocked, oracle_csr, oracle_matrix_renumbered, to_new
 
 pytestmark = pytest.mark.gpu
 
@@ -143,3 +143,50 @@ def test_packed_columns_of_the_csr_stream_kernel(reg, oracle):
                          tolerance=0.0, rel_tol=0.0, max_iter=10)
             np.testing.assert_array_equal(s.history(), ref.history)
             np.testing.assert_array_equal(xs, ref.x[new_id])
+
+
+def test_packed_columns_with_far_entries_above_two_million_rows(reg, oracle):
+    """Round 5: a chunk whose columns span 2^21 or more (a numbering along a space-filling curve above 2 M rows: a few
+    neighbours in blobs anywhere) keeps the packed 21-bit columns -- a window of 2^21 columns around its own rows, the
+    entries outside it listed apart and their products put right by the chunk's workgroup before the rows are summed.
+    A chain of 2.4 M cells with 3000 couplings across more than 2^21 rows (both triangles: far entries below and above
+    the window) and 2000 medium ones; plain, residual and two-dot instantiations, STREAM on and off, against the oracle."""
+    n = (1 << 21) + 300000
+    rng = np.random.default_rng(11)
+    own = np.arange(n - 1, dtype=np.int64)
+    far_lo = rng.choice(200000, 3000, replace=False).astype(np.int64)
+    far_up = far_lo + (1 << 21) + rng.integers(0, 90000, far_lo.size)
+    mid_lo = rng.choice(n - 700000, 2000, replace=False).astype(np.int64)
+    mid_up = mid_lo + rng.integers(2, 600000, mid_lo.size)
+    lo = np.concatenate([own, far_lo, mid_lo])
+    up = np.concatenate([own + 1, far_up, mid_up])
+    assert (up < n).all()
+    key = lo * n + up
+    _, first = np.unique(key, return_index=True)
+    lo, up = lo[first], up[first]                                  # (sorted by owner, then neighbour; duplicates dropped)
+    F = lo.size
+    for asym in (False, True):
+        case = synthetic.LduCase(n, lo.astype(np.int32), up.astype(np.int32), rng.uniform(8.0, 9.0, n),
+                                 rng.uniform(-1.0, -0.25, F), rng.uniform(-1.0, -0.25, F) if asym else None)
+        for stream in (0.0, 1e18):
+            cfg = capi.default_config(solver=capi.SOLVER_BICGSTAB if asym else capi.SOLVER_CG,
+                                      preconditioner=capi.PRECOND_BJ, tolerance=0.0, rel_tol=0.0, max_iter=6,
+                                      export_res=1, matrix_format=capi.FORMAT_CSR, adapt_min_iter=0,
+                                      compress_indices=1, renumber=capi.RENUMBER_OFF)
+            s = reg.solver(f"far_{int(asym)}_{int(stream > 0)}", cfg)
+            s.set_property("streamAboveBytes", stream)
+            s.set_property("spmvForceLayout", 2.0)                 # the packed columns, whatever the one-off timing says
+            s.set_matrix(case)
+            assert s.get_property("spmvLayout") == 3.0
+            assert 2 * 3000 * 0.9 < s.get_property("csr21FarEntries") <= 2 * (3000 + 2000)
+            A, (rp, cols, vals) = oracle_matrix(oracle, case)
+            x = rng.uniform(-1, 1, n)
+            np.testing.assert_array_equal(s.spmv(x), oracle.spmv(rp, cols, vals, x))
+            b = rng.uniform(-1, 1, n)
+            xs, perf = s.solve(b, x.copy())
+            fn = oracle.bicgstab if asym else oracle.cg
+            with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+                ref = fn(A, b, x.copy(), oracle.jacobi_generate_scalar(rp, cols, vals), tolerance=0.0, rel_tol=0.0,
+                         max_iter=6)
+            np.testing.assert_array_equal(s.history(), ref.history)
+            np.testing.assert_array_equal(xs, ref.x)
