@@ -172,7 +172,9 @@ def test_packed_columns_with_far_entries_above_two_million_rows(reg, oracle):
             cfg = capi.default_config(solver=capi.SOLVER_BICGSTAB if asym else capi.SOLVER_CG,
                                       preconditioner=capi.PRECOND_BJ, tolerance=0.0, rel_tol=0.0, max_iter=6,
                                       export_res=1, matrix_format=capi.FORMAT_CSR, adapt_min_iter=0,
-                                      compress_indices=1, renumber=capi.RENUMBER_OFF)
+                                      compress_indices=1, renumber=capi.RENUMBER_OFF,
+                                      symmetric_half=0)            # (the full-storage path: what an asymmetric or
+                                                                   #  irregular matrix runs on)
             s = reg.solver(f"far_{int(asym)}_{int(stream > 0)}", cfg)
             s.set_property("streamAboveBytes", stream)
             s.set_property("spmvForceLayout", 2.0)                 # the packed columns, whatever the one-off timing says
