@@ -933,7 +933,10 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
                 rep.curve_far_entries = far;
             }
             rep.curve_packable = packable;
-            if (rep.ratio_curve < r && packable) {
+            // (and only where it gathers clearly better than RCM -- a hex mesh: 0.091 against 0.102, but the compressed
+            //  layout's 16-bit deltas do not survive the curve and the 12-byte CSR-stream kernel would run: 79.9 against
+            //  77.3 us per CG turn at 128^3 shuffled; a Voronoi mesh: 0.12 against 0.175)
+            if (rep.ratio_curve <= 0.8 * r && packable) {
                 cand.swap(curve);
                 cand_old.swap(curve_old);
                 r = rep.ratio_curve;
