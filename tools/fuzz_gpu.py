@@ -113,7 +113,12 @@ def main():
             cfgkw["krylov_dim"] = int(rng.integers(2, 12))
         props = {"streamAboveBytes": float(rng.choice([0.0, 1e18])), "fusedFinalizers": float(rng.integers(0, 2)),
                  "fusedTurn": float(rng.integers(0, 2)), "fusedTurnBig": float(rng.integers(0, 2)),
-                 "hipGraph": float(rng.integers(0, 2))}
+                 "hipGraph": float(rng.integers(0, 2)),
+                 # (round 5: folded GKOBiCGStab / GKOGMRES turns, W rows sorted inside the windows, one-pass block Jacobi
+                 #  through the permutation, STREAM decision on the turn's working set, band-aware workgroup order)
+                 "bicgFold": float(rng.integers(0, 2)), "gmresFold": float(rng.integers(0, 2)),
+                 "isaiSortRows": float(rng.integers(0, 2)), "bjFusedPerm": float(rng.integers(0, 2)),
+                 "streamTurnSet": float(rng.integers(0, 2)), "spmvBandRows": float(rng.choice([-1.0, 0.0, 4096.0]))}
         tag = f"case {it}: {kind} n={case.n_cells} sym={case.lower is None} {solver} precond={pc}/{block} " \
               f"{ {k: cfgkw[k] for k in ('compress_indices', 'symmetric_half', 'matrix_format', 'max_iter', 'renumber', 'sparsity_power')} } {props}"
         only = os.environ.get("OGL_FUZZ_ONLY")
