@@ -156,7 +156,9 @@ def test_packed_columns_with_far_entries_above_two_million_rows(reg, oracle):
     own = np.arange(n - 1, dtype=np.int64)
     far_lo = rng.choice(200000, 3000, replace=False).astype(np.int64)
     far_up = far_lo + (1 << 21) + rng.integers(0, 90000, far_lo.size)
-    mid_lo = rng.choice(n - 700000, 2000, replace=False).astype(np.int64)
+    # (medium couplings: 1500 anywhere, 500 out of the first chunk's rows -- more than 255 distinct offsets in one chunk, so
+    #  the compressed layout needs 32-bit columns there, the pattern counts as irregular and the packed columns are built)
+    mid_lo = np.concatenate([rng.choice(n - 700000, 1500, replace=False), rng.integers(0, 512, 500)]).astype(np.int64)
     mid_up = mid_lo + rng.integers(2, 600000, mid_lo.size)
     lo = np.concatenate([own, far_lo, mid_lo])
     up = np.concatenate([own + 1, far_up, mid_up])
