@@ -7,6 +7,11 @@
  *
  * PARITY: LDU conversion pinned by the reference's gtest vectors; Krylov arithmetic
  * "parity unpinned" (Ginkgo absent) -- see the header.
+ *
+ * Three reduction modes (orc_set_reduction): SEQUENTIAL = the reference executor's left-to-right sums (the
+ * semantics under test), BLOCKED = the HIP kernels' fixed tree (bit-for-bit checks of the device), EXACT = error-free
+ * transformations rounded once (the arbiter between the two; pinned against rational arithmetic in
+ * tests/test_oracle_exact.py).
  */
 #include "ogl_oracle.h"
 
