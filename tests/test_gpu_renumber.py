@@ -336,3 +336,47 @@ def test_block_jacobi_through_the_permutation_both_applies(reg, oracle, chunk_ro
             ref2 = fn(A, to_new(b, new_id), np.zeros_like(b), P, **extra, **skw)
         np.testing.assert_array_equal(s2.history(), ref2.history)
         np.testing.assert_array_equal(x2, ref2.x[new_id])
+
+
+@pytest.mark.parametrize("name,kw", [("bj1", dict(preconditioner=capi.PRECOND_BJ)),
+                                     ("gisai", dict(preconditioner=capi.PRECOND_GISAI)),
+                                     ("bj3_backend", dict(preconditioner=capi.PRECOND_BJ, max_block_size=3))])
+def test_stored_preconditioner_of_another_numbering_is_not_applied(oracle, chunk_rows, name, kw):
+    """the preconditioner store is shared by all fields of a registry (Preconditioner.H:357).  A stored
+    inverse diagonal, W, or block Jacobi whose VALUES are laid out in the device numbering of the field that generated
+    it would be a silently permuted operator for a field whose device copy is numbered differently: such an object is
+    regenerated for the solve instead (`PrecondData::foreign_to`), and the second field's history is the oracle's with
+    ITS OWN preconditioner.  (Blocks kept block-major in the caller's order stay portable, as in the reference: the
+    applying solver carries the vectors through its permutation.)"""
+    a = synthetic.renumber_case(synthetic.poisson_case(14), 700, seed=1)
+    b_case = synthetic.renumber_case(synthetic.poisson_case(14), 700, seed=2)            # same sizes, another numbering
+    skw = dict(tolerance=1e-11, rel_tol=0.0, max_iter=200)
+    r = capi.Registry()
+    try:
+        sols = []
+        for tag, case in (("A", a), ("B", b_case)):
+            s = r.solver(f"store_{name}_{tag}", cfg(caching=3, **kw, **skw))
+            if name == "bj3_backend":
+                s.set_property("precondCallerNumbering", 0.0)
+            s.set_matrix(case)
+            if tag == "B":      # (this field's counter says "use the stored object": Preconditioner.H:384-418)
+                s.set_property("preconditionerCaching", 2.0)
+            rhs = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
+            x, perf = s.solve(rhs, np.zeros_like(rhs))
+            sols.append((s, case, rhs, x))
+        s, case, rhs, x = sols[1]
+        new_id = s.renumbering()
+        assert not np.array_equal(new_id, sols[0][0].renumbering())
+        A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+        if name == "bj3_backend":
+            P = oracle.Precond(rp, cols, vals, 3)                                         # the backend's own blocks
+        elif kw["preconditioner"] == capi.PRECOND_BJ:
+            P = oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, kw.get("max_block_size", 1))
+        else:
+            P = oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, isai="general")
+        with blocked(oracle, chunk_rows):
+            ref = oracle.cg(A, to_new(rhs, new_id), np.zeros_like(rhs), P, **skw)
+        np.testing.assert_array_equal(s.history(), ref.history)
+        np.testing.assert_array_equal(x, ref.x[new_id])
+    finally:
+        r.close()
