@@ -23,7 +23,7 @@ matrix, b and x already resident in HBM.
               two short child runs of this command under `rocprofv3 --kernel-trace --pmc <counter>` (separate
               passes, children of this process, nothing exec'ed in place); when that is not possible (no
               rocprofv3, this process itself profiled, a pass fails) the committed summary of exactly these
-              kernels (profiles/r*_pmc*_summary.json, refused when kernels.hip has changed) is quoted instead
+              kernels (profiles/r*_pmc*_summary.json, refused when the kernel sources have changed) is quoted instead
               and `traffic_measured_in_this_run` says so.
   roofline_general = the same measurement for the general layouts on the same system, after the headline
               and outside its timed region: --full-storage (k_spmv_sell, pattern codes), --no-compress
@@ -158,9 +158,16 @@ def parse():
 
 
 def kernels_sha16():
+    """Hash of the Krylov-loop kernel sources (csrc/device_common.hpp + kernels_*.hip, in name order): the tag
+    tools/pmc_summary.py writes into a PMC summary."""
+    import glob
     import hashlib
-    with open(os.path.join(ROOT, "ogl_amd", "csrc", "kernels.hip"), "rb") as fh:
-        return hashlib.sha256(fh.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ogl_amd", "csrc")
+    for f in [os.path.join(csrc, "device_common.hpp")] + sorted(glob.glob(os.path.join(csrc, "kernels_*.hip"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel, variant=""):
@@ -169,7 +176,7 @@ def pmc_traffic(kernel, variant=""):
     separate rocprofv3 --pmc runs).  Units and the gfx950 correction per MI355X_MICROARCH.md "HBM":
     counters are KiB, FETCH_SIZE reads half the bytes of a wide coalesced stream (calibrated here on
     k_cg_step1: 2 x 118,111 KiB = 241.9 MB measured vs 24 N = 241.9 MB algorithmic).  The summary records
-    the hash of kernels.hip it was collected with; a summary of other kernels yields None."""
+    the hash of the kernel sources it was collected with; a summary of other kernels yields None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc{variant}_summary.json")))
     if not files:
@@ -179,7 +186,7 @@ def pmc_traffic(kernel, variant=""):
     rel = os.path.relpath(files[-1], ROOT)
     meta = d.get("_meta", {})
     if meta.get("kernels_sha16") != kernels_sha16():
-        return None, f"{rel} was collected with other kernels (kernels.hip {meta.get('kernels_sha16')}): stale"
+        return None, f"{rel} was collected with other kernels (kernel sources {meta.get('kernels_sha16')}): stale"
     k = d.get(kernel)
     if not k or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
         return None, f"{rel} holds no counters for {kernel}"
@@ -671,7 +678,7 @@ def main():
                    (sv.get_property("csr21MatrixBytes") + 16 * n_rows) if layout == "csr21" else b_csr)
         merged = None
         if (in_loop and layout == "sym" and args.solver == "GKOCG" and prop_or(sv, "fusedTurnInUse", 0.0) == 1.0):
-            # the in-loop kernel on half storage is step_1x + SpMV in one launch (k_cg_turn_sym / _big, kernels.hip):
+            # the in-loop kernel on half storage is step_1x + SpMV in one launch (k_cg_turn_sym / _big, kernels_spmv_sym.hip):
             # besides the SpMV's bytes it reads z and x and writes x and the new p of its rows
             nd, fast = int(prop_or(sv, 'spmvSymPlanes', 0)), 'true' if prop_or(sv, 'spmvSymFast', 0.0) == 1.0 else 'false'
             small = prop_or(sv, "fusedFinalizersInUse", 0.0) == 1.0

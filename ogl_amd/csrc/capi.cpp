@@ -367,7 +367,7 @@ extern "C" int ogl_solver_spmv(ogl_solver *s, const ogl_scalar *x, ogl_scalar *y
     OGL_TRY(s->download_rows(y, s->d_q.p));
     OGL_HIP_CHECK(hipGetLastError());
     // a neighbour whose halo values did not arrive within the time-out leaves the LOCAL product behind and raises
-    // comm_error in the device scalars (kernels.hip halo_fused_add / k_halo_finish): never hand that out silently
+    // comm_error in the device scalars (device_common.hpp halo_fused_add / kernels_comm.hip k_halo_finish): never hand that out silently
     if (s->pat.non_local_nnz > 0 && s->peer_halo) {
         DevScalars sc;
         OGL_HIP_CHECK(hipMemcpy(&sc, s->d_scal.p, sizeof(sc), hipMemcpyDeviceToHost));

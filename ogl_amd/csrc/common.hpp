@@ -15,7 +15,7 @@ namespace ogl {
 std::string &last_error();
 int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
-// Geometry of the deterministic reduction tree and of the CSR-stream SpMV (kernels.hip).
+// Geometry of the deterministic reduction tree and of the CSR-stream SpMV (device_common.hpp, kernels_*.hip).
 // One workgroup = BLOCK threads = one chunk of CHUNK_ROWS consecutive rows; thread t owns the
 // ROWS_PER_THREAD consecutive rows starting at chunk_start + t * ROWS_PER_THREAD.
 #if defined(__HIPCC__)

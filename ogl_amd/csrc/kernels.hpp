@@ -1,4 +1,4 @@
-// kernels.hpp -- launchers of the hand-written gfx950 kernels (kernels.hip).
+// kernels.hpp -- launchers of the hand-written gfx950 kernels (kernels_*.hip; what they share: device_common.hpp).
 // Everything the Krylov loop of the reference delegates to Ginkgo.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -301,7 +301,7 @@ void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, con
                       double *part_rho, double *part_norm, const DevScalars *s, double *z_out = nullptr,
                       const HaloPutFused *put = nullptr);
 
-// Small systems: the same pair with the finalisers folded in (kernels.hip).  Every workgroup reduces the
+// Small systems: the same pair with the finalisers folded in (kernels_krylov.hip).  Every workgroup reduces the
 // per-chunk partials itself in the finaliser's order; the scalars are read from `sin` and written to `sout`.
 //   step_1x_fin: check on (part_rho, part_norm) of the previous step_2r (first: of the initial residual), the
 //                pending x update (not when `first`), then step_1
@@ -335,7 +335,7 @@ void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in,
 // vprev != nullptr: H = sum(part_in) -> *h_out, w -= H vprev; then the partials of w . vdot (w . w when vdot is nullptr)
 void launch_gmres_mgs_fold(hipStream_t st, int32_t n, double *w, const double *vprev, double *h_out, const double *vdot,
                            const double *part_in, double *part_out, const DevScalars *gate);
-// GKOBiCGStab with the finalisers folded into the step kernels (<= FUSED_FIN_MAX_CHUNKS chunks, one rank; kernels.hip):
+// GKOBiCGStab with the finalisers folded into the step kernels (<= FUSED_FIN_MAX_CHUNKS chunks, one rank; kernels_krylov.hip):
 // scalars go sin -> sout; a kernel never writes a partial array it reads
 void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,
                        double *y, const DevScalars *sin, DevScalars *sout, const double *part_rho,

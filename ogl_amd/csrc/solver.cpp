@@ -2540,7 +2540,7 @@ int ogl_solver::krylov_plan(KrylovRun &k)
     const bool small = !multi && nc >= 1 &&
                        nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
                        prop("fusedFinalizers", 1.0) != 0.0;
-    // small single-rank GKOCG systems: finalisers folded into the step kernels, 3 launches per turn (kernels.hip)
+    // small single-rank GKOCG systems: finalisers folded into the step kernels, 3 launches per turn (kernels_krylov.hip)
     const bool fused = k.fused = !bicg && !gmres && !generic && small;
     k.s2 = s + 1;
     // ... and the same for small single-rank GKOBiCGStab systems: three finalisers folded into step_1 / step_2 / step_3
@@ -2560,7 +2560,7 @@ int ogl_solver::krylov_plan(KrylovRun &k)
     //  where the merged kernel runs 152 us for the 162 of step_1x + SpMV and step_2r pays 8 N more bytes for keeping z)
     // Several ranks (peer-put transport with the non-local part inside the local kernel): the same merge, 4 launches
     // per turn instead of 5 -- the neighbours' step_2r puts z of their send rows, this rank keeps the old p of its halo
-    // columns and forms p_new there itself (kernels.hip, k_cg_turn_sym_big<.., HALO>), so the merged kernel has
+    // columns and forms p_new there itself (kernels_spmv_sym.hip, k_cg_turn_sym_big<.., HALO>), so the merged kernel has
     // nothing to put and only waits for a put of the PREVIOUS launch.  Every rank must run the same turn (what the
     // neighbours put differs): agreed below together with the global row count.
     bool merged = !bicg && !gmres && !generic && nc >= 1 && use_sym() && cfg.matrix_format != OGL_FORMAT_ELL &&
@@ -2918,7 +2918,7 @@ int ogl_solver::turn_cg_merged(KrylovRun &k, int enq, int pe)
 }
 
 // GKOCG, 5 launches (the headline's turn): step_1x | SpMV | beta | step_2r | check.  x += t p is deferred into the next
-// turn's step_1x (kernels.hip): p is read once (peer-put transport: the halo values of the SpMV are put by step_1x itself)
+// turn's step_1x (kernels_krylov.hip): p is read once (peer-put transport: the halo values of the SpMV are put by step_1x itself)
 int ogl_solver::turn_cg_five_launch(KrylovRun &k, int, int pe)
 {
     hipStream_t st = k.st;

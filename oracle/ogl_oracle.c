@@ -461,7 +461,7 @@ void orc_set_reduction(int mode, orc_label chunk_rows) {
     if (chunk_rows > 0) g_chunk_rows = chunk_rows;
 }
 
-/* The fixed reduction tree of the HIP kernels (ogl_amd/csrc/kernels.hip, block_reduce):
+/* The fixed reduction tree of the HIP kernels (ogl_amd/csrc/device_common.hpp, block_sum / reduce_partials):
  * a chunk is chunk_rows consecutive rows handled by 256 threads; thread t owns the
  * chunk_rows/256 consecutive rows starting at t*chunk_rows/256, summed in order from 0;
  * 64-lane xor tree (offsets 32,16,8,4,2,1); the 4 wave sums are added left to right.  The

@@ -55,7 +55,7 @@ def allreduce(a):
 
 
 def allreduce_rank_order(a):
-    """((0 + v_0) + v_1) + ... : the order of the peer-write all-reduce (kernels.hip)."""
+    """((0 + v_0) + v_1) + ... : the order of the peer-write all-reduce (device_common.hpp peer_allreduce2)."""
     mine = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
     parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, mine)

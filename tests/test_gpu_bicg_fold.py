@@ -1,5 +1,5 @@
 """GKOBiCGStab on small single-rank systems folds its three finalisers into the step kernels (k_bicg_fold1/2/3,
-kernels.hip: 5 launches per turn instead of 8).  Wherever the criterion stops -- at the head of a turn, at the mid-turn
+kernels_krylov.hip: 5 launches per turn instead of 8).  Wherever the criterion stops -- at the head of a turn, at the mid-turn
 check on s (bicgstab::finalize then applies x += alpha y), by maxIter anywhere in the batches of 8 turns, by tolerance,
 before the first turn -- history, x, counters and residuals must hold the same bits as the oracle's and as the
 8-launch turn's.  Reference: Solver/BiCGStab/GKOBiCGStab.H:16-117, StoppingCriterion/StoppingCriterion.C:71-151.

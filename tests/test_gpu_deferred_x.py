@@ -1,4 +1,4 @@
-"""GKOCG defers `x += t p` into the next turn's step_1x kernel (kernels.hip) and flushes it after a
+"""GKOCG defers `x += t p` into the next turn's step_1x kernel (kernels_krylov.hip) and flushes it after a
 stop.  Wherever the criterion stops -- before the first turn, in the middle of an enqueued batch of 16
 turns, at a batch boundary, or with the check of the last turn the host enqueues (maxIter) -- x must
 hold the same bits as the oracle's."""
@@ -27,7 +27,7 @@ def system(oracle):
     return case, b, A, oracle.jacobi_generate_scalar(rp, cols, vals)
 
 
-# The three shapes of a GKOCG turn (kernels.hip): small systems fold the finalisers into the step kernels (the check of
+# The three shapes of a GKOCG turn (kernels_krylov.hip, kernels_spmv_sym.hip): small systems fold the finalisers into the step kernels (the check of
 # a turn runs at the head of the next one) -- 3 launches, or 2 on half storage, where step_1x and the SpMV are one
 # kernel (k_cg_turn_sym: p_new recomputed at the gathered columns); larger systems run the five-launch turn, or with
 # property fusedTurnBig the same merge between the single-workgroup finalisers (four launches, k_cg_turn_sym_big)

@@ -1,7 +1,7 @@
 """north_star's "residual history matching the reference to 1e-12 rel", settled with an exact arbiter (VERDICT r4
 item 3).  Three histories of the same GKOCG + BJ solve:
 
-  gpu    the HIP path (fixed reduction tree, kernels.hip:10-14)
+  gpu    the HIP path (fixed reduction tree, device_common.hpp:10-14)
   seq    the oracle in the reference executor's left-to-right order ([UPSTREAM] Ginkgo reference kernels)
   exact  the oracle with every dot / norm1 / sum / SpMV row sum accumulated by error-free transformations and rounded
          once (ORC_REDUCE_EXACT, pinned against rational arithmetic in tests/test_oracle_exact.py)

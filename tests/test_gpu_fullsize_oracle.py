@@ -4,7 +4,7 @@ alone, and is compared BIT FOR BIT with the oracle run in the device's reduction
 plus a stated bound against the oracle in the reference executor's left-to-right order.
 
   (a) reductions at n = 10,077,696: dot / norm1 / sum (19,683 per-chunk partials -> the finaliser's second and third
-      batches of 8,192, kernels.hip reduce_partials)
+      batches of 8,192, device_common.hpp reduce_partials)
   (b) GKOCG + BJ and GKOCG (none) at 216^3, 30 turns: matrix, history, x, norm factor, iteration count
       (the STREAM instantiation of the half-storage SpMV with the band-aware workgroup order, inside a solve)
   (c) 136^3 (one rank's share of configs[3]) with the merged step_1x + SpMV kernel ON BY DEFAULT, and 100^3

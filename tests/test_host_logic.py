@@ -133,8 +133,14 @@ def test_update_w_interface_matches_oracle(oracle):
     a = capi.host_non_symmetric_update_w_interface(loc[2], 2.0, case.diag, case.upper, case.lower, cc)
     b = oracle.non_symmetric_update_w_interface(loc[2], 2.0, case.diag, case.upper, case.lower, cc)
     np.testing.assert_array_equal(a, b)
-    a = capi.host_symmetric_update_w_interface(loc[2][:case.n_cells], 2.0, case.diag, case.upper, cc)
-    b = oracle.symmetric_update_w_interface(loc[2][:case.n_cells], 2.0, case.diag, case.upper, cc)
+    # the symmetric variant on the mapping of a symmetric pattern (positions: upper | diag | interfaces)
+    case = synthetic.poisson_block(5, 4, 3, symmetric=True, periodic_x=True, off_upper=-0.9)
+    ifs = _orc_ifaces(oracle, case)
+    _, loc, _, _ = capi.host_pattern(case)
+    cc = oracle.collect_interface_coeffs(ifs, True)
+    assert loc[2].max() < case.upper.size + case.diag.size + cc.size
+    a = capi.host_symmetric_update_w_interface(loc[2], 2.0, case.diag, case.upper, cc)
+    b = oracle.symmetric_update_w_interface(loc[2], 2.0, case.diag, case.upper, cc)
     np.testing.assert_array_equal(a, b)
 
 

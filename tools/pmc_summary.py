@@ -34,8 +34,12 @@ def main():
     # which kernels these counters belong to: bench.py refuses a summary collected with other kernels
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import hashlib
-    with open(os.path.join(root, "ogl_amd", "csrc", "kernels.hip"), "rb") as fh:
-        sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+    h = hashlib.sha256()  # = bench.py kernels_sha16(): device_common.hpp + kernels_*.hip in name order
+    csrc = os.path.join(root, "ogl_amd", "csrc")
+    for f in [os.path.join(csrc, "device_common.hpp")] + sorted(glob.glob(os.path.join(csrc, "kernels_*.hip"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    sha = h.hexdigest()[:16]
     head = None
     for d in dirs:  # the bench line of the profiled run carries nothing about git: the pass script exports it
         head = head or os.environ.get("OGL_GIT_HEAD")
