@@ -193,10 +193,13 @@ extern "C" int ogl_solver_set_matrix_like(ogl_solver *s, const ogl_ldu_view *ldu
 {
     OGL_GUARD_BEGIN
     if (!s || !ldu) return fail(OGL_ERR_INVALID, "NULL argument");
+    // (the donor is looked at during this call only: the pointer is dropped again on every way out)
+    struct Lend {
+        ogl_solver *s;
+        ~Lend() { s->share_from = nullptr; }
+    } lend{s};
     s->share_from = (donor && donor != s && donor->reg == s->reg) ? donor : nullptr;
-    const int rc = s->set_matrix(*ldu);
-    s->share_from = nullptr;
-    return rc;
+    return s->set_matrix(*ldu);
     OGL_GUARD_END
 }
 
