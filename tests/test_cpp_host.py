@@ -86,3 +86,5 @@ def test_host_layout_builders_under_sanitizers(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("symx rc=0") == len(cases) and "ERROR" not in r.stderr
+    # ... and the numbering code (reverse Cuthill-McKee, Hilbert order, the renumbered pattern with and without centres)
+    assert r.stdout.count("numbering rcm rc=0") == len(cases) and r.stdout.count("hilbert rc=0") == len(cases), r.stdout[-2000:]
