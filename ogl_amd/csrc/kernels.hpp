@@ -359,6 +359,10 @@ void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const do
 
 // --- GMRES vector kernels ([UPSTREAM] gmres::restart / finish_arnoldi / solve_krylov) ---
 // out = in / *denom
+// out = in / *denom and w = out * inv_diag in one pass (scalar Jacobi: the scaling of a new basis vector waits for the
+// turn that applies the preconditioner to it)
+void launch_gmres_scale_mul(hipStream_t st, int32_t n, double *out, const double *in, const double *denom,
+                            const double *inv_diag, double *w, const DevScalars *gate);
 void launch_gmres_scale(hipStream_t st, int32_t n, double *out, const double *in,
                         const double *denom, const DevScalars *gate);
 // modified Gram-Schmidt link: if (vprev) w -= (*hprev) * vprev ; partial of w . vdot (vdot == nullptr: w . w)
@@ -386,10 +390,11 @@ enum FinPhase {
     FIN_BICG_ALPHA = 5,  // beta <- sum0 ; alpha = rho / beta
     FIN_BICG_CHECK2 = 6, // mid-turn criterion check on sum0 = sum|s|
     FIN_BICG_OMEGA = 7,  // gamma <- sum0 ; beta <- sum1 ; omega = gamma / beta
+    // (the criterion check of a GKOGMRES turn -- on stale_norm, the sum|r| of the last restart -- has no launch of its own:
+    //  FinArgs::check_after runs it at the end of the finaliser before it, restart or column)
     FIN_GMRES_RESTART = 8,  // rn = sqrt(sum0) -> rnc[0], beta ; stale_norm = sum1   (gmres::restart)
     FIN_GMRES_H = 9,        // H(k, it) = sum0                                        (finish_arnoldi)
     FIN_GMRES_COL = 10,     // H(it+1, it) = sqrt(sum0) -> beta ; Givens ; rnc        (givens_rotation)
-    FIN_GMRES_CHECK = 11,   // criterion check on stale_norm
     FIN_GMRES_SOLVE = 12,   // y = R^-1 rnc for `turn` columns                        (solve_krylov)
     // single rank: FIN_BICG_CHECK2 and FIN_BICG_OMEGA in one launch, after the second SpMV (which then runs even when
     // the mid-turn check stops the solve: its result is not used); sums: s.t, t.t and, from part_extra, sum|s|
@@ -484,6 +489,7 @@ struct FinArgs {
     double *gm = nullptr;  // GMRES dense state
     int32_t m = 0;         // GMRES krylov_dim
     int32_t k = 0;         // GMRES row of H (FIN_GMRES_H)
+    int32_t check_after = 0;  // FIN_GMRES_RESTART / FIN_GMRES_COL: the criterion check of the turn that follows, in the same launch
 };
 void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a);
 

@@ -874,6 +874,24 @@ __global__ __launch_bounds__(BLOCK) void k_gmres_scale(int n, double *__restrict
     st2(out, rp, v);
 }
 
+__global__ __launch_bounds__(BLOCK) void k_gmres_scale_mul(int n, double *__restrict__ out, const double *in,
+                                                           const double *__restrict__ denom,
+                                                           const double *__restrict__ inv_diag,
+                                                           double *__restrict__ w, const DevScalars *gate)
+{
+    if (gate && gate->stop) return;
+    const double d = *denom;
+    const RowPair rp = my_rows(blockIdx.x, n);
+    double2 v = ld2(in, rp);  // (in may be out: the vector scaled in place)
+    const double2 vi = ld2(inv_diag, rp);
+    v.x = v.x / d;
+    v.y = v.y / d;
+    st2(out, rp, v);
+    v.x = v.x * vi.x;
+    v.y = v.y * vi.y;
+    st2(w, rp, v);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_gmres_mgs(int n, double *__restrict__ w,
                                                      const double *__restrict__ vprev,
                                                      const double *__restrict__ hprev,
@@ -1121,6 +1139,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
         g.rnc[0] = rn;
         L.beta = rn;  // V_0 = r / rn
         L.stale_norm = v1;
+        if (a.check_after) criterion_check(&L, L.crit, L.stale_norm, a.history);
     } else if (PHASE == FIN_GMRES_H) {  // finish_arnoldi: H(k, it)
         GmresState g(a.gm, a.m);
         g.h(a.k, a.turn) = v0;
@@ -1149,8 +1168,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void k_finalize(DevScalars *s, FinArgs a
         g.h(it + 1, it) = 0.0;
         g.rnc[it + 1] = -g.gs[it] * g.rnc[it];
         g.rnc[it] = g.gc[it] * g.rnc[it];
-    } else if (PHASE == FIN_GMRES_CHECK) {
-        criterion_check(&L, L.crit, L.stale_norm, a.history);
+        if (a.check_after) criterion_check(&L, L.crit, L.stale_norm, a.history);
     } else if (PHASE == FIN_GMRES_SOLVE) {  // solve_upper_triangular over `turn` columns
         GmresState g(a.gm, a.m);
         for (int i = a.turn - 1; i >= 0; --i) {
@@ -1381,6 +1399,14 @@ void launch_gmres_scale(hipStream_t st, int32_t n, double *out, const double *in
     hipLaunchKernelGGL(k_gmres_scale, dim3(nc), dim3(BLOCK), 0, st, n, out, in, denom, gate);
 }
 
+void launch_gmres_scale_mul(hipStream_t st, int32_t n, double *out, const double *in, const double *denom,
+                            const double *inv_diag, double *w, const DevScalars *gate)
+{
+    const int nc = (int)n_chunks(n);
+    if (nc == 0) return;
+    hipLaunchKernelGGL(k_gmres_scale_mul, dim3(nc), dim3(BLOCK), 0, st, n, out, in, denom, inv_diag, w, gate);
+}
+
 void launch_gmres_mgs(hipStream_t st, int32_t n, double *w, const double *vprev,
                       const double *hprev, const double *vdot, double *part,
                       const DevScalars *gate)
@@ -1451,9 +1477,6 @@ void launch_finalize(hipStream_t st, int phase, DevScalars *s, const FinArgs &a)
         break;
     case FIN_GMRES_COL:
         hipLaunchKernelGGL((k_finalize<FIN_GMRES_COL>), grid, block, 0, st, s, a);
-        break;
-    case FIN_GMRES_CHECK:
-        hipLaunchKernelGGL((k_finalize<FIN_GMRES_CHECK>), grid, block, 0, st, s, a);
         break;
     case FIN_GMRES_SOLVE:
         hipLaunchKernelGGL((k_finalize<FIN_GMRES_SOLVE>), grid, block, 0, st, s, a);

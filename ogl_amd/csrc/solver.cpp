@@ -2505,6 +2505,9 @@ struct ogl_solver::KrylovRun {
     double *gm_h(int i, int j) const { return gm + (size_t)j * (m + 1) + i; }
     double *p_of_turn(int turn) const { return (merged && (turn & 1)) ? p1 : p0; }  // p that turn `turn` reads
     double *p_halo_of_turn(int turn) const { return ph + (size_t)(turn & 1) * n_halo; }
+    // scalar Jacobi: V_it is divided by its norm at the head of turn `it`, in the pass that applies the preconditioner
+    bool gmres_scale_late() const { return gmres && !generic && has_diag; }
+    bool has_diag = false;
     bool folded() const { return fused || bicg_fold; }  // the check of a turn runs at the head of the next kernel
 };
 
@@ -2536,6 +2539,7 @@ int ogl_solver::krylov_plan(KrylovRun &k)
     // block Jacobi (maxBlockSize > 1): z = M^-1 r is materialised by its own kernel; the scalar
     // case stays fused into the step kernels
     const bool generic = k.generic = precond_data && precond_data->kind >= 2;  // block Jacobi, ISAI, GISAI
+    k.has_diag = precond != nullptr;
     const bool multi = k.multi = reg->comm->multi();
     const bool small = !multi && nc >= 1 &&
                        nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
@@ -2750,13 +2754,17 @@ int ogl_solver::krylov_prepare(KrylovRun &k)
     return OGL_OK;
 }
 
-// gmres::restart: rn = ||r||, rnc[0] = rn, V_0 = r / rn; the criterion keeps sum|r| of this r
+// gmres::restart: rn = ||r||, rnc[0] = rn, V_0 = r / rn; the criterion keeps sum|r| of this r.  gate == nullptr: the
+// restart before the first turn, whose finaliser runs the first check too.  With scalar Jacobi the division waits for the
+// turn that follows (k_gmres_scale_mul).
 int ogl_solver::gmres_restart(KrylovRun &k, const DevScalars *gate)
 {
     launch_cg_rho_norm(k.st, k.n, d_r.p, nullptr, d_part0.p, d_part1.p, gate);  // r.r and sum|r|
     k.fg.n_sums = 2;
+    k.fg.check_after = gate ? 0 : 1;
     OGL_TRY(finalize(FIN_GMRES_RESTART, k.fg));
-    launch_gmres_scale(k.st, k.n, d_V.p, d_r.p, k.beta_ptr, gate);
+    k.fg.check_after = 0;
+    if (!k.gmres_scale_late()) launch_gmres_scale(k.st, k.n, d_V.p, d_r.p, k.beta_ptr, gate);
     return OGL_OK;
 }
 
@@ -2788,9 +2796,7 @@ int ogl_solver::turn_gmres(KrylovRun &k, int enq, int pe)
     const int n = k.n, m = k.m;
     const int64_t ldv = k.ldv;
     DevScalars *s = k.s;
-    FinArgs &fg = k.fg;
-    fg.n_sums = 0;
-    OGL_TRY(finalize(FIN_GMRES_CHECK, fg));
+    FinArgs &fg = k.fg;  // (the check at the head of this turn ran in the finaliser before it: restart or the last column's)
     if (enq > 0 && enq % m == 0) {
         OGL_TRY(gmres_update_x(k, m, s));
         OGL_TRY(dist_spmv(SPMV_RESIDUAL, d_x.p, d_b.p, d_r.p, SpmvDots{}, s));
@@ -2802,8 +2808,8 @@ int ogl_solver::turn_gmres(KrylovRun &k, int enq, int pe)
     if (k.generic) {
         apply_preconditioner(v_it, d_w.p, s);
         w = d_w.p;
-    } else if (precond) {
-        launch_mul(st, n, d_w.p, v_it, precond, s);
+    } else if (precond) {  // V_it = (r | the last turn's new vector) / its norm, w = M^-1 V_it
+        launch_gmres_scale_mul(st, n, v_it, it == 0 ? d_r.p : v_it, k.beta_ptr, precond, d_w.p, s);
         w = d_w.p;
     }
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
@@ -2821,7 +2827,9 @@ int ogl_solver::turn_gmres(KrylovRun &k, int enq, int pe)
         }
         launch_gmres_mgs_fold(st, n, nx, v_it, k.gm_h(it, it), nullptr, pin, pout, s);
         fg.part[0] = pout;
-        OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
+        fg.check_after = 1;
+        OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence, the next turn's check
+        fg.check_after = 0;
         fg.part[0] = d_part0.p;
     } else {
         for (int j = 0; j <= it; ++j) {
@@ -2832,9 +2840,11 @@ int ogl_solver::turn_gmres(KrylovRun &k, int enq, int pe)
             OGL_TRY(finalize(FIN_GMRES_H, fg));
         }
         launch_gmres_mgs(st, n, nx, v_it, k.gm_h(it, it), nullptr, d_part0.p, s);
-        OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence
+        fg.check_after = 1;
+        OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence, the next turn's check
+        fg.check_after = 0;
     }
-    launch_gmres_scale(st, n, nx, nx, k.beta_ptr, s);
+    if (!k.gmres_scale_late()) launch_gmres_scale(st, n, nx, nx, k.beta_ptr, s);
     return OGL_OK;
 }
 
