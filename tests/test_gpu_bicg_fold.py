@@ -170,3 +170,30 @@ def test_gmres_folded_links_same_bits(reg, oracle, shape, sym):
                 ref = oracle.gmres(A, b, np.zeros_like(b), P, **okw)
             np.testing.assert_array_equal(out[0][1], ref.history)
             np.testing.assert_array_equal(out[0][0], ref.x)
+
+
+@pytest.mark.parametrize("precond,block", [(capi.PRECOND_BJ, 1), (capi.PRECOND_NONE, 1), (capi.PRECOND_BJ, 4)])
+@pytest.mark.parametrize("krylov_dim", [1, 3, 5])
+def test_gmres_stops_anywhere_around_the_restarts(reg, oracle, system, precond, block, krylov_dim):
+    """The turn's criterion check runs at the end of the finaliser before it (the restart's before the first turn, else the
+    last column's: FinArgs::check_after), and with scalar Jacobi a new basis vector is divided by its norm only at the head
+    of the next turn, in the pass that applies the preconditioner to it (k_gmres_scale_mul) -- V_0 after a restart
+    included.  maxIter at, one before and one after every cycle boundary, the first turn, Krylov dimension 1 (a restart
+    every turn), and stops by tolerance inside a cycle: history, x and counters hold the oracle's bits, folded Gram-Schmidt
+    links or not.  Solver/GMRES/GKOGMRES.H:13-113, StoppingCriterion/StoppingCriterion.C:71-151."""
+    case, b, A, (rp, cols, vals) = system
+    P = None if precond == capi.PRECOND_NONE else oracle.Precond(rp, cols, vals, block)
+    runs = [dict(tolerance=0.0, rel_tol=0.0, max_iter=mi) for mi in range(1, 3 * krylov_dim + 3)]
+    runs += [dict(tolerance=tol, rel_tol=0.0, max_iter=60) for tol in (3e-1, 3e-2, 1e-3)]
+    for i, kw in enumerate(runs):
+        with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+            ref = oracle.gmres(A, b, np.zeros_like(b), P, krylov_dim=krylov_dim, **kw)
+        for fold in (1.0, 0.0):
+            s = reg.solver(f"gr_{precond}_{block}_{krylov_dim}_{int(fold)}", capi.default_config(
+                solver=capi.SOLVER_GMRES, preconditioner=precond, max_block_size=block, krylov_dim=krylov_dim, export_res=1,
+                adapt_min_iter=0, update_init_guess=1, **kw)).set_matrix(case)
+            s.set_property("gmresFold", fold)
+            x, perf = s.solve(b, np.zeros_like(b))
+            assert perf.n_iterations == ref.n_iterations, (kw, fold)
+            np.testing.assert_array_equal(s.history(), ref.history, err_msg=str((kw, fold)))
+            np.testing.assert_array_equal(x, ref.x, err_msg=str((kw, fold)))
