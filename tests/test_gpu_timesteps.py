@@ -41,3 +41,27 @@ def test_time_steps_leave_no_memory_behind():
     (dev0, rss0), (dev1, rss1) = marks[20], marks[160]
     assert abs(dev1 - dev0) < 1.0, (marks, "device memory in use moved over 140 time steps")
     assert rss1 - rss0 < 16.0, (marks, "host resident set grew over 140 time steps")
+
+
+def test_registries_come_and_go_without_residue():
+    """A registry per run (objectRegistry analogue, DevicePersistent/Base/Base.H:53-137): creating one, solving on it and
+    closing it -- stream, events, pinned staging buffers, every field's device arrays -- gives everything back."""
+    torch = pytest.importorskip("torch")
+    case = synthetic.poisson_case(20)
+    b = synthetic.rhs_for_x_star(case)[0]
+
+    def in_use():
+        free, total = torch.cuda.mem_get_info(0)
+        return (total - free) / 1e6
+
+    marks = {}
+    for i in range(41):
+        reg = capi.Registry()
+        for name, pc in (("p", capi.PRECOND_BJ), ("q", capi.PRECOND_ISAI)):
+            s = reg.solver(name, capi.default_config(preconditioner=pc, tolerance=1e-8, rel_tol=0.0, max_iter=200)).set_matrix(case)
+            x, perf = s.solve(b, np.zeros_like(b))
+            assert perf.final_residual < 1e-8
+        reg.close()
+        if i in (5, 40):
+            marks[i] = in_use()
+    assert abs(marks[40] - marks[5]) < 1.0, marks
