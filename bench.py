@@ -39,6 +39,7 @@ matrix, b and x already resident in HBM.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -256,7 +257,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+            # started plainly (`python bench.py --gpus N`, the form the driver uses at N = 1): this process becomes the
+            # launcher -- the N ranks are CHILD processes of torch.distributed.run, started before anything here has
+            # touched the GPU (no import of torch, no HIP call), never a re-exec -- and leaves with their exit code; the
+            # ranks' output (rank 0's one JSON line) passes straight through
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            raise SystemExit(subprocess.call(cmd, env=env))
         args.gpus = world
 
     import numpy as np

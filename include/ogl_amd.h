@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define OGL_AMD_ABI_VERSION 3
+/* 4: ogl_ldu_view gained `cell_centres` (a caller built against 3 hands over a shorter struct: the plug-in compares
+ * ogl_abi_version() with this value in its constructor, OGLAdapter.H); ogl_memory_ledger, ogl_registry_mem_info. */
+#define OGL_AMD_ABI_VERSION 4
 
 typedef int32_t ogl_label;
 typedef double ogl_scalar;
@@ -172,6 +174,9 @@ typedef struct ogl_perf {
     double t_copy_back_ms;      /* x D2H (lduLduBase.H:278-279) */
     double spmv_avg_ms;         /* mean in-loop SpMV kernel time (profile_kernels=1), else 0 */
     int32_t spmv_launches;
+    int32_t reserved0;
+    double t_res_norm_us;       /* time_for_res_norm_eval: one evaluated criterion check, measured (lduLduBase.H:287) */
+    double n_global_rows;       /* partition.get_total_size() (lduLduBase.H:294-295): rows over all ranks */
 } ogl_perf;
 
 /* ------------------------------------------------------------------------------------ */
@@ -236,6 +241,24 @@ typedef struct ogl_comm_info {
     int32_t transport, rank, n_ranks, ranks_seen, peer_mesh, device;
 } ogl_comm_info;
 int ogl_registry_comm_info(ogl_registry *reg, ogl_comm_info *info);
+
+/* What the library holds, process-wide (all registries): every hipMalloc / hipHostMalloc it makes is booked, every
+ * hipFree / hipHostFree unbooked (csrc/ledger.hpp).  The reference's device objects belong to the objectRegistry and
+ * live as long as it does (DevicePersistent/Base/Base.H:53-137, HostMatrix.C:79-95: created once per field, updated in
+ * place afterwards); a time-step loop must therefore leave device_bytes / pinned_bytes exactly where they were after
+ * the first steps, and closing the last registry must bring all of them to 0.  Also readable per solver as the
+ * properties deviceBytesInUse / pinnedBytesInUse (process-wide numbers, same source). */
+typedef struct ogl_memory_ledger {
+    int64_t device_bytes, device_blocks, device_peak_bytes, device_alloc_calls;
+    int64_t pinned_bytes, pinned_blocks, pinned_peak_bytes, pinned_alloc_calls;
+    int64_t streams, events, graph_execs;       /* live runtime objects the library created */
+    int64_t events_created, graph_execs_created; /* ... and how many it has created so far */
+    int64_t unknown_frees;                       /* frees of pointers the ledger never booked (always 0) */
+} ogl_memory_ledger;
+int ogl_memory_ledger_read(ogl_memory_ledger *out);
+/* hipMemGetInfo of the registry's device (what the DRIVER sees in use: the library's blocks plus the runtime's own
+ * pools and every other user of the device). */
+int ogl_registry_mem_info(ogl_registry *reg, int64_t *free_bytes, int64_t *total_bytes);
 
 /* ------------------------------------------------------------------------------------ */
 /* The plug-in path                                                                      */

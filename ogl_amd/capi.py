@@ -60,7 +60,8 @@ class Perf(C.Structure):
                 ("norm_factor", C.c_double), ("t_update_matrix_ms", C.c_double),
                 ("t_upload_ms", C.c_double), ("t_solve_ms", C.c_double),
                 ("t_copy_back_ms", C.c_double), ("spmv_avg_ms", C.c_double),
-                ("spmv_launches", C.c_int32)]
+                ("spmv_launches", C.c_int32), ("reserved0", C.c_int32), ("t_res_norm_us", C.c_double),
+                ("n_global_rows", C.c_double)]
 
 
 class MatrixDims(C.Structure):
@@ -93,8 +94,25 @@ EXPORTED_SYMBOLS = [
     "ogl_host_non_symmetric_update", "ogl_host_pattern", "ogl_host_adapt_criterion",
     "ogl_host_sell_check", "ogl_host_sym_check", "ogl_host_symx_check", "ogl_solver_get_renumbering", "ogl_host_rcm", "ogl_host_hilbert_order",
     "ogl_host_gather_sector_ratio", "ogl_host_pattern_renumbered",
-    "ogl_host_addressing_fingerprint", "ogl_registry_comm_info",
+    "ogl_host_addressing_fingerprint", "ogl_registry_comm_info", "ogl_memory_ledger_read", "ogl_registry_mem_info",
 ]
+
+
+class MemoryLedger(C.Structure):
+    """ogl_memory_ledger: what the library holds, process-wide (csrc/ledger.hpp)."""
+    _fields_ = [(n, C.c_int64) for n in (
+        "device_bytes", "device_blocks", "device_peak_bytes", "device_alloc_calls",
+        "pinned_bytes", "pinned_blocks", "pinned_peak_bytes", "pinned_alloc_calls",
+        "streams", "events", "graph_execs", "events_created", "graph_execs_created", "unknown_frees")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def memory_ledger() -> MemoryLedger:
+    out = MemoryLedger()
+    _check(lib().ogl_memory_ledger_read(C.byref(out)))
+    return out
 
 
 class OglError(RuntimeError):
@@ -237,6 +255,12 @@ class Registry:
         assert len(blob) == PEER_HANDLE_BYTES * n_ranks
         buf = C.create_string_buffer(blob, len(blob))
         _check(lib().ogl_registry_peer_connect(self._h, rank, n_ranks, buf))
+
+    def mem_info(self):
+        """(free, total) bytes of the registry's device as the driver sees them (hipMemGetInfo)."""
+        free, total = C.c_int64(), C.c_int64()
+        _check(lib().ogl_registry_mem_info(self._h, C.byref(free), C.byref(total)))
+        return free.value, total.value
 
     def comm_info(self):
         info = CommInfo()

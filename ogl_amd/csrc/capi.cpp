@@ -40,7 +40,7 @@ extern "C" int ogl_registry_create(ogl_registry **out, int device_id, void *hip_
     if (hip_stream) {
         reg->stream = static_cast<hipStream_t>(hip_stream);
     } else {
-        OGL_HIP_CHECK(hipStreamCreateWithFlags(&reg->stream, hipStreamNonBlocking));
+        OGL_HIP_CHECK(stream_create(&reg->stream));
         reg->own_stream = true;
     }
     reg->comm = std::make_unique<SelfComm>();
@@ -141,6 +141,19 @@ extern "C" int ogl_registry_comm_info(ogl_registry *reg, ogl_comm_info *info)
     info->peer_mesh = reg->peer_ready ? 1 : 0;
     info->device = reg->device;
     return OGL_OK;
+}
+
+extern "C" int ogl_registry_mem_info(ogl_registry *reg, int64_t *free_bytes, int64_t *total_bytes)
+{
+    OGL_GUARD_BEGIN
+    if (!reg) return fail(OGL_ERR_INVALID, "registry is NULL");
+    OGL_HIP_CHECK(hipSetDevice(reg->device));
+    size_t f = 0, t = 0;
+    OGL_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return OGL_OK;
+    OGL_GUARD_END
 }
 
 template <class T>
@@ -297,6 +310,12 @@ extern "C" int ogl_solver_export_system(ogl_solver *s, const char *directory)
 extern "C" int ogl_solver_get_property(ogl_solver *s, const char *key, double *value)
 {
     if (!s || !key || !value) return fail(OGL_ERR_INVALID, "NULL argument");
+    if (!std::strcmp(key, "deviceBytesInUse") || !std::strcmp(key, "pinnedBytesInUse")) {  // (process-wide: csrc/ledger.hpp)
+        ogl_memory_ledger l;
+        ogl::ledger::snapshot(&l);
+        *value = (double)(key[0] == 'd' ? l.device_bytes : l.pinned_bytes);
+        return OGL_OK;
+    }
     auto it = s->props.find(key);
     if (it == s->props.end()) return fail(OGL_ERR_INVALID, "no property %s", key);
     *value = it->second;

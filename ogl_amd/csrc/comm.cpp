@@ -30,20 +30,20 @@ HostComm::HostComm(int r, int n, ogl_allreduce_sum_fn ar, ogl_neighbour_exchange
 
 HostComm::~HostComm()
 {
-    if (pin_send_) (void)hipHostFree(pin_send_);
-    if (pin_recv_) (void)hipHostFree(pin_recv_);
+    ledger::pinned_free(pin_send_);
+    ledger::pinned_free(pin_recv_);
 }
 
 int HostComm::reserve(size_t doubles)
 {
     if (doubles <= cap_) return OGL_OK;
-    if (pin_send_) (void)hipHostFree(pin_send_);
-    if (pin_recv_) (void)hipHostFree(pin_recv_);
+    ledger::pinned_free(pin_send_);
+    ledger::pinned_free(pin_recv_);
     pin_send_ = pin_recv_ = nullptr;
     cap_ = 0;
     const size_t want = doubles + doubles / 2 + 64;
-    OGL_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pin_send_), want * sizeof(double), 0));
-    OGL_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pin_recv_), want * sizeof(double), 0));
+    OGL_HIP_TRY(ledger::pinned_malloc(reinterpret_cast<void **>(&pin_send_), want * sizeof(double)));
+    OGL_HIP_TRY(ledger::pinned_malloc(reinterpret_cast<void **>(&pin_recv_), want * sizeof(double)));
     cap_ = want;
     return OGL_OK;
 }
@@ -174,10 +174,10 @@ int RcclComm::self_test(hipStream_t st)
 {
     if (n_ranks < 2) return OGL_OK;
     double *d = nullptr;
-    OGL_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 8 * sizeof(double)));
+    OGL_HIP_TRY(ledger::dev_malloc(reinterpret_cast<void **>(&d), 8 * sizeof(double)));
     struct Free {
         double *p;
-        ~Free() { (void)hipFree(p); }
+        ~Free() { ledger::dev_free(p); }
     } guard{d};
     // Both stages run on EVERY rank whatever the first one gave: a rank that left after a wrong all-reduce would leave
     // the others waiting in the ring (ncclSend / ncclRecv have no time-out).  The verdict is agreed afterwards by a

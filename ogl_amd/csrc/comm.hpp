@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "ledger.hpp"
 
 namespace ogl {
 

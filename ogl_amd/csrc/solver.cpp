@@ -38,7 +38,7 @@ struct EventPair {  // destroyed on every return path
     ~EventPair()
     {
         for (auto &x : e)
-            if (x) (void)hipEventDestroy(x);
+            if (x) ev_destroy(x);
     }
     hipEvent_t &operator[](int i) { return e[i]; }
 };
@@ -163,8 +163,8 @@ Stager::~Stager()
 {
     delete pool_;
     for (int i = 0; i < NBUF; ++i) {
-        if (pin_[i]) (void)hipHostFree(pin_[i]);
-        if (ev_[i]) (void)hipEventDestroy(ev_[i]);
+        ledger::pinned_free(pin_[i]);
+        if (ev_[i]) ev_destroy(ev_[i]);
     }
 }
 
@@ -172,8 +172,8 @@ int Stager::init(size_t chunk_bytes)
 {
     if (chunk_) return OGL_OK;
     for (int i = 0; i < NBUF; ++i) {
-        OGL_HIP_CHECK(hipHostMalloc(&pin_[i], chunk_bytes, 0));
-        OGL_HIP_CHECK(hipEventCreateWithFlags(&ev_[i], hipEventDisableTiming));
+        OGL_HIP_CHECK(ledger::pinned_malloc(&pin_[i], chunk_bytes));
+        OGL_HIP_CHECK(ev_create(&ev_[i], hipEventDisableTiming));
     }
     chunk_ = chunk_bytes;
     const char *e = std::getenv("OGL_STAGE_THREADS");
@@ -251,11 +251,11 @@ ogl_registry::~ogl_registry()
     cached_precond.row_block.release();
     if (comm_stream) {
         (void)hipStreamSynchronize(comm_stream);
-        (void)hipStreamDestroy(comm_stream);
-        (void)hipEventDestroy(ev_packed);
-        (void)hipEventDestroy(ev_received);
+        stream_destroy(comm_stream);
+        ev_destroy(ev_packed);
+        ev_destroy(ev_received);
     }
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    if (own_stream && stream) stream_destroy(stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -274,10 +274,10 @@ int ogl_registry::peer_export(void *handle_out)
         arena_used = 0;
         const size_t bytes = (PEER_ARENA_OFF + arena_words) * sizeof(unsigned long long);
         // fine-grained: stores from other GPUs become visible to a kernel that is already running
-        OGL_HIP_CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+        OGL_HIP_CHECK(ledger::dev_malloc(&p, bytes, /*fine_grained=*/true));
         OGL_HIP_CHECK(hipMemset(p, 0, PEER_ARENA_OFF * sizeof(unsigned long long)));
         peer_local = static_cast<unsigned long long *>(p);
-        OGL_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&peer_error), sizeof(int32_t)));
+        OGL_HIP_CHECK(ledger::dev_malloc(reinterpret_cast<void **>(&peer_error), sizeof(int32_t)));
         OGL_HIP_CHECK(hipMemset(peer_error, 0, sizeof(int32_t)));
         OGL_HIP_CHECK(hipDeviceSynchronize());
     }
@@ -384,9 +384,15 @@ int ogl_registry::peer_connect(int rank, int n_ranks, const void *handles)
         for (int i = 0; i < n_ranks; i += 2)
             launch_peer_allreduce(stream, peer_next(), ids.p + i, std::min(2, n_ranks - i), peer_error);
         OGL_HIP_CHECK(hipMemcpyAsync(all.data(), ids.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        int32_t gather_err = 0;
+        OGL_HIP_CHECK(hipMemcpyAsync(&gather_err, peer_error, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         OGL_HIP_CHECK(hipStreamSynchronize(stream));
         for (int a = 0; a < n_ranks; ++a)
             for (int b = a + 1; b < n_ranks; ++b) peer_shared_device = peer_shared_device || all[(size_t)a] == all[(size_t)b];
+        // a timed-out or partial gather (an id of 0 = missing: the ids are offset by 1) must not let ranks decide
+        // differently: such a mesh runs the conservative single-waiter halo path on every rank that saw the gap
+        for (int a = 0; a < n_ranks; ++a) peer_shared_device = peer_shared_device || all[(size_t)a] == 0.0;
+        if (gather_err != 0) peer_shared_device = true;
     }
     peer_ready = true;
     return OGL_OK;
@@ -400,8 +406,8 @@ void ogl_registry::peer_close()
             (void)hipIpcCloseMemHandle(m);
             m = nullptr;
         }
-    if (peer_local) (void)hipFree(peer_local);
-    if (peer_error) (void)hipFree(peer_error);
+    ledger::dev_free(peer_local);
+    ledger::dev_free(peer_error);
     peer_local = nullptr;
     peer_error = nullptr;
     peer = PeerArgs{};
@@ -531,7 +537,10 @@ int ogl_registry::allreduce(double *dev, int n)
 
 void ogl_solver::drop_cg_graph()
 {
-    if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
+    if (cg_graph) {
+        (void)hipGraphExecDestroy(cg_graph);
+        ledger::destroyed(ledger::GRAPH_EXEC);
+    }
     cg_graph = nullptr;
     cg_graph_key.clear();
 }
@@ -539,11 +548,13 @@ void ogl_solver::drop_cg_graph()
 ogl_solver::~ogl_solver()
 {
     drop_cg_graph();
-    if (h_scal) (void)hipHostFree(h_scal);
+    ledger::pinned_free(h_scal);
     for (auto &e : poll_ev)
-        if (e) (void)hipEventDestroy(e);
+        if (e) ev_destroy(e);
     for (auto &e : prof_ev)
-        if (e) (void)hipEventDestroy(e);
+        if (e) ev_destroy(e);
+    for (auto &e : chk_ev)
+        if (e) ev_destroy(e);
 }
 
 double ogl_solver::prop(const std::string &key, double dflt) const
@@ -778,8 +789,8 @@ int ogl_solver::tune_symx()
 {
     hipStream_t st = reg->stream;
     EventPair ev;
-    OGL_HIP_CHECK(hipEventCreate(&ev[0]));
-    OGL_HIP_CHECK(hipEventCreate(&ev[1]));
+    OGL_HIP_CHECK(ev_create(&ev[0]));
+    OGL_HIP_CHECK(ev_create(&ev[1]));
     OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, ((size_t)pat.n_rows + 2) * sizeof(double), st));
     SpmvDots dots;
     dots.with = d_p.p;
@@ -1369,8 +1380,8 @@ int ogl_solver::tune_spmv_layout()
 {
     hipStream_t st = reg->stream;
     EventPair ev;
-    OGL_HIP_CHECK(hipEventCreate(&ev[0]));
-    OGL_HIP_CHECK(hipEventCreate(&ev[1]));
+    OGL_HIP_CHECK(ev_create(&ev[0]));
+    OGL_HIP_CHECK(ev_create(&ev[1]));
     OGL_HIP_CHECK(hipMemsetAsync(d_p.p, 0, ((size_t)pat.n_rows + 2) * sizeof(double), st));
     SpmvDots dots;
     dots.with = d_p.p;
@@ -1448,8 +1459,8 @@ int ogl_solver::ensure_vectors()
     OGL_TRY(d_part2.alloc(nc, st));
     OGL_TRY(d_scal.alloc(2, st));  // (two slots: the fused-finaliser kernels of small systems ping-pong between them)
     if (!h_scal) {
-        OGL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_scal), 2 * sizeof(DevScalars), 0));
-        for (auto &e : poll_ev) OGL_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        OGL_HIP_CHECK(ledger::pinned_malloc(reinterpret_cast<void **>(&h_scal), 2 * sizeof(DevScalars)));
+        for (auto &e : poll_ev) OGL_HIP_CHECK(ev_create(&e, hipEventDisableTiming));
     }
     return OGL_OK;
 }
@@ -1459,10 +1470,13 @@ bool ogl_solver::saw_addressing(const ogl_ldu_view &ldu) const
     if (seen_lower_addr != ldu.lower_addr || seen_upper_addr != ldu.upper_addr || seen_faces != ldu.n_faces ||
         (ogl_label)seen_iface_cells.size() != ldu.n_interfaces)
         return false;
-    for (ogl_label i = 0; i < ldu.n_interfaces; ++i)
-        if (seen_iface_cells[(size_t)i].first != ldu.interfaces[i].face_cells ||
-            seen_iface_cells[(size_t)i].second != ldu.interfaces[i].size)
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+        const SeenIface &a = seen_iface_cells[(size_t)i];
+        const ogl_interface &b = ldu.interfaces[i];
+        if (a.face_cells != b.face_cells || a.size != b.size || a.kind != b.kind || a.neighb_proc != b.neighb_proc ||
+            a.neighb_patch != b.neighb_patch)
             return false;
+    }
     return true;
 }
 
@@ -1496,6 +1510,11 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     hipStream_t st = reg->stream;
     TraceRange trace("update_matrix", field);
     const double t0 = now_ms();
+    // (what a later sibling may take over from THIS call is recorded at its successful end only: a call that fails part-way
+    //  leaves nothing to be trusted)
+    seen_lower_addr = seen_upper_addr = nullptr;
+    seen_faces = -1;
+    seen_iface_cells.clear();
     const bool try_sell = cfg.matrix_format != OGL_FORMAT_ELL && cfg.compress_indices;
     // ---- coefficients (update_local_matrix_data :592-705) ----
     // MatrixInitFunctor::update only overwrites the matrix values when updateSysMatrix is set
@@ -1990,8 +2009,10 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     seen_upper_addr = ldu.upper_addr;
     seen_faces = ldu.n_faces;
     seen_iface_cells.clear();
-    for (ogl_label i = 0; i < ldu.n_interfaces; ++i)
-        seen_iface_cells.emplace_back(ldu.interfaces[i].face_cells, ldu.interfaces[i].size);
+    for (ogl_label i = 0; i < ldu.n_interfaces; ++i) {
+        const ogl_interface &f = ldu.interfaces[i];
+        seen_iface_cells.push_back(SeenIface{f.face_cells, f.size, f.kind, f.neighb_proc, f.neighb_patch});
+    }
     t_update_matrix_ms = now_ms() - t0;
     return OGL_OK;
 }
@@ -2380,9 +2401,9 @@ int ogl_solver::dist_spmv(int mode, const double *x, const double *b, double *y,
         // pack on the compute stream, exchange on the communication stream: the neighbour copies
         // fly while the local SpMV below runs; the non-local kernel waits for their arrival
         if (!reg->comm_stream) {
-            OGL_HIP_CHECK(hipStreamCreateWithFlags(&reg->comm_stream, hipStreamNonBlocking));
-            OGL_HIP_CHECK(hipEventCreateWithFlags(&reg->ev_packed, hipEventDisableTiming));
-            OGL_HIP_CHECK(hipEventCreateWithFlags(&reg->ev_received, hipEventDisableTiming));
+            OGL_HIP_CHECK(stream_create(&reg->comm_stream));
+            OGL_HIP_CHECK(ev_create(&reg->ev_packed, hipEventDisableTiming));
+            OGL_HIP_CHECK(ev_create(&reg->ev_received, hipEventDisableTiming));
         }
         launch_pack(st, halo(), x, d_send.p, gate);
         OGL_HIP_CHECK(hipEventRecord(reg->ev_packed, st));
@@ -2495,7 +2516,7 @@ struct ogl_solver::KrylovRun {
     bool is_final = false;
     int max_checks = 0, max_turns = 0;
     int prof_stride = 0, prof_cap = 0;
-    EventPair ev_chk;
+    hipEvent_t ev_chk[2] = {nullptr, nullptr};  // (the solver's own pair, created once: ogl_solver::chk_ev)
     double t_start = 0.0;
     FinArgs fg{}, chk{}, f1{}, f2{};  // GMRES finaliser arguments; the head-of-turn check; one / two partial arrays
     const double *beta_ptr = nullptr;
@@ -2627,7 +2648,8 @@ int ogl_solver::krylov_prepare(KrylovRun &k)
     // maxIter keeps the loop going, as in the reference
     k.max_checks = std::max(crit.max_iter, crit.min_iter) + crit.frequency + 1;
     k.max_turns = bicg ? k.max_checks / 2 + 1 : k.max_checks;  // CG and GMRES: one check per turn
-    OGL_TRY(d_history.alloc((size_t)k.max_checks + 4, st));
+    // (sized by what the keywords allow, not by this solve's adaptive frequency / minIter: the same block solve after solve)
+    OGL_TRY(d_history.alloc((size_t)std::max(k.max_checks, crit.max_iter + std::max(1, cfg.norm_eval_limit) + 1) + 4, st));
     if (cfg.export_res)
         OGL_HIP_CHECK(hipMemsetAsync(d_history.p, 0, d_history.n * sizeof(double), st));
     if (k.bicg_fold) {  // (a folded kernel never writes a partial array it reads: six of them per turn)
@@ -2659,11 +2681,13 @@ int ogl_solver::krylov_prepare(KrylovRun &k)
     k.prof_cap = k.prof_stride ? std::min((k.max_turns + k.prof_stride - 1) / k.prof_stride, 4096) : 0;
     while ((int)prof_ev.size() < 2 * k.prof_cap) {
         hipEvent_t e;
-        OGL_HIP_CHECK(hipEventCreate(&e));
+        OGL_HIP_CHECK(ev_create(&e));
         prof_ev.push_back(e);
     }
-    OGL_HIP_CHECK(hipEventCreate(&k.ev_chk[0]));
-    OGL_HIP_CHECK(hipEventCreate(&k.ev_chk[1]));
+    for (int i = 0; i < 2; ++i) {  // (once per solver, not per solve: no runtime object comes and goes with a time step)
+        if (!chk_ev[i]) OGL_HIP_CHECK(ev_create(&chk_ev[i]));
+        k.ev_chk[i] = chk_ev[i];
+    }
 
     k.t_start = now_ms();
     launch_reset_scalars(st, s, crit);
@@ -3102,7 +3126,10 @@ int ogl_solver::krylov_loop(KrylovRun &k)
             (uintptr_t)d_symx_ex_lrow.p, (uintptr_t)symx_fast, (uintptr_t)d_spill_chunks.p, (uintptr_t)d_z.p,
             (uintptr_t)d_band_order.p, (uintptr_t)d_band_order.n, (uintptr_t)d_s21_far_idx.p, (uintptr_t)d_s21_far_col.p};
         if (!cg_graph || key != cg_graph_key) {
-            if (cg_graph) (void)hipGraphExecDestroy(cg_graph);
+            if (cg_graph) {
+                (void)hipGraphExecDestroy(cg_graph);
+                ledger::destroyed(ledger::GRAPH_EXEC);
+            }
             cg_graph = nullptr;
             OGL_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             const int before = k.enq;
@@ -3120,6 +3147,7 @@ int ogl_solver::krylov_loop(KrylovRun &k)
                 cg_graph = nullptr;
                 return fail(OGL_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
             }
+            ledger::created(ledger::GRAPH_EXEC);
             cg_graph_key = key;
         }
         OGL_HIP_CHECK(hipGraphLaunch(cg_graph, st));
@@ -3225,6 +3253,8 @@ int ogl_solver::krylov_finish(KrylovRun &k, ogl_perf *perf)
     const double time_per_iter = t_solve * 1e3 / std::max(perf->n_iterations, 1);
     const double res_norm_time = std::max(1e-3, (double)chk_ms * 1e3);
     double rel_cost = time_per_iter / res_norm_time;
+    perf->t_res_norm_us = res_norm_time;
+    perf->n_global_rows = k.n_global;
     if (reg->comm->multi()) {  // broadcast from rank 0 (:291-292) so every rank adapts alike
         double v = reg->comm->rank == 0 ? rel_cost : 0.0;
         OGL_HIP_CHECK(hipMemcpy(sums_ptr(s), &v, sizeof(double), hipMemcpyHostToDevice));
@@ -3303,9 +3333,10 @@ int ogl_solver::time_spmv(int repeats, double *avg_ms)
     if (!matrix_set) return fail(OGL_ERR_STATE, "time_spmv before set_matrix");
     OGL_HIP_CHECK(hipSetDevice(reg->device));
     hipStream_t st = reg->stream;
-    hipEvent_t e0, e1;
-    OGL_HIP_CHECK(hipEventCreate(&e0));
-    OGL_HIP_CHECK(hipEventCreate(&e1));
+    EventPair ev;
+    OGL_HIP_CHECK(ev_create(&ev[0]));
+    OGL_HIP_CHECK(ev_create(&ev[1]));
+    hipEvent_t e0 = ev[0], e1 = ev[1];
     OGL_TRY(dist_spmv(SPMV_PLAIN, d_b.p, nullptr, d_q.p, SpmvDots{d_b.p, d_part0.p, nullptr}, nullptr));  // warm-up
     OGL_HIP_CHECK(hipEventRecord(e0, st));
     for (int i = 0; i < repeats; ++i) {
@@ -3317,8 +3348,6 @@ int ogl_solver::time_spmv(int repeats, double *avg_ms)
     OGL_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
     OGL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *avg_ms = repeats > 0 ? (double)ms / repeats : 0.0;
     return OGL_OK;
 }

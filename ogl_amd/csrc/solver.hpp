@@ -36,31 +36,42 @@ namespace ogl {
 template <class T>
 struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0;    // elements in use
+    size_t cap = 0;  // elements allocated (>= n)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        ledger::dev_free(p);
         p = nullptr;
-        n = 0;
+        n = cap = 0;
     }
     void swap(DevBuf &o)
     {
         std::swap(p, o.p);
         std::swap(n, o.n);
+        std::swap(cap, o.cap);
     }
-    // (re)allocate `count` elements, zero-filled
+    // `count` elements, zero-filled when the size changes.  A block that is large enough (and not more than four times
+    // too large) is kept: sizes that go back and forth from solve to solve -- the registry-wide preconditioner store
+    // taking scalar Jacobi, blocks, W in turn (Preconditioner.H:357: one key for all fields), a residual history whose
+    // length follows the adaptive evaluation frequency -- then cost no hipFree / hipMalloc pair per time step, and the
+    // same pointers come back (a captured hipGraph stays valid).
     int alloc(size_t count, hipStream_t st)
     {
         if (count == n && p) return OGL_OK;
+        if (p && count > 0 && count <= cap && count >= cap / 4) {
+            OGL_HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(T), st));
+            n = count;
+            return OGL_OK;
+        }
         release();
         if (count == 0) return OGL_OK;
-        OGL_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        OGL_HIP_CHECK(ledger::dev_malloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
         OGL_HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(T), st));
-        n = count;
+        n = cap = count;
         return OGL_OK;
     }
 };
@@ -401,6 +412,7 @@ struct ogl_solver {
     ogl::DevBuf<double> d_history;
     ogl::DevScalars *h_scal = nullptr;  // pinned, 2 slots
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    hipEvent_t chk_ev[2] = {nullptr, nullptr};  // brackets one evaluated criterion check per solve (time_for_res_norm_eval)
     bool x_resident = false, b_resident = false;
     ogl::PrecondData own_precond;              // regenerated-for-this-solve preconditioner
     const ogl::PrecondData *precond_data = nullptr;  // the one in use (own or the registry's)
@@ -465,7 +477,11 @@ struct ogl_solver {
     // the addressing arrays of the last set_matrix (a sibling on the same arrays need not hash them again)
     const ogl_label *seen_lower_addr = nullptr, *seen_upper_addr = nullptr;
     ogl_label seen_faces = -1;
-    std::vector<std::pair<const ogl_label *, ogl_label>> seen_iface_cells;
+    struct SeenIface {  // (everything addressing_fingerprint mixes in per interface, by identity / value)
+        const ogl_label *face_cells;
+        ogl_label size, kind, neighb_proc, neighb_patch;
+    };
+    std::vector<SeenIface> seen_iface_cells;
     bool saw_addressing(const ogl_ldu_view &ldu) const;
     bool peer_safe_wait() const;
     double stream_above_bytes() const;

@@ -167,6 +167,11 @@ TEST(cpu_component_sibling_names)
     EXPECT_TRUE(!componentSiblings("Ux", "Ux") && !componentSiblings("Ux", "p") && !componentSiblings("x", "y"));
     EXPECT_TRUE(!componentSiblings("Ux", "Vx") && !componentSiblings("Ux", "Uxx") && !componentSiblings("k", "p"));
     EXPECT_TRUE(!componentSiblings("Ua", "Ub") && !componentSiblings("", ""));
+    // the donor is an EARLIER component of the same solveSegregated loop: Ux never takes from the Uz before it
+    EXPECT_TRUE(earlierComponent("Ux", "Uy") && earlierComponent("Uy", "Uz") && earlierComponent("Ux", "Uz"));
+    EXPECT_TRUE(earlierComponent("Rxx", "Rxy") && earlierComponent("Ryz", "Rzz"));
+    EXPECT_TRUE(!earlierComponent("Uz", "Ux") && !earlierComponent("Uy", "Ux") && !earlierComponent("Ux", "Ux"));
+    EXPECT_TRUE(!earlierComponent("Ux", "p") && !earlierComponent("Rzz", "Rxx"));
 }
 
 // ------------------------------------------------------------------ dictionary / selection (cpu)
@@ -343,8 +348,10 @@ TEST(gpu_property_keywords_reach_the_backend)
 TEST(gpu_GKOCG_BJ_cyclic_patches) { run_gkocg_case(true); }
 
 // fvMatrix<vector>::solveSegregated: ONE lduMatrix, the solvers of Ux, Uy, Uz built one after the other, diag() changed in
-// between.  The second and third component take the first one's device copy of upper / lower (offDiagReused) and give
-// the bits of a full upload; a new time step, a field that is no sibling, or off-diagonals written to in between: full upload.
+// between.  With `componentCoeffsReuse true` the second and third component take the first one's device copy of upper /
+// lower (offDiagReused) and give the bits of a full upload; a new time step, a field that is no sibling, a LATER component
+// as the donor, or off-diagonals written to in between: full upload.  Without the keyword every component uploads all
+// (the reference's behaviour, HostMatrix.C:644-682).
 TEST(gpu_momentum_components_share_the_off_diagonals)
 {
     Case c;
@@ -354,8 +361,8 @@ TEST(gpu_momentum_components_share_the_off_diagonals)
     dictionary d;
     d.add("solver", "GKOBiCGStab").add("preconditioner", pc).add("tolerance", 1e-10).add("relTol", 0.0);
     d.add("maxIter", 300).add("export", "true").add("matrixFormat", "Csr").add("executor", "hip").add("adaptMinIter", "false");
-    dictionary d_off = d;
-    d_off.add("componentCoeffsReuse", "false");
+    dictionary d_off = d;   // (the default: no reuse)
+    d.add("componentCoeffsReuse", "true");
     const scalarField diag0(c.A->diag());
     auto component = [&](const char *name, int cmpt, const dictionary &dict, scalarField &psi, double &reused) {
         for (label i = 0; i < c.n; ++i) c.A->diag()[i] = diag0[i] + 0.01 * cmpt * (1 + i % 5);   // (addBoundaryDiag)
@@ -392,11 +399,46 @@ TEST(gpu_momentum_components_share_the_off_diagonals)
     EXPECT_EQ(rr, 0.0);
     component("Uz", 2, d, z, rr);
     EXPECT_EQ(rr, 1.0);
+    component("Ux", 0, d, z, rr);   // the next outer corrector, same time index: Uz is not an earlier component of Ux
+    EXPECT_EQ(rr, 0.0);
     c.A->upper()[0] *= 1.5;
-    component("Ux", 0, d, z, rr);
+    component("Uy", 1, d, z, rr);
     EXPECT_EQ(rr, 0.0);
-    component("p", 0, d, z, rr);   // (no sibling of Ux)
+    component("p", 0, d, z, rr);   // (no sibling of Uy)
     EXPECT_EQ(rr, 0.0);
+}
+
+// The default plug-in path trusts nothing: ONE coefficient that no sampled checksum would look at (24,648 faces: the
+// sample of ogl_solver_set_matrix_like takes every 6th entry) changes between the constructors of Ux and Uy, and Uy's
+// device matrix has it (HostMatrix.C:644-682: the reference uploads every time).
+TEST(gpu_an_unsampled_coefficient_change_between_components_reaches_the_device)
+{
+    Case c;
+    build_poisson(c, 24, 20, 18, false, true);
+    dictionary pc;
+    pc.add("preconditioner", "BJ").add("maxBlockSize", 1);
+    dictionary d;
+    d.add("solver", "GKOBiCGStab").add("preconditioner", pc).add("tolerance", 1e-10).add("relTol", 0.0);
+    d.add("maxIter", 300).add("matrixFormat", "Csr").add("executor", "hip").add("adaptMinIter", "false");
+    Foam::Time::index() = 21;
+    scalarField source(c.n);
+    for (label i = 0; i < c.n; ++i) source[i] = std::sin(0.37 * i) + 0.25;
+    auto solve_as = [&](const char *name, scalarField &psi, double &reused) {
+        auto solver = lduMatrix::solver::New(name, *c.A, c.bou, c.intc, c.ifaces, d);
+        solver->solve(psi, source, 0);
+        reused = dynamic_cast<const GKOlduBaseSolver &>(*solver).backend_property("offDiagReused");
+    };
+    double r0, r1, r2;
+    scalarField ux(c.n, 0.0), uy(c.n, 0.0), fresh(c.n, 0.0);
+    solve_as("Ux", ux, r0);
+    const label face = 1;                      // 1 % 6 != 0 and not the last face: outside the sample
+    EXPECT_TRUE(c.A->upper().size() > 2 * 4096);
+    c.A->upper()[face] *= 3.0;
+    solve_as("Uy", uy, r1);
+    solve_as("fresh", fresh, r2);              // a field that never had a sibling: what a full upload gives
+    EXPECT_TRUE(r0 == 0.0 && r1 == 0.0 && r2 == 0.0);
+    EXPECT_TRUE(std::memcmp(uy.cdata(), fresh.cdata(), sizeof(scalar) * c.n) == 0);
+    EXPECT_TRUE(std::memcmp(uy.cdata(), ux.cdata(), sizeof(scalar) * c.n) != 0);
 }
 
 TEST(gpu_unsupported_coupled_patch_is_fatal)

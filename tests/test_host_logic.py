@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(capi.EXPORTED_SYMBOLS)
     for sym in sorted(declared):
         assert hasattr(lib, sym), sym
-    assert lib.ogl_abi_version() == 3
+    assert lib.ogl_abi_version() == 4
 
 
 def test_no_device_fails_loudly():
