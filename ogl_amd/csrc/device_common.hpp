@@ -375,6 +375,117 @@ __device__ __forceinline__ void reduce_partials_as_finaliser(const double (&pv)[
 }
 static_assert(FIN_BLOCK % BLOCK == 0 && FIN_WAVES == N_WAVES * (FIN_BLOCK / BLOCK), "virtual finaliser threads");
 
+#ifndef LEAD_SCOPE
+#define LEAD_SCOPE __HIP_MEMORY_SCOPE_SYSTEM  // (agent scope on coarse-grained memory measured no faster)
+#endif
+// ------------------------------------------------------------------------------------------
+// Leader finalisation (large single-rank systems; LeadBox, kernels.hpp).  The kernel that CONSUMES a finaliser's scalars
+// runs the finaliser itself: its first 16 workgroups -- dispatched first -- are the 16 wavefronts of k_finalize's tree
+// (same order of additions, same bits) and publish their sums in an uncached (fine-grained) mailbox; every workgroup
+// polls the mailbox, adds the 16 sums and runs the scalar logic on its own copy of the scalars; workgroup 0 stores the
+// new scalars for later kernels.  One launch and one dispatch gap fewer per finaliser.  Visibility: the mailbox words
+// carry their own tag (the launch sequence number from the INPUT scalar slot, which no workgroup of this launch writes),
+// 32 payload bits each, so no fence and no ordering between the words is needed; the partials and the input scalars
+// were written by earlier kernels.  (A finaliser folded into the PRODUCER needs a release per workgroup: measured 4 x
+// slower, HISTORY r5 item 14; ONE leader workgroup walking all partials in four batches behind the chip's row loads:
+// 13 us against the 10 of the launch it replaces, round 6.)
+// ------------------------------------------------------------------------------------------
+// The finaliser's 16 wavefronts become the first 16 workgroups of the launch ("leaders"; 32 for two arrays: workgroup b is
+// wavefront b % 16 of array b / 16): a leader stages the partials of virtual threads 64 w .. 64 w + 63 (partials v,
+// v + 1024, ... each) through LDS with all of its 256 threads -- up to 8 loads per thread in ONE memory round trip for
+// systems of up to 16.7 M rows, a tile more beyond -- adds them in the finaliser's order (one wavefront), runs the xor
+// tree and publishes the sum.  EVERY workgroup then fetches the 16 (x K) sums and adds them left to right itself, as
+// the folded kernels of small systems do with their own copies.
+constexpr int LEAD_TILE = 32;                  // partials per virtual thread staged at once
+constexpr int LEAD_STAGE = LEAD_TILE * WAVE;   // doubles of LDS (16 KB: eight workgroups per CU keep their place)
+__device__ __forceinline__ void lead_wave_sums(const LeadBox &L, uint32_t tag, const double *__restrict__ part, int m, int w,
+                                               int array, double *stage /* LEAD_STAGE */)
+{
+    constexpr int LOADS = LEAD_TILE * WAVE / BLOCK;  // per thread and tile
+    static_assert(LOADS * BLOCK == LEAD_TILE * WAVE, "a tile is whole loads of the workgroup");
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+    const int per_thread = (m + FIN_BLOCK - 1) / FIN_BLOCK;  // partials of a virtual thread (the last ones may be missing)
+    double s = 0.0;
+    for (int k0 = 0; k0 < per_thread; k0 += LEAD_TILE) {
+        double v[LOADS];
+#pragma unroll
+        for (int e = 0; e < LOADS; ++e) {
+            const int idx = e * BLOCK + t, k = idx / WAVE, ln = idx % WAVE;
+            const long i = (long)(w * WAVE + ln) + (long)FIN_BLOCK * (k0 + k);
+            v[e] = i < m ? part[i] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < LOADS; ++e) stage[e * BLOCK + t] = v[e];
+        __syncthreads();
+        if (wave == 0) {
+            const int k_end = min(LEAD_TILE, per_thread - k0);
+            for (int k = 0; k < k_end; ++k)
+                if ((long)(w * WAVE + lane) + (long)FIN_BLOCK * (k0 + k) < m) s += stage[k * WAVE + lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        s = wave_sum(s);
+        // every replica of the mailbox gets the two half-words (lane r -> replica r): the pollers spread over the
+        // replicas, so that 19,683 workgroups do not fetch the same cache lines from one memory channel
+        if (lane < LEAD_REPLICAS) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+            unsigned long long *box = L.box + (size_t)lane * LEAD_REPLICA_STRIDE + array * 2 * FIN_WAVES + 2 * w;
+            __hip_atomic_store(box, ((unsigned long long)tag << 32) | (uint32_t)bits, __ATOMIC_RELAXED, LEAD_SCOPE);
+            __hip_atomic_store(box + 1, ((unsigned long long)tag << 32) | (uint32_t)(bits >> 32), __ATOMIC_RELAXED, LEAD_SCOPE);
+        }
+    }
+}
+
+// word i of the mailbox: [tag : 32 | payload : 32], one atomic 8-byte store / load each (payload: half of a double)
+// Threads 0 .. n_words - 1 of a polling workgroup fetch one word each: half-word i of vals[] (the doubles the leaders
+// published, in mailbox order); returns (to every thread) false when a leader never published (time-out: a defect, not
+// a state of the solve -- the caller raises comm_error and leaves).
+__device__ __forceinline__ bool lead_wait(const LeadBox &L, int n_words, uint32_t tag, double *vals, int *timed_out)
+{
+    if (threadIdx.x == 0) *timed_out = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < n_words) {
+        const unsigned long long *src = L.box + (size_t)(blockIdx.x % LEAD_REPLICAS) * LEAD_REPLICA_STRIDE + threadIdx.x;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, LEAD_SCOPE);
+            if ((uint32_t)(w >> 32) == tag) {
+                reinterpret_cast<uint32_t *>(vals)[threadIdx.x] = (uint32_t)w;
+                break;
+            }
+            if (wall_clock64() - t0 > L.timeout_ticks) {
+                *timed_out = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    return *timed_out == 0;
+}
+// The leaders of a launch that finalises K partial arrays: workgroup b < 16 K is wavefront b % 16 of array b / 16.
+template <int K>
+__device__ __forceinline__ void lead_leaders(const LeadBox &L, uint32_t tag, const double *__restrict__ p0,
+                                             const double *__restrict__ p1, const double *__restrict__ p2, int m,
+                                             double *stage)
+{
+    if ((int)blockIdx.x < K * FIN_WAVES) {
+        const int a = blockIdx.x / FIN_WAVES;
+        lead_wave_sums(L, tag, a == 0 ? p0 : (a == 1 ? p1 : p2), m, blockIdx.x % FIN_WAVES, a, stage);
+    }
+}
+
+// the 16 wavefront sums of array a, left to right (fin_block_sum); a rolled loop: one thread per workgroup runs it, and
+// its registers would be every thread's (the step kernels live on 8 wavefronts per SIMD)
+__device__ __forceinline__ double lead_total(const double *vals, int a)
+{
+    double sum = vals[a * FIN_WAVES];
+#pragma unroll 1
+    for (int w = 1; w < FIN_WAVES; ++w) sum += vals[a * FIN_WAVES + w];
+    return sum;
+}
+
 // StoppingCriterion.C:71-151 on the device.  `norm` is sum|r| over all ranks.
 __device__ inline void criterion_check(DevScalars *s, const DevCriterion &c, double norm, double *history)
 {

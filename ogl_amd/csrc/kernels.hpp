@@ -39,7 +39,8 @@ struct DevScalars {
     // and rank, so that a scaling curve below DESIGN.md section 6's table can be attributed.
     uint32_t halo_waits;
     unsigned long long halo_wait_ticks, reduce_wait_ticks;
-    uint32_t reduce_waits, pad_;
+    uint32_t reduce_waits;
+    uint32_t launch_seq;  // leader finalisation (LeadBox): tag of the next leader launch's mailbox words
 };
 
 // Persistent device CSR ("<field>_matrix", CsrMatrixWrapper.H:163-210) + halo part.
@@ -75,6 +76,18 @@ struct DevHalo {
     int32_t n_send = 0;
     const int32_t *send_idxs = nullptr;     // rows gathered into the send buffer
 };
+
+// Mailbox of the leader finalisation (device_common.hpp): a few 8-byte words in fine-grained (uncached) device memory,
+// written by workgroup 0 of a launch and polled by the others.  box == nullptr: every workgroup reduces the partials
+// itself (small systems) -- or the finalisers are launches of their own.
+struct LeadBox {
+    unsigned long long *box = nullptr;
+    long long timeout_ticks = 0;  // wall_clock64 ticks (10 ns) a polling workgroup waits before it gives the solve up
+    int32_t early_loads = 0;      // 1: a polling workgroup asks for its rows before it polls (else after)
+};
+constexpr int LEAD_BOX_WORDS = 96;  // 16 wavefront sums x up to 3 arrays x 2 half-words
+constexpr int LEAD_REPLICAS = 16;   // copies of the mailbox (workgroup b polls copy b % 16), LEAD_REPLICA_STRIDE words apart
+constexpr int LEAD_REPLICA_STRIDE = 544;  // 4352 bytes: 4 KiB + 256, so that the copies fall into different channels
 
 enum SpmvMode { SPMV_PLAIN = 0, SPMV_RESIDUAL = 1 };
 
@@ -306,19 +319,22 @@ void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, con
 //   step_1x_fin: check on (part_rho, part_norm) of the previous step_2r (first: of the initial residual), the
 //                pending x update (not when `first`), then step_1
 //   step_2r_fin: beta from part_beta, then step_2r
+// lead.box != nullptr (any number of chunks): workgroup 0 alone reduces and publishes, the others poll (LeadBox)
 void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
                           const DevScalars *sin, DevScalars *sout, const double *part_rho,
-                          const double *part_norm, double *history, int first);
+                          const double *part_norm, double *history, int first, const LeadBox &lead = LeadBox{});
 void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                           double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
-                          const double *part_beta, double *z_out = nullptr);  // z_out: z = r / d kept for k_cg_turn_sym
+                          const double *part_beta, double *z_out = nullptr,  // z_out: z = r / d kept for k_cg_turn_sym
+                          const LeadBox &lead = LeadBox{});
 constexpr int FUSED_FIN_MAX_CHUNKS = 1024;  // up to 524,288 rows: one partial per virtual finaliser thread
 // step_1x_fin and the SpMV on half storage in one launch (p_new = z + (rho/rho') p recomputed at the gathered
 // columns; it goes to p_out != p_in for the own rows): a turn is this + step_2r_fin.  z: what step_2r_fin's z_out
 // (or, before the first turn, launch_mul) has left; r itself without a preconditioner
 void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x, const double *z,
                         double *q, double *part_beta, const DevScalars *sin, DevScalars *sout,
-                        const double *part_rho, const double *part_norm, double *history, int first);
+                        const double *part_rho, const double *part_norm, double *history, int first,
+                        const LeadBox &lead = LeadBox{});
 // ... and between the single-workgroup finalisers of larger systems (scalars as k_cg_step1x reads them):
 // turn = this | FIN_BETA | step_2r (z_out) | FIN_CG_CHECK
 // Several ranks (hf.chunk_bptr != nullptr; peer-put transport): the neighbours have put the z of the halo columns
@@ -339,14 +355,14 @@ void launch_gmres_mgs_fold(hipStream_t st, int32_t n, double *w, const double *v
 // scalars go sin -> sout; a kernel never writes a partial array it reads
 void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,
                        double *y, const DevScalars *sin, DevScalars *sout, const double *part_rho,
-                       const double *part_norm, double *history);
+                       const double *part_norm, double *history, const LeadBox &lead = LeadBox{});
 void launch_bicg_fold2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv, const double *inv_diag,
                        double *z, double *part_norm_out, const DevScalars *sin, DevScalars *sout,
-                       const double *part_beta);
+                       const double *part_beta, const LeadBox &lead = LeadBox{});
 void launch_bicg_fold3(hipStream_t st, int32_t n, double *x, double *r, const double *sv, const double *t,
                        const double *y, const double *z, const double *rr, double *part_rho_out, double *part_norm_out,
                        const DevScalars *sin, DevScalars *sout, const double *part_gamma, const double *part_tt,
-                       const double *part_snorm, double *history, int turn);
+                       const double *part_snorm, double *history, int turn, const LeadBox &lead = LeadBox{});
 void launch_bicg_step1(hipStream_t st, int32_t n, double *p, const double *r, const double *v,
                        const double *inv_diag, double *y, const DevScalars *s);
 void launch_bicg_step2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv,

@@ -299,17 +299,27 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__
 //   [check of the previous turn + pending x update + step_1]  ->  SpMV  ->  [beta + step_2r]
 // ------------------------------------------------------------------------------------------
 
+// LEAD (systems of more than FUSED_FIN_MAX_CHUNKS chunks): the first 16 workgroups are the finaliser's 16 wavefronts and
+// publish their sums; every workgroup fetches them, adds them and runs the same logic (leader finalisation, device_common.hpp)
+template <bool LEAD>
 __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restrict__ p, double *__restrict__ x,
                                                          const double *__restrict__ r,
                                                          const double *__restrict__ inv_diag,
                                                          const DevScalars *sin, DevScalars *sout,
                                                          const double *__restrict__ part_rho,
                                                          const double *__restrict__ part_norm, int n_part,
-                                                         double *history, int first)
+                                                         double *history, int first, LeadBox lead)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[4];
     __shared__ int sh_stop;
+    __shared__ double lead_words[LEAD ? LEAD_BOX_WORDS / 2 : 1];
+    __shared__ double lead_stage[LEAD ? LEAD_STAGE : 1];
+    __shared__ int lead_timed_out;
+    const uint32_t seq = LEAD ? sin->launch_seq : 0u;
+    // (the leaders first of all: their partial loads go out ahead of the chip's row loads, and nothing below -- not even
+    //  the stop flag -- sits between the launch and the sums everybody else will wait for; after a stop nobody polls)
+    if (LEAD) lead_leaders<2>(lead, seq, part_rho, part_norm, nullptr, n_part, lead_stage);
     // everything this workgroup will need is asked for at once -- the scalars, the partials and its own rows of
     // p, x, r, 1/d: one memory round trip instead of three in a row (scalars -> partials -> vectors).  The
     // scalars are read field by field into registers (a private copy of the struct would live in scratch memory,
@@ -325,17 +335,45 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
         reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
             reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
     const RowPair rp = my_rows(blockIdx.x, n);
-    double2 vp = ld2(p, rp);
-    double2 vx = ld2_stream(x, rp);
-    double2 vz = ld2_stream(r, rp);
-    double2 vi;
+    double2 vp, vx, vz, vi;
     vi.x = vi.y = 1.0;
-    if (inv_diag) vi = ld2_stream(inv_diag, rp);
+    const bool early = !LEAD || lead.early_loads != 0;
+    if (early) {
+        vp = ld2(p, rp);
+        vx = ld2_stream(x, rp);
+        vz = ld2_stream(r, rp);
+        if (inv_diag) vi = ld2_stream(inv_diag, rp);
+    }
     double pv[2][FIN_VT];
-    load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
+    if (!LEAD) load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
     if (stopped) return;  // (the solve has ended: workgroup 0 has handed the scalars on, nothing else to do)
-    double v[2];
-    reduce_partials_as_finaliser<2>(pv, n_part, red, v);  // (its barriers order the copy above before the stores below)
+    double v[2] = {0.0, 0.0};
+    if (LEAD) {
+        // x += t_j p of the turn this check will close needs nothing the leaders compute (prev_rho = the incoming rho,
+        // beta as it stands): it goes out while the mailbox is awaited -- same scalars, same bits, one store less behind the wait
+        if (early && !first && s_beta != 0.0) {
+            const double t = s_rho / s_beta;
+            vx.x += t * vp.x;
+            vx.y += t * vp.y;
+            st2_stream(x, rp, vx);
+        }
+        if (!lead_wait(lead, 4 * FIN_WAVES, seq, lead_words, &lead_timed_out)) {
+            if (threadIdx.x == 0) sout->comm_error = sout->stop = 1;
+            return;
+        }
+        if (!early) {
+            vp = ld2(p, rp);
+            vx = ld2_stream(x, rp);
+            vz = ld2_stream(r, rp);
+            if (inv_diag) vi = ld2_stream(inv_diag, rp);
+        }
+        if (threadIdx.x == 0) {
+            v[0] = lead_total(lead_words, 0);
+            v[1] = lead_total(lead_words, 1);
+        }
+    } else {
+        reduce_partials_as_finaliser<2>(pv, n_part, red, v);  // (its barriers order the copy above before the stores below)
+    }
     if (threadIdx.x == 0) {
         // FIN_CG_CHECK: swap(prev_rho, rho) of the previous turn, then criterion_check (StoppingCriterion.C:71-151)
         const double prev_rho = s_rho, rho = v[0];
@@ -373,12 +411,13 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
                 sout->res = res;
             }
             if (stop) sout->stop = 1;
+            if (LEAD) sout->launch_seq = seq + 1;
         }
     }
     __syncthreads();
     const double beta = sh[0], prev = sh[1], rho = sh[2];
     const int stop = sh_stop;
-    if (!first && beta != 0.0) {  // x += t_j p of the turn this check closed (same scalars, same bits as step_2)
+    if (!(LEAD && lead.early_loads) && !first && beta != 0.0) {  // x += t_j p of the turn this check closed (same scalars, same bits as step_2)
         const double t = prev / beta;
         vx.x += t * vp.x;
         vx.y += t * vp.y;
@@ -395,17 +434,23 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
     st2(p, rp, vp);
 }
 
+template <bool LEAD>
 __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restrict__ r,
                                                          const double *__restrict__ q,
                                                          const double *__restrict__ inv_diag,
                                                          double *__restrict__ part_rho,
                                                          double *__restrict__ part_norm, const DevScalars *sin,
                                                          DevScalars *sout, const double *__restrict__ part_beta,
-                                                         int n_part, double *__restrict__ z_out)
+                                                         int n_part, double *__restrict__ z_out, LeadBox lead)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[2];
     __shared__ double slot[2 * N_WAVES];
+    __shared__ double lead_words[LEAD ? LEAD_BOX_WORDS / 2 : 1];
+    __shared__ double lead_stage[LEAD ? LEAD_STAGE : 1];
+    __shared__ int lead_timed_out;
+    const uint32_t seq = LEAD ? sin->launch_seq : 0u;
+    if (LEAD) lead_leaders<1>(lead, seq, part_beta, nullptr, nullptr, n_part, lead_stage);  // (as step_1x_fin)
     // (all loads up front and the scalars field by field, as in step_1x_fin)
     const int stopped = sin->stop;
     const double s_rho = sin->rho;
@@ -414,20 +459,39 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r_fin(int n, double *__restri
             reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
     const int chunk = blockIdx.x;
     const RowPair rp = my_rows(chunk, n);
-    double2 vr = ld2(r, rp);
-    const double2 vq = ld2_stream(q, rp);  // q: last use of this turn
-    double2 vi;
+    double2 vr, vq, vi;
     vi.x = vi.y = 1.0;
-    if (inv_diag) vi = ld2(inv_diag, rp);
+    const bool early = !LEAD || lead.early_loads != 0;
+    if (early) {
+        vr = ld2(r, rp);
+        vq = ld2_stream(q, rp);  // q: last use of this turn
+        if (inv_diag) vi = ld2(inv_diag, rp);
+    }
     double pv[2][FIN_VT];
-    load_partials_as_finaliser<1>(part_beta, nullptr, n_part, pv);
+    if (!LEAD) load_partials_as_finaliser<1>(part_beta, nullptr, n_part, pv);
     if (stopped) return;
-    double v[2];
-    reduce_partials_as_finaliser<1>(pv, n_part, red, v);
+    double v[2] = {0.0, 0.0};
+    if (LEAD) {
+        if (!lead_wait(lead, 2 * FIN_WAVES, seq, lead_words, &lead_timed_out)) {
+            if (threadIdx.x == 0) sout->comm_error = sout->stop = 1;
+            return;
+        }
+        if (!early) {
+            vr = ld2(r, rp);
+            vq = ld2_stream(q, rp);
+            if (inv_diag) vi = ld2(inv_diag, rp);
+        }
+        if (threadIdx.x == 0) v[0] = lead_total(lead_words, 0);
+    } else {
+        reduce_partials_as_finaliser<1>(pv, n_part, red, v);
+    }
     if (threadIdx.x == 0) {
         sh[0] = s_rho;
         sh[1] = v[0];
-        if (blockIdx.x == 0) sout->beta = v[0];  // FIN_BETA
+        if (blockIdx.x == 0) {
+            sout->beta = v[0];  // FIN_BETA
+            if (LEAD) sout->launch_seq = seq + 1;
+        }
     }
     __syncthreads();
     const double rho = sh[0], beta = sh[1];
@@ -600,17 +664,24 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_step3(int n, double *__restrict_
 // ------------------------------------------------------------------------------------------
 // FIN_CG_CHECK + step_1.  The closing check of a solve is one more launch of this kernel (the step it then takes on
 // p is harmless: the solve has stopped, or fails with "did not stop").
+// LEAD (any number of chunks): leader finalisation as in k_cg_step1x_fin<true>
+template <bool LEAD>
 __global__ __launch_bounds__(BLOCK) void k_bicg_fold1(int n, double *__restrict__ p, const double *__restrict__ r,
                                                       const double *__restrict__ v,
                                                       const double *__restrict__ inv_diag, double *__restrict__ y,
                                                       const DevScalars *sin, DevScalars *sout,
                                                       const double *__restrict__ part_rho,
                                                       const double *__restrict__ part_norm, int n_part,
-                                                      double *history)
+                                                      double *history, LeadBox lead)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[2];
     __shared__ int sh_stop;
+    __shared__ double lead_words[LEAD ? LEAD_BOX_WORDS / 2 : 1];
+    __shared__ double lead_stage[LEAD ? LEAD_STAGE : 1];
+    __shared__ int lead_timed_out;
+    const uint32_t seq = LEAD ? sin->launch_seq : 0u;
+    if (LEAD) lead_leaders<2>(lead, seq, part_rho, part_norm, nullptr, n_part, lead_stage);
     // (everything asked for at once, the scalars field by field: see k_cg_step1x_fin)
     const int stopped = sin->stop;
     const double s_rho = sin->rho, alpha = sin->alpha, omega = sin->omega, s_nf = sin->norm_factor,
@@ -629,10 +700,21 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold1(int n, double *__restrict_
     vi.x = vi.y = 1.0;
     if (inv_diag) vi = ld2_stream(inv_diag, rp);
     double pv[2][FIN_VT];
-    load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
+    if (!LEAD) load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
     if (stopped) return;
-    double vsum[2];
-    reduce_partials_as_finaliser<2>(pv, n_part, red, vsum);
+    double vsum[2] = {0.0, 0.0};
+    if (LEAD) {
+        if (!lead_wait(lead, 4 * FIN_WAVES, seq, lead_words, &lead_timed_out)) {
+            if (threadIdx.x == 0) sout->comm_error = sout->stop = 1;
+            return;
+        }
+        if (threadIdx.x == 0) {
+            vsum[0] = lead_total(lead_words, 0);
+            vsum[1] = lead_total(lead_words, 1);
+        }
+    } else {
+        reduce_partials_as_finaliser<2>(pv, n_part, red, vsum);
+    }
     if (threadIdx.x == 0) {
         // FIN_CG_CHECK: swap(prev_rho, rho) of the previous turn, then criterion_check (StoppingCriterion.C:71-151)
         const double prev_rho = s_rho, rho = vsum[0];
@@ -669,6 +751,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold1(int n, double *__restrict_
                 sout->res = res;
             }
             if (stop) sout->stop = 1;
+            if (LEAD) sout->launch_seq = seq + 1;
         }
     }
     __syncthreads();
@@ -690,16 +773,22 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold1(int n, double *__restrict_
 }
 
 // FIN_BICG_ALPHA + step_2
+template <bool LEAD>
 __global__ __launch_bounds__(BLOCK) void k_bicg_fold2(int n, const double *__restrict__ r,
                                                       const double *__restrict__ v, double *__restrict__ sv,
                                                       const double *__restrict__ inv_diag, double *__restrict__ z,
                                                       double *__restrict__ part_norm_out, const DevScalars *sin,
                                                       DevScalars *sout, const double *__restrict__ part_beta,
-                                                      int n_part)
+                                                      int n_part, LeadBox lead)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[2];
     __shared__ double slot[N_WAVES];
+    __shared__ double lead_words[LEAD ? LEAD_BOX_WORDS / 2 : 1];
+    __shared__ double lead_stage[LEAD ? LEAD_STAGE : 1];
+    __shared__ int lead_timed_out;
+    const uint32_t seq = LEAD ? sin->launch_seq : 0u;
+    if (LEAD) lead_leaders<1>(lead, seq, part_beta, nullptr, nullptr, n_part, lead_stage);
     const int stopped = sin->stop;
     const double s_rho = sin->rho;
     if (blockIdx.x == 0 && threadIdx.x < sizeof(DevScalars) / 8)
@@ -713,10 +802,18 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold2(int n, const double *__res
     vi.x = vi.y = 1.0;
     if (inv_diag) vi = ld2_stream(inv_diag, rp);
     double pv[2][FIN_VT];
-    load_partials_as_finaliser<1>(part_beta, nullptr, n_part, pv);
+    if (!LEAD) load_partials_as_finaliser<1>(part_beta, nullptr, n_part, pv);
     if (stopped) return;
-    double vsum[2];
-    reduce_partials_as_finaliser<1>(pv, n_part, red, vsum);
+    double vsum[2] = {0.0, 0.0};
+    if (LEAD) {
+        if (!lead_wait(lead, 2 * FIN_WAVES, seq, lead_words, &lead_timed_out)) {
+            if (threadIdx.x == 0) sout->comm_error = sout->stop = 1;
+            return;
+        }
+        if (threadIdx.x == 0) vsum[0] = lead_total(lead_words, 0);
+    } else {
+        reduce_partials_as_finaliser<1>(pv, n_part, red, vsum);
+    }
     if (threadIdx.x == 0) {  // beta = rr.v ; alpha = rho / beta (0 when beta == 0)
         const double beta = vsum[0], alpha = (beta != 0.0) ? s_rho / beta : 0.0;
         sh[0] = alpha;
@@ -724,6 +821,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold2(int n, const double *__res
         if (blockIdx.x == 0) {
             sout->beta = beta;
             sout->alpha = alpha;
+            if (LEAD) sout->launch_seq = seq + 1;
         }
     }
     __syncthreads();
@@ -747,6 +845,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold2(int n, const double *__res
 }
 
 // FIN_BICG_CHECK2_OMEGA + step_3 (bicgstab::finalize, x += alpha y, when the mid-turn check stops the solve)
+template <bool LEAD>
 __global__ __launch_bounds__(BLOCK) void k_bicg_fold3(int n, double *__restrict__ x, double *__restrict__ r,
                                                       const double *__restrict__ sv, const double *__restrict__ t,
                                                       const double *__restrict__ y, const double *__restrict__ z,
@@ -756,12 +855,17 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold3(int n, double *__restrict_
                                                       DevScalars *sout, const double *__restrict__ part_gamma,
                                                       const double *__restrict__ part_tt,
                                                       const double *__restrict__ part_snorm, int n_part,
-                                                      double *history, int turn)
+                                                      double *history, int turn, LeadBox lead)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[1];
     __shared__ int sh_stop;
     __shared__ double slot[2 * N_WAVES];
+    __shared__ double lead_words[LEAD ? LEAD_BOX_WORDS / 2 : 1];
+    __shared__ double lead_stage[LEAD ? LEAD_STAGE : 1];
+    __shared__ int lead_timed_out;
+    const uint32_t seq = LEAD ? sin->launch_seq : 0u;
+    if (LEAD) lead_leaders<3>(lead, seq, part_gamma, part_tt, part_snorm, n_part, lead_stage);
     const int stopped = sin->stop;
     const double alpha = sin->alpha, s_nf = sin->norm_factor, s_init = sin->init_res;
     const int s_iter = sin->iter, s_evals = sin->n_evals;
@@ -777,12 +881,26 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold3(int n, double *__restrict_
     const double2 vy = ld2_stream(y, rp), vz = ld2_stream(z, rp), vs = ld2_stream(sv, rp), vt = ld2_stream(t, rp),
                   vrr = ld2_stream(rr, rp);
     double pv[2][FIN_VT], pn[2][FIN_VT];
-    load_partials_as_finaliser<2>(part_gamma, part_tt, n_part, pv);
-    load_partials_as_finaliser<1>(part_snorm, nullptr, n_part, pn);
+    if (!LEAD) {
+        load_partials_as_finaliser<2>(part_gamma, part_tt, n_part, pv);
+        load_partials_as_finaliser<1>(part_snorm, nullptr, n_part, pn);
+    }
     if (stopped) return;
-    double vsum[2], vnorm[2];
-    reduce_partials_as_finaliser<2>(pv, n_part, red, vsum);
-    reduce_partials_as_finaliser<1>(pn, n_part, red, vnorm);
+    double vsum[2] = {0.0, 0.0}, vnorm[2] = {0.0, 0.0};
+    if (LEAD) {
+        if (!lead_wait(lead, 6 * FIN_WAVES, seq, lead_words, &lead_timed_out)) {
+            if (threadIdx.x == 0) sout->comm_error = sout->stop = 1;
+            return;
+        }
+        if (threadIdx.x == 0) {
+            vsum[0] = lead_total(lead_words, 0);
+            vsum[1] = lead_total(lead_words, 1);
+            vnorm[0] = lead_total(lead_words, 2);
+        }
+    } else {
+        reduce_partials_as_finaliser<2>(pv, n_part, red, vsum);
+        reduce_partials_as_finaliser<1>(pn, n_part, red, vnorm);
+    }
     if (threadIdx.x == 0) {
         // the mid-turn check on s (criterion_check, StoppingCriterion.C:71-151), then gamma = s.t, beta = t.t,
         // omega = gamma / beta unless it stopped
@@ -824,6 +942,7 @@ __global__ __launch_bounds__(BLOCK) void k_bicg_fold3(int n, double *__restrict_
                 sout->beta = vsum[1];
                 sout->omega = omega;
             }
+            if (LEAD) sout->launch_seq = seq + 1;
         }
     }
     __syncthreads();
@@ -1189,6 +1308,7 @@ __global__ void k_reset_scalars(DevScalars *s, DevCriterion crit)
     z.prev_rho = 1.0;
     z.alpha = z.omega = z.gamma = z.beta = 1.0;
     z.norm_factor = 1.0;  // StoppingCriterion.H:136
+    z.launch_seq = 1;     // (0 is what an untouched LeadBox word carries)
     *s = z;
 }
 
@@ -1296,22 +1416,30 @@ void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, con
 
 void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
                           const DevScalars *sin, DevScalars *sout, const double *part_rho,
-                          const double *part_norm, double *history, int first)
+                          const double *part_norm, double *history, int first, const LeadBox &lead)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_cg_step1x_fin, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, sin, sout, part_rho,
-                       part_norm, nc, history, first);
+    if (lead.box && nc >= 3 * FIN_WAVES)
+        hipLaunchKernelGGL(k_cg_step1x_fin<true>, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, sin, sout, part_rho,
+                           part_norm, nc, history, first, lead);
+    else
+        hipLaunchKernelGGL(k_cg_step1x_fin<false>, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, sin, sout, part_rho,
+                           part_norm, nc, history, first, LeadBox{});
 }
 
 void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                           double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
-                          const double *part_beta, double *z_out)
+                          const double *part_beta, double *z_out, const LeadBox &lead)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_cg_step2r_fin, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho, part_norm, sin,
-                       sout, part_beta, nc, z_out);
+    if (lead.box && nc >= 3 * FIN_WAVES)
+        hipLaunchKernelGGL(k_cg_step2r_fin<true>, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho, part_norm, sin,
+                           sout, part_beta, nc, z_out, lead);
+    else
+        hipLaunchKernelGGL(k_cg_step2r_fin<false>, dim3(nc), dim3(BLOCK), 0, st, n, r, q, inv_diag, part_rho, part_norm, sin,
+                           sout, part_beta, nc, z_out, LeadBox{});
 }
 
 void launch_cg_step2(hipStream_t st, int32_t n, double *x, double *r, const double *p,
@@ -1362,33 +1490,45 @@ void launch_gmres_mgs_fold(hipStream_t st, int32_t n, double *w, const double *v
 
 void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,
                        double *y, const DevScalars *sin, DevScalars *sout, const double *part_rho,
-                       const double *part_norm, double *history)
+                       const double *part_norm, double *history, const LeadBox &lead)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_bicg_fold1, dim3(nc), dim3(BLOCK), 0, st, n, p, r, v, inv_diag, y, sin, sout, part_rho,
-                       part_norm, nc, history);
+    if (lead.box && nc >= 3 * FIN_WAVES)
+        hipLaunchKernelGGL(k_bicg_fold1<true>, dim3(nc), dim3(BLOCK), 0, st, n, p, r, v, inv_diag, y, sin, sout, part_rho,
+                           part_norm, nc, history, lead);
+    else
+        hipLaunchKernelGGL(k_bicg_fold1<false>, dim3(nc), dim3(BLOCK), 0, st, n, p, r, v, inv_diag, y, sin, sout, part_rho,
+                           part_norm, nc, history, LeadBox{});
 }
 
 void launch_bicg_fold2(hipStream_t st, int32_t n, const double *r, const double *v, double *sv, const double *inv_diag,
                        double *z, double *part_norm_out, const DevScalars *sin, DevScalars *sout,
-                       const double *part_beta)
+                       const double *part_beta, const LeadBox &lead)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_bicg_fold2, dim3(nc), dim3(BLOCK), 0, st, n, r, v, sv, inv_diag, z, part_norm_out, sin, sout,
-                       part_beta, nc);
+    if (lead.box && nc >= 3 * FIN_WAVES)
+        hipLaunchKernelGGL(k_bicg_fold2<true>, dim3(nc), dim3(BLOCK), 0, st, n, r, v, sv, inv_diag, z, part_norm_out, sin,
+                           sout, part_beta, nc, lead);
+    else
+        hipLaunchKernelGGL(k_bicg_fold2<false>, dim3(nc), dim3(BLOCK), 0, st, n, r, v, sv, inv_diag, z, part_norm_out, sin,
+                           sout, part_beta, nc, LeadBox{});
 }
 
 void launch_bicg_fold3(hipStream_t st, int32_t n, double *x, double *r, const double *sv, const double *t,
                        const double *y, const double *z, const double *rr, double *part_rho_out, double *part_norm_out,
                        const DevScalars *sin, DevScalars *sout, const double *part_gamma, const double *part_tt,
-                       const double *part_snorm, double *history, int turn)
+                       const double *part_snorm, double *history, int turn, const LeadBox &lead)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_bicg_fold3, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr, part_rho_out,
-                       part_norm_out, sin, sout, part_gamma, part_tt, part_snorm, nc, history, turn);
+    if (lead.box && nc >= 3 * FIN_WAVES)
+        hipLaunchKernelGGL(k_bicg_fold3<true>, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr, part_rho_out,
+                           part_norm_out, sin, sout, part_gamma, part_tt, part_snorm, nc, history, turn, lead);
+    else
+        hipLaunchKernelGGL(k_bicg_fold3<false>, dim3(nc), dim3(BLOCK), 0, st, n, x, r, sv, t, y, z, rr, part_rho_out,
+                           part_norm_out, sin, sout, part_gamma, part_tt, part_snorm, nc, history, turn, LeadBox{});
 }
 
 void launch_gmres_scale(hipStream_t st, int32_t n, double *out, const double *in,

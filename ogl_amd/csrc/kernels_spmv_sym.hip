@@ -265,7 +265,9 @@ __device__ __forceinline__ double2 turn_sym_rows(const TurnSymRegs<ND> &R, unsig
     return acc;
 }
 
-template <int ND, bool FAST>
+// LEAD (more than FUSED_FIN_MAX_CHUNKS chunks): the first 32 workgroups of the launch are the finaliser's wavefronts, every
+// workgroup fetches their sums from the mailbox (leader finalisation, device_common.hpp; k_cg_step1x_fin<true>)
+template <int ND, bool FAST, bool LEAD>
 __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks, SymOffsets off,
                                                        const uint8_t *__restrict__ mask,
                                                        const double *__restrict__ planes,
@@ -276,12 +278,17 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks,
                                                        DevScalars *sout, const double *__restrict__ part_rho,
                                                        const double *__restrict__ part_norm, int n_part,
                                                        double *history, int first,
-                                                       const int *__restrict__ block_order)
+                                                       const int *__restrict__ block_order, LeadBox lbox)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[4];
     __shared__ int sh_stop;
     __shared__ double slot[N_WAVES];
+    __shared__ double lead_words[LEAD ? LEAD_BOX_WORDS / 2 : 1];
+    __shared__ double lead_stage[LEAD ? LEAD_STAGE : 1];
+    __shared__ int lead_timed_out;
+    const uint32_t seq = LEAD ? sin->launch_seq : 0u;
+    if (LEAD) lead_leaders<2>(lbox, seq, part_rho, part_norm, nullptr, n_part, lead_stage);  // (by launch position, not by chunk)
     const int chunk = block_order ? block_order[blockIdx.x] : xcd_chunk(blockIdx.x);
     if (chunk < 0 || chunk >= n_chunks) return;
     const bool lead = chunk == 0;  // the workgroup that stores the scalars and the history entry
@@ -299,13 +306,24 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks,
     const unsigned mm = *reinterpret_cast<const unsigned short *>(mask + rp.row);
     const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
     double pv[2][FIN_VT];
-    load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
+    if (!LEAD) load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
     double2 vx = ld2(x, rp);
     TurnSymRegs<ND> R;
     turn_sym_load<ND, FAST, false>(R, chunk, rp, n_rows, off, planes, p_in, z);
     if (stopped) return;  // (the solve has ended: the lead workgroup has handed the scalars on)
-    double v[2];
-    reduce_partials_as_finaliser<2>(pv, n_part, red, v);
+    double v[2] = {0.0, 0.0};
+    if (LEAD) {
+        if (!lead_wait(lbox, 4 * FIN_WAVES, seq, lead_words, &lead_timed_out)) {
+            if (threadIdx.x == 0) sout->comm_error = sout->stop = 1;
+            return;
+        }
+        if (threadIdx.x == 0) {
+            v[0] = lead_total(lead_words, 0);
+            v[1] = lead_total(lead_words, 1);
+        }
+    } else {
+        reduce_partials_as_finaliser<2>(pv, n_part, red, v);
+    }
     if (threadIdx.x == 0) {
         // FIN_CG_CHECK as in k_cg_step1x_fin (StoppingCriterion.C:71-151)
         const double prev_rho = s_rho, rho = v[0];
@@ -343,6 +361,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_turn_sym(int n_rows, int n_chunks,
                 sout->res = res;
             }
             if (stop) sout->stop = 1;
+            if (LEAD) sout->launch_seq = seq + 1;
         }
     }
     __syncthreads();
@@ -492,18 +511,27 @@ void launch_spmv_sym(hipStream_t st, const DevSym &A, int mode, const double *x,
 
 void launch_cg_turn_sym(hipStream_t st, const DevSym &A, const double *p_in, double *p_out, double *x, const double *z,
                         double *q, double *part_beta, const DevScalars *sin, DevScalars *sout,
-                        const double *part_rho, const double *part_norm, double *history, int first)
+                        const double *part_rho, const double *part_norm, double *history, int first, const LeadBox &lead)
 {
     if (A.n_rows == 0) return;
     const int nc = (int)n_chunks(A.n_rows);
     const dim3 grid(A.block_order ? A.n_blocks : xcd_grid(nc)), block(BLOCK);
+    const bool led = lead.box && nc >= 3 * FIN_WAVES;
     SymOffsets off;
     for (int j = 0; j < SYM_MAX_OFFSETS; ++j) off.d[j] = A.d[j];
     bool fast = A.nd >= 2 && A.d[1] == 1;
     for (int j = 2; j < A.nd; ++j) fast = fast && (A.d[j] % 2 == 0);
-#define OGL_TURN_K(ND, FAST)                                                                                        \
-    hipLaunchKernelGGL((k_cg_turn_sym<ND, FAST>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, p_in, p_out, \
-                       x, z, q, part_beta, sin, sout, part_rho, part_norm, nc, history, first, A.block_order)
+#define OGL_TURN_K(ND, FAST)                                                                                                  \
+    do {                                                                                                                      \
+        if (led)                                                                                                              \
+            hipLaunchKernelGGL((k_cg_turn_sym<ND, FAST, true>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes, p_in, \
+                               p_out, x, z, q, part_beta, sin, sout, part_rho, part_norm, nc, history, first, A.block_order,  \
+                               lead);                                                                                         \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_cg_turn_sym<ND, FAST, false>), grid, block, 0, st, A.n_rows, nc, off, A.mask, A.planes,     \
+                               p_in, p_out, x, z, q, part_beta, sin, sout, part_rho, part_norm, nc, history, first,           \
+                               A.block_order, LeadBox{});                                                                     \
+    } while (0)
 #define OGL_TURN_ND(ND)              \
     do {                             \
         if (fast)                    \

@@ -549,6 +549,7 @@ ogl_solver::~ogl_solver()
 {
     drop_cg_graph();
     ledger::pinned_free(h_scal);
+    ledger::dev_free(lead_box);
     for (auto &e : poll_ev)
         if (e) ev_destroy(e);
     for (auto &e : prof_ev)
@@ -2512,6 +2513,7 @@ struct ogl_solver::KrylovRun {
     size_t n_halo = 0;
     double *p0 = nullptr, *p1 = nullptr, *ph = nullptr;  // p of even / odd turns (merged turn), old p at the halo columns
     double *z_kept = nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
+    LeadBox lead{};  // leader finalisation of the folded turn (box == nullptr: every workgroup reduces for itself)
     DevCriterion crit{};
     bool is_final = false;
     int max_checks = 0, max_turns = 0;
@@ -2566,17 +2568,25 @@ int ogl_solver::krylov_plan(KrylovRun &k)
                        nc <= std::min((int)prop("fusedFinMaxChunks", (double)FUSED_FIN_MAX_CHUNKS), FUSED_FIN_MAX_CHUNKS) &&
                        prop("fusedFinalizers", 1.0) != 0.0;
     // small single-rank GKOCG systems: finalisers folded into the step kernels, 3 launches per turn (kernels_krylov.hip)
-    const bool fused = k.fused = !bicg && !gmres && !generic && small;
+    // ... and for LARGER single-rank GKOCG systems the same three launches with the LEADER finalisation (device_common.hpp):
+    // workgroup 0 of the consuming kernel is the finaliser, the others poll its mailbox -- instead of two
+    // single-workgroup launches (10 + 7 us at 10 M rows) and their dispatch gaps per turn (property leadFinalizers)
+    const bool lead_any = !multi && !small && nc >= 3 * 16 && prop("leadFinalizers", 1.0) != 0.0;
+    const bool lead_ok = lead_any && !bicg && !gmres && !generic;
+    bool fused = k.fused = !bicg && !gmres && !generic && (small || lead_ok);
+    k.lead = LeadBox{};
     k.s2 = s + 1;
     // ... and the same for small single-rank GKOBiCGStab systems: three finalisers folded into step_1 / step_2 / step_3
     // (k_bicg_fold1/2/3: 5 launches per turn instead of 8, plus the preconditioner's own)
-    k.bicg_fold = bicg && small && prop("bicgFold", 1.0) != 0.0;
+    // (larger systems: the same five launches with the leader finalisation, any preconditioner -- the 2 M-row momentum
+    //  systems of configs[2] spend a tenth of a turn in three single-workgroup launches and their gaps)
+    k.bicg_fold = bicg && (small || lead_any) && prop("bicgFold", 1.0) != 0.0;
     // ... and for small single-rank GKOGMRES systems the finaliser between two Gram-Schmidt links is folded into the next
     // link's kernel (k_gmres_mgs_fold: one launch per link instead of two)
     k.gmres_fold = gmres && small && prop("gmresFold", 1.0) != 0.0;
     k.slot_s[0] = s;
     k.slot_s[1] = k.s2;
-    props["fusedFinalizersInUse"] = (fused || k.bicg_fold || k.gmres_fold) ? 1.0 : 0.0;
+    props["fusedFinalizersInUse"] = (((fused || k.bicg_fold) && small) || k.gmres_fold) ? 1.0 : 0.0;
     // ... and on half storage step_1x(_fin) and the SpMV are one kernel (k_cg_turn_sym, k_cg_turn_sym_big): 2 launches
     // per turn for small systems, 4 for larger ones, p alternating between two buffers (single rank: with halos the
     // put and the wait for the neighbours' puts would sit in one kernel)
@@ -2589,7 +2599,7 @@ int ogl_solver::krylov_plan(KrylovRun &k)
     // nothing to put and only waits for a put of the PREVIOUS launch.  Every rank must run the same turn (what the
     // neighbours put differs): agreed below together with the global row count.
     bool merged = !bicg && !gmres && !generic && nc >= 1 && use_sym() && cfg.matrix_format != OGL_FORMAT_ELL &&
-                  (fused ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
+                  ((fused && small) ? prop("fusedTurn", 1.0) != 0.0 : prop("fusedTurnBig", sym().stream ? 0.0 : 1.0) != 0.0);
     if (multi)
         merged = merged && peer_halo && prop("haloFused", 1.0) != 0.0 && prop("fusedTurnMulti", 1.0) != 0.0 &&
                  !peer_safe_wait();
@@ -2606,6 +2616,22 @@ int ogl_solver::krylov_plan(KrylovRun &k)
         k.n_global = got[0];
         merged = got[1] == 0.0;
     }
+    if ((lead_ok && fused) || (lead_any && k.bicg_fold)) {
+        // (with the merged kernel two launches per turn, k_cg_turn_sym<.., LEAD> | k_cg_step2r_fin<LEAD>; that kernel has no
+        //  streaming instantiation: the merge is on by default only where matrix and vectors live in the Infinity Cache)
+        if (!lead_box) {
+            void *b = nullptr;
+            OGL_HIP_CHECK(ledger::dev_malloc(&b, LEAD_REPLICAS * LEAD_REPLICA_STRIDE * sizeof(unsigned long long), /*fine_grained=*/true));
+            lead_box = static_cast<unsigned long long *>(b);
+        }
+        // (tags restart at 1 with every solve: no word of an earlier solve may survive)
+        OGL_HIP_CHECK(hipMemsetAsync(lead_box, 0, LEAD_REPLICAS * LEAD_REPLICA_STRIDE * sizeof(unsigned long long), st));
+        k.lead.box = lead_box;
+        k.lead.timeout_ticks = (long long)(prop("leadTimeoutS", 10.0) * 1e8);
+        k.lead.early_loads = prop("leadEarlyLoads", 1.0) != 0.0 ? 1 : 0;
+    }
+    props["leadFinalizersInUse"] = k.lead.box ? 1.0 : 0.0;
+    props["fusedFinalizersInUse"] = (((fused || k.bicg_fold) && small) || k.gmres_fold) ? 1.0 : 0.0;
     k.merged = merged;
     k.fused2 = fused && merged;
     k.merged_halo = merged && multi && pat.non_local_nnz > 0;  // (a rank without neighbours: the single-rank kernel)
@@ -2897,10 +2923,10 @@ int ogl_solver::turn_cg_two_launch(KrylovRun &k, int enq, int pe)
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
     launch_cg_turn_sym(st, sym(), k.p_of_turn(enq), k.p_of_turn(enq + 1), d_x.p, k.z_kept ? k.z_kept : d_r.p,
-                       d_q.p, d_part2.p, k.s, k.s2, d_part0.p, d_part1.p, d_history.p, enq == 0 ? 1 : 0);
+                       d_q.p, d_part2.p, k.s, k.s2, d_part0.p, d_part1.p, d_history.p, enq == 0 ? 1 : 0, k.lead);
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
-    launch_cg_step2r_fin(st, k.n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p, k.z_kept);
+    launch_cg_step2r_fin(st, k.n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p, k.z_kept, k.lead);
     return OGL_OK;
 }
 
@@ -2912,12 +2938,12 @@ int ogl_solver::turn_cg_three_launch(KrylovRun &k, int enq, int pe)
     const int n = k.n;
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
     launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_r.p, precond, k.s, k.s2, d_part0.p, d_part1.p, d_history.p,
-                         enq == 0 ? 1 : 0);
+                         enq == 0 ? 1 : 0, k.lead);
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
     OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, k.s2));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
-    launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p);
+    launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p, nullptr, k.lead);
     return OGL_OK;
 }
 
@@ -2983,7 +3009,7 @@ int ogl_solver::turn_bicg_folded(KrylovRun &k, int enq, int pe)
     double *y = k.y, *z = k.z;
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
     launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, y, slot_s[cur], slot_s[cur ^ 1], d_part0.p,
-                      d_part1.p, d_history.p);
+                      d_part1.p, d_history.p, k.lead);
     cur ^= 1;
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     if (k.generic) apply_preconditioner(d_p.p, y, slot_s[cur]);
@@ -2991,12 +3017,12 @@ int ogl_solver::turn_bicg_folded(KrylovRun &k, int enq, int pe)
     OGL_TRY(dist_spmv(SPMV_PLAIN, y, nullptr, d_v.p, SpmvDots{d_rr.p, d_part2.p, nullptr}, slot_s[cur]));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
     launch_bicg_fold2(st, n, d_r.p, d_v.p, d_s.p, precond, z, d_part3.p, slot_s[cur], slot_s[cur ^ 1],
-                      d_part2.p);
+                      d_part2.p, k.lead);
     cur ^= 1;
     if (k.generic) apply_preconditioner(d_s.p, z, slot_s[cur]);
     OGL_TRY(dist_spmv(SPMV_PLAIN, z, nullptr, d_t.p, SpmvDots{d_s.p, d_part4.p, d_part5.p}, slot_s[cur]));
     launch_bicg_fold3(st, n, d_x.p, d_r.p, d_s.p, d_t.p, y, z, d_rr.p, d_part0.p, d_part1.p, slot_s[cur],
-                      slot_s[cur ^ 1], d_part4.p, d_part5.p, d_part3.p, d_history.p, enq);
+                      slot_s[cur ^ 1], d_part4.p, d_part5.p, d_part3.p, d_history.p, enq, k.lead);
     cur ^= 1;
     return OGL_OK;
 }
@@ -3124,7 +3150,8 @@ int ogl_solver::krylov_loop(KrylovRun &k)
             (uintptr_t)d_symx_chunks_general.p, (uintptr_t)d_symx_chunks_general.n, (uintptr_t)d_symx_mask.p,
             (uintptr_t)d_symx_ex_rowptr.p, (uintptr_t)d_symx_ex_cols.p, (uintptr_t)d_symx_ex_vals.p,
             (uintptr_t)d_symx_ex_lrow.p, (uintptr_t)symx_fast, (uintptr_t)d_spill_chunks.p, (uintptr_t)d_z.p,
-            (uintptr_t)d_band_order.p, (uintptr_t)d_band_order.n, (uintptr_t)d_s21_far_idx.p, (uintptr_t)d_s21_far_col.p};
+            (uintptr_t)d_band_order.p, (uintptr_t)d_band_order.n, (uintptr_t)d_s21_far_idx.p, (uintptr_t)d_s21_far_col.p,
+            (uintptr_t)k.lead.box, (uintptr_t)k.lead.early_loads};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) {
                 (void)hipGraphExecDestroy(cg_graph);
@@ -3179,10 +3206,11 @@ int ogl_solver::krylov_finish(KrylovRun &k, ogl_perf *perf)
     DevScalars *s = k.s, *s2 = k.s2;
     const bool bicg = k.bicg, gmres = k.gmres, fused = k.fused, bicg_fold = k.bicg_fold;
     if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
-        launch_cg_step1x_fin(st, n, k.p_of_turn(k.enq), d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0);
+        launch_cg_step1x_fin(st, n, k.p_of_turn(k.enq), d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0,
+                             k.lead);
     if (bicg_fold) {  // the check that closes the last turn run so far (a plain copy of the scalars when the solve has stopped)
         launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, k.y, k.slot_s[k.cur], k.slot_s[k.cur ^ 1], d_part0.p,
-                          d_part1.p, d_history.p);
+                          d_part1.p, d_history.p, k.lead);
         k.cur ^= 1;
     }
     OGL_HIP_CHECK(hipStreamSynchronize(st));

@@ -412,6 +412,7 @@ struct ogl_solver {
     ogl::DevBuf<double> d_history;
     ogl::DevScalars *h_scal = nullptr;  // pinned, 2 slots
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    unsigned long long *lead_box = nullptr;  // LeadBox of the leader finalisation (fine-grained, LEAD_BOX_WORDS words)
     hipEvent_t chk_ev[2] = {nullptr, nullptr};  // brackets one evaluated criterion check per solve (time_for_res_norm_eval)
     bool x_resident = false, b_resident = false;
     ogl::PrecondData own_precond;              // regenerated-for-this-solve preconditioner
