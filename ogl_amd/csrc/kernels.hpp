@@ -64,6 +64,9 @@ struct DevCsr {
     // chunks of rows r and r +- band on one XCD; -1 = no chunk), n_blocks entries; nullptr = the XCD groups above
     const int32_t *block_order = nullptr;
     int32_t n_blocks = 0;
+    // CSR-stream kernel: rounds in which a pass's 4096 products go through LDS (2: half the LDS, six workgroups per CU
+    // instead of four -- measured 199 against 196 us at 216^3: the kernel does not wait for wavefronts; property spmvLdsRounds)
+    int32_t lds_rounds = 1;
 };
 
 // Rows that own non-local entries, for "y += A_non_local * recv" (distributed::Matrix::apply).

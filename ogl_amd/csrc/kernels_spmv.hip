@@ -18,7 +18,10 @@ namespace {
 // STREAM: the matrix is larger than the Infinity Cache -- values and columns are streamed past the caches
 // (non-temporal), which then hold the vectors; a matrix that fits keeps the default policy and is served from
 // the cache turn after turn.
-template <int MODE, int NDOT, bool STREAM>
+// ROUNDS: the 4096 entries a workgroup has in registers per pass go through LDS in this many rounds (products of round h
+// stored, rows summed over that range, next round): 2 rounds = 16 KiB of LDS instead of 32, six resident workgroups per CU
+// instead of four (84 VGPRs), same order of additions.
+template <int MODE, int NDOT, bool STREAM, int ROUNDS>
 __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     int n_rows, int n_chunks, const int *__restrict__ row_ptrs, const int *__restrict__ cols,
     const double *__restrict__ vals, const double *__restrict__ x, const double *__restrict__ b,
@@ -26,7 +29,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     double *__restrict__ dot2_partials, const DevScalars *gate, int xgroup, HaloFused hf,
     const int *__restrict__ block_order)
 {
-    __shared__ __attribute__((aligned(16))) double prod[SPMV_TILE];
+    constexpr int LDS_TILE = SPMV_TILE / ROUNDS;
+    static_assert(LDS_TILE >= CHUNK_ROWS && SPMV_TILE % (ROUNDS * BLOCK * 2) == 0, "rounds of whole groups; halo_fused_add needs CHUNK_ROWS doubles");
+    __shared__ __attribute__((aligned(16))) double prod[LDS_TILE];
     __shared__ double slot[N_WAVES];
     if (gate && gate->stop) return;
     // (banded patterns: the chunks of rows r and r +- band on one XCD, band_block_order -- as the half-storage kernels)
@@ -54,6 +59,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
     // two 16-byte loads the two instructions share their lines and a non-temporal hint fetches them twice:
     // 208 us instead of 186, profiles/spmv_tune_r02.txt.)
     constexpr int GROUPS = SPMV_TILE / (BLOCK * 2);
+    constexpr int RGROUPS = GROUPS / ROUNDS;  // groups per LDS round
     typedef double d2v __attribute__((ext_vector_type(2)));
     typedef int i2v __attribute__((ext_vector_type(2)));
     for (int t0 = nz0 & ~3; t0 < nz1; t0 += SPMV_TILE) {
@@ -71,27 +77,34 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_stream(
                 cc[g] = *reinterpret_cast<const i2v *>(cols + ec);
             }
         }
+        double2 pr[GROUPS];
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const double x0 = x[cc[g].x], x1 = x[cc[g].y];
-            double2 p0;
-            p0.x = va[g].x * x0;
-            p0.y = va[g].y * x1;
-            *reinterpret_cast<double2 *>(prod + (g * BLOCK + tid) * 2) = p0;
+            pr[g].x = va[g].x * x0;
+            pr[g].y = va[g].y * x1;
         }
-        __syncthreads();
-        const int t1 = t0 + SPMV_TILE;
 #pragma unroll
-        for (int j = 0; j < ROWS_PER_THREAD; ++j) {
-            const int kb = max(rs[j], t0), ke = min(rs[j + 1], t1);
-            for (int k = kb; k < ke; ++k) {
-                if (MODE == SPMV_RESIDUAL)
-                    acc[j] -= prod[k - t0];
-                else
-                    acc[j] += prod[k - t0];
+        for (int h = 0; h < ROUNDS; ++h) {
+            const int h0 = t0 + h * LDS_TILE;
+            if (ROUNDS > 1 && h0 >= nz1) break;  // (workgroup-uniform)
+#pragma unroll
+            for (int g = 0; g < RGROUPS; ++g)
+                *reinterpret_cast<double2 *>(prod + (g * BLOCK + tid) * 2) = pr[h * RGROUPS + g];
+            __syncthreads();
+            const int h1 = h0 + LDS_TILE;
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+                const int kb = max(rs[j], h0), ke = min(rs[j + 1], h1);
+                for (int k = kb; k < ke; ++k) {
+                    if (MODE == SPMV_RESIDUAL)
+                        acc[j] -= prod[k - h0];
+                    else
+                        acc[j] += prod[k - h0];
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     if (hf.chunk_bptr) halo_fused_add<MODE>(hf, chunk, acc[0], acc[1], prod);
@@ -367,9 +380,17 @@ void launch_spmv(hipStream_t st, const DevCsr &A, int mode, const double *x, con
     const int xg = A.xcd_group > 0 ? A.xcd_group : XCD_GROUP;
     const bool ordered = A.block_order && !A.codes21;
     const dim3 grid(ordered ? A.n_blocks : xcd_grid(nc, xg)), block(BLOCK);
-#define OGL_SPMV_K(MODE, NDOT, STREAM)                                                                     \
-    hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs,  \
-                       A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf, A.block_order)
+#define OGL_SPMV_K(MODE, NDOT, STREAM)                                                                              \
+    do {                                                                                                            \
+        if (A.lds_rounds == 1)                                                                                      \
+            hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM, 1>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs, \
+                               A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf,           \
+                               A.block_order);                                                                      \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_spmv_stream<MODE, NDOT, STREAM, 2>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs, \
+                               A.cols, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf,           \
+                               A.block_order);                                                                      \
+    } while (0)
 #define OGL_SPMV21_K(MODE, NDOT, STREAM)                                                                   \
     hipLaunchKernelGGL((k_spmv_stream21<MODE, NDOT, STREAM>), grid, block, 0, st, A.n_rows, nc, A.row_ptrs, \
                        A.chunks21, A.codes21, A.vals, x, b, y, dots.with, dots.part, dots.part_yy, gate, xg, hf, \

@@ -618,6 +618,7 @@ DevCsr ogl_solver::csr() const
     A.vals = d_vals.p;
     A.stream = 12.0 * (double)pat.local_nnz + 44.0 * (double)pat.n_rows + turn_extra_bytes() > stream_above_bytes();
     A.xcd_group = xcd_group();
+    A.lds_rounds = prop("spmvLdsRounds", 1.0) == 2.0 ? 2 : 1;
     if (d_band_order.n) {
         A.block_order = d_band_order.p;
         A.n_blocks = (int32_t)d_band_order.n;
@@ -3151,7 +3152,7 @@ int ogl_solver::krylov_loop(KrylovRun &k)
             (uintptr_t)d_symx_ex_rowptr.p, (uintptr_t)d_symx_ex_cols.p, (uintptr_t)d_symx_ex_vals.p,
             (uintptr_t)d_symx_ex_lrow.p, (uintptr_t)symx_fast, (uintptr_t)d_spill_chunks.p, (uintptr_t)d_z.p,
             (uintptr_t)d_band_order.p, (uintptr_t)d_band_order.n, (uintptr_t)d_s21_far_idx.p, (uintptr_t)d_s21_far_col.p,
-            (uintptr_t)k.lead.box, (uintptr_t)k.lead.early_loads};
+            (uintptr_t)k.lead.box, (uintptr_t)k.lead.early_loads, (uintptr_t)(prop("spmvLdsRounds", 1.0) == 2.0)};
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) {
                 (void)hipGraphExecDestroy(cg_graph);
