@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -102,10 +103,17 @@ RcclApi &rccl()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // OGL_RCCL_LIBRARY: a site's own build of RCCL -- or the test suite's stand-in (tests/cpp/rccl_standin.cpp), with
+        // which this transport runs with several ranks on a box that has one GPU.  Named explicitly it is the only candidate.
+        const char *site = std::getenv("OGL_RCCL_LIBRARY");
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) {
-            api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (api.handle) break;
+        if (site && *site) {
+            api.handle = dlopen(site, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *n : names) {
+                api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (api.handle) break;
+            }
         }
         if (!api.handle) {
             api.error = std::string("cannot load librccl: ") + dlerror();

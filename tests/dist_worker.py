@@ -87,8 +87,10 @@ def gather_global(case, x):
 
 
 def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
+    # (the stand-in for librccl adds the ranks' contributions in rank order, like the peer mailboxes: tests/cpp/rccl_standin.cpp)
+    standin = args.mode == "gpu-rccl" and bool(os.environ.get("OGL_RCCL_LIBRARY"))
     A, (rp, cols, vals), nl, comm = oracle_dist_matrix(
-        case, allreduce_rank_order if args.mode == "gpu-peer" else allreduce)
+        case, allreduce_rank_order if (args.mode == "gpu-peer" or standin) else allreduce)
     if glob is None:
         # --no-global (full-size decomposed configs): nothing of the assembled system is built -- b = A x* through the
         # oracle's own distributed product (halo exchange over gloo), every check is rank-local or collective
@@ -160,6 +162,9 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
             uid = [capi.rccl_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             reg.init_rccl(rank, world, uid[0])
+            info = reg.comm_info()
+            assert info.transport == 2 and info.ranks_seen == world and info.n_ranks == world, (
+                info.transport, info.ranks_seen, info.n_ranks)
         cfg = capi.default_config(
             solver=capi.SOLVER_GMRES if args.gmres else
             (capi.SOLVER_BICGSTAB if args.asym else capi.SOLVER_CG), krylov_dim=args.gmres,
@@ -184,7 +189,7 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
             p_rp, p_cols, p_vals, _ = orc.permute_csr(rp, cols, vals, new_id)
             n_rows_, n_cols_, n_vals_, n_ord = orc.permute_non_local(nl[0], nl[1], nl[3], new_id)
             ex2 = make_exchange(None)
-            ar = allreduce_rank_order if args.mode == "gpu-peer" else allreduce
+            ar = allreduce_rank_order if (args.mode == "gpu-peer" or standin) else allreduce
             A = orc.DistMatrix(p_rp, p_cols, p_vals, orc.rowptr_from_rows(case.n_cells, n_rows_), n_cols_,
                                n_vals_, new_id[comm[2]].astype(np.int32), n_halo=n_rows_.size,
                                exchange=lambda s_: ex2(comm[0], comm[1], s_), allreduce=ar,
@@ -235,7 +240,7 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
         with blocked(orc, capi.lib().ogl_reduction_chunk_rows()):
             ref = solve(A, b_o, np.zeros_like(b), inv, **skw)
         ref.x = ref.x[new_id]                      # back to the caller's order
-        if args.mode in ("gpu-host", "gpu-peer"):
+        if args.mode in ("gpu-host", "gpu-peer") or standin:
             # same local trees, same order of the sum over ranks: bit-identical
             assert perf.n_iterations == (ref.n_iterations // 2 if (args.asym and not args.gmres)
                                          else ref.n_iterations)
@@ -250,6 +255,13 @@ def run_case(args, rank, world, case, glob, xs_g, b_g, skw, state, round_no):
 
 
 def main():
+    if os.environ.get("OGL_DIST_FAULT_S"):      # a rank that hangs says where (python stack of every thread) before it is killed
+        import faulthandler
+        import signal
+        import threading
+        faulthandler.dump_traceback_later(float(os.environ["OGL_DIST_FAULT_S"]), exit=False)
+        # ... and, with OGL_SEGV_TRACE=1, the native stack of the main thread (libogl_amd's SIGABRT handler)
+        threading.Timer(float(os.environ["OGL_DIST_FAULT_S"]) + 1.0, lambda: signal.pthread_kill(threading.main_thread().ident, signal.SIGABRT)).start()
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", required=True)
     ap.add_argument("--shape", default="8,8,8")

@@ -22,8 +22,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(n, *args, timeout=600):
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def run_ranks(n, *args, timeout=600, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "dist_worker.py"), *args]
@@ -294,3 +294,69 @@ def test_gpu_peer_starved_puts_fail_loudly():
         pytest.skip("eight ranks x 96^3 did not starve each other on this box")
     assert "halo exchange timed out" in p.stderr or "timed out" in p.stderr, p.stderr[-3000:]
     assert "Mismatched elements" not in p.stderr, p.stderr[-3000:]
+
+
+# ---- the RCCL rung with MORE THAN ONE RANK, on one GPU: a stand-in for librccl ----
+# Real RCCL refuses two ranks on one device, and the pool has 1-GPU boxes: until a node with a device per rank runs the
+# driver's scaling bench, the transport the OpenFOAM hook uses by default (ogl_amd/foam/GKOSolvers.C:76-105) would have
+# executed at world_size 1 only.  tests/cpp/rccl_standin.cpp provides the ten entry points comm.cpp binds (shared memory
+# between the rank processes, stream-synchronous, all-reduce in rank order); through OGL_RCCL_LIBRARY it takes librccl's
+# place, and everything ABOVE the library call runs as it will on a node: ncclCommInitRank + the collective self-test, the
+# grouped ncclSend / ncclRecv of every halo exchange on the communication stream with its two events, the ncclAllReduce
+# between the reduce- and the logic-finaliser, the agreement on pattern rebuilds -- for slabs, 2 x 2 x 2 cuts, random
+# partitions with 1 .. n-1 neighbours per rank, all three solvers; every rank bit-identical to the distributed oracle.
+# Reference: DevicePersistent/ExecutorHandler/ExecutorHandler.H:140-144,167-172, CsrMatrixWrapper.H:195-204.
+STANDIN = os.path.join(ROOT, "tests", "cpp", "librccl_standin.so")
+
+
+def rccl_standin_ranks(n, *args, **kw):
+    if not os.path.exists(STANDIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "librccl_standin.so"])
+    return run_ranks(n, "--mode", "gpu-rccl", *args, extra_env={"OGL_RCCL_LIBRARY": STANDIN}, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,procs,n", [("16,16,16", "1,1,2", 2), ("12,12,12", "2,2,1", 4), ("12,12,12", "1,1,3", 3),
+                                          ("12,12,12", "2,2,2", 8)])
+@pytest.mark.parametrize("precond", [0, 1])
+def test_gpu_rccl_rung_several_ranks(shape, procs, n, precond):
+    rccl_standin_ranks(n, "--shape", shape, "--procs", procs, "--precond", str(precond))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", [(21, 2), (22, 3), (23, 5), (24, 4)])
+def test_gpu_rccl_rung_random_partition(seed, n):
+    # ranks with 1 .. n-1 neighbours, interfaces of any length: asymmetric neighbour lists inside one ncclGroup
+    # (not more ranks than this: every collective of the stand-in is a host round trip of EVERY rank, and seven processes
+    #  time-sliced on one GPU took 10-15 s per collective in places -- slowness of the oversubscribed box, no deadlock:
+    #  the waits ended, gpurun_out/standin7_*.log of round 6)
+    rccl_standin_ranks(n, "--random", str(seed))
+
+
+@pytest.mark.gpu
+def test_gpu_rccl_rung_bicgstab_and_gmres():
+    rccl_standin_ranks(3, "--random", "25", "--asym", "1")
+    rccl_standin_ranks(3, "--random", "26", "--gmres", "15")
+    rccl_standin_ranks(2, "--shape", "10,10,10", "--procs", "1,1,2", "--renumber", "1")
+
+
+@pytest.mark.gpu
+def test_bench_started_plainly_spawns_its_ranks_and_times_the_rccl_rung():
+    """`python bench.py --gpus 2` (no launcher): the parent starts torch.distributed.run as a child before touching the GPU
+    and passes rank 0's JSON line through; with the peer mesh switched off the ladder stops at RCCL (the stand-in), whose
+    self-test and cross-rank self-check pass."""
+    import json
+    if not os.path.exists(STANDIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "librccl_standin.so"])
+    env = dict(os.environ, OGL_RCCL_LIBRARY=STANDIN, OGL_BENCH_PEER="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--edge", "48", "--iters", "40", "--cpu-iters", "0", "--no-general-legs"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    t = d["config"]["transport"]
+    assert t["kind"] == "rccl" and t["rccl_ranks_seen"] == 2, t
+    assert (d["config"]["selfcheck"] or {}).get("ok") is True, d["config"]["selfcheck"]
