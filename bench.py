@@ -207,7 +207,6 @@ def live_pmc_traffic(kernel, argv_tail):
     import glob
     import re
     import shutil
-    import subprocess
     import tempfile
     if _LIVE_PMC_STATE["broken"]:    # (one failed pass: the rest of the run quotes the committed summaries)
         return None, "skipped: " + _LIVE_PMC_STATE["broken"]
@@ -268,7 +267,8 @@ def main():
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
             env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-            raise SystemExit(subprocess.call(cmd, env=env))
+            # (this process has sent its own fd 1 to stderr, see the bottom of the file: the ranks get the REAL stdout)
+            raise SystemExit(subprocess.call(cmd, env=env, stdout=_REAL_STDOUT))
         args.gpus = world
 
     import numpy as np
@@ -584,7 +584,6 @@ def main():
         which connects, runs the cross-rank self-check and two short timed steps of this workload.  Children are
         ordinary child processes (nothing is exec'ed in place), watched with a time limit and ended by PID when it
         passes: a rung that hangs costs its time limit, not the run."""
-        import subprocess
         res = []
         base_port = int(os.environ.get("MASTER_PORT", "29500"))
         for idx, r in enumerate(full_ladder):
@@ -1033,7 +1032,6 @@ def main():
     if rank == 0 and world == 1 and args.cpu_iters != 0 and headline and not args.shuffle and not args.config:
         # a child process: thread placement must be fixed before an OpenMP runtime loads (this process
         # already carries torch's), and the oracle shares nothing with the GPU run
-        import subprocess
         env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
         base = [sys.executable, "-m", "oracle.cpu_baseline", "--edge", str(n), "--precond", args.precond,
                 "--iters", str(args.iters), "--seq-iters", str(args.cpu_iters)]
