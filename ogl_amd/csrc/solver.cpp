@@ -1,6 +1,8 @@
 // solver.cpp -- see solver.hpp.  Citations: reference tree (hpsim/OGL @ 2024-10-16).
 #include "solver.hpp"
 
+#include "launch_key.hpp"
+
 #include "setup_kernels.hpp"
 
 #include <algorithm>
@@ -542,7 +544,7 @@ void ogl_solver::drop_cg_graph()
         ledger::destroyed(ledger::GRAPH_EXEC);
     }
     cg_graph = nullptr;
-    cg_graph_key.clear();
+    cg_graph_key = 0;
 }
 
 ogl_solver::~ogl_solver()
@@ -3131,28 +3133,23 @@ int ogl_solver::krylov_loop(KrylovRun &k)
     auto enqueue_turns = [&](int count) -> int {
         // (the fused-finaliser turn: its first step_1x_fin differs from the later ones -- the first batch runs direct)
         if (!graphable || count != batch || (fused && k.enq == 0)) return krylov_enqueue(k, count);
-        const std::vector<uintptr_t> key{
-            (uintptr_t)k.n, (uintptr_t)batch, (uintptr_t)cfg.matrix_format, (uintptr_t)use_sell(),
-            (uintptr_t)d_p.p, (uintptr_t)d_x.p, (uintptr_t)d_r.p, (uintptr_t)d_q.p, (uintptr_t)precond,
-            (uintptr_t)d_part0.p, (uintptr_t)d_part1.p, (uintptr_t)k.s, (uintptr_t)d_history.p,
-            (uintptr_t)d_row_ptrs.p, (uintptr_t)d_cols.p, (uintptr_t)d_vals.p,
-            (uintptr_t)d_sell_chunks.p, (uintptr_t)d_sell_dict.p, (uintptr_t)d_sell_codes.p,
-            (uintptr_t)d_sell_vals.p, (uintptr_t)d_spill_vals.p, (uintptr_t)n_spill, (uintptr_t)d_ell_cols.p, (uintptr_t)d_ell_vals.p,
-            (uintptr_t)ell_width, (uintptr_t)ell_stride, (uintptr_t)s21_use, (uintptr_t)d_s21_codes.p,
-            (uintptr_t)use_sym(), (uintptr_t)d_sym_planes.p, (uintptr_t)use_symx(), (uintptr_t)d_symx_planes.p,
-            (uintptr_t)fused, (uintptr_t)d_part2.p, (uintptr_t)k.merged, (uintptr_t)d_p2.p, (uintptr_t)k.z_kept,
-            // what the captured kernels take BY VALUE: the pattern the layouts belong to, the distances / mask / order
-            // of the half storage, the cache policy and the workgroup order (a rebuild with the same sizes usually
-            // gets the same pointers back: 32x64x32 -> 64x32x32)
-            (uintptr_t)pat_id, (uintptr_t)sym_nd, (uintptr_t)sym_d[0], (uintptr_t)sym_d[1], (uintptr_t)sym_d[2],
-            (uintptr_t)sym_d[3], (uintptr_t)d_sym_mask.p, (uintptr_t)d_sym_order.p, (uintptr_t)d_sym_order.n,
-            (uintptr_t)band_order_off, (uintptr_t)(int64_t)stream_above_bytes(), (uintptr_t)xcd_group(),
-            (uintptr_t)d_s21_chunks.p, (uintptr_t)d_symx_chunks.p, (uintptr_t)d_symx_chunks.n,
-            (uintptr_t)d_symx_chunks_general.p, (uintptr_t)d_symx_chunks_general.n, (uintptr_t)d_symx_mask.p,
-            (uintptr_t)d_symx_ex_rowptr.p, (uintptr_t)d_symx_ex_cols.p, (uintptr_t)d_symx_ex_vals.p,
-            (uintptr_t)d_symx_ex_lrow.p, (uintptr_t)symx_fast, (uintptr_t)d_spill_chunks.p, (uintptr_t)d_z.p,
-            (uintptr_t)d_band_order.p, (uintptr_t)d_band_order.n, (uintptr_t)d_s21_far_idx.p, (uintptr_t)d_s21_far_col.p,
-            (uintptr_t)k.lead.box, (uintptr_t)k.lead.early_loads, (uintptr_t)(prop("spmvLdsRounds", 1.0) == 2.0)};
+        // the key: every view a captured launcher reads, hashed field by field (launch_key.hpp), the vectors and scalar
+        // slots the turn kernels take, the turn's shape, and the pattern the layouts belong to (a rebuild with the same
+        // sizes usually gets the same pointers back: 32x64x32 -> 64x32x32)
+        KeyHasher kh;
+        kh(k.n), kh(batch), kh(cfg.matrix_format), kh(use_sell()), kh(use_sym()), kh(use_symx()), kh(symx_fast), kh(s21_use);
+        kh(k.fused), kh(k.fused2), kh(k.merged), kh(k.p0), kh(k.p1), kh(k.z_kept), kh(k.s), kh(k.s2), kh(pat_id);
+        for (const void *v : {(const void *)d_p.p, (const void *)d_x.p, (const void *)d_r.p, (const void *)d_q.p,
+                              (const void *)precond, (const void *)d_part0.p, (const void *)d_part1.p,
+                              (const void *)d_part2.p, (const void *)d_history.p, (const void *)d_z.p, (const void *)d_p2.p})
+            kh(v);
+        visit(kh, csr());
+        visit(kh, ell());
+        if (sell_state == 1) visit(kh, sell());
+        if (use_sym()) visit(kh, sym());
+        if (use_symx()) visit(kh, symx());
+        visit(kh, k.lead);
+        const uint64_t key = kh.h;
         if (!cg_graph || key != cg_graph_key) {
             if (cg_graph) {
                 (void)hipGraphExecDestroy(cg_graph);
@@ -3177,6 +3174,7 @@ int ogl_solver::krylov_loop(KrylovRun &k)
             }
             ledger::created(ledger::GRAPH_EXEC);
             cg_graph_key = key;
+            props["hipGraphCaptures"] = prop("hipGraphCaptures", 0.0) + 1.0;
         }
         OGL_HIP_CHECK(hipGraphLaunch(cg_graph, st));
         k.enq += batch;

@@ -376,7 +376,7 @@ struct ogl_solver {
     ogl::DevBuf<unsigned> d_ticket;             // last-workgroup ticket of k_pack_put_signal
     // a full batch of single-rank GKOCG turns captured as a hipGraph (run_krylov)
     hipGraphExec_t cg_graph = nullptr;
-    std::vector<uintptr_t> cg_graph_key;
+    uint64_t cg_graph_key = 0;  // hash of everything the captured launches bake in (launch_key.hpp)
     void drop_cg_graph();  // (every pattern / layout rebuild)
     int setup_peer_halo();
     ogl::PeerHalo peer_halo_args(uint32_t seq) const;
