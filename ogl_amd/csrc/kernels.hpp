@@ -353,7 +353,8 @@ void launch_cg_turn_sym_big(hipStream_t st, const DevSym &A, const double *p_in,
 // a Gram-Schmidt link with the finaliser of the PREVIOUS link folded in (<= FUSED_FIN_MAX_CHUNKS chunks, one rank):
 // vprev != nullptr: H = sum(part_in) -> *h_out, w -= H vprev; then the partials of w . vdot (w . w when vdot is nullptr)
 void launch_gmres_mgs_fold(hipStream_t st, int32_t n, double *w, const double *vprev, double *h_out, const double *vdot,
-                           const double *part_in, double *part_out, const DevScalars *gate);
+                           const double *part_in, double *part_out, const DevScalars *gate, const LeadBox &lead = LeadBox{},
+                           uint32_t tag = 0);  // (lead.box: leader finalisation, tag = a number no earlier launch of the solve used)
 // GKOBiCGStab with the finalisers folded into the step kernels (<= FUSED_FIN_MAX_CHUNKS chunks, one rank; kernels_krylov.hip):
 // scalars go sin -> sout; a kernel never writes a partial array it reads
 void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,

@@ -1042,25 +1042,38 @@ __global__ __launch_bounds__(BLOCK) void k_gmres_mgs(int n, double *__restrict__
 // H(k, it) = sum of the link's partials) folded into the next link's kernel -- every workgroup reduces the partials
 // itself in the finaliser's order (same bits), workgroup 0 stores H(k, it).  One launch per link instead of two; the
 // link reads `part_in` and writes `part_out` (never the same array: another workgroup may still be reducing).
+// LEAD (any number of chunks): leader finalisation (device_common.hpp); the tag of the launch comes from the host -- these
+// turns are never captured in a graph, and there are no ping-pong scalar slots here to carry a sequence number
+template <bool LEAD>
 __global__ __launch_bounds__(BLOCK) void k_gmres_mgs_fold(int n, double *__restrict__ w,
                                                           const double *__restrict__ vprev,
                                                           double *__restrict__ h_out,
                                                           const double *__restrict__ vdot,
                                                           const double *__restrict__ part_in, int n_part,
-                                                          double *__restrict__ part_out, const DevScalars *gate)
+                                                          double *__restrict__ part_out, const DevScalars *gate,
+                                                          LeadBox lead, uint32_t tag)
 {
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh_h;
     __shared__ double slot[N_WAVES];
+    __shared__ double lead_words[LEAD ? LEAD_BOX_WORDS / 2 : 1];
+    __shared__ double lead_stage[LEAD ? LEAD_STAGE : 1];
+    __shared__ int lead_timed_out;
+    if (LEAD && vprev) lead_leaders<1>(lead, tag, part_in, nullptr, nullptr, n_part, lead_stage);
     if (gate && gate->stop) return;
     const int chunk = blockIdx.x;
     const RowPair rp = my_rows(chunk, n);
     double2 vw = ld2(w, rp);
     if (vprev) {
         const double2 vp = ld2(vprev, rp);
-        double pv[2][FIN_VT], v[2];
-        load_partials_as_finaliser<1>(part_in, nullptr, n_part, pv);
-        reduce_partials_as_finaliser<1>(pv, n_part, red, v);
+        double pv[2][FIN_VT], v[2] = {0.0, 0.0};
+        if (LEAD) {
+            if (!lead_wait(lead, 2 * FIN_WAVES, tag, lead_words, &lead_timed_out)) return;  // (the host's poll of the solve times out)
+            if (threadIdx.x == 0) v[0] = lead_total(lead_words, 0);
+        } else {
+            load_partials_as_finaliser<1>(part_in, nullptr, n_part, pv);
+            reduce_partials_as_finaliser<1>(pv, n_part, red, v);
+        }
         if (threadIdx.x == 0) {
             sh_h = v[0];
             if (blockIdx.x == 0) *h_out = v[0];  // FIN_GMRES_H
@@ -1480,12 +1493,16 @@ void launch_bicg_step3(hipStream_t st, int32_t n, double *x, double *r, const do
 }
 
 void launch_gmres_mgs_fold(hipStream_t st, int32_t n, double *w, const double *vprev, double *h_out, const double *vdot,
-                           const double *part_in, double *part_out, const DevScalars *gate)
+                           const double *part_in, double *part_out, const DevScalars *gate, const LeadBox &lead, uint32_t tag)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
-    hipLaunchKernelGGL(k_gmres_mgs_fold, dim3(nc), dim3(BLOCK), 0, st, n, w, vprev, h_out, vdot, part_in, nc, part_out,
-                       gate);
+    if (lead.box && nc >= 3 * FIN_WAVES)
+        hipLaunchKernelGGL(k_gmres_mgs_fold<true>, dim3(nc), dim3(BLOCK), 0, st, n, w, vprev, h_out, vdot, part_in, nc,
+                           part_out, gate, lead, tag);
+    else
+        hipLaunchKernelGGL(k_gmres_mgs_fold<false>, dim3(nc), dim3(BLOCK), 0, st, n, w, vprev, h_out, vdot, part_in, nc,
+                           part_out, gate, LeadBox{}, 0u);
 }
 
 void launch_bicg_fold1(hipStream_t st, int32_t n, double *p, const double *r, const double *v, const double *inv_diag,

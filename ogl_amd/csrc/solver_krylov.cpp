@@ -194,6 +194,7 @@ struct ogl_solver::KrylovRun {
     double *p0 = nullptr, *p1 = nullptr, *ph = nullptr;  // p of even / odd turns (merged turn), old p at the halo columns
     double *z_kept = nullptr;  // z = r / d, left behind by step_2r_fin for the gathers
     LeadBox lead{};  // leader finalisation of the folded turn (box == nullptr: every workgroup reduces for itself)
+    uint32_t lead_tag = 0;  // GKOGMRES: tag of the last leader launch (host-side sequence, from 1 per solve)
     DevCriterion crit{};
     bool is_final = false;
     int max_checks = 0, max_turns = 0;
@@ -263,10 +264,12 @@ int ogl_solver::krylov_plan(KrylovRun &k)
     k.bicg_fold = bicg && (small || lead_any) && prop("bicgFold", 1.0) != 0.0;
     // ... and for small single-rank GKOGMRES systems the finaliser between two Gram-Schmidt links is folded into the next
     // link's kernel (k_gmres_mgs_fold: one launch per link instead of two)
-    k.gmres_fold = gmres && small && prop("gmresFold", 1.0) != 0.0;
+    // (larger systems: with the leader finalisation on request only, property gmresLead -- a Gram-Schmidt link moves 16 N
+    //  bytes, and the wait for the leaders costs it what the finaliser launch did: 216^3 GMRES(30) 1068 against 1047 us per turn)
+    k.gmres_fold = gmres && (small || (lead_any && prop("gmresLead", 0.0) != 0.0)) && prop("gmresFold", 1.0) != 0.0;
     k.slot_s[0] = s;
     k.slot_s[1] = k.s2;
-    props["fusedFinalizersInUse"] = (((fused || k.bicg_fold) && small) || k.gmres_fold) ? 1.0 : 0.0;
+    props["fusedFinalizersInUse"] = ((fused || k.bicg_fold || k.gmres_fold) && small) ? 1.0 : 0.0;
     // ... and on half storage step_1x(_fin) and the SpMV are one kernel (k_cg_turn_sym, k_cg_turn_sym_big): 2 launches
     // per turn for small systems, 4 for larger ones, p alternating between two buffers (single rank: with halos the
     // put and the wait for the neighbours' puts would sit in one kernel)
@@ -296,7 +299,7 @@ int ogl_solver::krylov_plan(KrylovRun &k)
         k.n_global = got[0];
         merged = got[1] == 0.0;
     }
-    if ((lead_ok && fused) || (lead_any && k.bicg_fold)) {
+    if ((lead_ok && fused) || (lead_any && (k.bicg_fold || k.gmres_fold))) {
         // (with the merged kernel two launches per turn, k_cg_turn_sym<.., LEAD> | k_cg_step2r_fin<LEAD>; that kernel has no
         //  streaming instantiation: the merge is on by default only where matrix and vectors live in the Infinity Cache)
         if (!lead_box) {
@@ -311,7 +314,7 @@ int ogl_solver::krylov_plan(KrylovRun &k)
         k.lead.early_loads = prop("leadEarlyLoads", 1.0) != 0.0 ? 1 : 0;
     }
     props["leadFinalizersInUse"] = k.lead.box ? 1.0 : 0.0;
-    props["fusedFinalizersInUse"] = (((fused || k.bicg_fold) && small) || k.gmres_fold) ? 1.0 : 0.0;
+    props["fusedFinalizersInUse"] = ((fused || k.bicg_fold || k.gmres_fold) && small) ? 1.0 : 0.0;
     k.merged = merged;
     k.fused2 = fused && merged;
     k.merged_halo = merged && multi && pat.non_local_nnz > 0;  // (a rank without neighbours: the single-rank kernel)
@@ -552,10 +555,11 @@ int ogl_solver::turn_gmres(KrylovRun &k, int enq, int pe)
         double *pin = d_part1.p, *pout = d_part0.p;  // (a link reads the partials of the one before it)
         for (int j = 0; j <= it; ++j) {
             launch_gmres_mgs_fold(st, n, nx, j > 0 ? d_V.p + (size_t)(j - 1) * ldv : nullptr,
-                                  j > 0 ? k.gm_h(j - 1, it) : nullptr, d_V.p + (size_t)j * ldv, pin, pout, s);
+                                  j > 0 ? k.gm_h(j - 1, it) : nullptr, d_V.p + (size_t)j * ldv, pin, pout, s, k.lead,
+                                  ++k.lead_tag);
             std::swap(pin, pout);
         }
-        launch_gmres_mgs_fold(st, n, nx, v_it, k.gm_h(it, it), nullptr, pin, pout, s);
+        launch_gmres_mgs_fold(st, n, nx, v_it, k.gm_h(it, it), nullptr, pin, pout, s, k.lead, ++k.lead_tag);
         fg.part[0] = pout;
         fg.check_after = 1;
         OGL_TRY(finalize(FIN_GMRES_COL, fg));  // ||nx||, Givens, residual-norm recurrence, the next turn's check

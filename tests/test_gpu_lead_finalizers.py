@@ -184,3 +184,30 @@ def test_bicgstab_stop_by_tolerance(reg, oracle, asym_system, tol, precond):
         ref = oracle.bicgstab(A, b, np.zeros_like(b), bicg_precond(oracle, csr, precond), tolerance=tol, rel_tol=0.0, max_iter=400)
     assert ref.n_iterations // 2 == got[1.0][1]
     np.testing.assert_array_equal(got[1.0][0], ref.x)
+
+
+# ---- GKOGMRES: k_gmres_mgs_fold<true> (one launch per Gram-Schmidt link instead of two) ----
+@pytest.mark.parametrize("precond", [capi.PRECOND_BJ, capi.PRECOND_NONE])
+@pytest.mark.parametrize("max_iter", [1, 7, 12, 25])
+def test_gmres_same_bits_as_the_separate_finalisers_and_the_oracle(reg, oracle, asym_system, precond, max_iter):
+    case, b, A, (rp, cols, vals) = asym_system
+    got = {}
+    for lead in (1.0, 0.0):
+        cfg = capi.default_config(solver=capi.SOLVER_GMRES, krylov_dim=10, preconditioner=precond, tolerance=0.0, rel_tol=0.0,
+                                  max_iter=max_iter, export_res=1, adapt_min_iter=0, update_init_guess=1)
+        s = reg.solver(f"lead_gmres_{precond}_{lead}", cfg)
+        s.set_property("leadFinalizers", lead)
+        s.set_property("gmresLead", lead)        # (off by default: no faster than the finaliser launches it replaces)
+        s.set_matrix(case)
+        x, perf = s.solve(b, np.zeros_like(b))
+        assert s.get_property("leadFinalizersInUse") == lead and s.get_property("fusedFinalizersInUse") == 0.0
+        got[lead] = (x, perf.n_iterations, s.history().copy())
+    assert got[1.0][1] == got[0.0][1]
+    np.testing.assert_array_equal(got[1.0][2], got[0.0][2])
+    np.testing.assert_array_equal(got[1.0][0], got[0.0][0])
+    P = oracle.Precond(rp, cols, vals, 1) if precond else None
+    with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+        ref = oracle.gmres(A, b, np.zeros_like(b), P, krylov_dim=10, tolerance=0.0, rel_tol=0.0, max_iter=max_iter)
+    assert ref.n_iterations == got[1.0][1]
+    np.testing.assert_array_equal(got[1.0][2], ref.history)
+    np.testing.assert_array_equal(got[1.0][0], ref.x)
