@@ -459,6 +459,7 @@ struct ogl_solver {
     int gmres_update_x(KrylovRun &k, int cols, const ogl::DevScalars *gate);
     int turn_gmres(KrylovRun &k, int enq, int pe);
     int turn_cg_generic(KrylovRun &k, int enq, int pe);
+    int turn_cg_generic_led(KrylovRun &k, int enq, int pe);
     int turn_cg_two_launch(KrylovRun &k, int enq, int pe);
     int turn_cg_three_launch(KrylovRun &k, int enq, int pe);
     int turn_cg_merged(KrylovRun &k, int enq, int pe);

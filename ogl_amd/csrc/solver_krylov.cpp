@@ -253,8 +253,10 @@ int ogl_solver::krylov_plan(KrylovRun &k)
     // workgroup 0 of the consuming kernel is the finaliser, the others poll its mailbox -- instead of two
     // single-workgroup launches (10 + 7 us at 10 M rows) and their dispatch gaps per turn (property leadFinalizers)
     const bool lead_any = !multi && !small && nc >= 3 * 16 && prop("leadFinalizers", 1.0) != 0.0;
-    const bool lead_ok = lead_any && !bicg && !gmres && !generic;
-    bool fused = k.fused = !bicg && !gmres && !generic && (small || lead_ok);
+    // (GKOCG with a materialised z -- block Jacobi, ISAI -- takes the leader finalisation too: the same two kernels with
+    //  z in r's place, the preconditioner's launches between step_2r and the next turn's check)
+    const bool lead_ok = lead_any && !bicg && !gmres;
+    bool fused = k.fused = !bicg && !gmres && ((small && !generic) || lead_ok);
     k.lead = LeadBox{};
     k.s2 = s + 1;
     // ... and the same for small single-rank GKOBiCGStab systems: three finalisers folded into step_1 / step_2 / step_3
@@ -599,6 +601,24 @@ int ogl_solver::turn_cg_generic(KrylovRun &k, int, int pe)
     return OGL_OK;
 }
 
+// ... with the leader finalisation (single rank, more than 1,024 chunks): [check of the previous turn + pending x update +
+// step_1 on the materialised z] | SpMV | [beta + step_2r] | M^-1 (z and the partials of r.z); scalars s -> s2 -> s
+int ogl_solver::turn_cg_generic_led(KrylovRun &k, int enq, int pe)
+{
+    hipStream_t st = k.st;
+    const int n = k.n;
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
+    launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_z.p, nullptr, k.s, k.s2, d_part0.p, d_part1.p, d_history.p, enq == 0 ? 1 : 0,
+                         k.lead);
+    if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, k.s2));
+    if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
+    launch_cg_step2r_fin(st, n, d_r.p, d_q.p, nullptr, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p, nullptr, k.lead);
+    apply_preconditioner(d_r.p, d_z.p, k.s, d_part0.p);  // z = M^-1 r and the partials of r.z (over step_2r's r.r)
+    return OGL_OK;
+}
+
 // small single-rank GKOCG on half storage, 2 launches: [check of the previous turn + pending x update + step_1 + SpMV] |
 // beta + step_2r
 int ogl_solver::turn_cg_two_launch(KrylovRun &k, int enq, int pe)
@@ -765,7 +785,7 @@ int ogl_solver::krylov_enqueue(KrylovRun &k, int count)
         else if (k.bicg)
             OGL_TRY(k.bicg_fold ? turn_bicg_folded(k, enq, pe) : turn_bicg(k, enq, pe));
         else if (k.generic)
-            OGL_TRY(turn_cg_generic(k, enq, pe));
+            OGL_TRY(k.fused ? turn_cg_generic_led(k, enq, pe) : turn_cg_generic(k, enq, pe));
         else if (k.fused2)
             OGL_TRY(turn_cg_two_launch(k, enq, pe));
         else if (k.fused)
@@ -886,8 +906,8 @@ int ogl_solver::krylov_finish(KrylovRun &k, ogl_perf *perf)
     DevScalars *s = k.s, *s2 = k.s2;
     const bool bicg = k.bicg, gmres = k.gmres, fused = k.fused, bicg_fold = k.bicg_fold;
     if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
-        launch_cg_step1x_fin(st, n, k.p_of_turn(k.enq), d_x.p, d_r.p, precond, s, s2, d_part0.p, d_part1.p, d_history.p, 0,
-                             k.lead);
+        launch_cg_step1x_fin(st, n, k.p_of_turn(k.enq), d_x.p, k.generic ? d_z.p : d_r.p, k.generic ? nullptr : precond, s, s2,
+                             d_part0.p, d_part1.p, d_history.p, 0, k.lead);
     if (bicg_fold) {  // the check that closes the last turn run so far (a plain copy of the scalars when the solve has stopped)
         launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, k.y, k.slot_s[k.cur], k.slot_s[k.cur ^ 1], d_part0.p,
                           d_part1.p, d_history.p, k.lead);

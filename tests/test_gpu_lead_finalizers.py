@@ -211,3 +211,44 @@ def test_gmres_same_bits_as_the_separate_finalisers_and_the_oracle(reg, oracle, 
     assert ref.n_iterations == got[1.0][1]
     np.testing.assert_array_equal(got[1.0][2], ref.history)
     np.testing.assert_array_equal(got[1.0][0], ref.x)
+
+
+# ---- GKOCG with a materialised z (block Jacobi, ISAI): turn_cg_generic_led -- the same two kernels with z in r's place ----
+@pytest.mark.parametrize("pc,k", [(capi.PRECOND_BJ, 4), (capi.PRECOND_ISAI, 1), (capi.PRECOND_GISAI, 1)])
+@pytest.mark.parametrize("max_iter", [1, 2, 17, 40])
+def test_cg_with_a_block_preconditioner(reg, oracle, system, pc, k, max_iter):
+    case, b, A, _ = system
+    rp, cols, vals = oracle_matrix(oracle, case)[1]
+    got = {}
+    for lead in (1.0, 0.0):
+        s = solver(reg, f"lead_gen_{pc}_{k}_{lead}", case, lead, preconditioner=pc, max_block_size=k, tolerance=0.0, rel_tol=0.0,
+                   max_iter=max_iter)
+        x, perf = s.solve(b, np.zeros_like(b))
+        assert s.get_property("leadFinalizersInUse") == lead
+        got[lead] = (x, perf.n_iterations, s.history().copy(), perf.final_residual)
+    assert got[1.0][1] == got[0.0][1] == max_iter + 1
+    np.testing.assert_array_equal(got[1.0][2], got[0.0][2])
+    np.testing.assert_array_equal(got[1.0][0], got[0.0][0])
+    assert got[1.0][3] == got[0.0][3]
+    P = (oracle.Precond(rp, cols, vals, k) if pc == capi.PRECOND_BJ
+         else oracle.Precond(rp, cols, vals, isai="spd" if pc == capi.PRECOND_ISAI else "general"))
+    with blocked(oracle, capi.lib().ogl_reduction_chunk_rows()):
+        ref = oracle.cg(A, b, np.zeros_like(b), P, tolerance=0.0, rel_tol=0.0, max_iter=max_iter)
+    assert ref.n_iterations == got[1.0][1]
+    np.testing.assert_array_equal(got[1.0][2], ref.history)
+    np.testing.assert_array_equal(got[1.0][0], ref.x)
+
+
+def test_cg_with_a_block_preconditioner_stops_by_tolerance(reg, oracle, system):
+    case, b, A, _ = system
+    got = {}
+    for lead in (1.0, 0.0):
+        s = solver(reg, f"lead_gen_tol_{lead}", case, lead, preconditioner=capi.PRECOND_BJ, max_block_size=4, tolerance=1e-7,
+                   rel_tol=0.0, max_iter=500)
+        x, perf = s.solve(b, np.zeros_like(b))
+        x2, perf2 = s.solve(b, np.zeros_like(b))
+        np.testing.assert_array_equal(x2, x)
+        got[lead] = (x, perf.n_iterations, s.history().copy())
+    assert got[1.0][1] == got[0.0][1]
+    np.testing.assert_array_equal(got[1.0][2], got[0.0][2])
+    np.testing.assert_array_equal(got[1.0][0], got[0.0][0])
