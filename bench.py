@@ -675,7 +675,7 @@ def main():
             if prop_or(sv, "symmetricHalfPerChunk", 0.0) == 1.0:
                 layout = "symx"  # ... with per-chunk distances and explicit exceptions (multi-block meshes)
         stream = "true" if prop_or(sv, "spmvStream", 0.0) == 1.0 else "false"
-        kernel = {"csr": f"k_spmv_stream<0, 1, {stream}>", "csr21": f"k_spmv_stream21<0, 1, {stream}>",
+        kernel = {"csr": f"k_spmv_stream<0, 1, {stream}, {int(prop_or(sv, 'spmvLdsRounds', 1.0))}>", "csr21": f"k_spmv_stream21<0, 1, {stream}>",
                   "ell": f"k_spmv_ell<0, 1, {stream}>",
                   "sell": f"k_spmv_sell<0, 1, {stream}>",
                   # (the lean instantiation -- chunks without explicit entries or with simple ones; the general one runs
