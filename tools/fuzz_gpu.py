@@ -118,7 +118,12 @@ def main():
                  #  through the permutation, STREAM decision on the turn's working set, band-aware workgroup order)
                  "bicgFold": float(rng.integers(0, 2)), "gmresFold": float(rng.integers(0, 2)),
                  "isaiSortRows": float(rng.integers(0, 2)), "bjFusedPerm": float(rng.integers(0, 2)),
-                 "streamTurnSet": float(rng.integers(0, 2)), "spmvBandRows": float(rng.choice([-1.0, 0.0, 4096.0]))}
+                 "streamTurnSet": float(rng.integers(0, 2)), "spmvBandRows": float(rng.choice([-1.0, 0.0, 4096.0])),
+                 # (round 6: leader finalisation -- with fusedFinMaxChunks 0 every system of 48 chunks or more takes it --
+                 #  and the CSR-stream kernel's LDS rounds)
+                 "fusedFinMaxChunks": float(rng.choice([1024.0, 0.0])), "leadFinalizers": float(rng.integers(0, 2)),
+                 "leadEarlyLoads": float(rng.integers(0, 2)), "gmresLead": float(rng.integers(0, 2)),
+                 "spmvLdsRounds": float(rng.integers(1, 3))}
         tag = f"case {it}: {kind} n={case.n_cells} sym={case.lower is None} {solver} precond={pc}/{block} " \
               f"{ {k: cfgkw[k] for k in ('compress_indices', 'symmetric_half', 'matrix_format', 'max_iter', 'renumber', 'sparsity_power')} } {props}"
         only = os.environ.get("OGL_FUZZ_ONLY")

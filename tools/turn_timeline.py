@@ -39,9 +39,6 @@ t_first = idx[first] - (per - 1) if solve[idx[first] - 1][2] != spmv and per > 1
 def us(ns):
     return ns / 1e3
 print(f"# solve #{starts.index(lo)} of {len(starts)}: {len(solve)} launches, {names[spmv]} x {spmv}, {per} launches per turn")
-span = solve[-1][1] - solve[0][0]
-busy = sum(r[1] - r[0] for r in solve)
-print(f"# first launch -> end of last: {us(span):.1f} us, inside kernels {us(busy):.1f} us, between kernels {us(span - busy):.1f} us")
 loop_lo, loop_hi = idx[first], idx[-1]
 turns = (len([i for i in idx if i >= loop_lo]) - 1)
 loop_span = solve[loop_hi][0] - solve[loop_lo][0]
@@ -67,7 +64,15 @@ for i in range(loop_lo, loop_hi):
 print("# in-loop averages: launches, mean duration, mean gap in front")
 for n, a in sorted(acc.items(), key=lambda kv: -kv[1][1]):
     print(f"    {a[0]:6d}  {us(a[1] / a[0]):8.2f} us  gap {us(a[2] / a[0]):5.2f} us  {n}")
-tail = solve[loop_hi + 1:]
-print(f"# epilogue (after the last in-loop SpMV): {len(tail)} launches, {us(solve[-1][1] - solve[loop_hi][1]):.1f} us:")
-for r in tail[:40]:
+# the epilogue ends where the host takes over (a gap of more than 100 us: copy-back, the next set_matrix, other legs)
+tail = []
+prev = solve[loop_hi][1]
+for r in solve[loop_hi + 1:]:
+    if r[0] - prev > 100000:
+        break
+    tail.append(r)
+    prev = r[1]
+print(f"# epilogue (after the last in-loop SpMV, up to the first host-side pause): {len(tail)} launches, "
+      f"{us((tail[-1][1] if tail else solve[loop_hi][1]) - solve[loop_hi][1]):.1f} us:")
+for r in tail:
     print(f"    {us(r[0] - solve[loop_hi][1]):9.1f}  {us(r[1] - r[0]):8.1f} us  {r[2]}")
