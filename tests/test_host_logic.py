@@ -172,3 +172,31 @@ def test_adapt_criterion_matches_oracle(oracle):
         got = capi.host_adapt_criterion(cfg, prev_iters, cost)
         exp = oracle.adapt_criterion(2, 3, export, prev_iters, True, 0.6, 100, cost)
         assert got == exp
+
+
+def test_memory_ledger_reads_without_a_device():
+    """ogl_memory_ledger_read is pure bookkeeping: with nothing allocated (no GPU here) every field is 0, and the struct
+    has the layout include/ogl_amd.h declares (14 x int64)."""
+    led = capi.memory_ledger()
+    assert ctypes_sizeof(led) == 14 * 8
+    d = led.as_dict()
+    assert set(d) == {"device_bytes", "device_blocks", "device_peak_bytes", "device_alloc_calls", "pinned_bytes", "pinned_blocks",
+                      "pinned_peak_bytes", "pinned_alloc_calls", "streams", "events", "graph_execs", "events_created",
+                      "graph_execs_created", "unknown_frees"}
+    if not _has_gpu():
+        assert all(v == 0 for v in d.values()), d
+
+
+def ctypes_sizeof(obj):
+    import ctypes
+    return ctypes.sizeof(obj)
+
+
+def _has_gpu():
+    import ctypes
+    n = ctypes.c_int(0)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
+    except OSError:
+        return False
