@@ -252,3 +252,25 @@ def test_cg_with_a_block_preconditioner_stops_by_tolerance(reg, oracle, system):
     assert got[1.0][1] == got[0.0][1]
     np.testing.assert_array_equal(got[1.0][2], got[0.0][2])
     np.testing.assert_array_equal(got[1.0][0], got[0.0][0])
+
+
+@pytest.mark.parametrize("merged", [0.0, 1.0])
+def test_leader_turns_replayed_as_a_graph(reg, system, merged):
+    """hipGraph on request for a system of this size: full batches of 16 leader turns are captured once and replayed (the tag
+    of a launch comes from the scalar slots, the mailbox is cleared outside the graph): same bits as stream launches."""
+    case, b, A, inv = system
+    got = {}
+    for graph in (1.0, 0.0):
+        s = solver(reg, f"lead_graph_{merged}_{graph}", case, 1.0, merged, preconditioner=capi.PRECOND_BJ, tolerance=0.0,
+                   rel_tol=0.0, max_iter=70)
+        s.set_property("hipGraph", graph)
+        x, perf = s.solve(b, np.zeros_like(b))
+        x2, perf2 = s.solve(b, np.zeros_like(b))
+        np.testing.assert_array_equal(x2, x)
+        assert s.get_property("leadFinalizersInUse") == 1.0
+        if graph:
+            assert s.get_property("hipGraphCaptures") >= 1.0
+        got[graph] = (x, perf.n_iterations, s.history().copy())
+    assert got[1.0][1] == got[0.0][1] == 71
+    np.testing.assert_array_equal(got[1.0][2], got[0.0][2])
+    np.testing.assert_array_equal(got[1.0][0], got[0.0][0])
