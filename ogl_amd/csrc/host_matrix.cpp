@@ -896,7 +896,8 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
             // in the two adjacent fronts): on a Voronoi mesh a chunk touches 0.029 distinct 64-byte sectors of x per
             // entry against 0.052 in RCM order.  The better of the two by the gather measure is taken.
             std::vector<ogl_label> curve, curve_old((size_t)N);
-            hilbert_order(N, hooks->centres, curve);
+            if (!(hooks->curve && hooks->curve(N, hooks->centres, curve) && (ogl_label)curve.size() == N))
+                hilbert_order(N, hooks->centres, curve);
             tm.lap("hilbert_order");
             for (ogl_label c = 0; c < N; ++c) curve_old[(size_t)curve[(size_t)c]] = c;
             rep.ratio_curve = gather_sector_ratio(N, p.row_ptrs.data(), p.cols.data(), curve.data(), curve_old.data());
@@ -908,7 +909,8 @@ int choose_numbering(HostPattern &p, int mode, bool try_sell, SellLayout *sell_o
             bool packable = true;
             if ((int64_t)N > ((int64_t)1 << STREAM21_BITS)) {
                 int64_t far = 0;
-                for (ogl_label k0 = 0; k0 < N; k0 += CHUNK_ROWS) {
+                const bool counted = hooks->curve_far && hooks->curve_far(p, curve, curve_old, far);
+                for (ogl_label k0 = 0; !counted && k0 < N; k0 += CHUNK_ROWS) {
                     ogl_label lo = N, hi = 0;
                     const ogl_label k1 = (ogl_label)std::min<int64_t>(N, (int64_t)k0 + CHUNK_ROWS);
                     for (ogl_label k = k0; k < k1; ++k) {

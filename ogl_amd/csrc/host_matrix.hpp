@@ -183,6 +183,11 @@ struct NumberingHooks {
     // cell centres (x, y, z per cell; ogl_ldu_view::cell_centres), nullptr = not given: a second candidate for the
     // order at large -- the cells along a Hilbert curve through their centres -- next to reverse Cuthill-McKee
     const double *centres = nullptr;
+    // ... and the two heavy steps of THAT candidate: the order along the curve (hilbert_order) and the count of entries that
+    // would fall outside their chunk's window of packed columns (both: false = left to the host code)
+    std::function<bool(ogl_label n, const double *centres, std::vector<ogl_label> &new_id)> curve;
+    std::function<bool(const HostPattern &p, const std::vector<ogl_label> &new_id, const std::vector<ogl_label> &old_of,
+                       int64_t &far)> curve_far;
 };
 // new_id[old] = position of cell `old` along the Hilbert curve (16 bits per axis over the bounding box) through the
 // cell centres; ties keep the caller's order

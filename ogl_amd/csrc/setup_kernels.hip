@@ -3,6 +3,8 @@
 // sorted by a key that is unique per entry, so every array comes out the same on every run.
 #include "setup_kernels.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 
 namespace ogl {
@@ -486,6 +488,110 @@ __global__ __launch_bounds__(BLOCK) void k_s21_fill(Stream21Build b, int n_chunk
         }
 }
 
+// ---- Hilbert keys (hilbert_key, host_matrix.cpp: J. Skilling, "Programming the Hilbert curve", AIP Conf. Proc. 707 (2004))
+__device__ inline unsigned long long hilbert_key_dev(uint32_t x, uint32_t y, uint32_t z)
+{
+    constexpr int BITS = 16;
+    uint32_t X[3] = {x, y, z};
+    for (uint32_t Q = 1u << (BITS - 1); Q > 1; Q >>= 1) {
+        const uint32_t P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (X[i] & Q) {
+                X[0] ^= P;
+            } else {
+                const uint32_t t = (X[0] ^ X[i]) & P;
+                X[0] ^= t;
+                X[i] ^= t;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 1; i < 3; ++i) X[i] ^= X[i - 1];
+    uint32_t t = 0;
+    for (uint32_t Q = 1u << (BITS - 1); Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) X[i] ^= t;
+    unsigned long long key = 0;
+    for (int b = BITS - 1; b >= 0; --b)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) key = (key << 1) | ((X[i] >> b) & 1u);
+    return key;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_hilbert_keys(int n, const double *__restrict__ centres, double lo0, double lo1,
+                                                        double lo2, double scale, unsigned long long *__restrict__ keys,
+                                                        int *__restrict__ cells)
+{
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n) return;
+    const double lo[3] = {lo0, lo1, lo2};
+    uint32_t q[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double v = (centres[3 * (size_t)c + d] - lo[d]) * scale;  // (-ffp-contract=off: the host's two roundings)
+        q[d] = (uint32_t)fmin(65535.0, fmax(0.0, v));
+    }
+    keys[c] = hilbert_key_dev(q[0], q[1], q[2]);
+    cells[c] = c;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_invert_order(int n, const int *__restrict__ sorted_cells, int *__restrict__ new_id)
+{
+    const int k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) new_id[sorted_cells[k]] = k;
+}
+
+// one workgroup per chunk of CHUNK_ROWS rows of the NEW numbering: smallest / largest new column of the chunk's entries;
+// when they span 2^21 or more, the entries outside the chunk's window (stream21_window_base) are counted
+__global__ __launch_bounds__(BLOCK) void k_curve_far_count(int n_rows, const int *__restrict__ row_ptrs,
+                                                           const int *__restrict__ cols, const int *__restrict__ new_id,
+                                                           const int *__restrict__ old_of, unsigned long long *far_out)
+{
+    __shared__ int s_lo[BLOCK], s_hi[BLOCK];
+    __shared__ unsigned long long s_far[BLOCK];
+    const int k0 = blockIdx.x * CHUNK_ROWS, k1 = min(n_rows, k0 + CHUNK_ROWS);
+    int lo = n_rows, hi = 0;
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += BLOCK) {
+        const int row = old_of[k];
+        for (int e = row_ptrs[row]; e < row_ptrs[row + 1]; ++e) {
+            const int c = new_id[cols[e]];
+            lo = min(lo, c);
+            hi = max(hi, c);
+        }
+    }
+    s_lo[threadIdx.x] = lo;
+    s_hi[threadIdx.x] = hi;
+    __syncthreads();
+    for (int w = BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_lo[threadIdx.x] = min(s_lo[threadIdx.x], s_lo[threadIdx.x + w]);
+            s_hi[threadIdx.x] = max(s_hi[threadIdx.x], s_hi[threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    lo = s_lo[0];
+    hi = s_hi[0];
+    if (hi < lo || (long long)hi - lo < (1ll << STREAM21_BITS)) return;  // (workgroup-uniform)
+    const long long base = stream21_window_base(k0, n_rows);
+    unsigned long long far = 0;
+    for (int k = k0 + (int)threadIdx.x; k < k1; k += BLOCK) {
+        const int row = old_of[k];
+        for (int e = row_ptrs[row]; e < row_ptrs[row + 1]; ++e) {
+            const long long d = (long long)new_id[cols[e]] - base;
+            far += (d < 0 || d >= (1ll << STREAM21_BITS)) ? 1 : 0;
+        }
+    }
+    s_far[threadIdx.x] = far;
+    __syncthreads();
+    for (int w = BLOCK / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s_far[threadIdx.x] += s_far[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_far[0]) atomicAdd(far_out, s_far[0]);
+}
+
 }  // namespace
 
 size_t scan_tmp_len(int64_t n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 2; }
@@ -604,6 +710,36 @@ void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes, 
     const int nc = (int)n_chunks(b.n_rows);
     if (nc == 0) return;
     hipLaunchKernelGGL(k_s21_fill, dim3(nc), dim3(BLOCK), 0, st, b, nc, codes, far_idx, far_col);
+}
+
+size_t hilbert_sort_temp_bytes(int32_t n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                             (const int *)nullptr, (int *)nullptr, n, 0, 48, (hipStream_t) nullptr);
+    return bytes;
+}
+
+int hilbert_order_device(hipStream_t st, int32_t n, const double *centres, const double lo[3], double scale,
+                         unsigned long long *keys, unsigned long long *keys_out, int32_t *cells, int32_t *cells_out,
+                         void *temp, size_t temp_bytes, int32_t *new_id)
+{
+    if (n <= 0) return OGL_OK;
+    hipLaunchKernelGGL(k_hilbert_keys, dim3(blocks_for(n)), dim3(BLOCK), 0, st, n, centres, lo[0], lo[1], lo[2], scale, keys,
+                       cells);
+    // (a radix sort is stable: cells with equal keys keep the caller's order, as std::sort of (key, cell) pairs gives)
+    const hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_out, cells, cells_out, n, 0, 48, st);
+    if (e != hipSuccess) return fail(OGL_ERR_HIP, "radix sort of the Hilbert keys failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k_invert_order, dim3(blocks_for(n)), dim3(BLOCK), 0, st, n, cells_out, new_id);
+    return OGL_OK;
+}
+
+void launch_curve_far_count(hipStream_t st, int32_t n_rows, const int32_t *row_ptrs, const int32_t *cols,
+                            const int32_t *new_id, const int32_t *old_of, unsigned long long *far_out)
+{
+    if (n_rows <= 0) return;
+    hipLaunchKernelGGL(k_curve_far_count, dim3((unsigned)n_chunks(n_rows)), dim3(BLOCK), 0, st, n_rows, row_ptrs, cols, new_id,
+                       old_of, far_out);
 }
 
 }  // namespace ogl

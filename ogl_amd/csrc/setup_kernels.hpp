@@ -118,4 +118,18 @@ void launch_stream21_plan(hipStream_t st, const Stream21Build &b);
 // codes and the far lists (far_idx / far_col: far[n_chunks] entries each; may be nullptr when that is 0)
 void launch_stream21_fill(hipStream_t st, const Stream21Build &b, uint4 *codes, int32_t *far_idx, int32_t *far_col);
 
+// ---- the cells along a Hilbert curve through their centres (hilbert_order, host_matrix.cpp: Skilling's transpose, 16 bits
+// per axis), on the device: keys, a stable radix sort of (key, cell), the inverse permutation.  The same numbering as the
+// host's: the keys are formed by the same double operations (lo and scale come from the host), ties keep the caller's order.
+// keys / cells: [n] each, in and out buffers of the sort; temp: hilbert_sort_temp_bytes(n) bytes
+size_t hilbert_sort_temp_bytes(int32_t n);
+int hilbert_order_device(hipStream_t st, int32_t n, const double *centres, const double lo[3], double scale,
+                         unsigned long long *keys, unsigned long long *keys_out, int32_t *cells, int32_t *cells_out,
+                         void *temp, size_t temp_bytes, int32_t *new_id);
+// entries of the pattern (caller's numbering: row_ptrs / cols) that would fall outside their chunk's 2^21-column window
+// in the numbering new_id / old_of (what choose_numbering counts before it takes the curve: STREAM21_MAX_FAR); *far_out
+// must be zero on entry
+void launch_curve_far_count(hipStream_t st, int32_t n_rows, const int32_t *row_ptrs, const int32_t *cols,
+                            const int32_t *new_id, const int32_t *old_of, unsigned long long *far_out);
+
 }  // namespace ogl

@@ -820,6 +820,61 @@ int ogl_solver::rcm_on_device(const HostPattern &hp, std::vector<ogl_label> &new
     return OGL_OK;
 }
 
+// The cells along a Hilbert curve through their centres (hilbert_order, host_matrix.cpp) on the device: bounding box on the
+// host (one pass over 3 N doubles), keys + stable radix sort + inverse permutation on the device.  Same numbering as the host's.
+int ogl_solver::curve_on_device(ogl_label n, const double *centres, std::vector<ogl_label> &new_id)
+{
+    new_id.clear();
+    if (n < 2) return OGL_OK;
+    hipStream_t st = reg->stream;
+    double lo[3] = {centres[0], centres[1], centres[2]}, hi[3] = {centres[0], centres[1], centres[2]};
+    for (ogl_label c = 0; c < n; ++c)
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = std::min(lo[d], centres[3 * (size_t)c + d]);
+            hi[d] = std::max(hi[d], centres[3 * (size_t)c + d]);
+        }
+    double ext = 0.0;
+    for (int d = 0; d < 3; ++d) ext = std::max(ext, hi[d] - lo[d]);
+    const double scale = ext > 0.0 ? 65535.0 / ext : 0.0;
+    DevBuf<double> d_c;
+    DevBuf<unsigned long long> keys, keys_out;
+    DevBuf<int32_t> cells, cells_out, nid;
+    DevBuf<unsigned char> temp;
+    const size_t temp_bytes = hilbert_sort_temp_bytes(n);
+    OGL_TRY(d_c.alloc(3 * (size_t)n, st));
+    OGL_TRY(keys.alloc((size_t)n, st));
+    OGL_TRY(keys_out.alloc((size_t)n, st));
+    OGL_TRY(cells.alloc((size_t)n, st));
+    OGL_TRY(cells_out.alloc((size_t)n, st));
+    OGL_TRY(nid.alloc((size_t)n, st));
+    OGL_TRY(temp.alloc(std::max<size_t>(temp_bytes, 16), st));
+    OGL_TRY(reg->stager.h2d(d_c.p, centres, 3 * (size_t)n * sizeof(double), st));
+    OGL_TRY(hilbert_order_device(st, n, d_c.p, lo, scale, keys.p, keys_out.p, cells.p, cells_out.p, temp.p, temp_bytes, nid.p));
+    new_id.resize((size_t)n);
+    OGL_TRY(reg->stager.d2h(new_id.data(), nid.p, (size_t)n * sizeof(int32_t), st));
+    return OGL_OK;
+}
+
+// ... and the entries that would fall outside their chunk's window of packed columns along that curve (choose_numbering)
+int ogl_solver::curve_far_on_device(const HostPattern &hp, const std::vector<ogl_label> &new_id,
+                                    const std::vector<ogl_label> &old_of, int64_t &far)
+{
+    hipStream_t st = reg->stream;
+    const int32_t N = hp.n_rows;
+    DevBuf<int32_t> nid, old;
+    DevBuf<unsigned long long> cnt;
+    OGL_TRY(nid.alloc((size_t)N, st));
+    OGL_TRY(old.alloc((size_t)N, st));
+    OGL_TRY(cnt.alloc(1, st));  // (zero-filled)
+    OGL_TRY(reg->stager.h2d(nid.p, new_id.data(), (size_t)N * sizeof(int32_t), st));
+    OGL_TRY(reg->stager.h2d(old.p, old_of.data(), (size_t)N * sizeof(int32_t), st));
+    launch_curve_far_count(st, N, d_row_ptrs.p, d_cols.p, nid.p, old.p, cnt.p);
+    unsigned long long got = 0;
+    OGL_TRY(reg->stager.d2h(&got, cnt.p, sizeof(got), st));
+    far = (int64_t)got;
+    return OGL_OK;
+}
+
 int ogl_solver::renumber_on_device(HostPattern &hp, const std::vector<ogl_label> &new_id)
 {
     hipStream_t st = reg->stream;
@@ -1404,7 +1459,18 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
                 };
             }
             // (cell centres, when the caller passes them: the Hilbert-curve candidate; property renumberCurve 0 = RCM only)
-            if (ldu.cell_centres && prop("renumberCurve", 1.0) != 0.0) hooks.centres = ldu.cell_centres;
+            if (ldu.cell_centres && prop("renumberCurve", 1.0) != 0.0) {
+                hooks.centres = ldu.cell_centres;
+                if (built_on_device && prop("curveOnDevice", 1.0) != 0.0) {
+                    hooks.curve = [&](ogl_label n, const double *centres, std::vector<ogl_label> &nid) {
+                        return curve_on_device(n, centres, nid) == OGL_OK && !nid.empty();
+                    };
+                    hooks.curve_far = [&](const HostPattern &hp, const std::vector<ogl_label> &nid,
+                                          const std::vector<ogl_label> &old, int64_t &far) {
+                        return curve_far_on_device(hp, nid, old, far) == OGL_OK;
+                    };
+                }
+            }
             OGL_TRY(choose_numbering(np, cfg.renumber, try_sell, &pre_sell, &pre_built, rep, &hooks));
         }
         pat_renumber_mode = cfg.renumber;

@@ -281,6 +281,10 @@ struct ogl_solver {
     int rcm_on_device(const ogl::HostPattern &hp, std::vector<ogl_label> &new_id);
     // device pattern rewritten into the numbering new_id (and downloaded into hp for the host-side layout code)
     int renumber_on_device(ogl::HostPattern &hp, const std::vector<ogl_label> &new_id);
+    // the Hilbert-curve candidate of the numbering policy on the device: keys + radix sort, and the far-entry count
+    int curve_on_device(ogl_label n, const double *centres, std::vector<ogl_label> &new_id);
+    int curve_far_on_device(const ogl::HostPattern &hp, const std::vector<ogl_label> &new_id,
+                            const std::vector<ogl_label> &old_of, int64_t &far);
     ogl::DevSym sym() const;
     bool use_sym() const
     {
