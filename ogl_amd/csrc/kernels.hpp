@@ -32,6 +32,8 @@ struct DevScalars {
     double stale_norm;                  // GMRES: sum|r| of the last restart (what the criterion sees)
     DevCriterion crit;                  // this solve's criterion (kernel arguments stay solve-independent)
     int32_t x_pending;                  // GKOCG: step_2r's x update is still to be applied by a step_1x
+    int32_t defer_valid;                // GKOCG, x touched every second turn: the head before left t_defer * (its old p) pending
+    double t_defer;
     // Where a multi-rank turn waits (per solve; wall_clock64 ticks of 10 ns): halo_wait_ticks = sum over the workgroups
     // that waited for the neighbours' puts of the longest of their flag waits (halo_waits of them: boundary workgroups
     // of the SpMV, or the single waiter of peerSafeWait / the separate finish kernel); reduce_wait_ticks = sum over
@@ -325,7 +327,8 @@ void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, con
 // lead.box != nullptr (any number of chunks): workgroup 0 alone reduces and publishes, the others poll (LeadBox)
 void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
                           const DevScalars *sin, DevScalars *sout, const double *part_rho,
-                          const double *part_norm, double *history, int first, const LeadBox &lead = LeadBox{});
+                          const double *part_norm, double *history, int first, const LeadBox &lead = LeadBox{},
+                          double *p_out = nullptr, int defer = 0);  // (p_out + defer 1 | 2: x touched every second turn, see the kernel)
 void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                           double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
                           const double *part_beta, double *z_out = nullptr,  // z_out: z = r / d kept for k_cg_turn_sym

@@ -207,7 +207,9 @@ struct ogl_solver::KrylovRun {
     double *y = nullptr, *z = nullptr;  // BiCGStab: identity preconditioner -> y aliases p, z aliases s
     int enq = 0;                        // turns enqueued so far
     double *gm_h(int i, int j) const { return gm + (size_t)j * (m + 1) + i; }
-    double *p_of_turn(int turn) const { return (merged && (turn & 1)) ? p1 : p0; }  // p that turn `turn` reads
+    bool defer2 = false;  // three-launch leader turn with two p buffers: x touched every second turn (k_cg_step1x_fin)
+    double *p_of_turn(int turn) const { return ((merged || defer2) && (turn & 1)) ? p1 : p0; }  // p that turn `turn` reads
+    int defer_of_turn(int turn) const { return defer2 ? ((turn & 1) ? 1 : 2) : 0; }
     double *p_halo_of_turn(int turn) const { return ph + (size_t)(turn & 1) * n_halo; }
     // scalar Jacobi: V_it is divided by its norm at the head of turn `it`, in the pass that applies the preconditioner
     bool gmres_scale_late() const { return gmres && !generic && has_diag; }
@@ -331,7 +333,10 @@ int ogl_solver::krylov_prepare(KrylovRun &k)
     const int n = k.n, nc = k.nc, m = k.m;
     DevScalars *s = k.s;
     const bool bicg = k.bicg, gmres = k.gmres, generic = k.generic, merged = k.merged;
-    if (merged) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
+    // (x every second turn: the leader turn of three launches -- not the merged kernel, which forms p_new at its gathers)
+    k.defer2 = k.lead.box != nullptr && k.fused && !k.fused2 && prop("deferX2", 1.0) != 0.0;
+    props["deferX2InUse"] = k.defer2 ? 1.0 : 0.0;
+    if (merged || k.defer2) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
     if (merged && precond) OGL_TRY(d_z.alloc((size_t)n + 2, st));
     k.n_halo = (size_t)pat.non_local_nnz;
     if (k.merged_halo) {  // old p at the halo columns, two buffers like p itself; p = 0 before the first turn
@@ -608,11 +613,12 @@ int ogl_solver::turn_cg_generic_led(KrylovRun &k, int enq, int pe)
     hipStream_t st = k.st;
     const int n = k.n;
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
-    launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_z.p, nullptr, k.s, k.s2, d_part0.p, d_part1.p, d_history.p, enq == 0 ? 1 : 0,
-                         k.lead);
+    double *p_new = k.p_of_turn(enq + 1);
+    launch_cg_step1x_fin(st, n, k.p_of_turn(enq), d_x.p, d_z.p, nullptr, k.s, k.s2, d_part0.p, d_part1.p, d_history.p,
+                         enq == 0 ? 1 : 0, k.lead, p_new, k.defer_of_turn(enq));
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-    OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, k.s2));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, p_new, nullptr, d_q.p, SpmvDots{p_new, d_part2.p, nullptr}, k.s2));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
     launch_cg_step2r_fin(st, n, d_r.p, d_q.p, nullptr, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p, nullptr, k.lead);
     apply_preconditioner(d_r.p, d_z.p, k.s, d_part0.p);  // z = M^-1 r and the partials of r.z (over step_2r's r.r)
@@ -641,11 +647,12 @@ int ogl_solver::turn_cg_three_launch(KrylovRun &k, int enq, int pe)
     hipStream_t st = k.st;
     const int n = k.n;
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
-    launch_cg_step1x_fin(st, n, d_p.p, d_x.p, d_r.p, precond, k.s, k.s2, d_part0.p, d_part1.p, d_history.p,
-                         enq == 0 ? 1 : 0, k.lead);
+    double *p_new = k.p_of_turn(enq + 1);
+    launch_cg_step1x_fin(st, n, k.p_of_turn(enq), d_x.p, d_r.p, precond, k.s, k.s2, d_part0.p, d_part1.p, d_history.p,
+                         enq == 0 ? 1 : 0, k.lead, p_new, k.defer_of_turn(enq));
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
-    OGL_TRY(dist_spmv(SPMV_PLAIN, d_p.p, nullptr, d_q.p, SpmvDots{d_p.p, d_part2.p, nullptr}, k.s2));
+    OGL_TRY(dist_spmv(SPMV_PLAIN, p_new, nullptr, d_q.p, SpmvDots{p_new, d_part2.p, nullptr}, k.s2));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe + 1], st));
     launch_cg_step2r_fin(st, n, d_r.p, d_q.p, precond, d_part0.p, d_part1.p, k.s2, k.s, d_part2.p, nullptr, k.lead);
     return OGL_OK;
@@ -839,7 +846,7 @@ int ogl_solver::krylov_loop(KrylovRun &k)
         // sizes usually gets the same pointers back: 32x64x32 -> 64x32x32)
         KeyHasher kh;
         kh(k.n), kh(batch), kh(cfg.matrix_format), kh(use_sell()), kh(use_sym()), kh(use_symx()), kh(symx_fast), kh(s21_use);
-        kh(k.fused), kh(k.fused2), kh(k.merged), kh(k.p0), kh(k.p1), kh(k.z_kept), kh(k.s), kh(k.s2), kh(pat_id);
+        kh(k.fused), kh(k.fused2), kh(k.merged), kh(k.defer2), kh(k.p0), kh(k.p1), kh(k.z_kept), kh(k.s), kh(k.s2), kh(pat_id);
         for (const void *v : {(const void *)d_p.p, (const void *)d_x.p, (const void *)d_r.p, (const void *)d_q.p,
                               (const void *)precond, (const void *)d_part0.p, (const void *)d_part1.p,
                               (const void *)d_part2.p, (const void *)d_history.p, (const void *)d_z.p, (const void *)d_p2.p})
@@ -907,7 +914,7 @@ int ogl_solver::krylov_finish(KrylovRun &k, ogl_perf *perf)
     const bool bicg = k.bicg, gmres = k.gmres, fused = k.fused, bicg_fold = k.bicg_fold;
     if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
         launch_cg_step1x_fin(st, n, k.p_of_turn(k.enq), d_x.p, k.generic ? d_z.p : d_r.p, k.generic ? nullptr : precond, s, s2,
-                             d_part0.p, d_part1.p, d_history.p, 0, k.lead);
+                             d_part0.p, d_part1.p, d_history.p, 0, k.lead, k.p_of_turn(k.enq + 1), k.defer_of_turn(k.enq));
     if (bicg_fold) {  // the check that closes the last turn run so far (a plain copy of the scalars when the solve has stopped)
         launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, k.y, k.slot_s[k.cur], k.slot_s[k.cur ^ 1], d_part0.p,
                           d_part1.p, d_history.p, k.lead);
