@@ -32,8 +32,10 @@ struct DevScalars {
     double stale_norm;                  // GMRES: sum|r| of the last restart (what the criterion sees)
     DevCriterion crit;                  // this solve's criterion (kernel arguments stay solve-independent)
     int32_t x_pending;                  // GKOCG: step_2r's x update is still to be applied by a step_1x
-    int32_t defer_valid;                // GKOCG, x touched every second turn: the head before left t_defer * (its old p) pending
-    double t_defer;
+    // GKOCG with x touched every K-th turn (PRing): bit i of defer_valid = the head of ring position i left
+    // t_ring[i] * (its old p, still intact in ring buffer i) pending
+    int32_t defer_valid;
+    double t_ring[8];
     // Where a multi-rank turn waits (per solve; wall_clock64 ticks of 10 ns): halo_wait_ticks = sum over the workgroups
     // that waited for the neighbours' puts of the longest of their flag waits (halo_waits of them: boundary workgroups
     // of the SpMV, or the single waiter of peerSafeWait / the separate finish kernel); reduce_wait_ticks = sum over
@@ -43,6 +45,15 @@ struct DevScalars {
     unsigned long long halo_wait_ticks, reduce_wait_ticks;
     uint32_t reduce_waits;
     uint32_t launch_seq;  // leader finalisation (LeadBox): tag of the next leader launch's mailbox words
+};
+
+// GKOCG, three-launch leader turn: K search-direction buffers used in turn (the head of turn j reads b[j % K] and writes
+// b[(j + 1) % K]), so that x is read and written by every K-th head only (k_cg_step1x_fin).  k == 0: p in place, x every turn.
+constexpr int P_RING_MAX = 8;
+struct PRing {
+    double *b[P_RING_MAX] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t k = 0;      // 0 | 2 | 4 | 8
+    int32_t phase = 0;  // turn % k of the head this is handed to
 };
 
 // Persistent device CSR ("<field>_matrix", CsrMatrixWrapper.H:163-210) + halo part.
@@ -328,7 +339,7 @@ void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, con
 void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
                           const DevScalars *sin, DevScalars *sout, const double *part_rho,
                           const double *part_norm, double *history, int first, const LeadBox &lead = LeadBox{},
-                          double *p_out = nullptr, int defer = 0);  // (p_out + defer 1 | 2: x touched every second turn, see the kernel)
+                          double *p_out = nullptr, const PRing &ring = PRing{});  // (ring.k > 0: x touched every k-th turn, see the kernel)
 void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,
                           double *part_rho, double *part_norm, const DevScalars *sin, DevScalars *sout,
                           const double *part_beta, double *z_out = nullptr,  // z_out: z = r / d kept for k_cg_turn_sym

@@ -301,21 +301,23 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step2r(int n, double *__restrict__
 
 // LEAD (systems of more than FUSED_FIN_MAX_CHUNKS chunks): the first 16 workgroups are the finaliser's 16 wavefronts and
 // publish their sums; every workgroup fetches them, adds them and runs the same logic (leader finalisation, device_common.hpp)
-template <bool LEAD>
-__global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restrict__ p, double *__restrict__ x,
+template <bool LEAD, int K>
+__global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *p, double *__restrict__ x,
                                                          const double *__restrict__ r,
                                                          const double *__restrict__ inv_diag,
                                                          const DevScalars *sin, DevScalars *sout,
                                                          const double *__restrict__ part_rho,
                                                          const double *__restrict__ part_norm, int n_part,
                                                          double *history, int first, LeadBox lead,
-                                                         double *__restrict__ p_out, int defer)
+                                                         double *p_out, PRing ring)
 {
-    // defer (two p buffers, p_out != p): x is touched every SECOND turn only.  A head with defer == 1 leaves its term
-    // t_j p_j of x pending (t_j goes into the scalars; p_j stays intact in `p`, which the next head does not write);
-    // the next head, defer == 2, finds that old p in ITS p_out before it overwrites it and adds both terms in order --
-    // (x + t_(j-1) p_(j-1)) + t_j p_j, the bits of two single updates -- for 81 MB less written and read per pair of
-    // turns at 10 M rows.  A head that stops the solve adds what is pending at once.  defer == 0: every turn, in place.
+    // K > 0 (a ring of K p buffers; p = ring.b[phase], p_out = ring.b[(phase + 1) % K]): x is touched by every K-th head
+    // only.  A head at ring position phase != 0 leaves its term t_j p_j of x pending: t_j goes into the scalars'
+    // t_ring[phase], p_j stays intact in its buffer, which nobody writes before the ring comes round.  The head at
+    // position 0 adds the K - 1 pending terms, oldest first (the oldest p sits in ITS p_out: read before it is
+    // overwritten), then its own -- ((x + t_(j-K+1) p_(j-K+1)) + ...) + t_j p_j, the bits of K single updates -- so that
+    // a turn moves 162 / K MB of x instead of 162 at 10 M rows, plus one read of each pending p.  A head that stops the
+    // solve adds what is pending at once.  K == 0: every turn, p in place.
     __shared__ double red[2 * FIN_WAVES];
     __shared__ double sh[4];
     __shared__ int sh_stop;
@@ -332,8 +334,13 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
     // and a kernel with scratch costs more to dispatch than the finaliser launch this is meant to save).
     const int stopped = sin->stop;
     const double s_rho = sin->rho, s_beta = sin->beta, s_nf = sin->norm_factor, s_init = sin->init_res;
-    const double s_tdefer = sin->t_defer;
-    const int s_defer_valid = sin->defer_valid;
+    const int phase = K > 0 ? ring.phase : 0;
+    const bool defers = K > 0 && phase != 0;  // this head leaves its term of x pending
+    const unsigned s_pending = K > 0 && !first ? (unsigned)sin->defer_valid : 0u;
+    constexpr int KQ = K > 0 ? K : 1;
+    double s_t[KQ];
+#pragma unroll
+    for (int i = 1; i < KQ; ++i) s_t[i] = sin->t_ring[i];
     const int s_iter = sin->iter, s_evals = sin->n_evals;
     const double c_tol = sin->crit.tolerance, c_rel = sin->crit.rel_tol;
     const int c_min = sin->crit.min_iter, c_max = sin->crit.max_iter, c_freq = sin->crit.frequency,
@@ -343,31 +350,43 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
         reinterpret_cast<unsigned long long *>(sout)[threadIdx.x] =
             reinterpret_cast<const unsigned long long *>(sin)[threadIdx.x];
     const RowPair rp = my_rows(blockIdx.x, n);
-    double2 vp, vx, vz, vi, vq;
+    double2 vp, vx, vz, vi, vq[KQ];
     vi.x = vi.y = 1.0;
-    vq.x = vq.y = 0.0;
+    // (the terms pending at ring positions 1 .. K-1: the head at position 0 asks for all of them with its other rows)
+    auto load_pending = [&](int upto) {
+#pragma unroll
+        for (int i = 1; i < KQ; ++i)
+            if (i < upto && ((s_pending >> i) & 1u)) vq[i] = ld2(ring.b[i], rp);
+    };
     const bool early = !LEAD || lead.early_loads != 0;
-    // this head's own term of x (t_j p_j) and the one the head before left pending
-    const bool own_term = !first && s_beta != 0.0, old_term = defer == 2 && !first && s_defer_valid != 0;
+    // this head's own term of x (t_j p_j)
+    const bool own_term = !first && s_beta != 0.0;
     if (early) {
         vp = ld2(p, rp);
-        if (defer != 1) vx = ld2_stream(x, rp);  // (a deferring head leaves x alone -- unless its check stops the solve)
-        if (old_term) vq = ld2(p_out, rp);       // (the old p of the head before: read before this head overwrites it)
+        if (!defers) {  // (a deferring head leaves x alone -- unless its check stops the solve)
+            vx = ld2_stream(x, rp);
+            load_pending(KQ);
+        }
         vz = ld2_stream(r, rp);
         if (inv_diag) vi = ld2_stream(inv_diag, rp);
     }
-    // x after this head (when it does not defer): the pending term first, then its own -- the order of two single updates
-    auto update_x = [&]() {
-        if (old_term) {
-            vx.x += s_tdefer * vq.x;
-            vx.y += s_tdefer * vq.y;
-        }
+    // x after this head (when it does not defer): the pending terms of positions 1 .. upto-1 first, then its own -- the
+    // order of single updates
+    auto update_x = [&](int upto) {
+        bool any = own_term;
+#pragma unroll
+        for (int i = 1; i < KQ; ++i)
+            if (i < upto && ((s_pending >> i) & 1u)) {
+                vx.x += s_t[i] * vq[i].x;
+                vx.y += s_t[i] * vq[i].y;
+                any = true;
+            }
         if (own_term) {
             const double t = s_rho / s_beta;
             vx.x += t * vp.x;
             vx.y += t * vp.y;
         }
-        if (old_term || own_term) st2_stream(x, rp, vx);
+        if (any) st2_stream(x, rp, vx);
     };
     double pv[2][FIN_VT];
     if (!LEAD) load_partials_as_finaliser<2>(part_rho, part_norm, n_part, pv);
@@ -376,15 +395,17 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
     if (LEAD) {
         // x += t_j p of the turn this check will close needs nothing the leaders compute (prev_rho = the incoming rho,
         // beta as it stands): it goes out while the mailbox is awaited -- same scalars, same bits, one store less behind the wait
-        if (early && defer != 1) update_x();
+        if (early && !defers) update_x(KQ);
         if (!lead_wait(lead, 4 * FIN_WAVES, seq, lead_words, &lead_timed_out)) {
             if (threadIdx.x == 0) sout->comm_error = sout->stop = 1;
             return;
         }
         if (!early) {
             vp = ld2(p, rp);
-            if (defer != 1) vx = ld2_stream(x, rp);
-            if (old_term) vq = ld2(p_out, rp);
+            if (!defers) {
+                vx = ld2_stream(x, rp);
+                load_pending(KQ);
+            }
             vz = ld2_stream(r, rp);
             if (inv_diag) vi = ld2_stream(inv_diag, rp);
         }
@@ -433,19 +454,20 @@ __global__ __launch_bounds__(BLOCK) void k_cg_step1x_fin(int n, double *__restri
             }
             if (stop) sout->stop = 1;
             if (LEAD) sout->launch_seq = seq + 1;
-            // what this head leaves pending for the next one (nothing when it updates x itself or stops)
-            sout->defer_valid = (defer == 1 && own_term && !stop) ? 1 : 0;
-            if (defer == 1 && own_term) sout->t_defer = s_rho / s_beta;
+            // what is pending after this head (nothing when it has updated x itself or stops)
+            sout->defer_valid = (defers && !stop) ? (int)(s_pending | (own_term ? 1u << phase : 0u)) : 0;
+            if (defers && own_term) sout->t_ring[phase] = s_rho / s_beta;
         }
     }
     __syncthreads();
     const double prev = sh[1], rho = sh[2];
     const int stop = sh_stop;
     // x += t_j p of the turn this check closed (same scalars, same bits as step_2) -- unless it went out before the wait
-    if (defer != 1 && !(LEAD && early)) update_x();
-    if (defer == 1 && stop && own_term) {  // a deferring head that ends the solve: its term goes in now
+    if (!defers && !(LEAD && early)) update_x(KQ);
+    if (defers && stop) {  // a deferring head that ends the solve: the terms pending so far and its own go in now
         vx = ld2_stream(x, rp);
-        update_x();
+        load_pending(phase);
+        update_x(phase);
     }
     if (stop) return;
     const double tmp = (prev == 0.0) ? 0.0 : rho / prev;
@@ -1453,18 +1475,31 @@ void launch_cg_step2r(hipStream_t st, int32_t n, double *r, const double *q, con
 
 void launch_cg_step1x_fin(hipStream_t st, int32_t n, double *p, double *x, const double *r, const double *inv_diag,
                           const DevScalars *sin, DevScalars *sout, const double *part_rho,
-                          const double *part_norm, double *history, int first, const LeadBox &lead, double *p_out, int defer)
+                          const double *part_norm, double *history, int first, const LeadBox &lead, double *p_out,
+                          const PRing &ring)
 {
     const int nc = (int)n_chunks(n);
     if (nc == 0) return;
     if (!p_out) p_out = p;
-    if (p_out == p) defer = 0;  // (the deferral needs the old p of the head before: two buffers)
-    if (lead.box && nc >= 3 * FIN_WAVES)
-        hipLaunchKernelGGL(k_cg_step1x_fin<true>, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, sin, sout, part_rho,
-                           part_norm, nc, history, first, lead, p_out, defer);
-    else
-        hipLaunchKernelGGL(k_cg_step1x_fin<false>, dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, sin, sout, part_rho,
-                           part_norm, nc, history, first, LeadBox{}, p_out, defer);
+    const bool led = lead.box && nc >= 3 * FIN_WAVES;
+    const LeadBox lb = led ? lead : LeadBox{};
+#define OGL_STEP1X(LEAD, K)                                                                                               \
+    hipLaunchKernelGGL((k_cg_step1x_fin<LEAD, K>), dim3(nc), dim3(BLOCK), 0, st, n, p, x, r, inv_diag, sin, sout,        \
+                       part_rho, part_norm, nc, history, first, lb, p_out, ring)
+#define OGL_STEP1X_K(LEAD)                                                                                                \
+    switch (ring.k) {                                                                                                     \
+    case 2: OGL_STEP1X(LEAD, 2); break;                                                                                   \
+    case 4: OGL_STEP1X(LEAD, 4); break;                                                                                   \
+    case 8: OGL_STEP1X(LEAD, 8); break;                                                                                   \
+    default: OGL_STEP1X(LEAD, 0); break;                                                                                  \
+    }
+    if (led) {
+        OGL_STEP1X_K(true)
+    } else {
+        OGL_STEP1X(false, 0);  // (every workgroup its own finaliser: x every turn, whatever buffers p and p_out are)
+    }
+#undef OGL_STEP1X_K
+#undef OGL_STEP1X
 }
 
 void launch_cg_step2r_fin(hipStream_t st, int32_t n, double *r, const double *q, const double *inv_diag,

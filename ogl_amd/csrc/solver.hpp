@@ -403,6 +403,7 @@ struct ogl_solver {
     // ---- vectors: "<field>_rhs", "<field>_solution" + Krylov work vectors ----
     ogl::DevBuf<double> d_x, d_b, d_r, d_p, d_q, d_w, d_inv_diag;
     ogl::DevBuf<double> d_p2;  // second p buffer of the 2-launch turn (k_cg_turn_sym)
+    ogl::DevBuf<double> d_pring[ogl::P_RING_MAX - 2];  // further p buffers of the leader turn's ring (PRing, deferX)
     ogl::DevBuf<double> d_p_halo;  // multi-rank merged turn: old / new p at the halo columns
     ogl::DevBuf<double> d_bj_tmp0, d_bj_tmp1;  // block Jacobi through a permutation, staged apply: in / out in the caller's order
     ogl::DevBuf<double> d_v, d_s, d_t, d_y, d_z, d_rr;  // BiCGStab

@@ -207,9 +207,18 @@ struct ogl_solver::KrylovRun {
     double *y = nullptr, *z = nullptr;  // BiCGStab: identity preconditioner -> y aliases p, z aliases s
     int enq = 0;                        // turns enqueued so far
     double *gm_h(int i, int j) const { return gm + (size_t)j * (m + 1) + i; }
-    bool defer2 = false;  // three-launch leader turn with two p buffers: x touched every second turn (k_cg_step1x_fin)
-    double *p_of_turn(int turn) const { return ((merged || defer2) && (turn & 1)) ? p1 : p0; }  // p that turn `turn` reads
-    int defer_of_turn(int turn) const { return defer2 ? ((turn & 1) ? 1 : 2) : 0; }
+    PRing ring{};  // three-launch leader turn with ring.k p buffers: x touched every ring.k-th turn (k_cg_step1x_fin)
+    double *p_of_turn(int turn) const  // p that turn `turn` reads
+    {
+        if (ring.k > 0) return ring.b[turn % ring.k];
+        return (merged && (turn & 1)) ? p1 : p0;
+    }
+    PRing ring_of_turn(int turn) const
+    {
+        PRing r = ring;
+        r.phase = ring.k > 0 ? turn % ring.k : 0;
+        return r;
+    }
     double *p_halo_of_turn(int turn) const { return ph + (size_t)(turn & 1) * n_halo; }
     // scalar Jacobi: V_it is divided by its norm at the head of turn `it`, in the pass that applies the preconditioner
     bool gmres_scale_late() const { return gmres && !generic && has_diag; }
@@ -333,10 +342,19 @@ int ogl_solver::krylov_prepare(KrylovRun &k)
     const int n = k.n, nc = k.nc, m = k.m;
     DevScalars *s = k.s;
     const bool bicg = k.bicg, gmres = k.gmres, generic = k.generic, merged = k.merged;
-    // (x every second turn: the leader turn of three launches -- not the merged kernel, which forms p_new at its gathers)
-    k.defer2 = k.lead.box != nullptr && k.fused && !k.fused2 && prop("deferX2", 1.0) != 0.0;
-    props["deferX2InUse"] = k.defer2 ? 1.0 : 0.0;
-    if (merged || k.defer2) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
+    // (x every K-th turn: the leader turn of three launches -- not the merged kernel, which forms p_new at its gathers;
+    //  property deferX = number of p buffers, 2 | 4 | 8, anything below 2 or deferX2 0: x every turn, p in place.  At 10 M
+    //  rows two buffers give +1.2 % over none, four the same as two, eight lose 6 % -- the pending directions push the
+    //  turn's other vectors out of the Infinity Cache: profiles/r06_defer_ab.txt)
+    int ring_k = 0;
+    if (k.lead.box != nullptr && k.fused && !k.fused2 && prop("deferX2", 1.0) != 0.0) {
+        const double want = prop("deferX", 2.0);
+        ring_k = want >= 8.0 ? 8 : want >= 4.0 ? 4 : want >= 2.0 ? 2 : 0;
+    }
+    props["deferXInUse"] = (double)ring_k;
+    props["deferX2InUse"] = ring_k ? 1.0 : 0.0;
+    if (merged || ring_k) OGL_TRY(d_p2.alloc((size_t)n + 2, st));
+    for (int i = 2; i < ring_k; ++i) OGL_TRY(d_pring[i - 2].alloc((size_t)n + 2, st));
     if (merged && precond) OGL_TRY(d_z.alloc((size_t)n + 2, st));
     k.n_halo = (size_t)pat.non_local_nnz;
     if (k.merged_halo) {  // old p at the halo columns, two buffers like p itself; p = 0 before the first turn
@@ -345,6 +363,8 @@ int ogl_solver::krylov_prepare(KrylovRun &k)
     }
     k.p0 = d_p.p;
     k.p1 = d_p2.p;
+    k.ring.k = ring_k;
+    for (int i = 0; i < ring_k; ++i) k.ring.b[i] = i == 0 ? d_p.p : i == 1 ? d_p2.p : d_pring[i - 2].p;
     k.ph = d_p_halo.p;
     k.z_kept = merged && precond ? d_z.p : nullptr;
 
@@ -615,7 +635,7 @@ int ogl_solver::turn_cg_generic_led(KrylovRun &k, int enq, int pe)
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
     double *p_new = k.p_of_turn(enq + 1);
     launch_cg_step1x_fin(st, n, k.p_of_turn(enq), d_x.p, d_z.p, nullptr, k.s, k.s2, d_part0.p, d_part1.p, d_history.p,
-                         enq == 0 ? 1 : 0, k.lead, p_new, k.defer_of_turn(enq));
+                         enq == 0 ? 1 : 0, k.lead, p_new, k.ring_of_turn(enq));
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
     OGL_TRY(dist_spmv(SPMV_PLAIN, p_new, nullptr, d_q.p, SpmvDots{p_new, d_part2.p, nullptr}, k.s2));
@@ -649,7 +669,7 @@ int ogl_solver::turn_cg_three_launch(KrylovRun &k, int enq, int pe)
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[0], st));
     double *p_new = k.p_of_turn(enq + 1);
     launch_cg_step1x_fin(st, n, k.p_of_turn(enq), d_x.p, d_r.p, precond, k.s, k.s2, d_part0.p, d_part1.p, d_history.p,
-                         enq == 0 ? 1 : 0, k.lead, p_new, k.defer_of_turn(enq));
+                         enq == 0 ? 1 : 0, k.lead, p_new, k.ring_of_turn(enq));
     if (enq == 0) OGL_HIP_CHECK(hipEventRecord(k.ev_chk[1], st));
     if (pe >= 0) OGL_HIP_CHECK(hipEventRecord(prof_ev[2 * pe], st));
     OGL_TRY(dist_spmv(SPMV_PLAIN, p_new, nullptr, d_q.p, SpmvDots{p_new, d_part2.p, nullptr}, k.s2));
@@ -846,11 +866,12 @@ int ogl_solver::krylov_loop(KrylovRun &k)
         // sizes usually gets the same pointers back: 32x64x32 -> 64x32x32)
         KeyHasher kh;
         kh(k.n), kh(batch), kh(cfg.matrix_format), kh(use_sell()), kh(use_sym()), kh(use_symx()), kh(symx_fast), kh(s21_use);
-        kh(k.fused), kh(k.fused2), kh(k.merged), kh(k.defer2), kh(k.p0), kh(k.p1), kh(k.z_kept), kh(k.s), kh(k.s2), kh(pat_id);
+        kh(k.fused), kh(k.fused2), kh(k.merged), kh(k.ring.k), kh(k.p0), kh(k.p1), kh(k.z_kept), kh(k.s), kh(k.s2), kh(pat_id);
         for (const void *v : {(const void *)d_p.p, (const void *)d_x.p, (const void *)d_r.p, (const void *)d_q.p,
                               (const void *)precond, (const void *)d_part0.p, (const void *)d_part1.p,
                               (const void *)d_part2.p, (const void *)d_history.p, (const void *)d_z.p, (const void *)d_p2.p})
             kh(v);
+        for (int i = 0; i < k.ring.k; ++i) kh((const void *)k.ring.b[i]);
         visit(kh, csr());
         visit(kh, ell());
         if (sell_state == 1) visit(kh, sell());
@@ -914,7 +935,7 @@ int ogl_solver::krylov_finish(KrylovRun &k, ogl_perf *perf)
     const bool bicg = k.bicg, gmres = k.gmres, fused = k.fused, bicg_fold = k.bicg_fold;
     if (fused)  // the check that closes the last turn run so far (a plain copy s -> s2 when the solve has stopped)
         launch_cg_step1x_fin(st, n, k.p_of_turn(k.enq), d_x.p, k.generic ? d_z.p : d_r.p, k.generic ? nullptr : precond, s, s2,
-                             d_part0.p, d_part1.p, d_history.p, 0, k.lead, k.p_of_turn(k.enq + 1), k.defer_of_turn(k.enq));
+                             d_part0.p, d_part1.p, d_history.p, 0, k.lead, k.p_of_turn(k.enq + 1), k.ring_of_turn(k.enq));
     if (bicg_fold) {  // the check that closes the last turn run so far (a plain copy of the scalars when the solve has stopped)
         launch_bicg_fold1(st, n, d_p.p, d_r.p, d_v.p, precond, k.y, k.slot_s[k.cur], k.slot_s[k.cur ^ 1], d_part0.p,
                           d_part1.p, d_history.p, k.lead);

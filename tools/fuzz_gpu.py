@@ -124,8 +124,8 @@ def main():
                  "fusedFinMaxChunks": float(rng.choice([1024.0, 0.0])), "leadFinalizers": float(rng.integers(0, 2)),
                  "leadEarlyLoads": float(rng.integers(0, 2)), "gmresLead": float(rng.integers(0, 2)),
                  "spmvLdsRounds": float(rng.integers(1, 3)),
-                 # (x advanced every second turn from two search directions, or every turn)
-                 "deferX2": float(rng.integers(0, 2))}
+                 # (x advanced by every K-th head from a ring of K search directions, or every turn)
+                 "deferX": float(rng.choice([0.0, 2.0, 4.0, 8.0]))}
         tag = f"case {it}: {kind} n={case.n_cells} sym={case.lower is None} {solver} precond={pc}/{block} " \
               f"{ {k: cfgkw[k] for k in ('compress_indices', 'symmetric_half', 'matrix_format', 'max_iter', 'renumber', 'sparsity_power')} } {props}"
         only = os.environ.get("OGL_FUZZ_ONLY")
