@@ -946,6 +946,9 @@ int ogl_solver::krylov_finish(KrylovRun &k, ogl_perf *perf)
     DevScalars fin;
     OGL_HIP_CHECK(hipMemcpy(&fin, bicg_fold ? k.slot_s[k.cur] : (fused ? s2 : s), sizeof(fin), hipMemcpyDeviceToHost));
     if (k.folded() && !fin.stop) return fail(OGL_ERR_STATE, "criterion did not stop within maxIter + frequency");
+    if (fin.comm_error && !k.multi && k.lead.box)
+        return fail(OGL_ERR_STATE, "leader finalisation timed out: the sums of a turn were not published within "
+                    "leadTimeoutS = %g s (check %d)", prop("leadTimeoutS", 10.0), fin.iter);
     if (fin.comm_error)
         return fail(OGL_ERR_COMM, "peer all-reduce timed out: a rank did not take part (check %d)",
                     fin.iter);

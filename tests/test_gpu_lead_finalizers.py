@@ -274,3 +274,21 @@ def test_leader_turns_replayed_as_a_graph(reg, system, merged):
     assert got[1.0][1] == got[0.0][1] == 71
     np.testing.assert_array_equal(got[1.0][2], got[0.0][2])
     np.testing.assert_array_equal(got[1.0][0], got[0.0][0])
+
+
+def test_a_leader_that_never_publishes_fails_the_solve_loudly(reg, system):
+    """leadTimeoutS 0: the polling workgroups give up at once -- the solve must end (no hang), report the defect by name,
+    and leave the solver usable: the next solve with the default time-out gives the bits of the one before the failure."""
+    case, b, _, _ = system
+    s = solver(reg, "lead_timeout", case, 1.0, preconditioner=capi.PRECOND_BJ, tolerance=0.0, rel_tol=0.0, max_iter=20)
+    x0, p0 = s.solve(b, np.zeros_like(b))
+    h0 = s.history().copy()
+    s.set_property("leadTimeoutS", 0.0)
+    with pytest.raises(capi.OglError) as e:
+        s.solve(b, np.zeros_like(b))
+    assert "leader finalisation timed out" in str(e.value)
+    s.set_property("leadTimeoutS", 10.0)
+    x1, p1 = s.solve(b, np.zeros_like(b))
+    assert p1.n_iterations == p0.n_iterations
+    np.testing.assert_array_equal(s.history(), h0)
+    np.testing.assert_array_equal(x1, x0)
