@@ -961,6 +961,32 @@ int ogl_solver::build_sym_on_device(const HostPattern &np, SymDistances *sd_out,
     return OGL_OK;
 }
 
+// The band of the device CSR arrays: the largest distance column - row when the pattern holds at most SYM_TABLE distinct
+// ones (a structured mesh in its own numbering), else 0.  One small kernel per pattern (k_sym_distances), cached.
+int ogl_solver::csr_band(int64_t *band)
+{
+    if (csr_band_pat != pat_id) {
+        hipStream_t st = reg->stream;
+        csr_band_rows = 0;
+        DevBuf<int32_t> work;  // [table | flags]
+        OGL_TRY(work.alloc(SYM_TABLE + SYM_FLAGS, st));
+        int32_t io[SYM_TABLE + SYM_FLAGS];
+        for (int j = 0; j < SYM_TABLE; ++j) io[j] = SYM_EMPTY;
+        for (int j = 0; j < SYM_FLAGS; ++j) io[SYM_TABLE + j] = 0;
+        OGL_HIP_CHECK(hipMemcpyAsync(work.p, io, sizeof(io), hipMemcpyHostToDevice, st));
+        launch_sym_distances(st, pat.n_rows, d_row_ptrs.p, d_cols.p, work.p, work.p + SYM_TABLE);
+        OGL_HIP_CHECK(hipMemcpyAsync(io, work.p, sizeof(io), hipMemcpyDeviceToHost, st));
+        OGL_HIP_CHECK(hipStreamSynchronize(st));
+        OGL_HIP_CHECK(hipGetLastError());
+        if (!io[SYM_TABLE + SYM_FLAG_TOO_MANY])
+            for (int j = 0; j < SYM_TABLE; ++j)
+                if (io[j] != SYM_EMPTY) csr_band_rows = std::max<int64_t>(csr_band_rows, io[j]);
+        csr_band_pat = pat_id;
+    }
+    *band = csr_band_rows;
+    return OGL_OK;
+}
+
 int SellDev::build(ogl_label n_rows, const ogl_label *row_ptrs, const ogl_label *cols, Stager &stager,
                    hipStream_t st, bool sort_windows)
 {
@@ -1727,11 +1753,18 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
     {   // Band-aware workgroup order of the compressed / CSR-stream kernels (the half-storage kernels take theirs from
         // their own distances): the chunks of rows r and r +- band run on one XCD, so a strip of x is fetched into one L2
         // instead of three.  Full storage of the 216^3 box, STREAM instantiation: 128.2 -> 124.6 us (0.718 -> 0.739 of
-        // peak); the plain CSR-stream kernel measures the same either way (195.7 / 195.8 us) and is left alone.  Property
-        // spmvBandRows: the band in rows, 0 = off, -1 (default) = the compressed layout's own largest offset on a
-        // banded pattern.
+        // peak); the plain CSR-stream kernel takes the same time either way (195.7 / 195.8 us) but fetches 14 % less over the
+        // fabric (1.19 -> 1.02 x the model's bytes, profiles/r06_pmc_nocompress_summary.json), so it gets the order too.
+        // Property spmvBandRows: the band in rows, 0 = off, -1 (default) = the largest offset of a banded pattern (the
+        // compressed layout's tables; for the CSR arrays the distance table of the half-storage set-up, csr_band()).
         int64_t band = (int64_t)prop("spmvBandRows", -1.0);
-        if (band < 0) band = (cfg.matrix_format != OGL_FORMAT_ELL && use_sell() && !use_sym() && !use_symx()) ? sell_band_rows : 0;
+        if (band < 0) {
+            const bool by_sell = cfg.matrix_format != OGL_FORMAT_ELL && use_sell() && !use_sym() && !use_symx();
+            const bool by_csr = cfg.matrix_format != OGL_FORMAT_ELL && !use_sell() && !use_sym() && !use_symx();
+            band = 0;
+            if (by_sell) band = sell_band_rows;
+            if (by_csr && pat.n_rows >= SPMV_TUNE_MIN_ROWS) OGL_TRY(csr_band(&band));
+        }
         if (band != band_order_rows) {
             d_band_order.release();
             band_order_rows = band;
