@@ -1763,7 +1763,8 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
             const bool by_csr = cfg.matrix_format != OGL_FORMAT_ELL && !use_sell() && !use_sym() && !use_symx();
             band = 0;
             if (by_sell) band = sell_band_rows;
-            if (by_csr && pat.n_rows >= SPMV_TUNE_MIN_ROWS) OGL_TRY(csr_band(&band));
+            // (single rank: the order has not been run next to the halo waits of a multi-rank SpMV on the CSR arrays)
+            if (by_csr && pat.n_rows >= SPMV_TUNE_MIN_ROWS && !reg->comm->multi()) OGL_TRY(csr_band(&band));
         }
         if (band != band_order_rows) {
             d_band_order.release();
