@@ -226,6 +226,8 @@ void launch_gather_coeffs(hipStream_t st, int32_t nnz, const int32_t *ldu_mappin
 void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag);
 // the same with diag_pos[i] = position of row i's first diagonal entry (-1: none), found once per pattern
 void launch_jacobi_generate_pos(hipStream_t st, const DevCsr &A, const int32_t *diag_pos, double *inv_diag);
+// ... from a contiguous copy of the diagonal in device-row order (the staged lduMatrix source)
+void launch_jacobi_generate_diag(hipStream_t st, int32_t n_rows, const double *diag, double *inv_diag);
 
 // Block Jacobi with maxBlockSize k > 1 (Preconditioner.H:91-105): inverted diagonal blocks,
 // row-major, `stride` x `stride` doubles per block.

@@ -1312,6 +1312,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         }
         if (cfg.reorder_on_host) {  // :608-633, scaling applied by the host update functions
             offdiag_valid = false;  // (d_source is not filled on this path: nothing for a sibling to take)
+            source_diag_valid = false;
             props["offDiagReused"] = 0.0;
             OGL_TRY(download_local_pattern(pat));
             std::vector<double> sorted(nnz);
@@ -1360,6 +1361,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
                 OGL_TRY(reg->stager.h2d(src + pat.diag_start() + N, iface.data(),
                                         iface.size() * sizeof(double), st));                  // :672-682
             launch_gather_coeffs(st, pat.local_nnz, d_ldu_mapping.p, src, d_vals.p);          // :700-703
+            source_diag_valid = true;  // (d_vals' diagonal = the N doubles at src + diag_start)
         }
         // ---- non-local coefficients (:708-732): tiny, permuted on the host ----
         if (pat.non_local_nnz) {
@@ -1440,6 +1442,7 @@ int ogl_solver::set_matrix(const ogl_ldu_view &ldu)
         OGL_TRY(d_vals.alloc(nnz + NNZ_PAD, st));
         OGL_TRY(d_ldu_mapping.alloc(nnz + NNZ_PAD, st));
         OGL_TRY(d_source.alloc((size_t)np.source_len() + NNZ_PAD, st));
+        source_diag_valid = false;
         OGL_TRY(d_diag_pos.alloc(std::max<size_t>(1, (size_t)np.n_rows), st));
         bool built_on_device = false;
         if (device_setup) OGL_TRY(build_pattern_on_device(ldu, np, &built_on_device));

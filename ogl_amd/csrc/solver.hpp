@@ -411,6 +411,7 @@ struct ogl_solver {
     ogl::DevBuf<double> d_isai_tmp;                     // ISAI(spd): W r before W^T
     ogl::DevBuf<double> d_part0, d_part1, d_part2;  // (part2: beta partials of the fused-finaliser turn)
     int64_t band_order_rows = 0, sell_band_rows = 0;
+    bool source_diag_valid = false;  // d_source's diagonal segment is the diagonal of d_vals (set by the coefficient update)
     int64_t csr_band_rows = 0;   // band of the device CSR arrays (csr_band), valid for pattern csr_band_pat
     uint64_t csr_band_pat = 0;
     int csr_band(int64_t *band);
