@@ -279,7 +279,8 @@ constexpr int MAX_ISAI_HUGE_ROW = 2048;
 // wide_rows[n_wide] = the rows with ISAI_THREAD_ROW < entries <= MAX_ISAI_ROW
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
                           const int32_t *w_cols, double *w_vals, int32_t max_row,
-                          const int32_t *wide_rows, int32_t n_wide);
+                          const int32_t *wide_rows, int32_t n_wide,
+                          bool group_lanes = true);  // rows of <= 8 entries: 4 | 8 lanes per row instead of a thread
 // huge_rows[first .. first + count): rows wider than MAX_ISAI_ROW; scratch_off[k] = where row huge_rows[k]'s
 // system starts in `scratch` (doubles)
 void launch_isai_generate_huge(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,

@@ -211,6 +211,135 @@ __global__ __launch_bounds__(64) void k_isai_generate(int n_rows, const int *__r
     for (int r = 0; r < bs; ++r) w_vals[w0 + r] = spd ? rhs[r] / scale : rhs[r];
 }
 
+// The same solve with G lanes per row (rows of at most G entries; 64 / G rows per wavefront): lane c of a group owns COLUMN
+// c of the row's dense system in registers (a[r] = A(r, c), every loop unrolled over G) and the right-hand side of ROW c.
+// The thread-per-row kernel above keeps its LD x LD system in scratch memory and walks it alone: 1.7 ms per generation on
+// the 2.1 M rows of configs[2], every solve.  Here the entries are looked up by G lanes side by side (the lanes of a group
+// search the SAME matrix row for their columns), the pivot column is scanned by its owner, the factors a[r][k] / a[k][k]
+// are formed once by lane k and handed round, and the back substitution takes the products a[r][j] * x[j] from their
+// owners in the serial order of j -- every element sees the operations of solve_dense (oracle/ogl_oracle.c) in the same
+// order, so the bits agree.
+template <int G>
+__global__ __launch_bounds__(BLOCK) void k_isai_generate_grp(int n_rows, const int *__restrict__ row_ptrs,
+                                                             const int *__restrict__ cols,
+                                                             const double *__restrict__ vals, int spd,
+                                                             const int *__restrict__ w_row_ptrs,
+                                                             const int *__restrict__ w_cols,
+                                                             double *__restrict__ w_vals)
+{
+    static_assert(G == 4 || G == 8, "group widths instantiated");
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    const int i = t / G, c = t % G;                 // row of W, this lane's column of its dense system
+    const int lane = threadIdx.x & (WAVE - 1), base = lane - c;  // first lane of the group within the wavefront
+    const bool live = i < n_rows;
+    const int w0 = live ? w_row_ptrs[i] : 0, bs = live ? w_row_ptrs[i + 1] - w0 : 0;
+    const bool row_ok = bs <= G;                    // (a wider row: k_isai_generate_wide takes it)
+    const bool on = live && row_ok && c < bs;
+    const int Jc = on ? w_cols[w0 + c] : -1;
+    // matrix row Jc, its first ROWE entries in registers (all loads in flight at once; a longer row -- a pattern beyond
+    // the stencil -- falls back to the search in memory): general ISAI needs A(Jc, J[r]), this lane's own row; the spd
+    // variant A(J[r], Jc), found in the registers of lane r
+    constexpr int ROWE = 8;
+    int ce[ROWE];
+    double ve[ROWE];
+    int rp0 = 0, len = 0;
+    if (on) {
+        rp0 = row_ptrs[Jc];
+        len = row_ptrs[Jc + 1] - rp0;
+    }
+#pragma unroll
+    for (int e = 0; e < ROWE; ++e) {
+        ce[e] = (on && e < len) ? cols[rp0 + e] : -1;
+        ve[e] = (on && e < len) ? vals[rp0 + e] : 0.0;
+    }
+    const bool longer = __any(on && len > ROWE);  // (wavefront-uniform: the shuffles below stay convergent)
+    double a[G];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+        const int Jr = __shfl(Jc, base + r, WAVE);
+        a[r] = 0.0;
+        if (longer) {
+            if (on && r < bs) a[r] = spd ? csr_entry(row_ptrs, cols, vals, Jr, Jc) : csr_entry(row_ptrs, cols, vals, Jc, Jr);
+        } else if (spd) {
+#pragma unroll
+            for (int e = ROWE - 1; e >= 0; --e) {  // (descending: the first match in the row's order is the one that stays)
+                const int col = __shfl(ce[e], base + r, WAVE);
+                const double val = __shfl(ve[e], base + r, WAVE);
+                if (on && r < bs && col == Jc) a[r] = val;
+            }
+        } else {
+#pragma unroll
+            for (int e = ROWE - 1; e >= 0; --e)
+                if (on && r < bs && ce[e] == Jr) a[r] = ve[e];
+        }
+    }
+    double rhs = (on && Jc == i) ? 1.0 : 0.0;  // of row c
+    // (pos: which member is the row itself)
+    int pos = 0;
+#pragma unroll
+    for (int r = 0; r < G; ++r)
+        if (__shfl(Jc, base + r, WAVE) == i && r < bs) pos = r;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        // pivot: lane k scans its column from row k down, first largest
+        int piv = k;
+        {
+            double best = fabs(a[k]);
+#pragma unroll
+            for (int r = k + 1; r < G; ++r)
+                if (r < bs && fabs(a[r]) > best) {
+                    best = fabs(a[r]);
+                    piv = r;
+                }
+        }
+        piv = __shfl(piv, base + k, WAVE);
+        const bool step = k < bs;  // (group-uniform)
+        if (step && piv != k) {
+            // rows k and piv change places: every lane in its column, lanes k and piv their right-hand sides
+            double ak = a[k], ap = 0.0;
+#pragma unroll
+            for (int r = 0; r < G; ++r)
+                if (r == piv) ap = a[r];
+#pragma unroll
+            for (int r = 0; r < G; ++r)
+                if (r == piv) a[r] = ak;
+            a[k] = ap;
+        }
+        {
+            const double rk = __shfl(rhs, base + k, WAVE), rp = __shfl(rhs, base + (piv < G ? piv : k), WAVE);
+            if (step && piv != k) {
+                if (c == k) rhs = rp;
+                else if (c == piv) rhs = rk;
+            }
+        }
+        // eliminate below the pivot: the factors come from lane k (one division each, as in the serial walk)
+        const double akk = __shfl(a[k], base + k, WAVE);
+        const double rk = __shfl(rhs, base + k, WAVE);
+        const double akc = a[k];
+#pragma unroll
+        for (int r = k + 1; r < G; ++r) {
+            const double f = __shfl(a[r] / akk, base + k, WAVE);
+            if (step && r < bs) {
+                if (c > k) a[r] -= f * akc;
+                if (c == r) rhs -= f * rk;
+            }
+        }
+    }
+    // back substitution: x[r] = (rhs[r] - sum_{j > r} a[r][j] x[j]) / a[r][r], j ascending; lane j owns a[r][j] and x[j]
+#pragma unroll
+    for (int r = G - 1; r >= 0; --r) {
+        double tv = rhs;  // (meaningful in lane r)
+#pragma unroll
+        for (int j = r + 1; j < G; ++j) {
+            const double pr = __shfl(a[r] * rhs, base + j, WAVE);  // lane j: a[r][j] * x[j] (x[j] is final by now)
+            if (j < bs) tv -= pr;
+        }
+        if (c == r && r < bs) rhs = tv / a[r];
+    }
+    const double xpos = __shfl(rhs, base + pos, WAVE);
+    if (on) w_vals[w0 + c] = spd ? rhs / sqrt(xpos) : rhs;
+}
+
 // The same solve for one WIDE row (ISAI_THREAD_ROW < entries <= MAX_ISAI_ROW) per wavefront: the
 // dense system sits in LDS, lane c owns column c.  Every element sees the operations of the
 // thread-per-row kernel (and of the oracle's solve_dense) in the same order, so the bits agree.
@@ -662,14 +791,20 @@ void launch_bj_apply_staged(hipStream_t st, const DevBlockJacobi &J, const doubl
 
 void launch_isai_generate(hipStream_t st, const DevCsr &A, int spd, const int32_t *w_row_ptrs,
                           const int32_t *w_cols, double *w_vals, int32_t max_row,
-                          const int32_t *wide_rows, int32_t n_wide)
+                          const int32_t *wide_rows, int32_t n_wide, bool group_lanes)
 {
     if (A.n_rows == 0) return;
     const dim3 grid((A.n_rows + 63) / 64), block(64);
 #define OGL_ISAI(LD)                                                                             \
     hipLaunchKernelGGL((k_isai_generate<LD>), grid, block, 0, st, A.n_rows, A.row_ptrs, A.cols,   \
                        A.vals, spd, w_row_ptrs, w_cols, w_vals)
-    if (max_row <= 8)
+    if (max_row <= 4 && group_lanes)
+        hipLaunchKernelGGL((k_isai_generate_grp<4>), dim3((unsigned)(((int64_t)A.n_rows * 4 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                           st, A.n_rows, A.row_ptrs, A.cols, A.vals, spd, w_row_ptrs, w_cols, w_vals);
+    else if (max_row <= 8 && group_lanes)
+        hipLaunchKernelGGL((k_isai_generate_grp<8>), dim3((unsigned)(((int64_t)A.n_rows * 8 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                           st, A.n_rows, A.row_ptrs, A.cols, A.vals, spd, w_row_ptrs, w_cols, w_vals);
+    else if (max_row <= 8)
         OGL_ISAI(8);
     else if (max_row <= 16)
         OGL_ISAI(16);

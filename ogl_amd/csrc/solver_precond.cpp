@@ -134,7 +134,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
             P.struct_stride = cfg.sparsity_power;
         }
         launch_isai_generate(st, csr(), spd ? 1 : 0, P.w_row_ptrs.p, P.w_cols.p, P.w_vals.p,
-                             P.w_max_row, P.wide_rows.p, P.n_wide_rows);
+                             P.w_max_row, P.wide_rows.p, P.n_wide_rows, prop("isaiGroupLanes", 1.0) != 0.0);
         // the dense systems of the huge rows live in a scratch of up to isaiScratchBytes that only this generation
         // needs: allocated here, released below (a field's own preconditioner plus the registry-wide cached one would
         // otherwise sit on 2 GiB each for the whole run)
