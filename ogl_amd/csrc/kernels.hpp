@@ -251,7 +251,8 @@ struct DevBlockJacobi {
 };
 constexpr int MAX_JACOBI_BLOCK = 32;
 // blocks[b] = inverse of A(block b, block b) by Gauss-Jordan with partial pivoting
-void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J);
+void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J,
+                        bool group_lanes = true);  // blocks of <= 8 rows: 4 | 8 lanes per block instead of a thread
 // out = M^-1 in : per row, the block row times the block's slice of `in`, summed left to right;
 // dot_part != nullptr: also the per-chunk partials of sum_i in_i * out_i
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,

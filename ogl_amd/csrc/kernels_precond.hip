@@ -145,6 +145,106 @@ __global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__r
     }
 }
 
+// The same inversion with G lanes per block (blocks of at most G rows, 64 / G blocks per wavefront): lane c owns COLUMN c of
+// its block in registers, every loop unrolled over G -- no scratch memory (the thread-per-block kernel above spends 1.4 ms
+// per generation on the 2.5 M blocks of BJ(4) at 216^3, every solve).  The pivot column is scanned by its owner, the row
+// swap is a swap inside every lane's column, the pivot row is scaled by one division per lane, f = a[i][k] comes from
+// lane k: every element sees invert_block's operations in invert_block's order, so the bits agree.
+template <int G>
+__global__ __launch_bounds__(BLOCK) void k_bj_generate_grp(int n_blocks, const int *__restrict__ block_ptrs,
+                                                           const int *__restrict__ row_ptrs,
+                                                           const int *__restrict__ cols,
+                                                           const double *__restrict__ vals,
+                                                           double *__restrict__ blocks, int ld,
+                                                           const int *__restrict__ rows, const int *__restrict__ pos,
+                                                           int by_device_row)
+{
+    static_assert(G == 4 || G == 8, "group widths instantiated");
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    const int b = t / G, c = t % G;
+    const int lane = threadIdx.x & (WAVE - 1), base = lane - c;
+    const bool live = b < n_blocks;
+    const int r0 = live ? block_ptrs[b] : 0, bs = live ? block_ptrs[b + 1] - r0 : 0;
+    double a[G];
+    int perm[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        a[i] = 0.0;
+        perm[i] = i;
+    }
+    // member row i of the block: every lane of the group walks it (the loads are shared) and keeps the entry of its column
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        if (i < bs) {
+            const int r = rows ? rows[r0 + i] : r0 + i;
+            for (int k = row_ptrs[r]; k < row_ptrs[r + 1]; ++k) {
+                const int cc = (rows ? pos[cols[k]] : cols[k]) - r0;
+                if (cc == c && c < bs) a[i] = vals[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const bool step = k < bs;  // (group-uniform)
+        int piv = k;
+        {
+            double best = fabs(a[k]);
+#pragma unroll
+            for (int i = k + 1; i < G; ++i)
+                if (i < bs && fabs(a[i]) > best) {
+                    best = fabs(a[i]);
+                    piv = i;
+                }
+        }
+        piv = __shfl(piv, base + k, WAVE);
+        if (step && piv != k) {
+            const double ak = a[k];
+            double ap = 0.0;
+            int pp = 0;
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (i == piv) {
+                    ap = a[i];
+                    pp = perm[i];
+                    a[i] = ak;
+                    perm[i] = perm[k];
+                }
+            a[k] = ap;
+            perm[k] = pp;
+        }
+        const double d = __shfl(a[k], base + k, WAVE);
+        if (step) {
+            if (c == k) a[k] = 1.0;
+            if (c < bs) a[k] /= d;
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (i == k) continue;
+            const double f = __shfl(a[i], base + k, WAVE);  // a[i][k], before lane k clears it
+            if (step && i < bs) {
+                if (c == k) a[i] = 0.0;
+                if (c < bs) a[i] -= f * a[k];
+            }
+        }
+    }
+    // block-major, `ld` doubles per block row -- through a permutation (by_device_row) member i's row of the inverse goes
+    // to its DEVICE row; column j of the inverse is the column whose pivot history says perm[j] (the row swaps undone)
+    if (!live) return;
+    const bool dev = rows && by_device_row;
+    int tgt = c;
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        if (j == c && c < bs) tgt = perm[j];
+    if (c < ld) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (i >= (dev ? bs : ld)) continue;
+            double *o = dev ? blocks + (size_t)rows[r0 + i] * ld : blocks + (size_t)b * ld * ld + (size_t)i * ld;
+            o[tgt] = (i < bs && c < bs) ? a[i] : 0.0;
+        }
+    }
+}
+
 // ISAI generate: same operation order as oracle/ogl_oracle.c (csr_entry, solve_dense)
 __device__ double csr_entry(const int *__restrict__ row_ptrs, const int *__restrict__ cols,
                             const double *__restrict__ vals, int r, int c)
@@ -735,14 +835,22 @@ void launch_jacobi_generate(hipStream_t st, const DevCsr &A, double *inv_diag)
                        A.row_ptrs, A.cols, A.vals, inv_diag);
 }
 
-void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J)
+void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J, bool group_lanes)
 {
     if (J.n_blocks == 0) return;
     const dim3 grid((J.n_blocks + 63) / 64), block(64);
 #define OGL_BJ(LD)                                                                              \
     hipLaunchKernelGGL((k_bj_generate<LD>), grid, block, 0, st, J.n_blocks, J.block_ptrs,        \
                        A.row_ptrs, A.cols, A.vals, J.blocks, J.stride, J.rows, J.pos, J.by_device_row)
-    if (J.stride <= 2)
+#define OGL_BJ_GRP(G)                                                                                                   \
+    hipLaunchKernelGGL((k_bj_generate_grp<G>), dim3((unsigned)(((int64_t)J.n_blocks * G + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,  \
+                       st, J.n_blocks, J.block_ptrs, A.row_ptrs, A.cols, A.vals, J.blocks, J.stride, J.rows, J.pos,      \
+                       J.by_device_row)
+    if (J.stride <= 4 && J.stride > 1 && group_lanes)
+        OGL_BJ_GRP(4);
+    else if (J.stride <= 8 && J.stride > 1 && group_lanes)
+        OGL_BJ_GRP(8);
+    else if (J.stride <= 2)
         OGL_BJ(2);
     else if (J.stride <= 4)
         OGL_BJ(4);
@@ -753,6 +861,7 @@ void launch_bj_generate(hipStream_t st, const DevCsr &A, const DevBlockJacobi &J
     else
         OGL_BJ(32);
 #undef OGL_BJ
+#undef OGL_BJ_GRP
 }
 
 void launch_bj_apply(hipStream_t st, const DevBlockJacobi &J, const double *in, double *out,

@@ -209,7 +209,7 @@ int ogl_solver::generate_preconditioner(PrecondData &P)
         P.through_perm = through_perm;
         P.perm_pat_id = through_perm ? pat_id : 0;
 
-        launch_bj_generate(st, csr(), J);
+        launch_bj_generate(st, csr(), J, prop("bjGroupLanes", 1.0) != 0.0);
         P.kind = 2;
         P.stride = cfg.max_block_size;
     }
