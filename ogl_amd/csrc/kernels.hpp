@@ -248,6 +248,8 @@ struct DevBlockJacobi {
     // ... and the block rows are stored at their device rows (rows[position] * stride; the direct apply) instead of
     // block-major in the caller's order (the staged apply)
     int32_t by_device_row = 0;
+    // k_bj_apply_perm: consecutive 512-position ranges one XCD takes (0: chosen from the size, 4 .. 256)
+    int32_t perm_xcd_group = 0;
 };
 constexpr int MAX_JACOBI_BLOCK = 32;
 // blocks[b] = inverse of A(block b, block b) by Gauss-Jordan with partial pivoting

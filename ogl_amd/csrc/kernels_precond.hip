@@ -771,12 +771,19 @@ __global__ __launch_bounds__(CHUNK_ROWS) void k_bj_apply_perm(int n_rows, const 
                                                               const int *__restrict__ row_block,
                                                               const double *__restrict__ blocks, int ld, int uniform,
                                                               const double *__restrict__ in, double *__restrict__ out,
-                                                              const DevScalars *gate, const int *__restrict__ rows)
+                                                              const DevScalars *gate, const int *__restrict__ rows,
+                                                              int xgroup)
 {
     constexpr int HALO = MAX_JACOBI_BLOCK - 1;
     __shared__ double v[CHUNK_ROWS + 2 * HALO];
     if (gate && gate->stop) return;
-    const int c0 = blockIdx.x * CHUNK_ROWS, at = c0 + (int)threadIdx.x;
+    // slabs of `xgroup` consecutive ranges per XCD: the scattered 8-byte reads of `in` and writes of `out` of neighbouring
+    // positions land in the same 64-byte sectors (positions close in the caller's order are close in the device's), and
+    // only one L2 fetches / merges a sector when its positions run on ONE XCD -- with the ranges dealt round-robin every
+    // sector crossed the fabric once per XCD (2.1 M rows shuffled in windows of 65,536, BJ(4): 53 -> 31 us per apply, 137 -> 114 us per turn)
+    const int range = xcd_chunk(blockIdx.x, xgroup);
+    if ((long)range * CHUNK_ROWS >= n_rows) return;
+    const int c0 = range * CHUNK_ROWS, at = c0 + (int)threadIdx.x;
     const int dev = at < n_rows ? rows[at] : -1;
     v[HALO + threadIdx.x] = dev >= 0 ? in[dev] : 0.0;
     if (threadIdx.x < 2 * HALO) {  // the positions before and behind the range
@@ -882,8 +889,10 @@ void launch_bj_apply_staged(hipStream_t st, const DevBlockJacobi &J, const doubl
 {
     if (J.n_rows == 0) return;
     if (!tmp_in) {  // the fused form: one pass over the blocks in the caller's order, then the dot partials
-        hipLaunchKernelGGL(k_bj_apply_perm, dim3((unsigned)n_chunks(J.n_rows)), dim3(CHUNK_ROWS), 0, st, J.n_rows,
-                           J.block_ptrs, J.row_block, J.blocks, J.stride, J.uniform, in, out, gate, J.rows);
+        const int nc = (int)n_chunks(J.n_rows);
+        const int xg = J.perm_xcd_group > 0 ? J.perm_xcd_group : std::max(4, std::min(256, nc / 32));
+        hipLaunchKernelGGL(k_bj_apply_perm, dim3((unsigned)xcd_grid(nc, xg)), dim3(CHUNK_ROWS), 0, st, J.n_rows,
+                           J.block_ptrs, J.row_block, J.blocks, J.stride, J.uniform, in, out, gate, J.rows, xg);
         if (dot_part) launch_partials_dot(st, J.n_rows, in, out, dot_part, gate);
         return;
     }

@@ -274,6 +274,7 @@ void ogl_solver::apply_preconditioner(const double *in, double *out, const DevSc
         J.rows = d_new_id.p;
         J.pos = d_old_of.p;
         J.by_device_row = precond_data->by_device_row ? 1 : 0;
+        J.perm_xcd_group = (int32_t)prop("bjPermXcdGroup", 0.0);
         if (!precond_data->by_device_row) {
             // (property bjFusedPerm 0: the three-launch form with two staging vectors, for A/B)
             const bool fused_perm = prop("bjFusedPerm", 1.0) != 0.0 && in != out;
