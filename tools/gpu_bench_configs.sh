@@ -32,6 +32,9 @@ run cg_bj_368        --iters 50 --edge 368
 # proxies of the unstructured configs (cells renumbered at random in windows of 65536; the backend renumbers itself)
 run c3_cg_bj_128s     --iters 100 --edge 128 --shuffle 65536
 run c3_bicg_isai_128s --iters 100 --edge 128 --shuffle 65536 --solver GKOBiCGStab --asym --precond ISAI
+# ... block Jacobi through the backend's renumbering (the blocks stay the caller's: applied through the permutation)
+run c3_cg_bj4_128s    --iters 100 --edge 128 --shuffle 65536 --block-size 4
+run c3_cg_bj8_128s    --iters 100 --edge 128 --shuffle 65536 --block-size 8
 # ... and on the kind of mesh pitzDaily is (three blockMesh blocks of 60 / 90 / 40 x 104 x 104 cells, 2.06 M, numbered block by block)
 run c3_cg_bj_blocks3     --iters 100 --edge 104 --blocks 60,90,40
 run c3_bicg_isai_blocks3 --iters 100 --edge 104 --blocks 60,90,40 --solver GKOBiCGStab --asym --precond ISAI
