@@ -380,3 +380,25 @@ def test_stored_preconditioner_of_another_numbering_is_not_applied(oracle, chunk
         np.testing.assert_array_equal(x, ref.x[new_id])
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("group", [0.0, 1.0, 3.0, 7.0, 1000.0])
+def test_block_jacobi_through_the_permutation_in_xcd_slabs(reg, oracle, chunk_rows, group):
+    """k_bj_apply_perm deals its 512-position ranges to the XCDs in slabs (bjPermXcdGroup; 0: chosen from the size): whatever
+    the slab length -- one, odd, longer than the system -- every range is taken exactly once, and the bits are the oracle's
+    (125 ranges: the last slab of every setting is only partly filled)."""
+    case = synthetic.renumber_case(synthetic.poisson_case(40), 4096)
+    b = synthetic.apply_case(case, synthetic.x_star(case.global_index, case.global_n))
+    skw = dict(tolerance=1e-10, rel_tol=0.0, max_iter=60)
+    s = reg.solver(f"rnbj_slab_{group}", cfg(preconditioner=capi.PRECOND_BJ, max_block_size=4, **skw))
+    s.set_property("bjPermXcdGroup", group)
+    s.set_matrix(case)
+    new_id = s.renumbering()
+    x, perf = s.solve(b, np.zeros_like(b))
+    A, (rp, cols, vals) = oracle_matrix_renumbered(oracle, case, new_id)
+    P = oracle_precond_renumbered(oracle, case, rp, cols, vals, new_id, 4)
+    with blocked(oracle, chunk_rows):
+        ref = oracle.cg(A, to_new(b, new_id), np.zeros_like(b), P, **skw)
+    assert perf.n_iterations == ref.n_iterations
+    np.testing.assert_array_equal(s.history(), ref.history)
+    np.testing.assert_array_equal(x, ref.x[new_id])
