@@ -145,6 +145,30 @@ __global__ __launch_bounds__(64) void k_bj_generate(int n_blocks, const int *__r
     }
 }
 
+// Value of lane `idx` of this lane's group of G (idx: a constant once the loops are unrolled).  Groups of four are the
+// hardware's quads: a DPP quad_perm move (full-rate vector ALU) instead of a trip through the LDS crossbar.
+__device__ __forceinline__ int quad_get(int v, int idx)
+{
+    switch (idx & 3) {
+    case 0: return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true);
+    case 1: return __builtin_amdgcn_mov_dpp(v, 0x55, 0xf, 0xf, true);
+    case 2: return __builtin_amdgcn_mov_dpp(v, 0xaa, 0xf, 0xf, true);
+    default: return __builtin_amdgcn_mov_dpp(v, 0xff, 0xf, 0xf, true);
+    }
+}
+template <int G>
+__device__ __forceinline__ int grp_get(int v, int base, int idx)
+{
+    if (G == 4) return quad_get(v, idx);
+    return __shfl(v, base + idx, WAVE);
+}
+template <int G>
+__device__ __forceinline__ double grp_get(double v, int base, int idx)
+{
+    if (G == 4) return __hiloint2double(quad_get(__double2hiint(v), idx), quad_get(__double2loint(v), idx));
+    return __shfl(v, base + idx, WAVE);
+}
+
 // The same inversion with G lanes per block (blocks of at most G rows, 64 / G blocks per wavefront): lane c owns COLUMN c of
 // its block in registers, every loop unrolled over G -- no scratch memory (the thread-per-block kernel above spends 1.4 ms
 // per generation on the 2.5 M blocks of BJ(4) at 216^3, every solve).  The pivot column is scanned by its owner, the row
@@ -196,7 +220,7 @@ __global__ __launch_bounds__(BLOCK) void k_bj_generate_grp(int n_blocks, const i
                     piv = i;
                 }
         }
-        piv = __shfl(piv, base + k, WAVE);
+        piv = grp_get<G>(piv, base, k);
         if (step && piv != k) {
             const double ak = a[k];
             double ap = 0.0;
@@ -212,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void k_bj_generate_grp(int n_blocks, const i
             a[k] = ap;
             perm[k] = pp;
         }
-        const double d = __shfl(a[k], base + k, WAVE);
+        const double d = grp_get<G>(a[k], base, k);
         if (step) {
             if (c == k) a[k] = 1.0;
             if (c < bs) a[k] /= d;
@@ -220,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void k_bj_generate_grp(int n_blocks, const i
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             if (i == k) continue;
-            const double f = __shfl(a[i], base + k, WAVE);  // a[i][k], before lane k clears it
+            const double f = grp_get<G>(a[i], base, k);  // a[i][k], before lane k clears it
             if (step && i < bs) {
                 if (c == k) a[i] = 0.0;
                 if (c < bs) a[i] -= f * a[k];
@@ -356,15 +380,15 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_grp(int n_rows, const i
     double a[G];
 #pragma unroll
     for (int r = 0; r < G; ++r) {
-        const int Jr = __shfl(Jc, base + r, WAVE);
+        const int Jr = grp_get<G>(Jc, base, r);
         a[r] = 0.0;
         if (longer) {
             if (on && r < bs) a[r] = spd ? csr_entry(row_ptrs, cols, vals, Jr, Jc) : csr_entry(row_ptrs, cols, vals, Jc, Jr);
         } else if (spd) {
 #pragma unroll
             for (int e = ROWE - 1; e >= 0; --e) {  // (descending: the first match in the row's order is the one that stays)
-                const int col = __shfl(ce[e], base + r, WAVE);
-                const double val = __shfl(ve[e], base + r, WAVE);
+                const int col = grp_get<G>(ce[e], base, r);
+                const double val = grp_get<G>(ve[e], base, r);
                 if (on && r < bs && col == Jc) a[r] = val;
             }
         } else {
@@ -378,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_grp(int n_rows, const i
     int pos = 0;
 #pragma unroll
     for (int r = 0; r < G; ++r)
-        if (__shfl(Jc, base + r, WAVE) == i && r < bs) pos = r;
+        if (grp_get<G>(Jc, base, r) == i && r < bs) pos = r;
 #pragma unroll
     for (int k = 0; k < G; ++k) {
         // pivot: lane k scans its column from row k down, first largest
@@ -392,7 +416,7 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_grp(int n_rows, const i
                     piv = r;
                 }
         }
-        piv = __shfl(piv, base + k, WAVE);
+        piv = grp_get<G>(piv, base, k);
         const bool step = k < bs;  // (group-uniform)
         if (step && piv != k) {
             // rows k and piv change places: every lane in its column, lanes k and piv their right-hand sides
@@ -406,19 +430,19 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_grp(int n_rows, const i
             a[k] = ap;
         }
         {
-            const double rk = __shfl(rhs, base + k, WAVE), rp = __shfl(rhs, base + (piv < G ? piv : k), WAVE);
+            const double rk = grp_get<G>(rhs, base, k), rp = __shfl(rhs, base + (piv < G ? piv : k), WAVE);
             if (step && piv != k) {
                 if (c == k) rhs = rp;
                 else if (c == piv) rhs = rk;
             }
         }
         // eliminate below the pivot: the factors come from lane k (one division each, as in the serial walk)
-        const double akk = __shfl(a[k], base + k, WAVE);
-        const double rk = __shfl(rhs, base + k, WAVE);
+        const double akk = grp_get<G>(a[k], base, k);
+        const double rk = grp_get<G>(rhs, base, k);
         const double akc = a[k];
 #pragma unroll
         for (int r = k + 1; r < G; ++r) {
-            const double f = __shfl(a[r] / akk, base + k, WAVE);
+            const double f = grp_get<G>(a[r] / akk, base, k);
             if (step && r < bs) {
                 if (c > k) a[r] -= f * akc;
                 if (c == r) rhs -= f * rk;
@@ -431,7 +455,7 @@ __global__ __launch_bounds__(BLOCK) void k_isai_generate_grp(int n_rows, const i
         double tv = rhs;  // (meaningful in lane r)
 #pragma unroll
         for (int j = r + 1; j < G; ++j) {
-            const double pr = __shfl(a[r] * rhs, base + j, WAVE);  // lane j: a[r][j] * x[j] (x[j] is final by now)
+            const double pr = grp_get<G>(a[r] * rhs, base, j);  // lane j: a[r][j] * x[j] (x[j] is final by now)
             if (j < bs) tv -= pr;
         }
         if (c == r && r < bs) rhs = tv / a[r];
